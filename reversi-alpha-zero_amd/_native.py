@@ -1,0 +1,75 @@
+"""ctypes binding of csrc/libraz.so (C ABI declared in include/raz.h).
+
+This is the ONLY bridge between the Python facade and the compute path.  There is no Python or
+CPU fallback: if the library is missing this module raises ImportError, and every batched call
+fails with RuntimeError when the HIP runtime reports an error (e.g. no GPU).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int8, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libraz.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built. "
+        "Run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root "
+        "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+u64p = POINTER(c_uint64)
+u8p = POINTER(c_uint8)
+
+# name -> (restype, argtypes).  Device-pointer arguments are passed as integers (c_void_p).
+SIGNATURES = {
+    "raz_abi_version": (c_int, []),
+    "raz_last_error": (c_char_p, []),
+    "raz_find_correct_moves": (c_uint64, [c_uint64, c_uint64]),
+    "raz_calc_flip": (c_uint64, [c_int, c_uint64, c_uint64]),
+    "raz_bit_count": (c_int, [c_uint64]),
+    "raz_flip_vertical": (c_uint64, [c_uint64]),
+    "raz_flip_diag_a1h8": (c_uint64, [c_uint64]),
+    "raz_rotate90": (c_uint64, [c_uint64]),
+    "raz_rotate180": (c_uint64, [c_uint64]),
+    "raz_bit_to_array": (c_int, [c_uint64, c_int, c_void_p]),
+    "raz_env_step": (c_int, [u64p, u64p, u8p, u8p, u64p, c_int]),
+    "raz_legal_moves_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_calc_flip_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_score_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_d4_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_planes_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_pick_kth_legal_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == ABI mismatch: fail at import, loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.raz_abi_version() != 1:
+    raise ImportError(f"libraz ABI version {lib.raz_abi_version()} != 1 (stale build?)")
+
+
+def last_error() -> str:
+    return (lib.raz_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "libraz"):
+    """Raise RuntimeError on a negative status code (SURVEY §8(b) error convention)."""
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def tensor_ptr(t):
+    """Device pointer of a contiguous torch tensor (torch is only the memory allocator here)."""
+    if not t.is_contiguous():
+        raise ValueError("libraz needs contiguous tensors")
+    return t.data_ptr()
+
+
+def current_stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,17 @@
+// raz_internal.h — error plumbing shared by the translation units of libraz.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/raz.h"
+
+// Record `msg` as the calling thread's last error and return `code`.
+int raz_fail(int code, const char* msg);
+// Same, formatting a HIP error.
+int raz_fail_hip(hipError_t e, const char* where);
+// hipGetLastError() after a launch -> RAZ_OK / RAZ_EDEVICE.
+int raz_check_launch(const char* where);
+
+#define RAZ_HIP_TRY(expr, where)                              \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return raz_fail_hip(_e, where); \
+    } while (0)
