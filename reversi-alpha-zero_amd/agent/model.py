@@ -1,0 +1,184 @@
+"""Policy/value residual CNN of reversi_zero/agent/model.py:28-72, as (a) a PyTorch module with the
+Keras graph's exact layer semantics — the fp32 reference the 1e-5 tolerance is measured against and
+the optional `torch` evaluation backend — and (b) the folded weight blob ("raznet v1") that both
+the HIP forward kernels (csrc/raz_net.hip) and the CPU oracle (oracle/orc_net.c) consume.
+
+Keras defaults restated: Conv2D use_bias=True; 3x3 convs padding="same", 1x1 head
+convs "valid"; BatchNormalization(axis=1) eps=1e-3, inference uses moving statistics;
+Flatten on channels_first => index c*64 + y*8 + x; Dense kernels stored (in, out); policy head
+softmax, value head tanh.  Initialisation = Keras defaults (glorot_uniform kernels, zero biases,
+BN gamma=1 beta=0 mean=0 var=1) from a seeded torch.Generator: trained h5 weights cannot be read
+in this environment (no h5py), so benches use random-init weights of the right architecture.
+"""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import torch
+from torch import nn
+
+RAZNET_MAGIC = 0x4E5A4152  # "RAZN"
+BN_EPS = 1e-3              # keras BatchNormalization default epsilon
+
+
+def _glorot_uniform_(w, fan_in, fan_out, gen):
+    limit = (6.0 / (fan_in + fan_out)) ** 0.5
+    with torch.no_grad():
+        w.copy_((torch.rand(w.shape, generator=gen, dtype=torch.float32) * 2 - 1) * limit)
+
+
+class _ConvBN(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)
+        self.bn = nn.BatchNorm2d(cout, eps=BN_EPS)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class ReversiNet(nn.Module):
+    """torch restatement of the Keras graph (agent/model.py:28-72).  Always used in eval() mode."""
+
+    def __init__(self, filters=256, res_layers=10, value_fc=256, filter_size=3):
+        super().__init__()
+        self.filters, self.res_layers, self.value_fc, self.filter_size = filters, res_layers, value_fc, filter_size
+        self.stem = _ConvBN(2, filters, filter_size)
+        self.res = nn.ModuleList(nn.ModuleList([_ConvBN(filters, filters, filter_size),
+                                                _ConvBN(filters, filters, filter_size)])
+                                 for _ in range(res_layers))
+        self.policy_conv = _ConvBN(filters, 2, 1)
+        self.policy_fc = nn.Linear(128, 64)
+        self.value_conv = _ConvBN(filters, 1, 1)
+        self.value_fc1 = nn.Linear(64, value_fc)
+        self.value_fc2 = nn.Linear(value_fc, 1)
+        self.eval()
+
+    def keras_init_(self, seed=0):
+        gen = torch.Generator().manual_seed(seed)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                k = m.kernel_size[0] * m.kernel_size[1]
+                _glorot_uniform_(m.weight, k * m.in_channels, k * m.out_channels, gen)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                _glorot_uniform_(m.weight, m.in_features, m.out_features, gen)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+                m.running_mean.zero_()
+                m.running_var.fill_(1.0)
+        return self
+
+    def randomize_bn_(self, seed=1):
+        """Give BN layers non-trivial statistics (tests: exercises the folding)."""
+        gen = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=gen))
+                    m.bias.copy_(torch.rand(m.bias.shape, generator=gen) - 0.5)
+                    m.running_mean.copy_(0.2 * (torch.rand(m.bias.shape, generator=gen) - 0.5))
+                    m.running_var.copy_(0.5 + torch.rand(m.bias.shape, generator=gen))
+        return self
+
+    def forward(self, x):
+        """x: (N,2,8,8) float32 planes [own, enemy] -> (policy (N,64) softmax, value (N,1) tanh)."""
+        x = torch.relu(self.stem(x))
+        for c1, c2 in self.res:
+            x = torch.relu(c2(torch.relu(c1(x))) + x)
+        p = torch.relu(self.policy_conv(x)).flatten(1)
+        p = torch.softmax(self.policy_fc(p), dim=1)
+        v = torch.relu(self.value_conv(x)).flatten(1)
+        v = torch.tanh(self.value_fc2(torch.relu(self.value_fc1(v))))
+        return p, v
+
+    # ---- folded blob -------------------------------------------------------------------------
+    @staticmethod
+    def _fold(cb):
+        """conv+BN -> (w', b') in float64, rounded once to float32."""
+        w = cb.conv.weight.detach().double()
+        b = cb.conv.bias.detach().double()
+        s = cb.bn.weight.detach().double() / torch.sqrt(cb.bn.running_var.detach().double() + cb.bn.eps)
+        w = w * s.view(-1, 1, 1, 1)
+        b = (b - cb.bn.running_mean.detach().double()) * s + cb.bn.bias.detach().double()
+        return w.float().contiguous(), b.float().contiguous()
+
+    def to_blob(self) -> bytes:
+        """raznet v1: int32[8] header {magic, version=1, F, R, V, filter_size, 0, 0} then float32:
+        conv0 w[F][2][3][3] b[F]; per block c1 w[F][F][3][3] b[F], c2 w b; policy conv w[2][F] b[2];
+        policy dense W[128][64] (in,out) b[64]; value conv w[1][F] b[1]; dense1 W[64][V] b[V];
+        dense2 W[V] b[1].  BN already folded."""
+        if self.filter_size != 3:
+            raise ValueError("raznet v1 supports cnn_filter_size=3 only (all shipped configs)")
+        parts = []
+        for cb in [self.stem] + [c for blk in self.res for c in blk]:
+            w, b = self._fold(cb)
+            parts += [w.reshape(-1), b]
+        w, b = self._fold(self.policy_conv)
+        parts += [w.reshape(-1), b, self.policy_fc.weight.detach().t().contiguous().reshape(-1),
+                  self.policy_fc.bias.detach()]
+        w, b = self._fold(self.value_conv)
+        parts += [w.reshape(-1), b, self.value_fc1.weight.detach().t().contiguous().reshape(-1),
+                  self.value_fc1.bias.detach(), self.value_fc2.weight.detach().reshape(-1),
+                  self.value_fc2.bias.detach()]
+        flat = torch.cat([p.float().reshape(-1) for p in parts]).cpu().numpy().astype(np.float32)
+        assert flat.size == blob_float_count(self.filters, self.res_layers, self.value_fc)
+        hdr = struct.pack("<8i", RAZNET_MAGIC, 1, self.filters, self.res_layers, self.value_fc, 3, 0, 0)
+        return hdr + flat.tobytes()
+
+
+def blob_float_count(F, R, V):
+    return (F * 18 + F) + R * 2 * (F * F * 9 + F) + (2 * F + 2) + (128 * 64 + 64) + (F + 1) + (64 * V + V) + (V + 1)
+
+
+def macs_per_position(F, R, V):
+    """Multiply-accumulates of one forward pass (325,648 mini; 755,343,616 for 256x10)."""
+    return 64 * (F * 18 + R * 2 * F * F * 9 + 2 * F + F) + 128 * 64 + 64 * V + V
+
+
+class ReversiModel:
+    """Same role and method names as the reference's ReversiModel (agent/model.py:22-101).
+    `self.model` is the torch module.  load/save use a JSON config + torch state-dict file (the
+    reference's Keras h5 files need h5py, absent here: interchange is a listed follow-up)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.model = None  # type: ReversiNet
+        self.digest = None
+
+    def build(self, seed=0):
+        mc = self.config.model
+        self.model = ReversiNet(mc.cnn_filter_num, mc.res_layer_num, mc.value_fc_size,
+                                mc.cnn_filter_size).keras_init_(seed)
+
+    @staticmethod
+    def fetch_digest(weight_path):
+        if os.path.exists(weight_path):
+            m = hashlib.sha256()
+            with open(weight_path, "rb") as f:
+                m.update(f.read())
+            return m.hexdigest()
+
+    def load(self, config_path, weight_path):
+        if os.path.exists(config_path) and os.path.exists(weight_path):
+            with open(config_path, "rt") as f:
+                c = json.load(f)
+            self.model = ReversiNet(c["cnn_filter_num"], c["res_layer_num"], c["value_fc_size"],
+                                    c.get("cnn_filter_size", 3))
+            self.model.load_state_dict(torch.load(weight_path, map_location="cpu"))
+            self.model.eval()
+            self.digest = self.fetch_digest(weight_path)
+            return True
+        return False
+
+    def save(self, config_path, weight_path):
+        m = self.model
+        with open(config_path, "wt") as f:
+            json.dump({"cnn_filter_num": m.filters, "res_layer_num": m.res_layers,
+                       "value_fc_size": m.value_fc, "cnn_filter_size": m.filter_size}, f)
+        torch.save(m.state_dict(), weight_path)
+        self.digest = self.fetch_digest(weight_path)

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Generate tests/golden/mcts_games.json: full self-play games played by the UNMODIFIED reference
+(worker/self_play.py start_game -> agent/player.py -> env -> lib/bitboard.py) with raz-rng-v1 and
+the raznet-forward-v1 net injected (oracle/ref_selfplay.py).  Build container only:
+    python tests/golden/make_golden_mcts.py
+Every number written is produced by reference code; this script only chooses configurations.
+All variants use parallel_search_num=1 (the reference's only reproducible mode, SURVEY §7 hard
+part 1) and the solver off (use_solver_turn=0; SURVEY §8(f) rank 1 is a later row).
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_harness as rh  # noqa: E402
+import ref_selfplay as rs  # noqa: E402
+from reversi_alpha_zero_amd.agent.model import ReversiNet  # noqa: E402
+
+NO_SOLVER = {"use_solver_turn": 0, "use_solver_turn_in_simulation": 0, "parallel_search_num": 1}
+
+VARIANTS = [
+    # name, yml, play overrides, play_data overrides, sims, (seed, game ids)
+    ("agz", "alpha_go_zero.yml", {}, {}, 40, 11, [0, 1, 5]),
+    ("agz_resign", "alpha_go_zero.yml", {"resign_threshold": -0.02, "allowed_resign_turn": 12,
+                                         "disable_resignation_rate": 0.0}, {}, 25, 12, [0, 1, 2]),
+    ("agz_noresign_draw", "alpha_go_zero.yml", {"resign_threshold": None}, {"drop_draw_game_rate": 0.5}, 20, 13, [4]),
+    ("mini_shared", "mini.yml", {"reset_mtcs_info_per_game": 1}, {}, 20, 14, [0, 7]),
+    ("default_shared_rethink", None, {"thinking_loop": 3, "required_visit_to_decide_action": 60,
+                                      "start_rethinking_turn": 6}, {}, 25, 15, [2]),
+    ("eval_like_nonoise", "alpha_go_zero.yml", {"noise_eps": 0, "change_tau_turn": 0}, {"save_policy_of_tau_1": True}, 30, 16, [0, 9]),
+    ("ch5_tau4_cpuct5", "ch5.yml", {"thinking_loop": 1}, {}, 30, 17, [3]),
+]
+
+
+def sparse(v):
+    return {str(i): x for i, x in enumerate(v) if x != 0}
+
+
+def main():
+    net = ReversiNet(16, 1, 16).keras_init_(0).randomize_bn_(3)
+    blob = net.to_blob()
+    out = {"_generator": "tests/golden/make_golden_mcts.py",
+           "net": {"filters": 16, "res_layers": 1, "value_fc": 16, "keras_init_seed": 0, "randomize_bn_seed": 3,
+                   "blob_sha256": hashlib.sha256(blob).hexdigest()},
+           "games": []}
+    for name, yml, play_over, pd_over, sims, seed, gids in VARIANTS:
+        for gid in gids:
+            over = {"play": dict(NO_SOLVER, **play_over), "play_data": pd_over}
+            cfg = rh.load_config(yml, over)
+            ref = rs.run_reference_game(cfg, blob, seed, gid, sims)
+            rows = ref.pop("play_rows")
+            plies = []
+            for p in ref.pop("plies"):
+                plies.append({"player": p["player"], "own": "0x%016x" % p["own"], "enemy": "0x%016x" % p["enemy"],
+                              "action": p["action"], "n": p["n"], "q": p["q"], "has_row": p["has_row"],
+                              "root_n": sparse(p["root_n"]), "root_w": sparse(p["root_w"]),
+                              "saved_policy": sparse(p["saved_policy"]) if p["saved_policy"] else None})
+            keys = ["thinking_loop", "required_visit_to_decide_action", "start_rethinking_turn", "c_puct",
+                    "noise_eps", "dirichlet_alpha", "change_tau_turn", "virtual_loss", "parallel_search_num",
+                    "resign_threshold", "allowed_resign_turn", "disable_resignation_rate", "use_solver_turn",
+                    "use_solver_turn_in_simulation", "share_mtcs_info_in_self_play"]
+            ref["resolved_play"] = {k: getattr(cfg.play, k) for k in keys}
+            ref["resolved_play_data"] = {"save_policy_of_tau_1": cfg.play_data.save_policy_of_tau_1,
+                                         "drop_draw_game_rate": cfg.play_data.drop_draw_game_rate}
+            g = dict(ref, variant=name, yml=yml, play_overrides=over["play"], play_data_overrides=pd_over,
+                     plies=plies, black="0x%016x" % ref["black"], white="0x%016x" % ref["white"])
+            g["play_rows_count"] = None if rows is None else len(rows)
+            g["play_rows_sha256"] = None if rows is None else hashlib.sha256(json.dumps(rows).encode()).hexdigest()
+            g["play_rows_head"] = None if rows is None else rows[:9]
+            out["games"].append(g)
+            print(name, gid, "plies", len(plies), "winner", ref["winner"], "resigned", ref["resigned_black"],
+                  ref["resigned_white"], "rows", g["play_rows_count"], "nn", ref["nn_positions"])
+    path = os.path.join(HERE, "mcts_games.json")
+    with open(path, "wt") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

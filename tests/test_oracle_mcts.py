@@ -1,0 +1,132 @@
+"""CPU: the C MCTS/self-play oracle (oracle/orc_mcts.c + orc_net.c + orc_rng.c) against full games
+played by the UNMODIFIED reference (tests/golden/mcts_games.json) — bit-exact: every action, every
+root N and W (float64), ActionWithEvaluation n/q, every saved policy, resignation flags, and the
+play_*.json rows the reference worker wrote (sha256 of the JSON text)."""
+import hashlib
+import json
+
+import pytest
+
+import oracle as O
+from oracle_util import load_mcts_golden, golden_net_blob, config_of, dense, rows_of_game
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return load_mcts_golden()
+
+
+@pytest.fixture(scope="module")
+def blob(golden):
+    return golden_net_blob(golden["net"])
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    import ctypes
+    lib = O.load_ext()
+    U4, U2 = ctypes.c_uint32 * 4, ctypes.c_uint32 * 2
+    kats = [([0] * 4, [0] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+            ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+            ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for c, k, exp in kats:
+        out = U4()
+        lib.orc_philox4x32_10(U4(*c), U2(*k), out)
+        assert list(out) == exp
+
+
+def test_det_math_accuracy():
+    import math
+    import numpy as np
+    lib = O.load_ext()
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.random(3000), 10 ** rng.uniform(-300, 300, 3000)]):
+        assert abs(lib.orc_det_log(x) - math.log(x)) <= 1e-15 * max(1.0, abs(math.log(x)))
+    for x in rng.uniform(-700, 700, 5000):
+        assert abs(lib.orc_det_exp(x) - math.exp(x)) <= 1e-15 * math.exp(x)
+    for x in rng.uniform(-80, 20, 5000).astype(np.float32):
+        assert abs(lib.orc_det_expf(float(x)) - math.exp(float(x))) <= 3e-7 * math.exp(float(x))
+    for x in rng.uniform(-12, 12, 5000).astype(np.float32):
+        assert abs(lib.orc_det_tanhf(float(x)) - math.tanh(float(x))) <= 3e-7
+
+
+def test_dirichlet_noise_of_mask_properties():
+    """The reference's own property test (test/lib/test_bitboard.py:115-122) on the injected sampler."""
+    import ctypes
+    lib = O.load_ext()
+    mask, out = 47289423, (ctypes.c_double * 64)()
+    for ev in range(50):
+        lib.orc_dirichlet_noise_of_mask(mask, 0.5, 1, 2, ev, ctypes.byref(out))
+        assert abs(sum(out) - 1.0) < 1e-12
+        for i in range(64):
+            assert (out[i] > 0) == bool(mask >> i & 1)
+
+
+def test_numpy_pairwise_sum_restatement():
+    """select_action's np.sum(float32[64]) is restated as numpy's 8-lane pairwise order."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        a = (rng.random(64) * (rng.random(64) < 0.3)).astype(np.float32)
+        r = [a[j] for j in range(8)]
+        for i in range(8, 64, 8):
+            for j in range(8):
+                r[j] = np.float32(r[j] + a[i + j])
+        s = np.float32(np.float32(np.float32(r[0] + r[1]) + np.float32(r[2] + r[3])) +
+                       np.float32(np.float32(r[4] + r[5]) + np.float32(r[6] + r[7])))
+        assert s == np.sum(a)
+
+
+def test_games_bit_exact_vs_reference(golden, blob):
+    assert len(golden["games"]) >= 10
+    for g in golden["games"]:
+        cfg = O.play_cfg_from_config(config_of(g))
+        plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"])
+        tag = f'{g["variant"]}/{g["game_id"]}'
+        assert [p["action"] for p in plies] == [p["action"] for p in g["plies"]], tag
+        assert summ["winner"] == g["winner"] and summ["turn"] == g["turn"], tag
+        assert (summ["black"], summ["white"]) == (int(g["black"], 16), int(g["white"], 16)), tag
+        assert (bool(summ["resigned_black"]), bool(summ["resigned_white"])) == \
+            (g["resigned_black"], g["resigned_white"]), tag
+        assert summ["n_expand"] == g["nn_positions"], tag
+        for i, (a, b) in enumerate(zip(plies, g["plies"])):
+            assert a["player"] == b["player"] and a["own"] == int(b["own"], 16) and a["enemy"] == int(b["enemy"], 16)
+            assert a["root_n"] == dense(b["root_n"]), (tag, i)
+            assert a["root_w"] == dense(b["root_w"]), (tag, i)
+            assert a["has_row"] == b["has_row"], (tag, i)
+            if a["action"] >= 0:
+                assert a["n"] == b["n"] and a["q"] == b["q"], (tag, i)
+            if b["has_row"]:
+                assert a["saved_policy"] == dense(b["saved_policy"]), (tag, i)
+        if not config_of(g).play.share_mtcs_info_in_self_play:
+            assert summ["n_mirror_hits"] == 0  # colour-swapped transpositions never occurred
+
+
+def test_play_rows_identical_to_reference_files(golden, blob):
+    for g in golden["games"]:
+        cfg = O.play_cfg_from_config(config_of(g))
+        plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"])
+        rows = rows_of_game(plies, summ["winner"])
+        dropped = summ["winner"] == 3 and not (g["resolved_play_data"]["drop_draw_game_rate"] <= summ["drop_draw_u"])
+        if g["play_rows_sha256"] is None:
+            assert dropped or not rows
+            continue
+        assert len(rows) == g["play_rows_count"]
+        assert rows[:9] == [[list(r[0]), r[1], r[2]] for r in g["play_rows_head"]]
+        assert hashlib.sha256(json.dumps(rows).encode()).hexdigest() == g["play_rows_sha256"], g["variant"]
+
+
+@pytest.mark.needs_reference
+def test_live_reference_game_matches_oracle(blob):
+    """A fresh differential run (new seed/config) against the imported reference, container only."""
+    import ref_harness as rh
+    import ref_selfplay as rs
+    cfg = rh.load_config("alpha_go_zero.yml", {"play": {"parallel_search_num": 1, "c_puct": 1.5, "noise_eps": 0.4,
+                                                         "dirichlet_alpha": 1.0, "change_tau_turn": 6}})
+    ref = rs.run_reference_game(cfg, blob, seed=99, game_id=123456, sims_per_move=15)
+    plies, summ = O.selfplay_game(O.play_cfg_from_config(cfg), blob, 99, 123456, 15)
+    assert [p["action"] for p in plies] == [p["action"] for p in ref["plies"]]
+    for a, b in zip(plies, ref["plies"]):
+        assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"]
+    assert summ["winner"] == ref["winner"]
