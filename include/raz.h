@@ -90,6 +90,103 @@ int raz_planes_batch(const uint64_t* own, const uint64_t* enemy, float* planes, 
 int raz_pick_kth_legal_batch(const uint64_t* legal, const uint32_t* rnd, uint8_t* action, size_t n,
                              raz_stream_t stream);
 
+/* ---- policy/value net: agent/model.py:28-72 evaluated as agent/api.py:30-45 predict() ------------
+ * Weights arrive as the host-side "raznet v1" blob (int32[8] header {0x4E5A4152,1,F,R,V,3,0,0} +
+ * float32 conv/dense parameters with BatchNorm folded; written by
+ * reversi_alpha_zero_amd.agent.model.ReversiNet.to_blob).  The caller owns the device buffers. */
+typedef struct {
+    int32_t filters, res_layers, value_fc, reserved;
+    void* d_weights;      /* device, >= raz_net_weight_bytes() */
+    size_t weight_bytes;
+} raz_net;
+
+size_t raz_net_weight_bytes(int filters, int res_layers, int value_fc); /* 0 = unsupported shape */
+size_t raz_net_scratch_bytes(int filters, int value_fc, size_t n);      /* HBM scratch for n positions */
+int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, void* d_weights, size_t d_bytes,
+                 raz_stream_t stream);
+/* ReversiModelAPI.predict (agent/api.py:30) for n positions given as (own, enemy) bitboards of the
+ * side to move — the planes of agent/player.py:307-309 are formed on the fly.  policy: n x 64
+ * float32 (softmax), value: n float32 (tanh).  active (nullable): positions with active[i]==0 are
+ * skipped and their outputs left untouched. */
+int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* enemy,
+                    const uint8_t* active, float* policy, float* value, size_t n, void* scratch,
+                    size_t scratch_bytes, raz_stream_t stream);
+
+/* ---- batched self-play engine --------------------------------------------------------------------
+ * Replaces, for n_games concurrent games, SelfPlayWorker.start_game (worker/self_play.py:139-175)
+ * driving two ReversiPlayer objects (agent/player.py:28-428) through ReversiEnv, with the leaf
+ * evaluations of ALL live games gathered into one raz_net_forward batch per simulation step
+ * (the reference batches at most prediction_queue_size=16 leaves per worker, player.py:329-355,
+ * plus Pipe fan-in, api.py:75-100).  One simulation is in flight per game, i.e. the reference's
+ * reproducible mode parallel_search_num=1 (SURVEY.md §7 hard part 1).
+ *
+ * Field names follow PlayConfig (config.py:128-166).  Randomness: raz-rng-v1 keyed by
+ * (seed, global game id), so results do not depend on n_games, slot order or GPU count. */
+typedef struct {
+    int32_t thinking_loop;                    /* config.py:133 */
+    int32_t required_visit_to_decide_action;  /* :134 */
+    int32_t start_rethinking_turn;            /* :135 */
+    int32_t change_tau_turn;                  /* :139 */
+    int32_t virtual_loss;                     /* :140 (parallel_search_num=1: only its rounding is observable) */
+    int32_t allowed_resign_turn;              /* :146 */
+    int32_t has_resign_threshold;             /* resign_threshold is not None */
+    int32_t share_mtcs_info;                  /* share_mtcs_info_in_self_play :131 */
+    int32_t mirror_updates;                   /* 1: also maintain the colour-mirrored key like player.py:279-280,
+                                                 323-324 (required when share_mtcs_info=1); 0: skip those writes
+                                                 (dead unless a colour-swapped transposition occurs) */
+    int32_t record_root_w;                    /* 1: also record root W per ply (parity tests) */
+    double c_puct;                            /* :136 */
+    double noise_eps;                         /* :137 */
+    double dirichlet_alpha;                   /* :138, must be in (0, 1] */
+    double resign_threshold;                  /* :145 */
+    double disable_resignation_rate;          /* :147 */
+    uint32_t n_games;                         /* game slots in flight (B) */
+    uint32_t nodes_per_game;                  /* node pool capacity per game */
+    uint32_t table_slots;                     /* hash slots per game, power of two >= 2*nodes_per_game */
+    uint32_t max_plies;                       /* record capacity per game (>= 64) */
+    uint32_t seed;
+    uint32_t reserved;
+} raz_engine_config;
+
+typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */
+
+typedef struct {
+    uint64_t finished_games;  /* games whose status != 0 */
+    uint64_t total_sims;      /* start_search_my_move invocations executed (SURVEY §8(d) metric) */
+    uint64_t nn_leaves;       /* leaf positions sent to the net */
+    uint64_t error_flags;     /* 0 = ok; 1 node pool full, 2 table full, 4 records full, 8 path overflow */
+} raz_engine_stats;
+
+size_t raz_engine_workspace_bytes(const raz_engine_config* cfg);
+/* d_workspace: device buffer of at least raz_engine_workspace_bytes(), 256-byte aligned, owned by
+ * the caller for the lifetime of the handle.  net: loaded with raz_net_load. */
+int raz_engine_create(const raz_engine_config* cfg, const raz_net* net, void* d_workspace,
+                      size_t workspace_bytes, void* d_net_scratch, size_t net_scratch_bytes,
+                      raz_engine** out);
+void raz_engine_destroy(raz_engine* e);
+/* Reset every slot to a fresh game: slot i plays global game id first_game_id + i with
+ * sims_per_move[i] simulations per move (host array of n_games entries; the reference decides this
+ * per game from the schedule, worker/self_play.py:145,262-272).  Slots i >= n_active stay idle. */
+int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
+                     uint32_t n_active, raz_stream_t stream);
+/* Enqueue n_steps simulation steps (each: tree kernel = backup + move logic + select, then one
+ * net batch over the gathered leaves).  Asynchronous. */
+int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
+/* Synchronise the stream and read the counters. */
+int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream);
+/* Copy finished-game records to host memory (synchronous).  headers: n_games*max_plies*48 bytes
+ * (struct layout in csrc/raz_engine.h: own u64, enemy u64, n f64, q f64, action i8, player u8,
+ * turn u8, has_row u8, sims u32, loops u32, pad u32); root_n: n_games*max_plies*64 u32;
+ * root_w: same count of f64 or NULL; n_plies, status (winner|flags), resigned[2], game_id,
+ * enable_resign: per game.  Any pointer may be NULL to skip that array. */
+int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* root_n, double* root_w,
+                            uint32_t* n_plies, uint8_t* status, uint8_t* resigned,
+                            uint32_t* game_id, uint8_t* enable_resign, uint64_t* final_black,
+                            uint64_t* final_white, raz_stream_t stream);
+/* Device pointers of the record arrays, for a caller that gathers them itself (e.g. RCCL):
+ * which = 0 headers, 1 root_n, 2 root_w, 3 n_plies, 4 status. */
+void* raz_engine_device_ptr(raz_engine* e, int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,49 @@ SIGNATURES = {
     "raz_pick_kth_legal_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
+
+
+class RazNet(ctypes.Structure):
+    """raz_net (include/raz.h)."""
+    _fields_ = [("filters", ctypes.c_int32), ("res_layers", ctypes.c_int32), ("value_fc", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("d_weights", c_void_p), ("weight_bytes", c_size_t)]
+
+
+class RazEngineConfig(ctypes.Structure):
+    """raz_engine_config (include/raz.h)."""
+    _fields_ = [("thinking_loop", ctypes.c_int32), ("required_visit_to_decide_action", ctypes.c_int32),
+                ("start_rethinking_turn", ctypes.c_int32), ("change_tau_turn", ctypes.c_int32),
+                ("virtual_loss", ctypes.c_int32), ("allowed_resign_turn", ctypes.c_int32),
+                ("has_resign_threshold", ctypes.c_int32), ("share_mtcs_info", ctypes.c_int32),
+                ("mirror_updates", ctypes.c_int32), ("record_root_w", ctypes.c_int32),
+                ("c_puct", ctypes.c_double), ("noise_eps", ctypes.c_double), ("dirichlet_alpha", ctypes.c_double),
+                ("resign_threshold", ctypes.c_double), ("disable_resignation_rate", ctypes.c_double),
+                ("n_games", c_uint32), ("nodes_per_game", c_uint32), ("table_slots", c_uint32),
+                ("max_plies", c_uint32), ("seed", c_uint32), ("reserved", c_uint32)]
+
+
+class RazEngineStats(ctypes.Structure):
+    _fields_ = [("finished_games", c_uint64), ("total_sims", c_uint64), ("nn_leaves", c_uint64),
+                ("error_flags", c_uint64)]
+
+
+SIGNATURES.update({
+    "raz_net_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "raz_net_scratch_bytes": (c_size_t, [c_int, c_int, c_size_t]),
+    "raz_net_load": (c_int, [POINTER(RazNet), ctypes.c_char_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "raz_net_forward": (c_int, [POINTER(RazNet), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_void_p, c_size_t, c_void_p]),
+    "raz_engine_workspace_bytes": (c_size_t, [POINTER(RazEngineConfig)]),
+    "raz_engine_create": (c_int, [POINTER(RazEngineConfig), POINTER(RazNet), c_void_p, c_size_t, c_void_p,
+                                  c_size_t, POINTER(c_void_p)]),
+    "raz_engine_destroy": (None, [c_void_p]),
+    "raz_engine_start": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
+    "raz_engine_step": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "raz_engine_stats_sync": (c_int, [c_void_p, POINTER(RazEngineStats), c_void_p]),
+    "raz_engine_read_records": (c_int, [c_void_p] * 11 + [c_void_p]),
+    "raz_engine_device_ptr": (c_void_p, [c_void_p, c_int]),
+})
+
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here == ABI mismatch: fail at import, loudly
     _fn.restype = _res

@@ -1,0 +1,767 @@
+// raz_engine.hip — the batched MCTS self-play engine: ONE WAVEFRONT PER GAME, LANE = BOARD SQUARE.
+//
+// What the reference does per game in Python (agent/player.py) and what happens here:
+//   * the three 64-vectors N / W / P of a position are one 1 KiB node block in HBM; a wave loads
+//     them with three fully coalesced requests, lane i holding action i (player.py:62-69);
+//   * PUCT (select_action_q_and_u, :395-428) is per-lane f32/f64 arithmetic in the reference's
+//     exact dtype order + wave reductions (exact integer sum of N, numpy's pairwise f32 sum of p,
+//     first-maximum argmax);
+//   * the board ops (find_correct_moves / calc_flip / step) are wave-uniform 64-bit integer code;
+//   * the transposition "dict" is a per-game open-addressing table probed 16 slots per request;
+//   * one kernel launch = for every game: back up the previous leaf (:264-281), run the per-move
+//     controller when a search completes (action_with_evaluation :82-134, start_game
+//     worker/self_play.py:155-162), then descend to the next leaf (search_my_move :217-262) and
+//     emit it for the cross-game net batch.  Terminal leaves need no net, so a game may complete
+//     several simulations inside one launch.
+//
+// Bit-exactness contract: every floating-point operation below is written in the order the
+// reference performs it under numpy 2 and the file is compiled with
+// -ffp-contract=off; tests/test_engine_gpu.py compares full games with the CPU oracle, which is
+// itself pinned to the unmodified reference.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "raz_bitboard.h"
+#include "raz_detmath.h"
+#include "raz_engine.h"
+#include "raz_internal.h"
+
+namespace {
+
+constexpr int kInnerMax = 8;  // max simulations completed per game per launch (terminal leaves)
+
+// ------------------------------------------------------------------ wave helpers
+// Lanes of the game's wave communicate through HBM (lane 0 writes game state, all lanes read it).
+// Each lane is a separate thread to the compiler, so such hand-offs need an acquire/release point
+// or an earlier load may be forwarded past another lane's store.  The workgroup IS one wave
+// (__launch_bounds__(64)), so this is a compiler/memory fence, not a real barrier.
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// np.sum over float32[64] in numpy's pairwise order: 8 running partials r[j] += a[8i+j], then
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Lane l ends with the total.
+__device__ __forceinline__ float wave_np_sum_f32(float a, int lane) {
+    const int j = lane & 7;
+    float t = __shfl(a, j);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t = t + __shfl(a, j + 8 * i);
+    t = t + __shfl_xor(t, 1);
+    t = t + __shfl_xor(t, 2);
+    t = t + __shfl_xor(t, 4);
+    return t;
+}
+
+// argmax with numpy's first-maximum rule; every lane gets the winning index.
+__device__ __forceinline__ int wave_argmax_f64(double v, int lane) {
+    int idx = lane;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const double ov = __shfl_xor(v, s);
+        const int oi = __shfl_xor(idx, s);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+    return idx;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const double ov = __shfl_xor(v, s);
+        v = ov > v ? ov : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ tree storage
+__device__ __forceinline__ uint32_t key_hash(raz_bb b, raz_bb w, uint32_t tagkey) {
+    unsigned long long x = b * 0x9E3779B97F4A7C15ULL ^ (w + tagkey) * 0xC2B2AE3D27D4EB4FULL;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 32;
+    return (uint32_t)x;
+}
+
+struct Found {
+    bool found;
+    uint32_t node;  // valid when found
+    uint32_t slot;  // matching slot, or first empty slot when !found; 0xffffffff = table full
+};
+
+__device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t tagkey,
+                            int lane) {
+    const raz_slot* tab = E.table + (size_t)g * E.H;
+    const uint32_t mask = E.H - 1;
+    const uint32_t h = key_hash(b, w, tagkey);
+    Found f;
+    f.found = false;
+    f.node = 0;
+    f.slot = 0xffffffffu;
+    for (uint32_t r = 0; r < E.H; r += RAZ_PROBE) {
+        const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
+        const raz_slot* s = tab + si;
+        const raz_bb sb = s->black, sw = s->white;
+        const uint32_t tag = s->tag, idx = s->idx;
+        const bool used = (tag >> 31) != 0;
+        const bool match = used && sb == b && sw == w && (tag & 7u) == tagkey;
+        const unsigned long long mm = __ballot(match) & 0xffffULL;
+        const unsigned long long em = __ballot(!used) & 0xffffULL;
+        if (mm) {
+            const int jj = __ffsll((long long)mm) - 1;
+            f.found = true;
+            f.node = __shfl(idx, jj);
+            f.slot = (h + r + (uint32_t)jj) & mask;
+            return f;
+        }
+        if (em) {
+            f.slot = (h + r + (uint32_t)(__ffsll((long long)em) - 1)) & mask;
+            return f;
+        }
+    }
+    return f;
+}
+
+__device__ __forceinline__ unsigned char* node_ptr(const raz_engine_dev& E, uint32_t g, uint32_t node) {
+    return E.nodes + ((size_t)g * E.C + node) * RAZ_NODE_BYTES;
+}
+__device__ __forceinline__ double* node_W(unsigned char* p) { return (double*)p; }
+__device__ __forceinline__ uint32_t* node_N(unsigned char* p) { return (uint32_t*)(p + 512); }
+__device__ __forceinline__ float* node_P(unsigned char* p) { return (float*)(p + 768); }
+
+// defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent.
+// Returns the node index, or 0xffffffff after flagging an error when out of space.
+__device__ uint32_t node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
+                             uint32_t owner, int lane) {
+    const uint32_t tagkey = np | (owner << 2);
+    Found f = table_find(E, g, b, w, tagkey, lane);
+    if (f.found) return f.node;
+    uint32_t used = E.pool_used[g];
+    if (f.slot == 0xffffffffu || used >= E.C) {
+        if (lane == 0) {
+            E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+            atomicOr(&E.counters[2], (unsigned long long)((f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL));
+        }
+        return 0xffffffffu;
+    }
+    const uint32_t node = used;
+    unsigned char* p = node_ptr(E, g, node);
+    node_W(p)[lane] = 0.0;
+    node_N(p)[lane] = 0u;
+    node_P(p)[lane] = 0.0f;
+    if (lane == 0) {
+        raz_slot* s = E.table + (size_t)g * E.H + f.slot;
+        s->black = b;
+        s->white = w;
+        s->idx = node;
+        s->tag = 0x80000000u | tagkey;
+        E.node_kb[(size_t)g * E.C + node] = b;
+        E.node_kw[(size_t)g * E.C + node] = w;
+        E.node_tag[(size_t)g * E.C + node] = tagkey;
+        E.pool_used[g] = used + 1;
+    }
+    wave_sync();
+    return node;
+}
+
+// ------------------------------------------------------------------ search-space env (player's view)
+struct Env {  // ReversiEnv in the searching player's coordinates: "black" = that player
+    raz_bb black, white;
+    uint32_t np;      // 1 or 2
+    uint32_t status;  // 0 running, else winner
+};
+
+__device__ __forceinline__ void env_step(Env& e, int action) {
+    raz_step_result r = bb_env_step(e.black, e.white, (int)e.np, action);
+    e.black = r.black;
+    e.white = r.white;
+    e.np = r.player;
+    e.status = r.status & RAZ_STATUS_WINNER_MASK;
+}
+
+// ------------------------------------------------------------------ select (agent/player.py:395-428)
+__device__ int select_action(const raz_engine_dev& E, uint32_t g, uint32_t node, const Env& env,
+                             bool is_root, uint32_t game_id, int lane) {
+    const raz_engine_config& c = E.cfg;
+    unsigned char* p = node_ptr(E, g, node);
+    const double Wi = node_W(p)[lane];
+    const uint32_t Ni = node_N(p)[lane];
+    const float Pi = node_P(p)[lane];
+    const raz_bb legal = env.np == 1 ? bb_legal_moves(env.black, env.white) : bb_legal_moves(env.white, env.black);
+    const uint32_t bit = (uint32_t)((legal >> lane) & 1ULL);
+    const uint32_t sumN = wave_sum_u32(Ni);
+    double xx = sqrt((double)sumN);  // np.sqrt(np.sum(N)); correctly rounded on gfx950 (probe)
+    if (xx < 1.0) xx = 1.0;           // max(xx_, 1)
+    float p32 = Pi * (float)bit;      // P * legal mask (float32)
+    const float sp = wave_np_sum_f32(p32, lane);
+    if (sp > 0.0f) p32 = p32 / sp;    // normalize(p, temperature == 1) in float32
+    const double Nd = (double)Ni;
+    double u;
+    if (is_root && c.noise_eps > 0.0) {  // (1-eps) p + eps Dir(alpha), fresh at every root visit (:415-417)
+        uint32_t ev = E.ev_dirichlet[g];
+        const uint32_t rank = (uint32_t)__popcll(legal & ((1ULL << lane) - 1ULL));
+        double gam = 0.0;
+        if (bit) gam = raz_gamma_sample(c.dirichlet_alpha, c.seed, game_id, ev, rank);
+        double acc = 0.0;
+        for (raz_bb m = legal; m; m &= m - 1) acc += __shfl(gam, __ffsll((long long)m) - 1);
+        const double noise = bit ? gam / acc : 0.0;
+        const float keep = (float)(1.0 - c.noise_eps);
+        const double p64 = (double)(keep * p32) + c.noise_eps * noise;
+        u = (c.c_puct * p64) * xx / (1.0 + Nd);
+        if (lane == 0) E.ev_dirichlet[g] = ev + 1;
+    } else {
+        const float cp = (float)c.c_puct;
+        u = ((double)(cp * p32)) * xx / (1.0 + Nd);
+    }
+    const double q = Wi / (Nd + 1e-5);
+    double v = (env.np == 1) ? (q + u + 1000.0) : (-q + u + 1000.0);
+    v = v * (double)bit;
+    return wave_argmax_f64(v, lane);
+}
+
+// ------------------------------------------------------------------ backup of the previous leaf
+__device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, int lane) {
+    const raz_engine_config& c = E.cfg;
+    const uint32_t kind = E.leaf_kind[g];
+    if (kind == RAZ_LEAF_NONE) return;
+    const uint32_t owner = c.share_mtcs_info ? 0u : pl;
+    const int depth = E.depth[g];
+    double leaf_v;
+    if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-327), second half
+        const uint32_t np = E.leaf_np[g];
+        const raz_bb kb = E.leaf_b[g], kw = E.leaf_w[g];
+        leaf_v = (double)E.nn_value[g];  // float(leaf_v)
+        if (np == 2) leaf_v = -leaf_v;   // :259-262
+        const uint32_t sym = E.leaf_sym[g];
+        // the net saw T(board); its policy q is over T-squares, so p[s] = q[T(s)]
+        const float pol = E.nn_policy[(size_t)g * 64 + bb_d4_square(lane, (sym >> 2) & 1, sym & 3)];
+        const uint32_t node = node_get(E, g, kb, kw, np, owner, lane);
+        if (node != 0xffffffffu) {
+            node_P(node_ptr(E, g, node))[lane] = pol;
+            if (lane == 0) E.node_tag[(size_t)g * E.C + node] |= (16u << pl);
+        }
+        if (c.mirror_updates) {
+            const uint32_t m = node_get(E, g, kw, kb, 3 - np, owner, lane);
+            if (m != 0xffffffffu) node_P(node_ptr(E, g, m))[lane] = pol;
+        }
+    } else {
+        leaf_v = (double)E.leaf_term_v[g];
+    }
+    const double vl = (double)c.virtual_loss;
+    for (int d = depth - 1; d >= 0; --d) {
+        const uint32_t node = E.path_node[(size_t)g * 64 + d];
+        const uint32_t pa = E.path_act[(size_t)g * 64 + d];
+        const uint32_t a = pa & 63u, npd = pa >> 6;
+        const double vlw = npd == 1 ? vl : -vl;
+        unsigned char* p = node_ptr(E, g, node);
+        if (lane == 0) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
+            node_N(p)[a] += 1u;
+            const double w0 = node_W(p)[a];
+            node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
+        }
+        if (c.mirror_updates) {  // another_side_counter_key (:279-280)
+            const raz_bb kb = E.node_kb[(size_t)g * E.C + node], kw = E.node_kw[(size_t)g * E.C + node];
+            const uint32_t m = node_get(E, g, kw, kb, 3 - npd, owner, lane);
+            if (m != 0xffffffffu && lane == 0) {
+                unsigned char* q = node_ptr(E, g, m);
+                node_N(q)[a] += 1u;
+                node_W(q)[a] = node_W(q)[a] - leaf_v;
+            }
+        }
+    }
+    if (lane == 0) {
+        E.leaf_kind[g] = RAZ_LEAF_NONE;
+        E.sims_left[g] -= 1;
+        E.move_sims[g] += 1;
+        E.g_sims[g] += 1;
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------ per-move controller
+// action_with_evaluation (:82-134) after a search (or the turn-0 bypass) has finished, then
+// SelfPlayWorker.start_game's env.step (worker/self_play.py:155-162).  Returns with the game either
+// searching again (phase SEARCH, sims_left > 0), waiting for a new move (phase NEW_MOVE) or DONE.
+__device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
+    const raz_engine_config& c = E.cfg;
+    const uint32_t player = E.g_player[g];
+    const uint32_t pl = player - 1;
+    const uint32_t owner = c.share_mtcs_info ? 0u : pl;
+    const raz_bb rb = E.root_black[g], rw = E.root_white[g];
+    const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
+    const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
+    const uint32_t game_id = E.g_game_id[g];
+    const uint32_t node = node_get(E, g, own, enemy, 1, owner, lane);
+    if (node == 0xffffffffu) {
+        if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
+        return;
+    }
+    unsigned char* p = node_ptr(E, g, node);
+    const uint32_t Ni = node_N(p)[lane];
+    const double Wi = node_W(p)[lane];
+    const double Nd = (double)Ni;
+    const double q = Wi / (Nd + 1e-5);
+    const uint32_t sumN = wave_sum_u32(Ni);
+    // calc_policy (:366-385)
+    double policy;
+    const int amax_n = wave_argmax_f64(Nd, lane);
+    if (turn < c.change_tau_turn)
+        policy = Nd / (double)sumN;
+    else
+        policy = (lane == amax_n) ? 1.0 : 0.0;
+    // np.random.choice(range(64), p=policy) (:112): cdf = cumsum; cdf /= cdf[-1]; searchsorted right
+    double acc = 0.0, cdf = 0.0;
+    for (int i = 0; i < 64; ++i) {
+        acc += __shfl(policy, i);
+        if (i == lane) cdf = acc;
+    }
+    cdf = cdf / acc;
+    const uint32_t ev = E.ev_choice[g];
+    double d0, d1;
+    raz_rng_pair(c.seed, game_id, RAZ_RNG_CHOICE, ev, 0, 0, d0, d1);
+    int action = __popcll(__ballot(cdf <= d0));
+    if (action > 63) action = 63;
+    if (lane == 0) E.ev_choice[g] = ev + 1;
+    // re-thinking rule (:113-118)
+    const int abv = wave_argmax_f64(q + (Ni > 0 ? 100.0 : 0.0), lane);
+    const double q_action = __shfl(q, action), q_abv = __shfl(q, abv);
+    const double n_action = __shfl(Nd, action);
+    const double value_diff = q_action - q_abv;
+    const uint32_t loops = E.loops_done[g] + 1;
+    const bool stop = (turn <= c.start_rethinking_turn) ||
+                      (value_diff > -0.01 && n_action >= (double)c.required_visit_to_decide_action) ||
+                      ((int)loops >= c.thinking_loop);
+    if (!stop) {  // another thinking loop on the same root (tree and N are kept)
+        if (lane == 0) {
+            E.loops_done[g] = loops;
+            E.sims_left[g] = (int32_t)E.sims_per_move[g];
+            E.g_phase[g] = RAZ_PHASE_SEARCH;
+        }
+        return;
+    }
+    // resignation (:123-130)
+    int final_action = action;
+    bool has_row = true;
+    if (c.has_resign_threshold) {
+        const double mx = wave_max_f64(q - (Ni == 0 ? 10.0 : 0.0));
+        if (mx <= c.resign_threshold) {
+            if (lane == 0) E.g_resigned[(size_t)g * 2 + pl] = 1;
+            if (E.g_enable_resign[g] && turn >= c.allowed_resign_turn) {
+                final_action = -1;
+                has_row = false;
+            }
+        }
+    }
+    // record the ply (rows + GGF are produced on the host from this)
+    const uint32_t ply = E.n_plies[g];
+    if (ply >= E.max_plies) {
+        if (lane == 0) {
+            E.g_error[g] |= RAZ_ERR_RECORDS_FULL;
+            atomicOr(&E.counters[2], (unsigned long long)RAZ_ERR_RECORDS_FULL);
+            E.g_phase[g] = RAZ_PHASE_DONE;
+        }
+        return;
+    }
+    const size_t ri = (size_t)g * E.max_plies + ply;
+    E.rec_n[ri * 64 + lane] = Ni;
+    if (E.rec_w) E.rec_w[ri * 64 + lane] = Wi;
+    if (lane == 0) {
+        raz_ply_header h;
+        h.own = own;
+        h.enemy = enemy;
+        h.n = final_action >= 0 ? n_action : 0.0;
+        h.q = final_action >= 0 ? q_action : 0.0;
+        h.action = (int8_t)final_action;
+        h.player = (uint8_t)player;
+        h.turn = (uint8_t)turn;
+        h.has_row = has_row ? 1 : 0;
+        h.sims = E.move_sims[g];
+        h.loops = loops;
+        h.pad = 0;
+        E.rec[ri] = h;
+        E.n_plies[g] = ply + 1;
+    }
+    // env.step(action) on the real board (worker/self_play.py:162)
+    raz_step_result r = bb_env_step(rb, rw, (int)player, final_action < 0 ? RAZ_ACTION_RESIGN : final_action);
+    if (lane == 0) {
+        E.root_black[g] = r.black;
+        E.root_white[g] = r.white;
+        E.g_player[g] = r.player;
+        E.g_status[g] = r.status;
+        E.loops_done[g] = 0;
+        E.move_sims[g] = 0;
+        if (r.status) {
+            E.g_phase[g] = RAZ_PHASE_DONE;
+            atomicAdd(&E.counters[0], 1ULL);
+        } else {
+            E.g_phase[g] = RAZ_PHASE_NEW_MOVE;
+        }
+    }
+    wave_sync();
+}
+
+// Start the mover's move: turn 0 -> bypass_first_move (:143-148), else arm a search.
+__device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
+    const raz_engine_config& c = E.cfg;
+    const uint32_t player = E.g_player[g];
+    const uint32_t pl = player - 1;
+    const raz_bb rb = E.root_black[g], rw = E.root_white[g];
+    const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
+    const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
+    if (turn > 0) {
+        if (lane == 0) {
+            E.sims_left[g] = (int32_t)E.sims_per_move[g];
+            E.g_phase[g] = RAZ_PHASE_SEARCH;
+        }
+    } else {
+        const uint32_t owner = c.share_mtcs_info ? 0u : pl;
+        const uint32_t node = node_get(E, g, own, enemy, 1, owner, lane);
+        if (node != 0xffffffffu) {
+            unsigned char* p = node_ptr(E, g, node);
+            const raz_bb legal = bb_legal_moves(own, enemy);
+            const int first = __ffsll((long long)legal) - 1;
+            const int cnt = bb_popcount(legal);
+            node_P(p)[lane] = (float)((double)((legal >> lane) & 1ULL) / (double)cnt);
+            if (lane == first) {
+                node_N(p)[lane] = 1u;
+                node_W(p)[lane] = 0.0;
+            }
+        }
+        if (lane == 0) {
+            E.sims_left[g] = 0;
+            E.g_phase[g] = RAZ_PHASE_SEARCH;  // "search" of zero simulations: decide immediately
+        }
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------ descent to the next leaf
+__device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
+    const raz_engine_config& c = E.cfg;
+    const uint32_t player = E.g_player[g];
+    const uint32_t pl = player - 1;
+    const uint32_t owner = c.share_mtcs_info ? 0u : pl;
+    const uint32_t game_id = E.g_game_id[g];
+    const raz_bb rb = E.root_black[g], rw = E.root_white[g];
+    Env env;  // ReversiEnv().update(own, enemy, Player.black) (:209)
+    env.black = player == 1 ? rb : rw;
+    env.white = player == 1 ? rw : rb;
+    env.np = 1;
+    env.status = 0;
+    int depth = 0;
+    uint32_t kind;
+    for (;;) {
+        if (env.status) {  // env.done (:226-232)
+            kind = RAZ_LEAF_TERMINAL;
+            if (lane == 0) E.leaf_term_v[g] = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
+            break;
+        }
+        const uint32_t tagkey = env.np | (owner << 2);
+        const Found f = table_find(E, g, env.black, env.white, tagkey, lane);
+        bool expanded = false;
+        if (f.found) expanded = ((E.node_tag[(size_t)g * E.C + f.node] >> (4 + pl)) & 1u) != 0;
+        if (!expanded) {  // leaf: expand_and_evaluate (:283-311), first half
+            kind = RAZ_LEAF_EXPAND;
+            const uint32_t ev = E.ev_expand[g];
+            double d0, d1;
+            raz_rng_pair(c.seed, game_id, RAZ_RNG_EXPAND, ev, 0, 0, d0, d1);
+            const int flip = d0 < 0.5 ? 1 : 0;   // random() < 0.5
+            const int rot = (int)(d1 * 4.0);     // int(random() * 4)
+            const raz_bb tb = bb_d4_apply(env.black, flip, rot), tw = bb_d4_apply(env.white, flip, rot);
+            if (lane == 0) {
+                E.ev_expand[g] = ev + 1;
+                E.leaf_b[g] = env.black;
+                E.leaf_w[g] = env.white;
+                E.leaf_np[g] = (uint8_t)env.np;
+                E.leaf_sym[g] = (uint8_t)(flip * 4 + rot);
+                E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
+                E.nn_enemy[g] = env.np == 1 ? tw : tb;
+            }
+            break;
+        }
+        if (depth >= 64) {
+            kind = RAZ_LEAF_NONE;
+            if (lane == 0) {
+                E.g_error[g] |= RAZ_ERR_PATH_FULL;
+                atomicOr(&E.counters[2], (unsigned long long)RAZ_ERR_PATH_FULL);
+            }
+            break;
+        }
+        const int a = select_action(E, g, f.node, env, depth == 0, game_id, lane);
+        if (lane == 0) {
+            E.path_node[(size_t)g * 64 + depth] = f.node;
+            E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
+        }
+        ++depth;
+        env_step(env, a);
+    }
+    if (lane == 0) {
+        E.leaf_kind[g] = (uint8_t)kind;
+        E.depth[g] = (uint8_t)depth;
+        E.nn_active[g] = kind == RAZ_LEAF_EXPAND ? 1 : 0;
+        if (kind == RAZ_LEAF_EXPAND) atomicAdd(&E.counters[3], 1ULL);
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------ the tree kernel
+__global__ __launch_bounds__(64) void k_tree(raz_engine_dev E) {
+    const uint32_t g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (g >= E.B) return;
+    if (lane == 0) E.nn_active[g] = 0;
+    wave_sync();
+    uint32_t sims_done = 0;
+    for (int it = 0; it < kInnerMax; ++it) {
+        uint32_t phase = E.g_phase[g];
+        if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
+        if (E.g_error[g]) break;
+        if (E.leaf_kind[g] != RAZ_LEAF_NONE) {
+            backup_leaf(E, g, (uint32_t)E.g_player[g] - 1, lane);
+            ++sims_done;
+        }
+        wave_sync();
+        // controller: loop because a decided move may immediately need another decision
+        // (turn-0 bypass) before a search with simulations starts
+        for (int guard = 0; guard < 8; ++guard) {
+            wave_sync();
+            phase = E.g_phase[g];
+            if (phase == RAZ_PHASE_NEW_MOVE) {
+                begin_move(E, g, lane);
+                continue;
+            }
+            if (phase == RAZ_PHASE_SEARCH && E.sims_left[g] <= 0) {
+                decide_move(E, g, lane);
+                continue;
+            }
+            break;
+        }
+        wave_sync();
+        phase = E.g_phase[g];
+        if (phase != RAZ_PHASE_SEARCH || E.sims_left[g] <= 0 || E.g_error[g]) break;
+        select_leaf(E, g, lane);
+        wave_sync();
+        if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL) break;  // needs the net: end of this launch's work
+    }
+    if (lane == 0 && sims_done) atomicAdd(&E.counters[1], (unsigned long long)sims_done);
+}
+
+__global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t* sims_per_move,
+                        uint32_t n_active) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    const bool act = g < n_active;
+    E.root_black[g] = RAZ_INIT_BLACK;
+    E.root_white[g] = RAZ_INIT_WHITE;
+    E.g_player[g] = RAZ_PLAYER_BLACK;
+    E.g_status[g] = 0;
+    E.g_phase[g] = act ? RAZ_PHASE_NEW_MOVE : RAZ_PHASE_IDLE;
+    E.g_game_id[g] = first_game_id + g;
+    E.g_resigned[(size_t)g * 2] = 0;
+    E.g_resigned[(size_t)g * 2 + 1] = 0;
+    double d0, d1;
+    raz_rng_pair(E.cfg.seed, first_game_id + g, RAZ_RNG_GAME, 0, 0, 0, d0, d1);
+    E.g_enable_resign[g] = E.cfg.disable_resignation_rate <= d0 ? 1 : 0;  // worker/self_play.py:144
+    E.ev_expand[g] = E.ev_choice[g] = E.ev_dirichlet[g] = 0;
+    E.sims_per_move[g] = sims_per_move[g];
+    E.sims_left[g] = 0;
+    E.loops_done[g] = 0;
+    E.move_sims[g] = 0;
+    E.pool_used[g] = 0;
+    E.n_plies[g] = 0;
+    E.g_error[g] = 0;
+    E.g_sims[g] = 0;
+    E.leaf_kind[g] = RAZ_LEAF_NONE;
+    E.nn_active[g] = 0;
+    E.depth[g] = 0;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Carve the workspace; with base == nullptr only the total size is computed.
+size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* E) {
+    size_t off = 0;
+    const size_t B = cfg.n_games, C = cfg.nodes_per_game, H = cfg.table_slots, MP = cfg.max_plies;
+    auto take = [&](size_t bytes) -> unsigned char* {
+        unsigned char* p = base ? base + off : nullptr;
+        off = align_up(off + bytes, 256);
+        return p;
+    };
+    raz_engine_dev d;
+    memset(&d, 0, sizeof d);
+    d.cfg = cfg;
+    d.B = (uint32_t)B; d.C = (uint32_t)C; d.H = (uint32_t)H; d.max_plies = (uint32_t)MP;
+    d.root_black = (unsigned long long*)take(B * 8);
+    d.root_white = (unsigned long long*)take(B * 8);
+    d.g_player = take(B); d.g_status = take(B); d.g_phase = take(B); d.g_enable_resign = take(B);
+    d.g_resigned = take(B * 2);
+    d.g_game_id = (uint32_t*)take(B * 4); d.ev_expand = (uint32_t*)take(B * 4);
+    d.ev_choice = (uint32_t*)take(B * 4); d.ev_dirichlet = (uint32_t*)take(B * 4);
+    d.sims_per_move = (uint32_t*)take(B * 4); d.loops_done = (uint32_t*)take(B * 4);
+    d.move_sims = (uint32_t*)take(B * 4); d.pool_used = (uint32_t*)take(B * 4);
+    d.n_plies = (uint32_t*)take(B * 4); d.g_error = (uint32_t*)take(B * 4);
+    d.sims_left = (int32_t*)take(B * 4);
+    d.g_sims = (unsigned long long*)take(B * 8);
+    d.leaf_kind = take(B); d.leaf_sym = take(B); d.leaf_np = take(B); d.depth = take(B); d.nn_active = take(B);
+    d.leaf_b = (unsigned long long*)take(B * 8); d.leaf_w = (unsigned long long*)take(B * 8);
+    d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
+    d.leaf_term_v = (float*)take(B * 4); d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
+    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
+    d.table = (raz_slot*)take(B * H * sizeof(raz_slot));
+    d.nodes = take(B * C * RAZ_NODE_BYTES);
+    d.node_kb = (unsigned long long*)take(B * C * 8); d.node_kw = (unsigned long long*)take(B * C * 8);
+    d.node_tag = (uint32_t*)take(B * C * 4);
+    d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
+    d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
+    d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
+    d.counters = (unsigned long long*)take(4 * 8);
+    if (E) *E = d;
+    return off;
+}
+
+int validate(const raz_engine_config* cfg) {
+    if (!cfg) return raz_fail(RAZ_EINVAL, "raz_engine: NULL config");
+    if (cfg->n_games == 0 || cfg->nodes_per_game == 0) return raz_fail(RAZ_EINVAL, "raz_engine: n_games and nodes_per_game must be > 0");
+    if (cfg->table_slots < 2 * (size_t)cfg->nodes_per_game || (cfg->table_slots & (cfg->table_slots - 1)) || cfg->table_slots < RAZ_PROBE)
+        return raz_fail(RAZ_EINVAL, "raz_engine: table_slots must be a power of two >= 2*nodes_per_game");
+    if (cfg->max_plies < 64) return raz_fail(RAZ_EINVAL, "raz_engine: max_plies must be >= 64");
+    if (!(cfg->dirichlet_alpha > 0.0) || cfg->dirichlet_alpha > 1.0)
+        return raz_fail(RAZ_EINVAL, "raz_engine: dirichlet_alpha must be in (0, 1] (all shipped configs use 0.5)");
+    if (cfg->thinking_loop < 1) return raz_fail(RAZ_EINVAL, "raz_engine: thinking_loop must be >= 1");
+    if (cfg->share_mtcs_info && !cfg->mirror_updates)
+        return raz_fail(RAZ_EINVAL, "raz_engine: share_mtcs_info=1 requires mirror_updates=1 (player.py:279-280)");
+    return RAZ_OK;
+}
+
+}  // namespace
+
+struct raz_engine {
+    raz_engine_dev dev;
+    raz_net net;
+    void* net_scratch;
+    size_t net_scratch_bytes;
+    uint32_t* d_sims;  // staging for sims_per_move (inside the workspace: reuse sims_left? no: own array)
+    bool started;
+};
+
+extern "C" size_t raz_engine_workspace_bytes(const raz_engine_config* cfg) {
+    if (validate(cfg) != RAZ_OK) return 0;
+    return carve(*cfg, nullptr, nullptr) + align_up((size_t)cfg->n_games * 4, 256);
+}
+
+extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* net, void* d_workspace,
+                                 size_t workspace_bytes, void* d_net_scratch, size_t net_scratch_bytes,
+                                 raz_engine** out) {
+    if (!out) return raz_fail(RAZ_EINVAL, "raz_engine_create: NULL out");
+    *out = nullptr;
+    int rc = validate(cfg);
+    if (rc != RAZ_OK) return rc;
+    if (!net || !net->d_weights) return raz_fail(RAZ_EINVAL, "raz_engine_create: net not loaded");
+    if (!d_workspace || ((uintptr_t)d_workspace & 255)) return raz_fail(RAZ_EINVAL, "raz_engine_create: workspace must be 256-byte aligned");
+    const size_t need = raz_engine_workspace_bytes(cfg);
+    if (workspace_bytes < need) return raz_fail(RAZ_ENOMEM, "raz_engine_create: workspace too small (raz_engine_workspace_bytes)");
+    if (net_scratch_bytes < raz_net_scratch_bytes(net->filters, net->value_fc, cfg->n_games))
+        return raz_fail(RAZ_ENOMEM, "raz_engine_create: net scratch too small (raz_net_scratch_bytes)");
+    raz_engine* e = new (std::nothrow) raz_engine;
+    if (!e) return raz_fail(RAZ_ENOMEM, "raz_engine_create: host allocation failed");
+    const size_t used = carve(*cfg, (unsigned char*)d_workspace, &e->dev);
+    e->d_sims = (uint32_t*)((unsigned char*)d_workspace + used);
+    e->net = *net;
+    e->net_scratch = d_net_scratch;
+    e->net_scratch_bytes = net_scratch_bytes;
+    e->started = false;
+    *out = e;
+    return RAZ_OK;
+}
+
+extern "C" void raz_engine_destroy(raz_engine* e) { delete e; }
+
+extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
+                                uint32_t n_active, raz_stream_t stream) {
+    if (!e || !sims_per_move) return raz_fail(RAZ_EINVAL, "raz_engine_start: NULL argument");
+    if (n_active > e->dev.B) return raz_fail(RAZ_EINVAL, "raz_engine_start: n_active > n_games");
+    hipStream_t s = (hipStream_t)stream;
+    const raz_engine_dev& d = e->dev;
+    RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)d.B * 4, hipMemcpyHostToDevice, s), "raz_engine_start: copy sims");
+    RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
+    RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 32, s), "raz_engine_start: clear counters");
+    hipLaunchKernelGGL(k_start, dim3((d.B + 255) / 256), dim3(256), 0, s, d, first_game_id, e->d_sims, n_active);
+    int rc = raz_check_launch("raz_engine_start");
+    if (rc == RAZ_OK) e->started = true;
+    return rc;
+}
+
+extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_step: NULL engine");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step: call raz_engine_start first");
+    hipStream_t s = (hipStream_t)stream;
+    const raz_engine_dev& d = e->dev;
+    for (uint32_t i = 0; i < n_steps; ++i) {
+        hipLaunchKernelGGL(k_tree, dim3(d.B), dim3(64), 0, s, d);
+        int rc = raz_check_launch("raz_engine_step: k_tree");
+        if (rc != RAZ_OK) return rc;
+        rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own, (const uint64_t*)d.nn_enemy, d.nn_active,
+                             d.nn_policy, d.nn_value, d.B, e->net_scratch, e->net_scratch_bytes, stream);
+        if (rc != RAZ_OK) return rc;
+    }
+    return RAZ_OK;
+}
+
+extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
+    if (!e || !out) return raz_fail(RAZ_EINVAL, "raz_engine_stats_sync: NULL argument");
+    unsigned long long c[4];
+    RAZ_HIP_TRY(hipMemcpyAsync(c, e->dev.counters, 32, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_stats_sync: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_stats_sync: sync");
+    out->finished_games = c[0];
+    out->total_sims = c[1];
+    out->error_flags = c[2];
+    out->nn_leaves = c[3];
+    return RAZ_OK;
+}
+
+extern "C" int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* root_n, double* root_w,
+                                       uint32_t* n_plies, uint8_t* status, uint8_t* resigned,
+                                       uint32_t* game_id, uint8_t* enable_resign, uint64_t* final_black,
+                                       uint64_t* final_white, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_read_records: NULL engine");
+    const raz_engine_dev& d = e->dev;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = d.B, MP = d.max_plies;
+#define RAZ_D2H(dst, src, bytes)                                                              \
+    if (dst) RAZ_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s), "raz_engine_read_records")
+    RAZ_D2H(headers, d.rec, B * MP * sizeof(raz_ply_header));
+    RAZ_D2H(root_n, d.rec_n, B * MP * 64 * 4);
+    if (root_w) {
+        if (!d.rec_w) return raz_fail(RAZ_ESTATE, "raz_engine_read_records: engine created with record_root_w=0");
+        RAZ_D2H(root_w, d.rec_w, B * MP * 64 * 8);
+    }
+    RAZ_D2H(n_plies, d.n_plies, B * 4);
+    RAZ_D2H(status, d.g_status, B);
+    RAZ_D2H(resigned, d.g_resigned, B * 2);
+    RAZ_D2H(game_id, d.g_game_id, B * 4);
+    RAZ_D2H(enable_resign, d.g_enable_resign, B);
+    RAZ_D2H(final_black, d.root_black, B * 8);
+    RAZ_D2H(final_white, d.root_white, B * 8);
+#undef RAZ_D2H
+    RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_read_records: sync");
+    return RAZ_OK;
+}
+
+extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) {
+    if (!e) return nullptr;
+    switch (which) {
+        case 0: return e->dev.rec;
+        case 1: return e->dev.rec_n;
+        case 2: return e->dev.rec_w;
+        case 3: return e->dev.n_plies;
+        case 4: return e->dev.g_status;
+        default: return nullptr;
+    }
+}

@@ -1,0 +1,276 @@
+// raz_net.hip — forward pass of the policy/value residual CNN (reference: agent/model.py:28-72,
+// evaluated through agent/api.py:30-45) for a batch of leaf positions given as bitboards.
+//
+// Numerics contract "raznet-forward-v1" (DESIGN.md §5): every output is ONE k-ordered fmaf chain
+//   conv3x3: acc = b[oc]; for tap=ky*3+kx: for ic: acc = fmaf(x[ic][nbr(sq,tap)] or 0, w, acc)
+//   block:   relu(conv1) ; relu(conv2 + skip)        heads: 1x1 conv chains over ic, dense chains over j
+//   softmax: max, det_expf(l - max), xor-butterfly sum (1,2,4,8,16,32), divide;  value: det_tanhf
+// which is what v_mfma_f32_* accumulates bit for bit, so this wave-per-position kernel, the MFMA
+// implicit-GEMM kernel for wide nets and the CPU oracle all agree to the last bit.
+//
+// Kernel `k_net_wave`: one wavefront per position, lane = board square.  Activations [F][64] live
+// in LDS (three buffers) when they fit, else in a caller-provided HBM scratch; 16 output channels
+// are accumulated at a time in registers; the 3x3 taps read the neighbouring lanes' activations
+// from LDS with an off-board predicate; weights are wave-uniform and pre-arranged as
+// [layer][oc/16][tap][ic][16] so one scalar s_load_dwordx16 feeds 16 fmafs.  Layer 0 reads its
+// input planes straight out of the two bitboards.  This is the right shape for narrow nets
+// (mini.yml: F=16, R=1) where a GEMM tile would be mostly padding; wide nets (F=256) go to the
+// MFMA kernel.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "raz_bitboard.h"
+#include "raz_detmath.h"
+#include "raz_internal.h"
+
+namespace {
+
+constexpr int32_t kMagic = 0x4E5A4152;
+
+struct NetDims {
+    int F, R, V;
+};
+
+// ---- device weight layout (floats) ----
+// conv layer l (0..2R): w at conv_off(l): [F/16][9][Cin][16], then bias [F]
+__host__ __device__ inline size_t conv_floats(int F, int cin) { return (size_t)F * 9 * cin + F; }
+__host__ __device__ inline size_t conv_off(int F, int l) {
+    return l == 0 ? 0 : conv_floats(F, 2) + (size_t)(l - 1) * conv_floats(F, F);
+}
+__host__ __device__ inline size_t heads_off(int F, int R) { return conv_off(F, 2 * R + 1); }
+// heads: pol_w [2][F], pol_b[2], pol_fc_w [128][64], pol_fc_b[64], val_w [F], val_b[1],
+//        val_fc1_w [64][V], val_fc1_b [V], val_fc2_w [V], val_fc2_b [1]
+__host__ __device__ inline size_t total_floats(int F, int R, int V) {
+    return heads_off(F, R) + (2 * (size_t)F + 2) + (128 * 64 + 64) + ((size_t)F + 1) + (64 * (size_t)V + V) + ((size_t)V + 1);
+}
+
+template <bool LDS_ACT>
+__global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, NetDims d,
+                                                 const raz_bb* __restrict__ own,
+                                                 const raz_bb* __restrict__ enemy,
+                                                 const uint8_t* __restrict__ active,
+                                                 float* __restrict__ policy, float* __restrict__ value,
+                                                 float* __restrict__ scratch, int n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pos = blockIdx.x;
+    if (pos >= n) return;
+    if (active && !active[pos]) return;
+    const int lane = threadIdx.x;
+    const int F = d.F, R = d.R, V = d.V;
+    float* buf0;
+    float* buf1;
+    float* buf2;
+    float* head;  // ph[128] vh[64] h1[V]
+    if (LDS_ACT) {
+        buf0 = smem;
+        buf1 = smem + F * 64;
+        buf2 = smem + 2 * F * 64;
+        head = smem + 3 * F * 64;
+    } else {
+        float* base = scratch + (size_t)pos * 3 * F * 64;
+        buf0 = base;
+        buf1 = base + F * 64;
+        buf2 = base + 2 * F * 64;
+        head = smem;
+    }
+    const raz_bb bo = own[pos], be = enemy[pos];
+    // neighbour index and validity for the 9 taps
+    const int y = lane >> 3, x = lane & 7;
+    int nbr[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        ok[t] = (yy >= 0) && (yy < 8) && (xx >= 0) && (xx < 8);
+        nbr[t] = ok[t] ? yy * 8 + xx : lane;
+    }
+    const int nlayers = 2 * R + 1;
+    float* bufs[3] = {buf0, buf1, buf2};
+    int ia = 0;  // which buffer holds the block input `a` (the stem writes bufs[0])
+    for (int l = 0; l < nlayers; ++l) {
+        const int cin = l == 0 ? 2 : F;
+        const float* w = W + conv_off(F, l);
+        const float* bias = w + (size_t)F * 9 * cin;
+        // stem: planes -> a.  Block: conv1 a -> t, conv2 t (+ skip a) -> u, then a := u.
+        const bool second = (l > 0) && ((l & 1) == 0);
+        const float* in = l == 0 ? nullptr : (second ? bufs[(ia + 1) % 3] : bufs[ia]);
+        const float* skip = second ? bufs[ia] : nullptr;
+        float* out = l == 0 ? bufs[0] : (second ? bufs[(ia + 2) % 3] : bufs[(ia + 1) % 3]);
+        for (int ocb = 0; ocb < F / 16; ++ocb) {
+            float acc[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = bias[ocb * 16 + o];
+            const float* wb = w + (size_t)ocb * 9 * cin * 16;
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                const float* wt = wb + (size_t)t * cin * 16;
+                if (l == 0) {
+                    const float x0 = ok[t] ? (float)((bo >> nbr[t]) & 1) : 0.0f;
+                    const float x1 = ok[t] ? (float)((be >> nbr[t]) & 1) : 0.0f;
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(x0, wt[o], acc[o]);
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(x1, wt[16 + o], acc[o]);
+                } else {
+#pragma unroll 4
+                    for (int ic = 0; ic < cin; ++ic) {
+                        const float xv = ok[t] ? in[ic * 64 + nbr[t]] : 0.0f;
+                        const float* w16 = wt + ic * 16;
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) acc[o] = fmaf(xv, w16[o], acc[o]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                float v = acc[o];
+                if (second) v = v + skip[(ocb * 16 + o) * 64 + lane];
+                out[(ocb * 16 + o) * 64 + lane] = v > 0.0f ? v : 0.0f;
+            }
+        }
+        if (!LDS_ACT) __threadfence_block();
+        __syncthreads();  // single-wave block: orders this layer's writes before neighbour reads
+        if (second) ia = (ia + 2) % 3;
+    }
+    const float* a = bufs[ia];  // trunk output [F][64]
+    const float* H = W + heads_off(F, R);
+    const float* pol_w = H;
+    const float* pol_b = pol_w + 2 * F;
+    const float* pfc_w = pol_b + 2;
+    const float* pfc_b = pfc_w + 128 * 64;
+    const float* val_w = pfc_b + 64;
+    const float* val_b = val_w + F;
+    const float* v1_w = val_b + 1;
+    const float* v1_b = v1_w + 64 * V;
+    const float* v2_w = v1_b + V;
+    const float* v2_b = v2_w + V;
+    float* ph = head;
+    float* vh = head + 128;
+    float* h1 = head + 192;
+    {
+        float p0 = pol_b[0], p1 = pol_b[1], v0 = val_b[0];
+        for (int ic = 0; ic < F; ++ic) {
+            const float xv = a[ic * 64 + lane];
+            p0 = fmaf(xv, pol_w[ic], p0);
+            p1 = fmaf(xv, pol_w[F + ic], p1);
+            v0 = fmaf(xv, val_w[ic], v0);
+        }
+        ph[lane] = p0 > 0.0f ? p0 : 0.0f;
+        ph[64 + lane] = p1 > 0.0f ? p1 : 0.0f;
+        vh[lane] = v0 > 0.0f ? v0 : 0.0f;
+    }
+    __syncthreads();
+    // policy dense 128 -> 64, lane = output square
+    float logit = pfc_b[lane];
+#pragma unroll 8
+    for (int j = 0; j < 128; ++j) logit = fmaf(ph[j], pfc_w[j * 64 + lane], logit);
+    float m = logit;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
+    const float e = raz_det_expf(logit - m);
+    float sum = e;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) sum = sum + __shfl_xor(sum, s);
+    policy[(size_t)pos * 64 + lane] = e / sum;
+    // value dense 64 -> V (relu), lane = hidden unit (loop if V > 64)
+    for (int o0 = 0; o0 < V; o0 += 64) {
+        const int o = o0 + lane;
+        if (o < V) {
+            float acc = v1_b[o];
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) acc = fmaf(vh[j], v1_w[j * V + o], acc);
+            h1[o] = acc > 0.0f ? acc : 0.0f;
+        }
+    }
+    __syncthreads();
+    float acc = v2_b[0];
+    for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
+    if (lane == 0) value[pos] = raz_det_tanhf(acc);
+}
+
+}  // namespace
+
+extern "C" size_t raz_net_weight_bytes(int filters, int res_layers, int value_fc) {
+    if (filters <= 0 || filters % 16 || res_layers < 0 || value_fc <= 0) return 0;
+    return total_floats(filters, res_layers, value_fc) * sizeof(float);
+}
+
+static size_t lds_bytes_for(int F, int V, bool lds_act) {
+    return ((lds_act ? (size_t)3 * F * 64 : 0) + 192 + (size_t)V) * sizeof(float);
+}
+static bool use_lds(int F, int V) { return lds_bytes_for(F, V, true) <= 64 * 1024; }
+
+extern "C" size_t raz_net_scratch_bytes(int filters, int value_fc, size_t n) {
+    if (use_lds(filters, value_fc)) return 0;
+    return n * 3 * (size_t)filters * 64 * sizeof(float);
+}
+
+// Re-arrange the canonical blob (agent/model.py to_blob; see include/raz.h) into the device layout
+// and copy it to caller-owned device memory.
+extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, void* d_weights,
+                            size_t d_bytes, raz_stream_t stream) {
+    if (!net || !blob || !d_weights) return raz_fail(RAZ_EINVAL, "raz_net_load: NULL argument");
+    if (blob_bytes < 32) return raz_fail(RAZ_EINVAL, "raz_net_load: blob too small");
+    int32_t h[8];
+    memcpy(h, blob, 32);
+    if (h[0] != kMagic || h[1] != 1 || h[5] != 3)
+        return raz_fail(RAZ_EINVAL, "raz_net_load: not a raznet v1 blob (3x3 filters)");
+    const int F = h[2], R = h[3], V = h[4];
+    if (F <= 0 || F % 16 || R < 0 || V <= 0)
+        return raz_fail(RAZ_EINVAL, "raz_net_load: filters must be a positive multiple of 16");
+    const size_t nsrc = ((size_t)F * 18 + F) + (size_t)R * 2 * ((size_t)F * F * 9 + F) + (2 * (size_t)F + 2) +
+                        (128 * 64 + 64) + ((size_t)F + 1) + (64 * (size_t)V + V) + ((size_t)V + 1);
+    if (blob_bytes != 32 + 4 * nsrc) return raz_fail(RAZ_EINVAL, "raz_net_load: blob size mismatch");
+    const size_t need = total_floats(F, R, V) * sizeof(float);
+    if (d_bytes < need) return raz_fail(RAZ_ENOMEM, "raz_net_load: device weight buffer too small");
+    const float* src = (const float*)((const char*)blob + 32);
+    std::vector<float> dst(total_floats(F, R, V));
+    for (int l = 0; l < 2 * R + 1; ++l) {
+        const int cin = l == 0 ? 2 : F;
+        float* w = dst.data() + conv_off(F, l);
+        for (int oc = 0; oc < F; ++oc)
+            for (int ic = 0; ic < cin; ++ic)
+                for (int t = 0; t < 9; ++t)
+                    w[(((size_t)(oc / 16) * 9 + t) * cin + ic) * 16 + (oc % 16)] = src[((size_t)oc * cin + ic) * 9 + t];
+        memcpy(w + (size_t)F * 9 * cin, src + (size_t)F * cin * 9, F * sizeof(float));
+        src += (size_t)F * cin * 9 + F;
+    }
+    const size_t nheads = total_floats(F, R, V) - heads_off(F, R);
+    memcpy(dst.data() + heads_off(F, R), src, nheads * sizeof(float));
+    RAZ_HIP_TRY(hipMemcpyAsync(d_weights, dst.data(), need, hipMemcpyHostToDevice, (hipStream_t)stream),
+                "raz_net_load: hipMemcpyAsync");
+    RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_load: sync");  // dst is a local
+    net->filters = F;
+    net->res_layers = R;
+    net->value_fc = V;
+    net->reserved = 0;
+    net->d_weights = d_weights;
+    net->weight_bytes = need;
+    return RAZ_OK;
+}
+
+extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* enemy,
+                               const uint8_t* active, float* policy, float* value, size_t n,
+                               void* scratch, size_t scratch_bytes, raz_stream_t stream) {
+    if (n == 0) return RAZ_OK;
+    if (!net || !net->d_weights || !own || !enemy || !policy || !value)
+        return raz_fail(RAZ_EINVAL, "raz_net_forward: NULL argument");
+    const int F = net->filters, V = net->value_fc;
+    NetDims d = {F, net->res_layers, V};
+    const bool lds = use_lds(F, V);
+    if (!lds) {
+        if (!scratch || scratch_bytes < raz_net_scratch_bytes(F, V, n))
+            return raz_fail(RAZ_ENOMEM, "raz_net_forward: scratch too small (raz_net_scratch_bytes)");
+    }
+    const size_t shm = lds_bytes_for(F, V, lds);
+    if (lds)
+        hipLaunchKernelGGL(k_net_wave<true>, dim3((unsigned)n), dim3(64), shm, (hipStream_t)stream,
+                           (const float*)net->d_weights, d, (const raz_bb*)own, (const raz_bb*)enemy, active,
+                           policy, value, (float*)scratch, (int)n);
+    else
+        hipLaunchKernelGGL(k_net_wave<false>, dim3((unsigned)n), dim3(64), shm, (hipStream_t)stream,
+                           (const float*)net->d_weights, d, (const raz_bb*)own, (const raz_bb*)enemy, active,
+                           policy, value, (float*)scratch, (int)n);
+    return raz_check_launch("raz_net_forward");
+}

@@ -1,0 +1,218 @@
+"""Host-side driver objects over the C ABI (include/raz.h): DeviceNet (raz_net_*) and
+SelfPlayEngine (raz_engine_*).  torch is used only to own HBM buffers and the HIP stream.
+
+SelfPlayEngine replaces, for a batch of concurrent games, the reference's
+SelfPlayWorker.start_game loop (worker/self_play.py:139-175) with two ReversiPlayers per game
+(agent/player.py); `records()` returns, per game, exactly the per-ply facts the reference worker
+keeps (ReversiPlayer.moves rows are derived from them in worker/self_play.py of this package).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+from ._native import lib, check
+
+PLY_HEADER = np.dtype([("own", "<u8"), ("enemy", "<u8"), ("n", "<f8"), ("q", "<f8"), ("action", "i1"),
+                       ("player", "u1"), ("turn", "u1"), ("has_row", "u1"), ("sims", "<u4"),
+                       ("loops", "<u4"), ("pad", "<u4")])
+assert PLY_HEADER.itemsize == 48
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class DeviceNet:
+    """The policy/value net resident in HBM (agent/api.py ReversiModelAPI role, device side)."""
+
+    def __init__(self, blob: bytes, device="cuda:0"):
+        import torch
+        import struct
+        magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
+        nbytes = lib.raz_net_weight_bytes(F, R, V)
+        if nbytes == 0:
+            raise ValueError(f"unsupported net shape F={F} R={R} V={V}")
+        self.device = torch.device(device)
+        self.filters, self.res_layers, self.value_fc = F, R, V
+        self._weights = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.c = N.RazNet()
+        with torch.cuda.device(self.device):
+            check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
+                                   _stream()), "raz_net_load")
+        self._scratch = None
+
+    def scratch(self, n):
+        import torch
+        need = lib.raz_net_scratch_bytes(self.filters, self.value_fc, n)
+        if need and (self._scratch is None or self._scratch.numel() < need):
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return (self._scratch.data_ptr(), self._scratch.numel()) if need else (None, 0)
+
+    def predict_bitboards(self, own, enemy):
+        """own/enemy: int64 device tensors (side to move's view).  -> (policy (n,64), value (n,))"""
+        import torch
+        n = own.numel()
+        policy = torch.empty((n, 64), dtype=torch.float32, device=self.device)
+        value = torch.empty((n,), dtype=torch.float32, device=self.device)
+        sp, sb = self.scratch(n)
+        with torch.cuda.device(self.device):
+            check(lib.raz_net_forward(ctypes.byref(self.c), own.data_ptr(), enemy.data_ptr(), None,
+                                      policy.data_ptr(), value.data_ptr(), n, sp, sb, _stream()), "raz_net_forward")
+        return policy, value
+
+
+def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
+                       record_root_w=False):
+    """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names)."""
+    p = config.play
+    if getattr(p, "parallel_search_num", 1) != 1:
+        raise ValueError("the engine implements the reference's reproducible mode parallel_search_num=1")
+    if (getattr(p, "use_solver_turn", 0) or 0) or (getattr(p, "use_solver_turn_in_simulation", 0) or 0):
+        raise ValueError("end-game solver (use_solver_turn) is not built yet: set it to 0 (SURVEY §8(f) rank 1)")
+    share = bool(p.share_mtcs_info_in_self_play)
+    mirror = share if mirror_updates is None else bool(mirror_updates)
+    slots = 16
+    while slots < 2 * nodes_per_game:
+        slots *= 2
+    c = N.RazEngineConfig(
+        thinking_loop=p.thinking_loop, required_visit_to_decide_action=p.required_visit_to_decide_action,
+        start_rethinking_turn=p.start_rethinking_turn, change_tau_turn=p.change_tau_turn,
+        virtual_loss=p.virtual_loss, allowed_resign_turn=p.allowed_resign_turn,
+        has_resign_threshold=int(p.resign_threshold is not None), share_mtcs_info=int(share),
+        mirror_updates=int(mirror), record_root_w=int(record_root_w), c_puct=float(p.c_puct),
+        noise_eps=float(p.noise_eps), dirichlet_alpha=float(p.dirichlet_alpha),
+        resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
+        disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
+        nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed, reserved=0)
+    return c
+
+
+class SelfPlayEngine:
+    def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
+                 max_plies=72, mirror_updates=None, record_root_w=False):
+        import torch
+        self.net = net
+        self.device = net.device
+        self.n_games = n_games
+        if nodes_per_game is None:
+            s = sims_hint or config.play.simulation_num_per_move
+            loops = max(1, config.play.thinking_loop)
+            share = bool(config.play.share_mtcs_info_in_self_play)
+            mirror = share if mirror_updates is None else bool(mirror_updates)
+            # every simulation adds at most one node (two with mirror keys); ~62 searched plies
+            nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
+        self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
+                                      record_root_w)
+        nbytes = lib.raz_engine_workspace_bytes(ctypes.byref(self.cfg))
+        if nbytes == 0:
+            raise ValueError("invalid engine config: " + N.last_error())
+        self.workspace_bytes = nbytes
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self._ws.data_ptr() + 255) // 256 * 256
+        sp, sb = net.scratch(n_games)
+        self._h = ctypes.c_void_p()
+        check(lib.raz_engine_create(ctypes.byref(self.cfg), ctypes.byref(net.c), base, nbytes, sp, sb,
+                                    ctypes.byref(self._h)), "raz_engine_create")
+        self.record_root_w = record_root_w
+        self.max_plies = max_plies
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.raz_engine_destroy(h)
+            self._h = None
+
+    def start(self, first_game_id, sims_per_move, n_active=None):
+        import torch
+        sims = np.full(self.n_games, sims_per_move, dtype=np.uint32) if np.isscalar(sims_per_move) \
+            else np.ascontiguousarray(sims_per_move, dtype=np.uint32)
+        assert sims.size == self.n_games
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_start(self._h, first_game_id, sims.ctypes.data,
+                                       self.n_games if n_active is None else n_active, _stream()), "raz_engine_start")
+        self.n_active = self.n_games if n_active is None else n_active
+
+    def step(self, n=1):
+        import torch
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_step(self._h, n, _stream()), "raz_engine_step")
+
+    def stats(self):
+        import torch
+        st = N.RazEngineStats()
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_stats_sync(self._h, ctypes.byref(st), _stream()), "raz_engine_stats_sync")
+        if st.error_flags:
+            raise RuntimeError(f"engine error flags {st.error_flags:#x} (1 node pool full, 2 table full, "
+                               f"4 records full, 8 path overflow): enlarge nodes_per_game/max_plies")
+        return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves}
+
+    def run(self, chunk=64, max_steps=10_000_000):
+        """Step until every active game has finished.  Returns the final stats."""
+        steps = 0
+        while True:
+            self.step(chunk)
+            steps += chunk
+            st = self.stats()
+            if st["finished_games"] >= self.n_active:
+                st["steps"] = steps
+                return st
+            if steps >= max_steps:
+                raise RuntimeError("engine did not finish within max_steps")
+
+    def read_raw(self):
+        import torch
+        B, MP = self.n_games, self.max_plies
+        hdr = np.zeros((B, MP), dtype=PLY_HEADER)
+        root_n = np.zeros((B, MP, 64), dtype=np.uint32)
+        root_w = np.zeros((B, MP, 64), dtype=np.float64) if self.record_root_w else None
+        n_plies = np.zeros(B, dtype=np.uint32)
+        status = np.zeros(B, dtype=np.uint8)
+        resigned = np.zeros((B, 2), dtype=np.uint8)
+        game_id = np.zeros(B, dtype=np.uint32)
+        enable_resign = np.zeros(B, dtype=np.uint8)
+        fb = np.zeros(B, dtype=np.uint64)
+        fw = np.zeros(B, dtype=np.uint64)
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_read_records(
+                self._h, hdr.ctypes.data, root_n.ctypes.data, root_w.ctypes.data if root_w is not None else None,
+                n_plies.ctypes.data, status.ctypes.data, resigned.ctypes.data, game_id.ctypes.data,
+                enable_resign.ctypes.data, fb.ctypes.data, fw.ctypes.data, _stream()), "raz_engine_read_records")
+        return dict(headers=hdr, root_n=root_n, root_w=root_w, n_plies=n_plies, status=status, resigned=resigned,
+                    game_id=game_id, enable_resign=enable_resign, final_black=fb, final_white=fw)
+
+    def records(self, save_policy_of_tau_1=True, change_tau_turn=None):
+        """Per game: (plies, summary) in the same shape oracle.selfplay_game returns."""
+        raw = self.read_raw()
+        ctt = self.cfg.change_tau_turn if change_tau_turn is None else change_tau_turn
+        out = []
+        for g in range(self.n_active):
+            plies = []
+            for i in range(int(raw["n_plies"][g])):
+                h = raw["headers"][g, i]
+                n = raw["root_n"][g, i].astype(np.float64)
+                plies.append({"player": int(h["player"]), "turn": int(h["turn"]), "own": int(h["own"]),
+                              "enemy": int(h["enemy"]), "action": int(h["action"]), "has_row": bool(h["has_row"]),
+                              "sims": int(h["sims"]), "loops": int(h["loops"]), "n": float(h["n"]), "q": float(h["q"]),
+                              "root_n": [float(v) for v in n],
+                              "root_w": [float(v) for v in raw["root_w"][g, i]] if raw["root_w"] is not None else None,
+                              "saved_policy": saved_policy(n, int(h["turn"]), ctt, save_policy_of_tau_1)})
+            st = int(raw["status"][g])
+            out.append((plies, {"winner": st & 0x0f, "status": st, "plies": len(plies),
+                                "game_id": int(raw["game_id"][g]), "enable_resign": int(raw["enable_resign"][g]),
+                                "resigned_black": int(raw["resigned"][g, 0]), "resigned_white": int(raw["resigned"][g, 1]),
+                                "black": int(raw["final_black"][g]), "white": int(raw["final_white"][g])}))
+        return out
+
+
+def saved_policy(root_n, turn, change_tau_turn, save_policy_of_tau_1):
+    """The policy stored with a training row (agent/player.py:132, 366-385), from the root visit
+    counts, with the reference's own numpy expressions."""
+    n = np.asarray(root_n, dtype=np.float64)
+    if save_policy_of_tau_1 or turn < change_tau_turn:
+        return list(n / np.sum(n))
+    ret = np.zeros(64)
+    ret[int(np.argmax(n))] = 1
+    return list(ret)
