@@ -1,147 +1,87 @@
 #!/usr/bin/env python
-"""bench.py — measures the self-play hot path on MI355X.  One JSON line on stdout (rank 0).
+"""bench.py — MCTS self-play throughput of the batched engine on MI355X.  ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sweep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--games B] [--sims S] [--net mini|ch5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload `sweep` (bitboard sweep leg of BASELINE.json's north star): one step = one
-`raz_step_batch` pass (ReversiEnv.step: flip + place + pass/terminal + next legal mask) over
-2^24 positions harvested from random self-play at uniformly random ply (SURVEY §8(d) "value
-distributions"), inputs resident in HBM, each step on its own copy of the batch (755 MB, larger
-than the 256 MiB Infinity Cache, so no step re-reads cached lines).
+Workload (BASELINE.json configs[1], SURVEY.md §8(d) "Config 2"): B = 4096 concurrent games per GPU
+from the initial position, mini.yml net (F=16, R=1, V=16; random-init, Keras initialisers, seed 0),
+S = 200 simulations per move, play settings of config/mini.yml (c_puct 5, change_tau_turn 10,
+Dirichlet root noise eps .25 / alpha .5, shared black/white tree, resign threshold -0.9 from turn
+10) with the declared overrides thinking_loop = 1 and end-game solver off (use_solver_turn = 0).
 
-Multi-GPU: positions shard across ranks with no data-path collective (weak scaling); the timed
-region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+A "step" is one pass of the hot path over the batch: the tree kernel (backup + per-move controller
++ PUCT descent for every live game) followed by ONE net evaluation of all gathered leaves.
+Without --steps the timed region runs the whole batch of games to completion and K is the number
+of steps that took; with --steps K exactly K steps are timed (from the opening position after W
+warm-up steps on a throw-away start).  metric = MCTS simulations/sec (start_search_my_move
+invocations / wall time, NN included, inputs resident in HBM), whole job over all GPUs.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s measured float4 copy)
-STEP_BYTES_PER_BOARD = 45  # include/raz.h raz_step_batch: 19 B read + 26 B written
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+TREE_BYTES_PER_SELECTION = 142   # per selection 126 B read + 16 B backup RMW
+TREE_BYTES_PER_SIM = 556         # expansion 280 B + leaf I/O 276 B
+
+NETS = {"mini": (16, 1, 16), "ch5": (256, 10, 256)}
 
 
-def harvest_positions(n, seed, dev):
-    """Random playouts on device; game g is frozen at a uniformly random ply in [0, 58]."""
-    import torch
-    from reversi_alpha_zero_amd.lib import bitboard as bb
-    black = torch.full((n,), 0x0000000810000000, dtype=torch.int64, device=dev)
-    white = torch.full((n,), 0x0000001008000000, dtype=torch.int64, device=dev)
-    player = torch.ones(n, dtype=torch.uint8, device=dev)
-    status = torch.zeros(n, dtype=torch.uint8, device=dev)
-    legal = bb.legal_moves_batch(black, white)
-    g = torch.Generator(device=dev).manual_seed(seed)
-    target = torch.randint(0, 59, (n,), generator=g, device=dev, dtype=torch.int32)
-    snap = [black.clone(), white.clone(), player.clone(), legal.clone()]
-    for ply in range(59):
-        take = (target == ply) & (status == 0)
-        for s, cur in zip(snap, (black, white, player, legal)):
-            s.copy_(torch.where(take, cur, s))
-        rnd = torch.randint(0, 2**31 - 1, (n,), generator=g, device=dev, dtype=torch.int32)
-        action = bb.pick_kth_legal_batch(legal, rnd)
-        bb.step_batch(black, white, player, status, legal, action)
-    rnd = torch.randint(0, 2**31 - 1, (n,), generator=g, device=dev, dtype=torch.int32)
-    action = bb.pick_kth_legal_batch(snap[3], rnd)
-    return snap[0], snap[1], snap[2], action
+def bench_config(args):
+    """Play settings: config/mini.yml:10-26 over the defaults of config.py:128-166, with the two
+    declared overrides (thinking_loop=1, solver off)."""
+    play = types.SimpleNamespace(
+        simulation_num_per_move=args.sims, share_mtcs_info_in_self_play=bool(args.share),
+        thinking_loop=1, required_visit_to_decide_action=40, start_rethinking_turn=10, c_puct=5,
+        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3, parallel_search_num=1,
+        resign_threshold=-0.9, allowed_resign_turn=10, disable_resignation_rate=0.1,
+        use_solver_turn=0, use_solver_turn_in_simulation=0)
+    return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
 
 
-def cpu_baseline_sweep(black, white, player, action, budget_s=10.0):
-    """Oracle (C port of env/reversi_env.py step) on one host core over a bounded sample."""
-    import numpy as np
-    import oracle
-    lib = oracle.load()
-    m = min(black.numel(), 1 << 21)
-    b = black[:m].cpu().numpy().view(np.uint64).copy()
-    w = white[:m].cpu().numpy().view(np.uint64).copy()
-    p = player[:m].cpu().numpy().copy()
-    a = action[:m].cpu().numpy().copy()
-    done_boards, acc, t0 = 0, 0.0, time.perf_counter()
-    while True:
-        bb_, ww, pp = b.copy(), w.copy(), p.copy()
-        st = np.zeros(m, dtype=np.uint8)
-        lg = np.zeros(m, dtype=np.uint64)
-        t1 = time.perf_counter()
-        lib.orc_step_n(bb_.ctypes.data, ww.ctypes.data, pp.ctypes.data, st.ctypes.data, lg.ctypes.data,
-                       a.ctypes.data, m)
-        dt = time.perf_counter() - t1
-        done_boards += m
-        acc += dt
-        if time.perf_counter() - t0 > budget_s:
-            break
-    return {"value": done_boards / acc, "unit": "boards/s", "cores": 1, "kind": "port",
-            "sample": f"{done_boards} env.step calls on harvested self-play positions (oracle/orc_bitboard.c, 1 thread)"}
-
-
-def run_sweep(args, rank, world, dev):
-    import torch
-    import torch.distributed as dist
-    from reversi_alpha_zero_amd.lib import bitboard as bb
-    n = args.boards
-    black, white, player, action = harvest_positions(n, 12345 + rank, dev)
-    copies = args.steps + args.warmup
-    sets = []
-    for _ in range(copies):
-        sets.append((black.clone(), white.clone(), player.clone(), torch.zeros(n, dtype=torch.uint8, device=dev),
-                     torch.empty(n, dtype=torch.int64, device=dev)))
-    torch.cuda.synchronize()
-    for i in range(args.warmup):
-        b, w, p, s, l = sets[i]
-        bb.step_batch(b, w, p, s, l, action)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+def cpu_baseline(cfg, blob, sims, budget_games):
+    """The oracle (C port of agent/player.py + env + bitboard + the same net), one game per thread on
+    the host cores (ctypes releases the GIL), same settings.  Reported, not optimised."""
+    import concurrent.futures as cf
+    import oracle as O
+    ocfg = O.play_cfg_from_config(cfg)
+    cores = min(os.cpu_count() or 1, budget_games)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        b, w, p, s, l = sets[args.warmup + i]
-        evs[i][0].record()
-        bb.step_batch(b, w, p, s, l, action)
-        evs[i][1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
-    total_boards = n * world * args.steps
-    out = {
-        "metric": "bitboard sweep: ReversiEnv.step positions/sec (sub-metric of MCTS sims/sec/GPU)",
-        "value": total_boards / elapsed, "unit": "boards/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"raz_step_batch over {n} positions/GPU harvested from random self-play "
-                               f"at uniform random ply (SURVEY §8(d))", "boards_per_gpu": n},
-        "roofline": {"bound": "hbm", "achieved": STEP_BYTES_PER_BOARD * n / (kern_ms * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                     "kernel": "k_step", "avg_kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": STEP_BYTES_PER_BOARD * n},
-    }
-    out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_sweep(black, white, player, action, args.cpu_budget)
-    return out
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        res = list(ex.map(lambda gid: O.selfplay_game(ocfg, blob, 0, gid, sims)[1], range(cores)))
+    dt = time.perf_counter() - t0
+    total = sum(r["n_sims"] for r in res)
+    return {"value": total / dt, "unit": "sims/s", "cores": cores, "kind": "port",
+            "games_per_hour": cores / dt * 3600.0,
+            "sample": f"{cores} complete self-play games, one per host thread, {sims} sims/move, same net and "
+                      f"play settings (oracle/orc_mcts.c: C port of the reference player; {total} sims in {dt:.1f} s)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sweep", choices=["sweep"])
-    ap.add_argument("--boards", type=int, default=1 << 24)
+    ap.add_argument("--steps", type=int, default=0, help="0 = run the batch of games to completion")
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=200)
+    ap.add_argument("--net", default="mini", choices=sorted(NETS))
+    ap.add_argument("--share", type=int, default=1, help="share_mtcs_info_in_self_play (mini.yml: True)")
+    ap.add_argument("--chunk", type=int, default=200, help="steps enqueued between completion polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=10.0)
+    ap.add_argument("--cpu-games", type=int, default=64)
     args = ap.parse_args()
 
     import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,16 +90,121 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import __graft_entry__ as g
     g.build()
-    out = run_sweep(args, rank, world, dev)
+    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+
+    F, R, V = NETS[args.net]
+    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
+    cfg = bench_config(args)
+    net = DeviceNet(blob, dev)
+    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims)
+    first_id = rank * args.games
+
+    # warm-up on a throw-away start (clocks, caches, code objects), then restart the same games
+    eng.start(first_id, args.sims)
+    eng.step(max(args.warmup, 1))
+    eng.stats()
+    eng.start(first_id, args.sims)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    steps, tree_ms, net_ms, timed_steps = 0, 0.0, 0.0, 0
+    if args.steps > 0:
+        left = args.steps
+        while left > 0:
+            n = min(args.chunk, left)
+            if (steps // args.chunk) % 8 == 0:   # sample kernel durations with HIP events 1 chunk in 8
+                a, b = eng.step_timed(n)
+                tree_ms, net_ms, timed_steps = tree_ms + a, net_ms + b, timed_steps + n
+            else:
+                eng.step(n)
+            steps, left = steps + n, left - n
+        st = eng.stats()
+    else:
+        while True:
+            if (steps // args.chunk) % 8 == 0:
+                a, b = eng.step_timed(args.chunk)
+                tree_ms, net_ms, timed_steps = tree_ms + a, net_ms + b, timed_steps + args.chunk
+            else:
+                eng.step(args.chunk)
+            steps += args.chunk
+            st = eng.stats()
+            if st["finished_games"] >= args.games:
+                break
+            if steps > 80 * args.sims * 4:
+                raise SystemExit("engine did not finish")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(st["total_sims"]), float(st["finished_games"]), float(st["nn_leaves"]),
+                        float(st["selections"]), elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        elapsed = float(mx[4].item())
+    total_sims, finished, leaves, selections = (float(tot[i].item()) for i in range(4))
+
+    # the single collective of the path: finished-game records -> rank 0 (timed separately)
+    t1 = time.perf_counter()
+    raw = eng.read_raw()
+    gather_bytes = 0
+    if world > 1:
+        for k in ("headers", "root_n", "n_plies", "status", "resigned", "game_id", "final_black", "final_white"):
+            t = torch.from_numpy(raw[k].view("u1").reshape(-1)).to(dev)
+            lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, lst, dst=0)
+            gather_bytes += t.numel() * world
+        torch.cuda.synchronize()
+    gather_s = time.perf_counter() - t1
+
     if rank == 0:
+        macs = macs_per_position(F, R, V)
+        per_launch_tree_bytes = (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / max(steps, 1)
+        tree_avg_ms = tree_ms / max(timed_steps, 1)
+        net_avg_ms = net_ms / max(timed_steps, 1)
+        leaves_per_launch = leaves / world / max(steps, 1)
+        kern = {
+            "k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms, "algorithmic_bytes_per_launch": per_launch_tree_bytes,
+                       "achieved": per_launch_tree_bytes / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "k_net_wave": {"bound": "mfma", "avg_ms": net_avg_ms, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
+                           "achieved": 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12 if net_avg_ms else None,
+                           "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"},
+        }
+        for k in kern.values():
+            k["frac"] = (k["achieved"] / k["peak"]) if k["achieved"] else None
+        dom = "k_tree" if tree_avg_ms >= net_avg_ms else "k_net_wave"
+        roof = dict(kern[dom], kernel=dom, traffic=None)
+        roof.pop("avg_ms")
+        roof["avg_kernel_ms"] = kern[dom]["avg_ms"]
+        out = {
+            "metric": "MCTS simulations/sec (self-play, NN included)", "value": total_sims / elapsed, "unit": "sims/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 tree statistics + f32 net",
+            "data": "synthetic (random-init net of the named architecture, games from the initial position)",
+            "config": {"workload": f"{args.games} concurrent self-play games/GPU, {args.net} net (F{F} R{R} V{V}), "
+                                   f"{args.sims} sims/move, mini.yml play settings, thinking_loop=1, solver off"
+                                   + ("" if args.steps == 0 else f", first {args.steps} steps only"),
+                       "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
+                       "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0},
+            "sims_per_sec_per_gpu": total_sims / elapsed / world,
+            "games_per_hour": finished / elapsed * 3600.0 if args.steps == 0 else None,
+            "finished_games": finished, "total_sims": total_sims, "nn_leaves": leaves,
+            "mean_selections_per_sim": selections / max(total_sims, 1.0),
+            "roofline": roof, "kernels": kern,
+            "record_gather": {"seconds": gather_s, "bytes": gather_bytes, "collective": "gather (RCCL)" if world > 1 else "none (1 GPU): D2H read"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, blob, args.sims, args.cpu_games)
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

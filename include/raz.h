@@ -155,6 +155,7 @@ typedef struct {
     uint64_t total_sims;      /* start_search_my_move invocations executed (SURVEY §8(d) metric) */
     uint64_t nn_leaves;       /* leaf positions sent to the net */
     uint64_t error_flags;     /* 0 = ok; 1 node pool full, 2 table full, 4 records full, 8 path overflow */
+    uint64_t selections;      /* select_action_q_and_u calls (sum of descent depths) */
 } raz_engine_stats;
 
 size_t raz_engine_workspace_bytes(const raz_engine_config* cfg);
@@ -172,6 +173,11 @@ int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims
 /* Enqueue n_steps simulation steps (each: tree kernel = backup + move logic + select, then one
  * net batch over the gathered leaves).  Asynchronous. */
 int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
+/* Same as raz_engine_step, with HIP events recorded on `stream` around every kernel: the summed
+ * durations (ms) of the tree kernel and the net kernel are ADDED to *tree_ms / *net_ms.
+ * Synchronises the stream. */
+int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, double* net_ms,
+                          raz_stream_t stream);
 /* Synchronise the stream and read the counters. */
 int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream);
 /* Copy finished-game records to host memory (synchronous).  headers: n_games*max_plies*48 bytes

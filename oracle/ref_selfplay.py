@@ -164,6 +164,7 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
            "winner": env.winner.value, "turn": env.turn, "black": env.board.black, "white": env.board.white,
            "resigned_black": bool(worker.black.resigned), "resigned_white": bool(worker.white.resigned),
            "nn_positions": api.positions, "play_rows": play_rows,
+           "ggf_moves": list(worker.move_history.moves),
            "mirror_or_total_keys": len(worker.black.var_n)}
     if own_tmp:
         import shutil

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <vector>
 #include "raz_bitboard.h"
 #include "raz_detmath.h"
 #include "raz_engine.h"
@@ -506,6 +507,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         E.depth[g] = (uint8_t)depth;
         E.nn_active[g] = kind == RAZ_LEAF_EXPAND ? 1 : 0;
         if (kind == RAZ_LEAF_EXPAND) atomicAdd(&E.counters[3], 1ULL);
+        atomicAdd(&E.counters[4], (unsigned long long)depth);
     }
     wave_sync();
 }
@@ -620,7 +622,7 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
     d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
-    d.counters = (unsigned long long*)take(4 * 8);
+    d.counters = (unsigned long long*)take(8 * 8);
     if (E) *E = d;
     return off;
 }
@@ -691,7 +693,7 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)d.B * 4, hipMemcpyHostToDevice, s), "raz_engine_start: copy sims");
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
-    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 32, s), "raz_engine_start: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_start: clear counters");
     hipLaunchKernelGGL(k_start, dim3((d.B + 255) / 256), dim3(256), 0, s, d, first_game_id, e->d_sims, n_active);
     int rc = raz_check_launch("raz_engine_start");
     if (rc == RAZ_OK) e->started = true;
@@ -716,14 +718,50 @@ extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t str
 
 extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
     if (!e || !out) return raz_fail(RAZ_EINVAL, "raz_engine_stats_sync: NULL argument");
-    unsigned long long c[4];
-    RAZ_HIP_TRY(hipMemcpyAsync(c, e->dev.counters, 32, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_stats_sync: copy");
+    unsigned long long c[8];
+    RAZ_HIP_TRY(hipMemcpyAsync(c, e->dev.counters, 64, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_stats_sync: copy");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_stats_sync: sync");
     out->finished_games = c[0];
     out->total_sims = c[1];
     out->error_flags = c[2];
     out->nn_leaves = c[3];
+    out->selections = c[4];
     return RAZ_OK;
+}
+
+// raz_engine_step with HIP events around every kernel launch on `stream` (the stream the kernels
+// run on): adds the elapsed milliseconds of the tree kernel and of the net kernel to *tree_ms /
+// *net_ms.  Synchronises the stream.  Used by bench.py for the live roofline numbers.
+extern "C" int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, double* net_ms,
+                                     raz_stream_t stream) {
+    if (!e || !tree_ms || !net_ms) return raz_fail(RAZ_EINVAL, "raz_engine_step_timed: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step_timed: call raz_engine_start first");
+    hipStream_t s = (hipStream_t)stream;
+    const raz_engine_dev& d = e->dev;
+    std::vector<hipEvent_t> ev(3 * (size_t)n_steps);
+    for (auto& x : ev) RAZ_HIP_TRY(hipEventCreate(&x), "raz_engine_step_timed: hipEventCreate");
+    int rc = RAZ_OK;
+    for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
+        hipEventRecord(ev[3 * i], s);
+        hipLaunchKernelGGL(k_tree, dim3(d.B), dim3(64), 0, s, d);
+        hipEventRecord(ev[3 * i + 1], s);
+        rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own, (const uint64_t*)d.nn_enemy, d.nn_active,
+                             d.nn_policy, d.nn_value, d.B, e->net_scratch, e->net_scratch_bytes, stream);
+        hipEventRecord(ev[3 * i + 2], s);
+    }
+    hipError_t err = hipStreamSynchronize(s);
+    if (rc == RAZ_OK && err == hipSuccess) {
+        for (uint32_t i = 0; i < n_steps; ++i) {
+            float a = 0.f, b = 0.f;
+            hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]);
+            hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]);
+            *tree_ms += a;
+            *net_ms += b;
+        }
+    }
+    for (auto& x : ev) hipEventDestroy(x);
+    if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step_timed: sync");
+    return rc;
 }
 
 extern "C" int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* root_n, double* root_w,

@@ -139,6 +139,15 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             check(lib.raz_engine_step(self._h, n, _stream()), "raz_engine_step")
 
+    def step_timed(self, n=1):
+        """step(n) with HIP events around each kernel; returns (tree_ms, net_ms) summed over n."""
+        import torch
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_step_timed(self._h, n, ctypes.byref(a), ctypes.byref(b), _stream()),
+                  "raz_engine_step_timed")
+        return a.value, b.value
+
     def stats(self):
         import torch
         st = N.RazEngineStats()
@@ -147,7 +156,8 @@ class SelfPlayEngine:
         if st.error_flags:
             raise RuntimeError(f"engine error flags {st.error_flags:#x} (1 node pool full, 2 table full, "
                                f"4 records full, 8 path overflow): enlarge nodes_per_game/max_plies")
-        return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves}
+        return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves,
+                "selections": st.selections}
 
     def run(self, chunk=64, max_steps=10_000_000):
         """Step until every active game has finished.  Returns the final stats."""

@@ -1,0 +1,350 @@
+"""The `self` worker on the batched engine — drop-in for reversi_zero/worker/self_play.py.
+
+`start(config)` is the reference's entry point (worker/self_play.py:28).  Instead of
+multi_process_num Python processes each playing one game at a time, ONE process per GPU keeps
+`games_in_flight` games resident on the device (SelfPlayEngine) and emits exactly the files the
+reference worker emits:
+    data/play_data/play_<timestamp>.json   rows [[own, enemy], policy64, z]   (self_play.py:180-194)
+    data/self_play-ggf/self_play-<ts>.ggf  (self_play.py:196-207, MoveHistory :275-299)
+    data/.self-play-game-idx               (self_play.py:136-137);  data/.force-sim honoured (:262-267)
+so the reference's `opt` / `eval` workers consume them unchanged.
+
+Multi-GPU: launched with torch.distributed (one rank per GPU); rank r plays global game ids
+[first + r*B, first + (r+1)*B); results do not depend on the sharding because every random draw is
+keyed by the global game id.  The only collective is a gather of finished-game records to rank 0
+(RCCL over xGMI on GPUs, gloo in the CPU tests), which then writes the files.
+"""
+import os
+from datetime import datetime
+from logging import getLogger
+
+import numpy as np
+
+from ..lib import bitboard as bb
+from ..lib.data_helper import get_game_data_filenames, write_game_data_to_file
+from ..lib.ggf import convert_action_to_move, make_ggf_string
+
+logger = getLogger(__name__)
+
+
+def read_as_int(filename):
+    """lib/file_util.py:4-12."""
+    if os.path.exists(filename):
+        try:
+            with open(filename, "rt") as f:
+                return int(str(f.read()).strip())
+        except ValueError:
+            pass
+    return None
+
+
+def decide_simulation_num_per_move(config, idx):
+    """worker/self_play.py:262-272: data/.force-sim overrides the per-game-index schedule."""
+    ret = read_as_int(config.resource.force_simulation_num_file)
+    if ret:
+        return ret
+    for min_idx, num in config.play.schedule_of_simulation_num_per_move:
+        if idx >= min_idx:
+            ret = num
+    return ret
+
+
+def rows_of_game(plies, winner):
+    """The training rows of one finished game in file order: black.moves + white.moves
+    (worker/self_play.py:183), each searched ply contributing its 8 symmetric rows
+    (agent/player.py:166-179: flip in {F,T} x rot_right in 0..3; boards by flip_vertical/rotate90,
+    policy by np.flipud / np.rot90(k=-rot)), z appended by finish_game (player.py:357-364,
+    self_play.py:219-231: black rows get black_win, white rows -black_win)."""
+    black_win = 1 if winner == 1 else (-1 if winner == 2 else 0)
+    per_player = {1: [], 2: []}
+    for p in plies:
+        if not p["has_row"]:
+            continue
+        policy = np.asarray(p["saved_policy"], dtype=np.float64)
+        z = black_win if p["player"] == 1 else -black_win
+        for flip in (False, True):
+            for rot in range(4):
+                o, e, pol = p["own"], p["enemy"], policy.reshape(8, 8)
+                if flip:
+                    o, e, pol = bb.flip_vertical(o), bb.flip_vertical(e), np.flipud(pol)
+                for _ in range(rot):
+                    o, e = bb.rotate90(o), bb.rotate90(e)
+                if rot:
+                    pol = np.rot90(pol, k=-rot)
+                per_player[p["player"]].append([(o, e), list(pol.reshape(64)), z])
+    return per_player[1] + per_player[2]
+
+
+def ggf_moves_of_game(plies):
+    """MoveHistory.move (worker/self_play.py:279-296): a pass is recorded as "PA" for the side that
+    could not move; resignation adds nothing."""
+    moves = []
+    for p in plies:
+        if p["action"] < 0:
+            continue
+        if (len(moves) % 2 == 0) != (p["player"] == 1):
+            moves.append(convert_action_to_move(None))
+        moves.append(f"{convert_action_to_move(p['action'])}/{p['q'] * 10}/{p['n']}")
+    return moves
+
+
+def drop_draw_uniform(seed, game_id):
+    """GAME-purpose second uniform of raz-rng-v1 (the np.random.random() of self_play.py:182)."""
+    from .._rng import rng_pair
+    return rng_pair(seed, game_id, 3, 0)[1]
+
+
+class BatchedSelfPlayWorker:
+    """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
+
+    def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1):
+        self.config = config
+        self.net_blob = net_blob
+        self.games_in_flight = games_in_flight
+        self.seed = seed
+        self.device = device
+        self.rank, self.world = rank, world
+        self.buffer = []
+        self.move_history_buffer = []
+        self.false_positive_count_of_resign = 0
+        self.resign_test_game_count = 0
+        self._engine = None
+        self._net = None
+        self._engine_key = None
+
+    # -- engine life cycle -------------------------------------------------------------------
+    def _get_engine(self, max_sims):
+        from ..engine import DeviceNet, SelfPlayEngine
+        key = (max_sims, self.config.play.resign_threshold, self.config.play.thinking_loop)
+        if self._net is None:
+            self._net = DeviceNet(self.net_blob, self.device)
+        if self._engine is None or self._engine_key != key:
+            self._engine = None
+            self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
+                                          sims_hint=max_sims)
+            self._engine_key = key
+        return self._engine
+
+    def play_batch(self, first_game_idx, n_games=None):
+        """Play global game ids first_game_idx + rank*B .. on this rank.  Returns [(plies, summary)]."""
+        n = self.games_in_flight if n_games is None else n_games
+        base = first_game_idx + self.rank * self.games_in_flight
+        sims = np.array([decide_simulation_num_per_move(self.config, base + i) for i in range(self.games_in_flight)],
+                        dtype=np.uint32)
+        eng = self._get_engine(int(sims.max()))
+        eng.start(base, sims, n_active=n)
+        stats = eng.run()
+        recs = eng.records(save_policy_of_tau_1=self.config.play_data.save_policy_of_tau_1)
+        self.last_stats = stats
+        return recs
+
+    # -- bookkeeping identical to the reference worker ---------------------------------------------
+    def finish_game(self, summary):
+        """self_play.py:219-260: resign false-positive accounting over the no-resign test games."""
+        w = summary["winner"]
+        if w == 1:
+            fp = bool(summary["resigned_black"])
+        elif w == 2:
+            fp = bool(summary["resigned_white"])
+        else:
+            fp = bool(summary["resigned_black"] or summary["resigned_white"])
+        if not summary["enable_resign"]:
+            self.resign_test_game_count += 1
+            if fp:
+                self.false_positive_count_of_resign += 1
+            self.check_and_update_resignation_threshold()
+
+    def check_and_update_resignation_threshold(self):
+        pc = self.config.play
+        if self.resign_test_game_count < 100 or pc.resign_threshold is None:
+            return
+        rate = self.false_positive_count_of_resign / self.resign_test_game_count
+        if rate >= pc.false_positive_threshold:
+            pc.resign_threshold -= pc.resign_threshold_delta
+        else:
+            pc.resign_threshold += pc.resign_threshold_delta
+        self.false_positive_count_of_resign = 0
+        self.resign_test_game_count = 0
+
+    def save_play_data(self, plies, summary, write=True):
+        """self_play.py:180-194."""
+        rows = rows_of_game(plies, summary["winner"])
+        is_draw = bool(rows) and rows[0][-1] == 0
+        if not is_draw or self.config.play_data.drop_draw_game_rate <= drop_draw_uniform(self.seed, summary["game_id"]):
+            self.buffer += rows
+        if not write or not self.buffer:
+            return None
+        rc = self.config.resource
+        game_id = datetime.now().strftime("%Y%m%d-%H%M%S.%f")
+        path = os.path.join(rc.play_data_dir, rc.play_data_filename_tmpl % game_id)
+        write_game_data_to_file(path, self.buffer)
+        self.buffer = []
+        return path
+
+    def save_ggf_data(self, plies, write=True):
+        """self_play.py:196-207."""
+        self.move_history_buffer.append(ggf_moves_of_game(plies))
+        if not write:
+            return None
+        rc = self.config.resource
+        game_id = datetime.now().strftime("%Y%m%d-%H%M%S.%f")
+        path = os.path.join(rc.self_play_ggf_data_dir, rc.ggf_filename_tmpl % game_id)
+        with open(path, "wt") as f:
+            for moves in self.move_history_buffer:
+                f.write(make_ggf_string("RAZ", "RAZ", moves=moves) + "\n")
+        self.move_history_buffer = []
+        return path
+
+    def remove_play_data(self):
+        """self_play.py:209-217."""
+        files = get_game_data_filenames(self.config.resource)
+        if len(files) < self.config.play_data.max_file_num:
+            return
+        for i in range(len(files) - self.config.play_data.max_file_num):
+            try:
+                os.remove(files[i])
+            except OSError:
+                pass
+
+    def emit(self, records, first_local_idx=1):
+        """Write one batch of finished games the way the reference loop would, game by game."""
+        pd = self.config.play_data
+        paths = []
+        for k, (plies, summary) in enumerate(records):
+            local_idx = first_local_idx + k
+            self.finish_game(summary)
+            p = self.save_play_data(plies, summary, write=local_idx % pd.nb_game_in_file == 0)
+            if p:
+                paths.append(p)
+            self.remove_play_data()
+            if pd.enable_ggf_data:
+                self.save_ggf_data(plies, write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
+        return paths
+
+    def run(self, total_games=None):
+        """_start (self_play.py:95-137): play batches until total_games (None = forever)."""
+        import torch.distributed as dist
+        rc = self.config.resource
+        if self.rank == 0:
+            rc.create_directories()
+        game_idx = read_as_int(rc.self_play_game_idx_file) or 0
+        local_idx = 1
+        while total_games is None or local_idx <= total_games:
+            recs = self.play_batch(game_idx)
+            allrecs = gather_records(recs, self.rank, self.world) if self.world > 1 else recs
+            if self.rank == 0:
+                self.emit(allrecs, local_idx)
+                game_idx += len(allrecs)
+                with open(rc.self_play_game_idx_file, "wt") as f:
+                    f.write(str(game_idx))
+            if self.world > 1:
+                t = [game_idx]
+                dist.broadcast_object_list(t, src=0)
+                game_idx = t[0]
+            local_idx += self.games_in_flight * self.world
+
+
+# ---- the single collective: finished-game records -> rank 0 ------------------------------------------
+def pack_records(records):
+    """Fixed-layout numpy packing of [(plies, summary)] for the gather: per game a 64-byte summary and
+    per ply 48 B header + 64 x u32 visit counts + 64 x f64 saved policy."""
+    n = len(records)
+    maxp = max((len(p) for p, _ in records), default=0)
+    summ = np.zeros((n, 8), dtype=np.int64)
+    hdr = np.zeros((n, maxp, 6), dtype=np.float64)   # player turn action has_row n q  (+ own/enemy below)
+    boards = np.zeros((n, maxp, 2), dtype=np.uint64)
+    sims = np.zeros((n, maxp, 2), dtype=np.int64)
+    rootn = np.zeros((n, maxp, 64), dtype=np.float64)
+    pol = np.zeros((n, maxp, 64), dtype=np.float64)
+    for i, (plies, s) in enumerate(records):
+        summ[i] = [s["winner"], s["status"], len(plies), s["game_id"], s["enable_resign"], s["resigned_black"],
+                   s["resigned_white"], 0]
+        boards_final = (s["black"], s["white"])
+        for j, p in enumerate(plies):
+            hdr[i, j] = [p["player"], p["turn"], p["action"], int(p["has_row"]), p["n"], p["q"]]
+            boards[i, j] = [p["own"], p["enemy"]]
+            sims[i, j] = [p["sims"], p["loops"]]
+            rootn[i, j] = p["root_n"]
+            pol[i, j] = p["saved_policy"]
+        summ[i, 7] = 0
+    finals = np.array([[s["black"], s["white"]] for _, s in records], dtype=np.uint64).reshape(n, 2)
+    return {"summ": summ, "hdr": hdr, "boards": boards, "sims": sims, "rootn": rootn, "pol": pol, "finals": finals}
+
+
+def unpack_records(pk):
+    out = []
+    for i in range(pk["summ"].shape[0]):
+        w, status, npl, gid, er, rb, rw, _ = (int(v) for v in pk["summ"][i])
+        plies = []
+        for j in range(npl):
+            pl, turn, act, hr, n, q = pk["hdr"][i, j]
+            plies.append({"player": int(pl), "turn": int(turn), "own": int(pk["boards"][i, j, 0]),
+                          "enemy": int(pk["boards"][i, j, 1]), "action": int(act), "has_row": bool(hr),
+                          "sims": int(pk["sims"][i, j, 0]), "loops": int(pk["sims"][i, j, 1]), "n": float(n),
+                          "q": float(q), "root_n": [float(v) for v in pk["rootn"][i, j]], "root_w": None,
+                          "saved_policy": [float(v) for v in pk["pol"][i, j]]})
+        out.append((plies, {"winner": w, "status": status, "plies": npl, "game_id": gid, "enable_resign": er,
+                            "resigned_black": rb, "resigned_white": rw, "black": int(pk["finals"][i, 0]),
+                            "white": int(pk["finals"][i, 1])}))
+    return out
+
+
+def gather_records(records, rank, world, device=None):
+    """Gather every rank's finished-game records on rank 0 (returns [] elsewhere), ordered by rank,
+    i.e. by global game id.  One all_gather of sizes + one gather per packed array — the only
+    communication in the whole self-play path."""
+    import torch
+    import torch.distributed as dist
+    pk = pack_records(records)
+    backend = dist.get_backend()
+    dev = torch.device(device) if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    shape = torch.tensor([pk["summ"].shape[0], pk["hdr"].shape[1]], dtype=torch.int64, device=dev)
+    shapes = [torch.zeros_like(shape) for _ in range(world)]
+    dist.all_gather(shapes, shape)
+    max_n = int(max(s[0] for s in shapes))
+    max_p = int(max(s[1] for s in shapes))
+    gathered = {}
+    for k in ("summ", "hdr", "boards", "sims", "rootn", "pol", "finals"):
+        a = pk[k]
+        pad_shape = (max_n,) + ((max_p,) + a.shape[2:] if a.ndim >= 3 else a.shape[1:])
+        buf = np.zeros(pad_shape, dtype=a.dtype)
+        buf[tuple(slice(0, s) for s in a.shape)] = a
+        view = buf.view(np.int64) if buf.dtype == np.uint64 else buf
+        t = torch.from_numpy(view).to(dev)
+        lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, lst, dst=0)
+        if rank == 0:
+            gathered[k] = [x.cpu().numpy().view(a.dtype) for x in lst]
+    if rank != 0:
+        return []
+    out = []
+    for r in range(world):
+        n_r, p_r = int(shapes[r][0]), int(shapes[r][1])
+        part = {k: gathered[k][r][:n_r] for k in gathered}
+        out += unpack_records(part)
+    return out
+
+
+def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0):
+    """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("the self-play engine is device-only: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if net_blob is None:
+        from ..agent.model import ReversiModel
+        m = ReversiModel(config)
+        if not m.load(config.resource.model_best_config_path, config.resource.model_best_weight_path):
+            m.build()
+        net_blob = m.model.to_blob()
+    w = BatchedSelfPlayWorker(config, net_blob, games_in_flight or 4096, seed=seed,
+                              device=f"cuda:{local}", rank=rank, world=world)
+    w.run(total_games)
+    return w
