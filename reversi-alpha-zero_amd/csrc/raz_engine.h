@@ -63,6 +63,7 @@ struct raz_engine_dev {
     uint32_t *sims_per_move, *loops_done, *move_sims, *pool_used, *n_plies, *g_error;
     int32_t* sims_left;
     unsigned long long* g_sims;  // simulations executed, per game
+    unsigned long long *g_leaves, *g_selections;  // leaves sent to the net / PUCT selections, per game
     // in-flight simulation
     uint8_t *leaf_kind, *leaf_sym, *leaf_np, *depth, *nn_active;
     unsigned long long *leaf_b, *leaf_w, *nn_own, *nn_enemy;
@@ -78,6 +79,6 @@ struct raz_engine_dev {
     raz_ply_header* rec;           // [B][max_plies]
     uint32_t* rec_n;               // [B][max_plies][64]
     double* rec_w;                 // [B][max_plies][64] or NULL
-    // global counters: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves evaluated
+    // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections
     unsigned long long* counters;
 };

@@ -145,10 +145,7 @@ __device__ uint32_t node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_
     if (f.found) return f.node;
     uint32_t used = E.pool_used[g];
     if (f.slot == 0xffffffffu || used >= E.C) {
-        if (lane == 0) {
-            E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-            atomicOr(&E.counters[2], (unsigned long long)((f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL));
-        }
+        if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
         return 0xffffffffu;
     }
     const uint32_t node = used;
@@ -364,7 +361,6 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     if (ply >= E.max_plies) {
         if (lane == 0) {
             E.g_error[g] |= RAZ_ERR_RECORDS_FULL;
-            atomicOr(&E.counters[2], (unsigned long long)RAZ_ERR_RECORDS_FULL);
             E.g_phase[g] = RAZ_PHASE_DONE;
         }
         return;
@@ -399,7 +395,6 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
         E.move_sims[g] = 0;
         if (r.status) {
             E.g_phase[g] = RAZ_PHASE_DONE;
-            atomicAdd(&E.counters[0], 1ULL);
         } else {
             E.g_phase[g] = RAZ_PHASE_NEW_MOVE;
         }
@@ -488,10 +483,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         }
         if (depth >= 64) {
             kind = RAZ_LEAF_NONE;
-            if (lane == 0) {
-                E.g_error[g] |= RAZ_ERR_PATH_FULL;
-                atomicOr(&E.counters[2], (unsigned long long)RAZ_ERR_PATH_FULL);
-            }
+            if (lane == 0) E.g_error[g] |= RAZ_ERR_PATH_FULL;
             break;
         }
         const int a = select_action(E, g, f.node, env, depth == 0, game_id, lane);
@@ -506,8 +498,8 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         E.leaf_kind[g] = (uint8_t)kind;
         E.depth[g] = (uint8_t)depth;
         E.nn_active[g] = kind == RAZ_LEAF_EXPAND ? 1 : 0;
-        if (kind == RAZ_LEAF_EXPAND) atomicAdd(&E.counters[3], 1ULL);
-        atomicAdd(&E.counters[4], (unsigned long long)depth);
+        if (kind == RAZ_LEAF_EXPAND) E.g_leaves[g] += 1;
+        E.g_selections[g] += (unsigned long long)depth;
     }
     wave_sync();
 }
@@ -519,14 +511,12 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E) {
     if (g >= E.B) return;
     if (lane == 0) E.nn_active[g] = 0;
     wave_sync();
-    uint32_t sims_done = 0;
     for (int it = 0; it < kInnerMax; ++it) {
         uint32_t phase = E.g_phase[g];
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (E.g_error[g]) break;
         if (E.leaf_kind[g] != RAZ_LEAF_NONE) {
             backup_leaf(E, g, (uint32_t)E.g_player[g] - 1, lane);
-            ++sims_done;
         }
         wave_sync();
         // controller: loop because a decided move may immediately need another decision
@@ -551,7 +541,29 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E) {
         wave_sync();
         if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL) break;  // needs the net: end of this launch's work
     }
-    if (lane == 0 && sims_done) atomicAdd(&E.counters[1], (unsigned long long)sims_done);
+}
+
+// Reduce the per-game statistics into counters[0..4] (one block).  Per-game words instead of
+// global atomics: 4096 waves hitting one address cost ~90 us per launch (one word saturates at
+// ~88 atomics/us on this chip).
+__global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
+    __shared__ unsigned long long sh[5][256];
+    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0;
+    for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
+        fin += E.g_status[g] != 0 ? 1 : 0;
+        sims += E.g_sims[g];
+        err |= E.g_error[g];
+        leaves += E.g_leaves[g];
+        sel += E.g_selections[g];
+    }
+    sh[0][threadIdx.x] = fin; sh[1][threadIdx.x] = sims; sh[2][threadIdx.x] = err;
+    sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel;
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        unsigned long long a = 0;
+        for (int i = 0; i < 256; ++i) a = (threadIdx.x == 2) ? (a | sh[2][i]) : (a + sh[threadIdx.x][i]);
+        E.counters[threadIdx.x] = a;
+    }
 }
 
 __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t* sims_per_move,
@@ -579,6 +591,8 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     E.n_plies[g] = 0;
     E.g_error[g] = 0;
     E.g_sims[g] = 0;
+    E.g_leaves[g] = 0;
+    E.g_selections[g] = 0;
     E.leaf_kind[g] = RAZ_LEAF_NONE;
     E.nn_active[g] = 0;
     E.depth[g] = 0;
@@ -610,6 +624,8 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.n_plies = (uint32_t*)take(B * 4); d.g_error = (uint32_t*)take(B * 4);
     d.sims_left = (int32_t*)take(B * 4);
     d.g_sims = (unsigned long long*)take(B * 8);
+    d.g_leaves = (unsigned long long*)take(B * 8);
+    d.g_selections = (unsigned long long*)take(B * 8);
     d.leaf_kind = take(B); d.leaf_sym = take(B); d.leaf_np = take(B); d.depth = take(B); d.nn_active = take(B);
     d.leaf_b = (unsigned long long*)take(B * 8); d.leaf_w = (unsigned long long*)take(B * 8);
     d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
@@ -719,6 +735,7 @@ extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t str
 extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
     if (!e || !out) return raz_fail(RAZ_EINVAL, "raz_engine_stats_sync: NULL argument");
     unsigned long long c[8];
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, e->dev);
     RAZ_HIP_TRY(hipMemcpyAsync(c, e->dev.counters, 64, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_stats_sync: copy");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_stats_sync: sync");
     out->finished_games = c[0];
