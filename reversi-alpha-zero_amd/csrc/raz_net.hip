@@ -23,6 +23,11 @@
 #include "raz_bitboard.h"
 #include "raz_detmath.h"
 #include "raz_internal.h"
+#include "raz_net_layout.h"
+
+bool raz_net_mfma_supported(int F, int V);
+int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
+                         const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s);
 
 namespace {
 
@@ -31,19 +36,6 @@ constexpr int32_t kMagic = 0x4E5A4152;
 struct NetDims {
     int F, R, V;
 };
-
-// ---- device weight layout (floats) ----
-// conv layer l (0..2R): w at conv_off(l): [F/16][9][Cin][16], then bias [F]
-__host__ __device__ inline size_t conv_floats(int F, int cin) { return (size_t)F * 9 * cin + F; }
-__host__ __device__ inline size_t conv_off(int F, int l) {
-    return l == 0 ? 0 : conv_floats(F, 2) + (size_t)(l - 1) * conv_floats(F, F);
-}
-__host__ __device__ inline size_t heads_off(int F, int R) { return conv_off(F, 2 * R + 1); }
-// heads: pol_w [2][F], pol_b[2], pol_fc_w [128][64], pol_fc_b[64], val_w [F], val_b[1],
-//        val_fc1_w [64][V], val_fc1_b [V], val_fc2_w [V], val_fc2_b [1]
-__host__ __device__ inline size_t total_floats(int F, int R, int V) {
-    return heads_off(F, R) + (2 * (size_t)F + 2) + (128 * 64 + 64) + ((size_t)F + 1) + (64 * (size_t)V + V) + ((size_t)V + 1);
-}
 
 template <bool LDS_ACT>
 __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, NetDims d,
@@ -202,7 +194,7 @@ static size_t lds_bytes_for(int F, int V, bool lds_act) {
 static bool use_lds(int F, int V) { return lds_bytes_for(F, V, true) <= 64 * 1024; }
 
 extern "C" size_t raz_net_scratch_bytes(int filters, int value_fc, size_t n) {
-    if (use_lds(filters, value_fc)) return 0;
+    if (raz_net_mfma_supported(filters, value_fc) || use_lds(filters, value_fc)) return 0;
     return n * 3 * (size_t)filters * 64 * sizeof(float);
 }
 
@@ -236,15 +228,33 @@ extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, v
         memcpy(w + (size_t)F * 9 * cin, src + (size_t)F * cin * 9, F * sizeof(float));
         src += (size_t)F * cin * 9 + F;
     }
-    const size_t nheads = total_floats(F, R, V) - heads_off(F, R);
+    const size_t nheads = wave_floats(F, R, V) - heads_off(F, R);
     memcpy(dst.data() + heads_off(F, R), src, nheads * sizeof(float));
+    {   // region 2: B operands of v_mfma_f32_16x16x4_f32, k = tap*Cin + ic (raz_net_layout.h)
+        const float* lsrc = (const float*)((const char*)blob + 32);
+        for (int l = 0; l < 2 * R + 1; ++l) {
+            const int cin = l == 0 ? 2 : F, ks = mfma_ksteps(F, l);
+            float* w = dst.data() + mfma_layer_off(F, R, V, l);
+            for (int nt = 0; nt < F / 16; ++nt)
+                for (int st = 0; st < ks; ++st)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int k = 4 * st + (ln >> 4), oc = nt * 16 + (ln & 15);
+                        float v = 0.0f;
+                        if (k < 9 * cin) {
+                            const int t = k / cin, ic = k % cin;
+                            v = lsrc[((size_t)oc * cin + ic) * 9 + t];
+                        }
+                        w[((size_t)nt * ks + st) * 64 + ln] = v;
+                    }
+            lsrc += (size_t)F * cin * 9 + F;
+        }
+    }
     RAZ_HIP_TRY(hipMemcpyAsync(d_weights, dst.data(), need, hipMemcpyHostToDevice, (hipStream_t)stream),
                 "raz_net_load: hipMemcpyAsync");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_load: sync");  // dst is a local
     net->filters = F;
     net->res_layers = R;
     net->value_fc = V;
-    net->reserved = 0;
     net->d_weights = d_weights;
     net->weight_bytes = need;
     return RAZ_OK;
@@ -257,6 +267,9 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     if (!net || !net->d_weights || !own || !enemy || !policy || !value)
         return raz_fail(RAZ_EINVAL, "raz_net_forward: NULL argument");
     const int F = net->filters, V = net->value_fc;
+    if (raz_net_mfma_supported(F, V) && net->reserved != 1)  // reserved == 1: force the VALU kernel (tests)
+        return raz_net_forward_mfma((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
+                                    value, n, (hipStream_t)stream);
     NetDims d = {F, net->res_layers, V};
     const bool lds = use_lds(F, V);
     if (!lds) {

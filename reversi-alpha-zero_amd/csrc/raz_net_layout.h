@@ -1,0 +1,27 @@
+// raz_net_layout.h — float offsets inside the device weight buffer of a loaded net (raz_net_load).
+// Region 1 ("wave" layout, used by k_net_wave): conv layer l at conv_off(l): [F/16][9][Cin][16] + bias[F];
+//   then the heads exactly as in the blob.
+// Region 2 ("mfma" layout, used by k_net_mfma) at mfma_off(): per conv layer, per 16-channel N tile,
+//   per k-step s, 64 floats: the B operand of v_mfma_f32_16x16x4_f32 for lane l, i.e. the weight of
+//   out-channel nt*16 + (l&15) at reduction index k = 4s + (l>>4), where k runs tap-major then input
+//   channel (k = tap*Cin + ic) — the order raznet-forward-v1 fixes; k beyond 9*Cin (layer 0) is 0.
+#pragma once
+#include <stddef.h>
+
+#define RAZ_HD_LAYOUT __host__ __device__ inline
+
+RAZ_HD_LAYOUT size_t conv_floats(int F, int cin) { return (size_t)F * 9 * cin + F; }
+RAZ_HD_LAYOUT size_t conv_off(int F, int l) {
+    return l == 0 ? 0 : conv_floats(F, 2) + (size_t)(l - 1) * conv_floats(F, F);
+}
+RAZ_HD_LAYOUT size_t heads_off(int F, int R) { return conv_off(F, 2 * R + 1); }
+RAZ_HD_LAYOUT size_t wave_floats(int F, int R, int V) {
+    return heads_off(F, R) + (2 * (size_t)F + 2) + (128 * 64 + 64) + ((size_t)F + 1) + (64 * (size_t)V + V) + ((size_t)V + 1);
+}
+RAZ_HD_LAYOUT int mfma_ksteps(int F, int l) { return l == 0 ? 5 : 9 * F / 4; }
+RAZ_HD_LAYOUT size_t mfma_layer_floats(int F, int l) { return (size_t)(F / 16) * mfma_ksteps(F, l) * 64; }
+RAZ_HD_LAYOUT size_t mfma_off(int F, int R, int V) { return (wave_floats(F, R, V) + 63) / 64 * 64; }
+RAZ_HD_LAYOUT size_t mfma_layer_off(int F, int R, int V, int l) {
+    return mfma_off(F, R, V) + (l == 0 ? 0 : mfma_layer_floats(F, 0) + (size_t)(l - 1) * mfma_layer_floats(F, 1));
+}
+RAZ_HD_LAYOUT size_t total_floats(int F, int R, int V) { return mfma_layer_off(F, R, V, 2 * R + 1); }

@@ -27,7 +27,7 @@ def _stream():
 class DeviceNet:
     """The policy/value net resident in HBM (agent/api.py ReversiModelAPI role, device side)."""
 
-    def __init__(self, blob: bytes, device="cuda:0"):
+    def __init__(self, blob: bytes, device="cuda:0", force_valu_kernel=False):
         import torch
         import struct
         magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -38,6 +38,7 @@ class DeviceNet:
         self.filters, self.res_layers, self.value_fc = F, R, V
         self._weights = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.c = N.RazNet()
+        self.c.reserved = 1 if force_valu_kernel else 0   # 1: wave-per-position VALU kernel even where MFMA applies
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")

@@ -28,7 +28,21 @@ def _positions(n, seed):
     return own, enemy
 
 
-@pytest.mark.parametrize("shape,n", [((16, 1, 16), 300), ((32, 2, 48), 40), ((128, 1, 256), 3)])
+@pytest.mark.parametrize("shape", [(16, 1, 16), (32, 2, 48), (64, 3, 80)])
+def test_net_mfma_kernel_equals_valu_kernel(shape):
+    """k_net_mfma (matrix cores) and k_net_wave (VALU) are the same function bit for bit."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    blob = ReversiNet(*shape).keras_init_(2).randomize_bn_(3).to_blob()
+    own, enemy = _positions(777, 4)
+    o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
+    pa, va = DeviceNet(blob, DEV).predict_bitboards(o, e)
+    pb, vb = DeviceNet(blob, DEV, force_valu_kernel=True).predict_bitboards(o, e)
+    assert torch.equal(pa.view(torch.int32), pb.view(torch.int32))
+    assert torch.equal(va.view(torch.int32), vb.view(torch.int32))
+
+
+@pytest.mark.parametrize("shape,n", [((16, 1, 16), 300), ((32, 2, 48), 40), ((64, 1, 32), 10), ((128, 1, 256), 3)])
 def test_net_kernel_bitwise_vs_oracle_and_torch(shape, n):
     """HIP forward == oracle forward bit for bit; both within 1e-5 of the fp32 torch graph."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
