@@ -6,10 +6,12 @@
 //
 // HBM layout (all arrays indexed by game slot g first, so one game's data is contiguous for the
 // wave that owns it and different games never share a cache line of mutable data):
-//   tree nodes   : node g,i = 1 KiB block  [W f64 x64 | N u32 x64 | P f32 x64]  + key/tag arrays
-//   hash table   : H slots of 32 B {black, white, tag, idx+1}, open addressing, linear probing,
-//                  probed 16 slots (512 B, one coalesced request) at a time
-//   per-sim path : 64 x (node idx u32, action|np u8)
+//   tree nodes   : node g,i = 1 KiB block  [W f64 x64 | N u32 x64 | P f32 x64]; P holds the prior
+//                  already masked by the legal moves and normalised (what select_action_q_and_u
+//                  recomputes at every visit, player.py:404-413, depends only on the node)
+//   hash table   : H slots of 32 B {black, white, legal, idx|tag, mirror}, open addressing, linear
+//                  probing, probed 16 slots (512 B, one coalesced request) at a time
+//   per-sim path : 64 x (node idx u32, slot idx u32, action|np u8)
 //   records      : per ply 48 B header + root N u32 x64 (+ optional root W f64 x64)
 #pragma once
 #include <stdint.h>
@@ -33,12 +35,16 @@
 #define RAZ_ERR_RECORDS_FULL 4u
 #define RAZ_ERR_PATH_FULL 8u
 
+// A table slot doubles as the node header: key, the mover's legal-move mask (computed once, when the
+// position is first reached), the node index and flags, and the node index of the colour-mirrored key.
 struct raz_slot {  // 32 bytes
     unsigned long long black, white;
-    uint32_t tag;   // bit31 used | owner<<2 | next_player
-    uint32_t idx;   // node index
-    unsigned long long pad;
+    unsigned long long legal;
+    uint32_t idx_tag;  // node index << 8 | used<<7 | expanded_by_white<<5 | expanded_by_black<<4 | owner<<2 | next_player
+    uint32_t mirror;   // node index of the mirrored key (player.py:391-393), 0xffffffff = not looked up yet
 };
+#define RAZ_SLOT_USED 0x80u
+#define RAZ_SLOT_KEYMASK 0x07u
 
 struct raz_ply_header {  // 48 bytes, one per recorded ply (== orc_ply_record minus the vectors)
     unsigned long long own, enemy;  // mover's view, as ReversiPlayer.action_with_evaluation gets them
@@ -66,15 +72,13 @@ struct raz_engine_dev {
     unsigned long long *g_leaves, *g_selections;  // leaves sent to the net / PUCT selections, per game
     // in-flight simulation
     uint8_t *leaf_kind, *leaf_sym, *leaf_np, *depth, *nn_active;
-    unsigned long long *leaf_b, *leaf_w, *nn_own, *nn_enemy;
+    unsigned long long *leaf_b, *leaf_w, *leaf_legal, *nn_own, *nn_enemy;
     float *leaf_term_v, *nn_policy /*[B][64]*/, *nn_value;
-    uint32_t* path_node /*[B][64]*/;
+    uint32_t *path_node /*[B][64]*/, *path_slot /*[B][64]*/;
     uint8_t* path_act /*[B][64]*/;
     // tree
     raz_slot* table;               // [B][H]
     unsigned char* nodes;          // [B][C][1024]
-    unsigned long long *node_kb, *node_kw;  // [B][C]
-    uint32_t* node_tag;            // [B][C]  next_player | owner<<2 | expanded0<<4 | expanded1<<5
     // records
     raz_ply_header* rec;           // [B][max_plies]
     uint32_t* rec_n;               // [B][max_plies][64]

@@ -39,14 +39,49 @@ constexpr int kInnerMax = 8;  // max simulations completed per game per launch (
 // (__launch_bounds__(64)), so this is a compiler/memory fence, not a real barrier.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
-    return v;
+// Values every lane holds identically (game state, keys, node indices) are moved to SGPRs so the
+// 64-bit board arithmetic and the address math run on the scalar unit.
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int uni(int x) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)x); }
+__device__ __forceinline__ raz_bb uni(raz_bb x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((raz_bb)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_f64(double v, int l) {
+    const uint64_t b = raz_f64_to_bits(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)b, l), hi = __builtin_amdgcn_readlane((uint32_t)(b >> 32), l);
+    return raz_bits_to_f64(((uint64_t)hi << 32) | lo);
+}
+
+// DPP lane permutations inside a row of 16: xor 1, xor 2 (quad_perm), then half-mirror and mirror,
+// which act as xor 4 / xor 8 once the smaller groups already agree.  VALU-rate, no LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double v) {
+    const uint64_t b = raz_f64_to_bits(v);
+    const uint32_t lo = dpp32<CTRL>((uint32_t)b), hi = dpp32<CTRL>((uint32_t)(b >> 32));
+    return raz_bits_to_f64(((uint64_t)hi << 32) | lo);
+}
+#define RAZ_DPP_XOR1 0xB1
+#define RAZ_DPP_XOR2 0x4E
+#define RAZ_DPP_HALF_MIRROR 0x141
+#define RAZ_DPP_MIRROR 0x140
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // exact, order-free
+    v += dpp32<RAZ_DPP_XOR1>(v);
+    v += dpp32<RAZ_DPP_XOR2>(v);
+    v += dpp32<RAZ_DPP_HALF_MIRROR>(v);
+    v += dpp32<RAZ_DPP_MIRROR>(v);
+    return lane_u32(v, 0) + lane_u32(v, 16) + lane_u32(v, 32) + lane_u32(v, 48);
 }
 
 // np.sum over float32[64] in numpy's pairwise order: 8 running partials r[j] += a[8i+j], then
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Lane l ends with the total.
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Only needed once per node (at expansion).
 __device__ __forceinline__ float wave_np_sum_f32(float a, int lane) {
     const int j = lane & 7;
     float t = __shfl(a, j);
@@ -58,27 +93,48 @@ __device__ __forceinline__ float wave_np_sum_f32(float a, int lane) {
     return t;
 }
 
-// argmax with numpy's first-maximum rule; every lane gets the winning index.
+// argmax with numpy's first-maximum rule; the result is wave-uniform.
+#define RAZ_ARGMAX_STEP(CTRL)                                   \
+    {                                                           \
+        const double ov = dpp64<CTRL>(v);                       \
+        const int oi = (int)dpp32<CTRL>((uint32_t)idx);         \
+        if (ov > v || (ov == v && oi < idx)) {                  \
+            v = ov;                                             \
+            idx = oi;                                           \
+        }                                                       \
+    }
 __device__ __forceinline__ int wave_argmax_f64(double v, int lane) {
     int idx = lane;
+    RAZ_ARGMAX_STEP(RAZ_DPP_XOR1)
+    RAZ_ARGMAX_STEP(RAZ_DPP_XOR2)
+    RAZ_ARGMAX_STEP(RAZ_DPP_HALF_MIRROR)
+    RAZ_ARGMAX_STEP(RAZ_DPP_MIRROR)
+    double bv = lane_f64(v, 0);
+    int bi = (int)lane_u32((uint32_t)idx, 0);
 #pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const double ov = __shfl_xor(v, s);
-        const int oi = __shfl_xor(idx, s);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
+    for (int r = 16; r < 64; r += 16) {
+        const double ov = lane_f64(v, r);
+        const int oi = (int)lane_u32((uint32_t)idx, r);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
         }
     }
-    return idx;
+    return bi;
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
+    double o;
+    o = dpp64<RAZ_DPP_XOR1>(v); v = o > v ? o : v;
+    o = dpp64<RAZ_DPP_XOR2>(v); v = o > v ? o : v;
+    o = dpp64<RAZ_DPP_HALF_MIRROR>(v); v = o > v ? o : v;
+    o = dpp64<RAZ_DPP_MIRROR>(v); v = o > v ? o : v;
+    double b = lane_f64(v, 0);
 #pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const double ov = __shfl_xor(v, s);
-        v = ov > v ? ov : v;
+    for (int r = 16; r < 64; r += 16) {
+        const double x = lane_f64(v, r);
+        b = x > b ? x : b;
     }
-    return v;
+    return b;
 }
 
 // ------------------------------------------------------------------ tree storage
@@ -90,10 +146,12 @@ __device__ __forceinline__ uint32_t key_hash(raz_bb b, raz_bb w, uint32_t tagkey
     return (uint32_t)x;
 }
 
-struct Found {
+struct Found {        // all fields wave-uniform
     bool found;
-    uint32_t node;  // valid when found
-    uint32_t slot;  // matching slot, or first empty slot when !found; 0xffffffff = table full
+    uint32_t node;    // valid when found
+    uint32_t slot;    // matching slot, or first empty slot when !found; 0xffffffff = table full
+    uint32_t tag;     // idx_tag & 0xff of the matching slot
+    raz_bb legal;     // legal mask stored with the node
 };
 
 __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t tagkey,
@@ -105,20 +163,25 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
     f.found = false;
     f.node = 0;
     f.slot = 0xffffffffu;
+    f.tag = 0;
+    f.legal = 0;
     for (uint32_t r = 0; r < E.H; r += RAZ_PROBE) {
         const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
         const raz_slot* s = tab + si;
-        const raz_bb sb = s->black, sw = s->white;
-        const uint32_t tag = s->tag, idx = s->idx;
-        const bool used = (tag >> 31) != 0;
-        const bool match = used && sb == b && sw == w && (tag & 7u) == tagkey;
+        const raz_bb sb = s->black, sw = s->white, sl = s->legal;
+        const uint32_t it = s->idx_tag;
+        const bool used = (it & RAZ_SLOT_USED) != 0;
+        const bool match = used && sb == b && sw == w && (it & RAZ_SLOT_KEYMASK) == tagkey;
         const unsigned long long mm = __ballot(match) & 0xffffULL;
         const unsigned long long em = __ballot(!used) & 0xffffULL;
         if (mm) {
             const int jj = __ffsll((long long)mm) - 1;
+            const uint32_t sit = lane_u32(it, jj);
             f.found = true;
-            f.node = __shfl(idx, jj);
+            f.node = sit >> 8;
+            f.tag = sit & 0xffu;
             f.slot = (h + r + (uint32_t)jj) & mask;
+            f.legal = ((raz_bb)lane_u32((uint32_t)(sl >> 32), jj) << 32) | lane_u32((uint32_t)sl, jj);
             return f;
         }
         if (em) {
@@ -136,17 +199,19 @@ __device__ __forceinline__ double* node_W(unsigned char* p) { return (double*)p;
 __device__ __forceinline__ uint32_t* node_N(unsigned char* p) { return (uint32_t*)(p + 512); }
 __device__ __forceinline__ float* node_P(unsigned char* p) { return (float*)(p + 768); }
 
-// defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent.
-// Returns the node index, or 0xffffffff after flagging an error when out of space.
-__device__ uint32_t node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
-                             uint32_t owner, int lane) {
+// defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent
+// (`legal` = legal moves of the side to move there, stored with the new node).  On return f holds
+// the slot; f.node == 0xffffffff after flagging an error when out of space.
+__device__ Found node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
+                          uint32_t owner, raz_bb legal, int lane) {
     const uint32_t tagkey = np | (owner << 2);
     Found f = table_find(E, g, b, w, tagkey, lane);
-    if (f.found) return f.node;
-    uint32_t used = E.pool_used[g];
+    if (f.found) return f;
+    const uint32_t used = uni(E.pool_used[g]);
     if (f.slot == 0xffffffffu || used >= E.C) {
         if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-        return 0xffffffffu;
+        f.node = 0xffffffffu;
+        return f;
     }
     const uint32_t node = used;
     unsigned char* p = node_ptr(E, g, node);
@@ -157,22 +222,24 @@ __device__ uint32_t node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_
         raz_slot* s = E.table + (size_t)g * E.H + f.slot;
         s->black = b;
         s->white = w;
-        s->idx = node;
-        s->tag = 0x80000000u | tagkey;
-        E.node_kb[(size_t)g * E.C + node] = b;
-        E.node_kw[(size_t)g * E.C + node] = w;
-        E.node_tag[(size_t)g * E.C + node] = tagkey;
+        s->legal = legal;
+        s->idx_tag = (node << 8) | RAZ_SLOT_USED | tagkey;
+        s->mirror = 0xffffffffu;
         E.pool_used[g] = used + 1;
     }
     wave_sync();
-    return node;
+    f.node = node;
+    f.tag = RAZ_SLOT_USED | tagkey;
+    f.legal = legal;
+    return f;
 }
 
 // ------------------------------------------------------------------ search-space env (player's view)
-struct Env {  // ReversiEnv in the searching player's coordinates: "black" = that player
+struct Env {  // ReversiEnv in the searching player's coordinates: "black" = that player.  Uniform.
     raz_bb black, white;
     uint32_t np;      // 1 or 2
     uint32_t status;  // 0 running, else winner
+    raz_bb legal;     // legal moves of the side to move (0 when done)
 };
 
 __device__ __forceinline__ void env_step(Env& e, int action) {
@@ -181,33 +248,32 @@ __device__ __forceinline__ void env_step(Env& e, int action) {
     e.white = r.white;
     e.np = r.player;
     e.status = r.status & RAZ_STATUS_WINNER_MASK;
+    e.legal = r.legal;
 }
 
 // ------------------------------------------------------------------ select (agent/player.py:395-428)
-__device__ int select_action(const raz_engine_dev& E, uint32_t g, uint32_t node, const Env& env,
+// The node's P already holds normalize(P * legal) in float32 (player.py:404-413 gives the same
+// vector at every visit of a node, so it is computed once, when the net's policy is stored).
+__device__ int select_action(const raz_engine_dev& E, uint32_t g, uint32_t node, raz_bb legal, uint32_t np,
                              bool is_root, uint32_t game_id, int lane) {
     const raz_engine_config& c = E.cfg;
     unsigned char* p = node_ptr(E, g, node);
     const double Wi = node_W(p)[lane];
     const uint32_t Ni = node_N(p)[lane];
-    const float Pi = node_P(p)[lane];
-    const raz_bb legal = env.np == 1 ? bb_legal_moves(env.black, env.white) : bb_legal_moves(env.white, env.black);
+    const float p32 = node_P(p)[lane];
     const uint32_t bit = (uint32_t)((legal >> lane) & 1ULL);
     const uint32_t sumN = wave_sum_u32(Ni);
     double xx = sqrt((double)sumN);  // np.sqrt(np.sum(N)); correctly rounded on gfx950 (probe)
     if (xx < 1.0) xx = 1.0;           // max(xx_, 1)
-    float p32 = Pi * (float)bit;      // P * legal mask (float32)
-    const float sp = wave_np_sum_f32(p32, lane);
-    if (sp > 0.0f) p32 = p32 / sp;    // normalize(p, temperature == 1) in float32
     const double Nd = (double)Ni;
     double u;
     if (is_root && c.noise_eps > 0.0) {  // (1-eps) p + eps Dir(alpha), fresh at every root visit (:415-417)
-        uint32_t ev = E.ev_dirichlet[g];
+        const uint32_t ev = uni(E.ev_dirichlet[g]);
         const uint32_t rank = (uint32_t)__popcll(legal & ((1ULL << lane) - 1ULL));
         double gam = 0.0;
         if (bit) gam = raz_gamma_sample(c.dirichlet_alpha, c.seed, game_id, ev, rank);
         double acc = 0.0;
-        for (raz_bb m = legal; m; m &= m - 1) acc += __shfl(gam, __ffsll((long long)m) - 1);
+        for (raz_bb m = legal; m; m &= m - 1) acc += lane_f64(gam, __ffsll((long long)m) - 1);
         const double noise = bit ? gam / acc : 0.0;
         const float keep = (float)(1.0 - c.noise_eps);
         const double p64 = (double)(keep * p32) + c.noise_eps * noise;
@@ -218,43 +284,66 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, uint32_t node,
         u = ((double)(cp * p32)) * xx / (1.0 + Nd);
     }
     const double q = Wi / (Nd + 1e-5);
-    double v = (env.np == 1) ? (q + u + 1000.0) : (-q + u + 1000.0);
+    double v = (np == 1) ? (q + u + 1000.0) : (-q + u + 1000.0);
     v = v * (double)bit;
     return wave_argmax_f64(v, lane);
+}
+
+// P as select_action_q_and_u will use it: p = P * legal; if np.sum(p) > 0: p = p / np.sum(p)  (float32)
+__device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal, int lane) {
+    float p32 = pol * (float)((legal >> lane) & 1ULL);
+    const float sp = wave_np_sum_f32(p32, lane);
+    if (sp > 0.0f) p32 = p32 / sp;
+    return p32;
+}
+
+// Node index of the colour-mirrored key of the node in `slot` (cached in the slot after the first
+// lookup).  another_side_counter_key, player.py:391-393.
+__device__ uint32_t mirror_node(const raz_engine_dev& E, uint32_t g, uint32_t slot, uint32_t owner, int lane) {
+    raz_slot* s = E.table + (size_t)g * E.H + slot;
+    uint32_t m = uni(s->mirror);
+    if (m != 0xffffffffu) return m;
+    const raz_bb kb = uni(s->black), kw = uni(s->white), lg = uni(s->legal);
+    const uint32_t np = uni(s->idx_tag) & 3u;
+    const Found f = node_get(E, g, kw, kb, 3 - np, owner, lg, lane);
+    if (f.node != 0xffffffffu && lane == 0) s->mirror = f.node;
+    return f.node;
 }
 
 // ------------------------------------------------------------------ backup of the previous leaf
 __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, int lane) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t kind = E.leaf_kind[g];
+    const uint32_t kind = uni((uint32_t)E.leaf_kind[g]);
     if (kind == RAZ_LEAF_NONE) return;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const int depth = E.depth[g];
+    const int depth = uni((int)E.depth[g]);
     double leaf_v;
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-327), second half
-        const uint32_t np = E.leaf_np[g];
-        const raz_bb kb = E.leaf_b[g], kw = E.leaf_w[g];
+        const uint32_t np = uni((uint32_t)E.leaf_np[g]);
+        const raz_bb kb = uni(E.leaf_b[g]), kw = uni(E.leaf_w[g]), lg = uni(E.leaf_legal[g]);
         leaf_v = (double)E.nn_value[g];  // float(leaf_v)
         if (np == 2) leaf_v = -leaf_v;   // :259-262
-        const uint32_t sym = E.leaf_sym[g];
+        const uint32_t sym = uni((uint32_t)E.leaf_sym[g]);
         // the net saw T(board); its policy q is over T-squares, so p[s] = q[T(s)]
         const float pol = E.nn_policy[(size_t)g * 64 + bb_d4_square(lane, (sym >> 2) & 1, sym & 3)];
-        const uint32_t node = node_get(E, g, kb, kw, np, owner, lane);
-        if (node != 0xffffffffu) {
-            node_P(node_ptr(E, g, node))[lane] = pol;
-            if (lane == 0) E.node_tag[(size_t)g * E.C + node] |= (16u << pl);
-        }
-        if (c.mirror_updates) {
-            const uint32_t m = node_get(E, g, kw, kb, 3 - np, owner, lane);
-            if (m != 0xffffffffu) node_P(node_ptr(E, g, m))[lane] = pol;
+        const float pn = masked_normalised_prior(pol, lg, lane);
+        const Found f = node_get(E, g, kb, kw, np, owner, lg, lane);
+        if (f.node != 0xffffffffu) {
+            node_P(node_ptr(E, g, f.node))[lane] = pn;
+            raz_slot* s = E.table + (size_t)g * E.H + f.slot;
+            if (lane == 0) s->idx_tag |= (16u << pl);
+            if (c.mirror_updates) {
+                const uint32_t m = mirror_node(E, g, f.slot, owner, lane);
+                if (m != 0xffffffffu) node_P(node_ptr(E, g, m))[lane] = pn;
+            }
         }
     } else {
         leaf_v = (double)E.leaf_term_v[g];
     }
     const double vl = (double)c.virtual_loss;
     for (int d = depth - 1; d >= 0; --d) {
-        const uint32_t node = E.path_node[(size_t)g * 64 + d];
-        const uint32_t pa = E.path_act[(size_t)g * 64 + d];
+        const uint32_t node = uni(E.path_node[(size_t)g * 64 + d]);
+        const uint32_t pa = uni((uint32_t)E.path_act[(size_t)g * 64 + d]);
         const uint32_t a = pa & 63u, npd = pa >> 6;
         const double vlw = npd == 1 ? vl : -vl;
         unsigned char* p = node_ptr(E, g, node);
@@ -264,8 +353,7 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
             node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
         }
         if (c.mirror_updates) {  // another_side_counter_key (:279-280)
-            const raz_bb kb = E.node_kb[(size_t)g * E.C + node], kw = E.node_kw[(size_t)g * E.C + node];
-            const uint32_t m = node_get(E, g, kw, kb, 3 - npd, owner, lane);
+            const uint32_t m = mirror_node(E, g, uni(E.path_slot[(size_t)g * 64 + d]), owner, lane);
             if (m != 0xffffffffu && lane == 0) {
                 unsigned char* q = node_ptr(E, g, m);
                 node_N(q)[a] += 1u;
@@ -288,14 +376,15 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
 // searching again (phase SEARCH, sims_left > 0), waiting for a new move (phase NEW_MOVE) or DONE.
 __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t player = E.g_player[g];
+    const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const raz_bb rb = E.root_black[g], rw = E.root_white[g];
+    const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
     const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
     const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
-    const uint32_t game_id = E.g_game_id[g];
-    const uint32_t node = node_get(E, g, own, enemy, 1, owner, lane);
+    const uint32_t game_id = uni(E.g_game_id[g]);
+    const Found fr = node_get(E, g, own, enemy, 1, owner, bb_legal_moves(own, enemy), lane);
+    const uint32_t node = fr.node;
     if (node == 0xffffffffu) {
         if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
         return;
@@ -316,11 +405,11 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     // np.random.choice(range(64), p=policy) (:112): cdf = cumsum; cdf /= cdf[-1]; searchsorted right
     double acc = 0.0, cdf = 0.0;
     for (int i = 0; i < 64; ++i) {
-        acc += __shfl(policy, i);
+        acc += lane_f64(policy, i);
         if (i == lane) cdf = acc;
     }
     cdf = cdf / acc;
-    const uint32_t ev = E.ev_choice[g];
+    const uint32_t ev = uni(E.ev_choice[g]);
     double d0, d1;
     raz_rng_pair(c.seed, game_id, RAZ_RNG_CHOICE, ev, 0, 0, d0, d1);
     int action = __popcll(__ballot(cdf <= d0));
@@ -328,10 +417,10 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     if (lane == 0) E.ev_choice[g] = ev + 1;
     // re-thinking rule (:113-118)
     const int abv = wave_argmax_f64(q + (Ni > 0 ? 100.0 : 0.0), lane);
-    const double q_action = __shfl(q, action), q_abv = __shfl(q, abv);
-    const double n_action = __shfl(Nd, action);
+    const double q_action = lane_f64(q, action), q_abv = lane_f64(q, abv);
+    const double n_action = lane_f64(Nd, action);
     const double value_diff = q_action - q_abv;
-    const uint32_t loops = E.loops_done[g] + 1;
+    const uint32_t loops = uni(E.loops_done[g]) + 1;
     const bool stop = (turn <= c.start_rethinking_turn) ||
                       (value_diff > -0.01 && n_action >= (double)c.required_visit_to_decide_action) ||
                       ((int)loops >= c.thinking_loop);
@@ -350,14 +439,14 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
         const double mx = wave_max_f64(q - (Ni == 0 ? 10.0 : 0.0));
         if (mx <= c.resign_threshold) {
             if (lane == 0) E.g_resigned[(size_t)g * 2 + pl] = 1;
-            if (E.g_enable_resign[g] && turn >= c.allowed_resign_turn) {
+            if (uni((uint32_t)E.g_enable_resign[g]) && turn >= c.allowed_resign_turn) {
                 final_action = -1;
                 has_row = false;
             }
         }
     }
     // record the ply (rows + GGF are produced on the host from this)
-    const uint32_t ply = E.n_plies[g];
+    const uint32_t ply = uni(E.n_plies[g]);
     if (ply >= E.max_plies) {
         if (lane == 0) {
             E.g_error[g] |= RAZ_ERR_RECORDS_FULL;
@@ -393,11 +482,7 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
         E.g_status[g] = r.status;
         E.loops_done[g] = 0;
         E.move_sims[g] = 0;
-        if (r.status) {
-            E.g_phase[g] = RAZ_PHASE_DONE;
-        } else {
-            E.g_phase[g] = RAZ_PHASE_NEW_MOVE;
-        }
+        E.g_phase[g] = r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE;
     }
     wave_sync();
 }
@@ -405,9 +490,9 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
 // Start the mover's move: turn 0 -> bypass_first_move (:143-148), else arm a search.
 __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t player = E.g_player[g];
+    const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
-    const raz_bb rb = E.root_black[g], rw = E.root_white[g];
+    const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
     const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
     const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
     if (turn > 0) {
@@ -417,10 +502,10 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
         }
     } else {
         const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-        const uint32_t node = node_get(E, g, own, enemy, 1, owner, lane);
-        if (node != 0xffffffffu) {
-            unsigned char* p = node_ptr(E, g, node);
-            const raz_bb legal = bb_legal_moves(own, enemy);
+        const raz_bb legal = bb_legal_moves(own, enemy);
+        const Found f = node_get(E, g, own, enemy, 1, owner, legal, lane);
+        if (f.node != 0xffffffffu) {
+            unsigned char* p = node_ptr(E, g, f.node);
             const int first = __ffsll((long long)legal) - 1;
             const int cnt = bb_popcount(legal);
             node_P(p)[lane] = (float)((double)((legal >> lane) & 1ULL) / (double)cnt);
@@ -440,16 +525,17 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
 // ------------------------------------------------------------------ descent to the next leaf
 __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t player = E.g_player[g];
+    const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const uint32_t game_id = E.g_game_id[g];
-    const raz_bb rb = E.root_black[g], rw = E.root_white[g];
+    const uint32_t game_id = uni(E.g_game_id[g]);
+    const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
     Env env;  // ReversiEnv().update(own, enemy, Player.black) (:209)
     env.black = player == 1 ? rb : rw;
     env.white = player == 1 ? rw : rb;
     env.np = 1;
     env.status = 0;
+    env.legal = 0;  // the root's mask comes from its table slot
     int depth = 0;
     uint32_t kind;
     for (;;) {
@@ -460,20 +546,22 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         }
         const uint32_t tagkey = env.np | (owner << 2);
         const Found f = table_find(E, g, env.black, env.white, tagkey, lane);
-        bool expanded = false;
-        if (f.found) expanded = ((E.node_tag[(size_t)g * E.C + f.node] >> (4 + pl)) & 1u) != 0;
+        const bool expanded = f.found && ((f.tag >> (4 + pl)) & 1u) != 0;
         if (!expanded) {  // leaf: expand_and_evaluate (:283-311), first half
             kind = RAZ_LEAF_EXPAND;
-            const uint32_t ev = E.ev_expand[g];
+            const uint32_t ev = uni(E.ev_expand[g]);
             double d0, d1;
             raz_rng_pair(c.seed, game_id, RAZ_RNG_EXPAND, ev, 0, 0, d0, d1);
             const int flip = d0 < 0.5 ? 1 : 0;   // random() < 0.5
             const int rot = (int)(d1 * 4.0);     // int(random() * 4)
             const raz_bb tb = bb_d4_apply(env.black, flip, rot), tw = bb_d4_apply(env.white, flip, rot);
+            raz_bb lg = f.found ? f.legal : env.legal;
+            if (depth == 0 && !f.found) lg = bb_legal_moves(env.black, env.white);
             if (lane == 0) {
                 E.ev_expand[g] = ev + 1;
                 E.leaf_b[g] = env.black;
                 E.leaf_w[g] = env.white;
+                E.leaf_legal[g] = lg;
                 E.leaf_np[g] = (uint8_t)env.np;
                 E.leaf_sym[g] = (uint8_t)(flip * 4 + rot);
                 E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
@@ -486,9 +574,10 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             if (lane == 0) E.g_error[g] |= RAZ_ERR_PATH_FULL;
             break;
         }
-        const int a = select_action(E, g, f.node, env, depth == 0, game_id, lane);
+        const int a = select_action(E, g, f.node, f.legal, env.np, depth == 0, game_id, lane);
         if (lane == 0) {
             E.path_node[(size_t)g * 64 + depth] = f.node;
+            E.path_slot[(size_t)g * 64 + depth] = f.slot;
             E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
         }
         ++depth;
@@ -628,13 +717,12 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.g_selections = (unsigned long long*)take(B * 8);
     d.leaf_kind = take(B); d.leaf_sym = take(B); d.leaf_np = take(B); d.depth = take(B); d.nn_active = take(B);
     d.leaf_b = (unsigned long long*)take(B * 8); d.leaf_w = (unsigned long long*)take(B * 8);
+    d.leaf_legal = (unsigned long long*)take(B * 8);
     d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
     d.leaf_term_v = (float*)take(B * 4); d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
-    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
+    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_slot = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
     d.table = (raz_slot*)take(B * H * sizeof(raz_slot));
     d.nodes = take(B * C * RAZ_NODE_BYTES);
-    d.node_kb = (unsigned long long*)take(B * C * 8); d.node_kw = (unsigned long long*)take(B * C * 8);
-    d.node_tag = (uint32_t*)take(B * C * 4);
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
     d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
