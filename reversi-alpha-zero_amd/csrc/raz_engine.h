@@ -6,18 +6,21 @@
 //
 // HBM layout (all arrays indexed by game slot g first, so one game's data is contiguous for the
 // wave that owns it and different games never share a cache line of mutable data):
-//   tree nodes   : node g,i = 1 KiB block  [W f64 x64 | N u32 x64 | P f32 x64]; P holds the prior
-//                  already masked by the legal moves and normalised (what select_action_q_and_u
-//                  recomputes at every visit, player.py:404-413, depends only on the node)
-//   hash table   : H slots of 32 B {black, white, legal, idx|tag, mirror}, open addressing, linear
-//                  probing, probed 16 slots (512 B, one coalesced request) at a time
-//   per-sim path : 64 x (node idx u32, slot idx u32, action|np u8)
+//   tree nodes   : node g,i = 1408-byte block [W f64 x64 | N u32 x64 | P f32 x64 | child u32 x64 | header];
+//                  P holds the prior already masked by the legal moves and normalised (what
+//                  select_action_q_and_u recomputes at every visit, player.py:404-413, depends only
+//                  on the node); child[a] links to the node reached by action a, so a descent costs
+//                  ONE dependent memory round trip per level; the header carries key, legal mask,
+//                  expanded flags and the index of the colour-mirrored node
+//   hash table   : H slots of 32 B {black, white, idx|tag}, open addressing, linear probing, probed
+//                  16 slots (512 B, one coalesced request) at a time; used only for first arrivals
+//   per-sim path : 64 x (node idx u32, action|np u8)
 //   records      : per ply 48 B header + root N u32 x64 (+ optional root W f64 x64)
 #pragma once
 #include <stdint.h>
 #include "../../include/raz.h"
 
-#define RAZ_NODE_BYTES 1024
+#define RAZ_NODE_BYTES 1408
 #define RAZ_SLOT_BYTES 32
 #define RAZ_PROBE 16
 
@@ -35,16 +38,30 @@
 #define RAZ_ERR_RECORDS_FULL 4u
 #define RAZ_ERR_PATH_FULL 8u
 
-// A table slot doubles as the node header: key, the mover's legal-move mask (computed once, when the
-// position is first reached), the node index and flags, and the node index of the colour-mirrored key.
+// Hash-table slot: key -> node index.  Only consulted when a position is reached for the first time
+// along an edge (afterwards the parent's child link leads straight to the node).
 struct raz_slot {  // 32 bytes
     unsigned long long black, white;
-    unsigned long long legal;
-    uint32_t idx_tag;  // node index << 8 | used<<7 | expanded_by_white<<5 | expanded_by_black<<4 | owner<<2 | next_player
-    uint32_t mirror;   // node index of the mirrored key (player.py:391-393), 0xffffffff = not looked up yet
+    uint32_t idx_tag;  // node index << 8 | used<<7 | owner<<2 | next_player
+    uint32_t pad0;
+    unsigned long long pad1;
 };
 #define RAZ_SLOT_USED 0x80u
 #define RAZ_SLOT_KEYMASK 0x07u
+
+// Header stored inside the node block (one 32-byte broadcast load with the node's vectors).
+struct raz_node_hdr {
+    unsigned long long black, white;  // key
+    unsigned long long legal;         // legal moves of the side to move (computed once)
+    uint32_t tag;                     // next_player | owner<<2 | expanded_by_black<<4 | expanded_by_white<<5
+    uint32_t mirror;                  // node index of the colour-mirrored key, 0xffffffff = none yet
+};
+#define RAZ_NODE_W 0
+#define RAZ_NODE_N 512
+#define RAZ_NODE_P 768
+#define RAZ_NODE_CHILD 1024   // u32 x64: node index + 1 of the position after action i, 0 = not linked yet
+#define RAZ_NODE_HDR 1280
+#define RAZ_NO_NODE 0xffffffffu
 
 struct raz_ply_header {  // 48 bytes, one per recorded ply (== orc_ply_record minus the vectors)
     unsigned long long own, enemy;  // mover's view, as ReversiPlayer.action_with_evaluation gets them
@@ -73,8 +90,9 @@ struct raz_engine_dev {
     // in-flight simulation
     uint8_t *leaf_kind, *leaf_sym, *leaf_np, *depth, *nn_active;
     unsigned long long *leaf_b, *leaf_w, *leaf_legal, *nn_own, *nn_enemy;
+    uint32_t *leaf_node, *leaf_slot, *root_node;  // existing node of the leaf (or RAZ_NO_NODE) / empty slot found / root node
     float *leaf_term_v, *nn_policy /*[B][64]*/, *nn_value;
-    uint32_t *path_node /*[B][64]*/, *path_slot /*[B][64]*/;
+    uint32_t* path_node /*[B][64]*/;
     uint8_t* path_act /*[B][64]*/;
     // tree
     raz_slot* table;               // [B][H]

@@ -149,9 +149,7 @@ __device__ __forceinline__ uint32_t key_hash(raz_bb b, raz_bb w, uint32_t tagkey
 struct Found {        // all fields wave-uniform
     bool found;
     uint32_t node;    // valid when found
-    uint32_t slot;    // matching slot, or first empty slot when !found; 0xffffffff = table full
-    uint32_t tag;     // idx_tag & 0xff of the matching slot
-    raz_bb legal;     // legal mask stored with the node
+    uint32_t slot;    // first empty slot when !found; 0xffffffff = table full
 };
 
 __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t tagkey,
@@ -163,12 +161,10 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
     f.found = false;
     f.node = 0;
     f.slot = 0xffffffffu;
-    f.tag = 0;
-    f.legal = 0;
     for (uint32_t r = 0; r < E.H; r += RAZ_PROBE) {
         const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
         const raz_slot* s = tab + si;
-        const raz_bb sb = s->black, sw = s->white, sl = s->legal;
+        const raz_bb sb = s->black, sw = s->white;
         const uint32_t it = s->idx_tag;
         const bool used = (it & RAZ_SLOT_USED) != 0;
         const bool match = used && sb == b && sw == w && (it & RAZ_SLOT_KEYMASK) == tagkey;
@@ -176,12 +172,8 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
         const unsigned long long em = __ballot(!used) & 0xffffULL;
         if (mm) {
             const int jj = __ffsll((long long)mm) - 1;
-            const uint32_t sit = lane_u32(it, jj);
             f.found = true;
-            f.node = sit >> 8;
-            f.tag = sit & 0xffu;
-            f.slot = (h + r + (uint32_t)jj) & mask;
-            f.legal = ((raz_bb)lane_u32((uint32_t)(sl >> 32), jj) << 32) | lane_u32((uint32_t)sl, jj);
+            f.node = lane_u32(it, jj) >> 8;
             return f;
         }
         if (em) {
@@ -195,43 +187,68 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
 __device__ __forceinline__ unsigned char* node_ptr(const raz_engine_dev& E, uint32_t g, uint32_t node) {
     return E.nodes + ((size_t)g * E.C + node) * RAZ_NODE_BYTES;
 }
-__device__ __forceinline__ double* node_W(unsigned char* p) { return (double*)p; }
-__device__ __forceinline__ uint32_t* node_N(unsigned char* p) { return (uint32_t*)(p + 512); }
-__device__ __forceinline__ float* node_P(unsigned char* p) { return (float*)(p + 768); }
+__device__ __forceinline__ double* node_W(unsigned char* p) { return (double*)(p + RAZ_NODE_W); }
+__device__ __forceinline__ uint32_t* node_N(unsigned char* p) { return (uint32_t*)(p + RAZ_NODE_N); }
+__device__ __forceinline__ float* node_P(unsigned char* p) { return (float*)(p + RAZ_NODE_P); }
+__device__ __forceinline__ uint32_t* node_child(unsigned char* p) { return (uint32_t*)(p + RAZ_NODE_CHILD); }
+__device__ __forceinline__ raz_node_hdr* node_hdr(unsigned char* p) { return (raz_node_hdr*)(p + RAZ_NODE_HDR); }
 
-// defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent
-// (`legal` = legal moves of the side to move there, stored with the new node).  On return f holds
-// the slot; f.node == 0xffffffff after flagging an error when out of space.
-__device__ Found node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
-                          uint32_t owner, raz_bb legal, int lane) {
-    const uint32_t tagkey = np | (owner << 2);
-    Found f = table_find(E, g, b, w, tagkey, lane);
-    if (f.found) return f;
+// Allocate a zeroed node for key (b, w, np, owner) in the EMPTY table slot `slot`.
+// Returns RAZ_NO_NODE after flagging an error when out of space.
+__device__ uint32_t node_create_at(const raz_engine_dev& E, uint32_t g, uint32_t slot, raz_bb b, raz_bb w,
+                                   uint32_t np, uint32_t owner, raz_bb legal, int lane) {
     const uint32_t used = uni(E.pool_used[g]);
-    if (f.slot == 0xffffffffu || used >= E.C) {
-        if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-        f.node = 0xffffffffu;
-        return f;
+    if (slot == 0xffffffffu || used >= E.C) {
+        if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+        return RAZ_NO_NODE;
     }
-    const uint32_t node = used;
-    unsigned char* p = node_ptr(E, g, node);
+    const uint32_t tagkey = np | (owner << 2);
+    unsigned char* p = node_ptr(E, g, used);
     node_W(p)[lane] = 0.0;
     node_N(p)[lane] = 0u;
     node_P(p)[lane] = 0.0f;
+    node_child(p)[lane] = 0u;
     if (lane == 0) {
-        raz_slot* s = E.table + (size_t)g * E.H + f.slot;
+        raz_node_hdr h;
+        h.black = b;
+        h.white = w;
+        h.legal = legal;
+        h.tag = tagkey;
+        h.mirror = RAZ_NO_NODE;
+        *node_hdr(p) = h;
+        raz_slot* s = E.table + (size_t)g * E.H + slot;
         s->black = b;
         s->white = w;
-        s->legal = legal;
-        s->idx_tag = (node << 8) | RAZ_SLOT_USED | tagkey;
-        s->mirror = 0xffffffffu;
+        s->idx_tag = (used << 8) | RAZ_SLOT_USED | tagkey;
         E.pool_used[g] = used + 1;
     }
     wave_sync();
-    f.node = node;
-    f.tag = RAZ_SLOT_USED | tagkey;
-    f.legal = legal;
-    return f;
+    return used;
+}
+
+// defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent.
+__device__ uint32_t node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
+                             uint32_t owner, raz_bb legal, int lane) {
+    const Found f = table_find(E, g, b, w, np | (owner << 2), lane);
+    if (f.found) return f.node;
+    return node_create_at(E, g, f.slot, b, w, np, owner, legal, lane);
+}
+
+// Node of the colour-mirrored key (another_side_counter_key, player.py:391-393), created and
+// cross-linked on first use.
+__device__ uint32_t ensure_mirror(const raz_engine_dev& E, uint32_t g, uint32_t node, uint32_t owner, int lane) {
+    raz_node_hdr* h = node_hdr(node_ptr(E, g, node));
+    const uint32_t m0 = uni(h->mirror);
+    if (m0 != RAZ_NO_NODE) return m0;
+    const raz_bb kb = uni(h->black), kw = uni(h->white), lg = uni(h->legal);
+    const uint32_t np = uni(h->tag) & 3u;
+    const uint32_t m = node_get(E, g, kw, kb, 3 - np, owner, lg, lane);
+    if (m != RAZ_NO_NODE && lane == 0) {
+        h->mirror = m;
+        node_hdr(node_ptr(E, g, m))->mirror = node;
+    }
+    wave_sync();
+    return m;
 }
 
 // ------------------------------------------------------------------ search-space env (player's view)
@@ -254,13 +271,9 @@ __device__ __forceinline__ void env_step(Env& e, int action) {
 // ------------------------------------------------------------------ select (agent/player.py:395-428)
 // The node's P already holds normalize(P * legal) in float32 (player.py:404-413 gives the same
 // vector at every visit of a node, so it is computed once, when the net's policy is stored).
-__device__ int select_action(const raz_engine_dev& E, uint32_t g, uint32_t node, raz_bb legal, uint32_t np,
-                             bool is_root, uint32_t game_id, int lane) {
+__device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uint32_t Ni, float p32,
+                             raz_bb legal, uint32_t np, bool is_root, uint32_t game_id, int lane) {
     const raz_engine_config& c = E.cfg;
-    unsigned char* p = node_ptr(E, g, node);
-    const double Wi = node_W(p)[lane];
-    const uint32_t Ni = node_N(p)[lane];
-    const float p32 = node_P(p)[lane];
     const uint32_t bit = (uint32_t)((legal >> lane) & 1ULL);
     const uint32_t sumN = wave_sum_u32(Ni);
     double xx = sqrt((double)sumN);  // np.sqrt(np.sum(N)); correctly rounded on gfx950 (probe)
@@ -297,19 +310,6 @@ __device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal
     return p32;
 }
 
-// Node index of the colour-mirrored key of the node in `slot` (cached in the slot after the first
-// lookup).  another_side_counter_key, player.py:391-393.
-__device__ uint32_t mirror_node(const raz_engine_dev& E, uint32_t g, uint32_t slot, uint32_t owner, int lane) {
-    raz_slot* s = E.table + (size_t)g * E.H + slot;
-    uint32_t m = uni(s->mirror);
-    if (m != 0xffffffffu) return m;
-    const raz_bb kb = uni(s->black), kw = uni(s->white), lg = uni(s->legal);
-    const uint32_t np = uni(s->idx_tag) & 3u;
-    const Found f = node_get(E, g, kw, kb, 3 - np, owner, lg, lane);
-    if (f.node != 0xffffffffu && lane == 0) s->mirror = f.node;
-    return f.node;
-}
-
 // ------------------------------------------------------------------ backup of the previous leaf
 __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, int lane) {
     const raz_engine_config& c = E.cfg;
@@ -317,48 +317,57 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
     if (kind == RAZ_LEAF_NONE) return;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
     const int depth = uni((int)E.depth[g]);
+    // every level of the path is an independent (node, action) cell: lane d handles level d
+    uint32_t my_node = 0, my_pa = 0;
+    if (lane < depth) {
+        my_node = E.path_node[(size_t)g * 64 + lane];
+        my_pa = E.path_act[(size_t)g * 64 + lane];
+    }
     double leaf_v;
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-327), second half
         const uint32_t np = uni((uint32_t)E.leaf_np[g]);
-        const raz_bb kb = uni(E.leaf_b[g]), kw = uni(E.leaf_w[g]), lg = uni(E.leaf_legal[g]);
+        const raz_bb lg = uni(E.leaf_legal[g]);
         leaf_v = (double)E.nn_value[g];  // float(leaf_v)
         if (np == 2) leaf_v = -leaf_v;   // :259-262
         const uint32_t sym = uni((uint32_t)E.leaf_sym[g]);
         // the net saw T(board); its policy q is over T-squares, so p[s] = q[T(s)]
         const float pol = E.nn_policy[(size_t)g * 64 + bb_d4_square(lane, (sym >> 2) & 1, sym & 3)];
         const float pn = masked_normalised_prior(pol, lg, lane);
-        const Found f = node_get(E, g, kb, kw, np, owner, lg, lane);
-        if (f.node != 0xffffffffu) {
-            node_P(node_ptr(E, g, f.node))[lane] = pn;
-            raz_slot* s = E.table + (size_t)g * E.H + f.slot;
-            if (lane == 0) s->idx_tag |= (16u << pl);
+        uint32_t node = uni(E.leaf_node[g]);
+        if (node == RAZ_NO_NODE) {  // first arrival at this position: create it in the slot select found
+            node = node_create_at(E, g, uni(E.leaf_slot[g]), uni(E.leaf_b[g]), uni(E.leaf_w[g]), np, owner, lg, lane);
+            if (node != RAZ_NO_NODE && depth > 0) {  // link the parent's edge to it
+                const uint32_t parent = uni(E.path_node[(size_t)g * 64 + depth - 1]);
+                const uint32_t pa = uni((uint32_t)E.path_act[(size_t)g * 64 + depth - 1]);
+                if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
+            }
+        }
+        if (node != RAZ_NO_NODE) {
+            unsigned char* p = node_ptr(E, g, node);
+            node_P(p)[lane] = pn;
+            if (lane == 0) node_hdr(p)->tag |= (16u << pl);
             if (c.mirror_updates) {
-                const uint32_t m = mirror_node(E, g, f.slot, owner, lane);
-                if (m != 0xffffffffu) node_P(node_ptr(E, g, m))[lane] = pn;
+                const uint32_t m = ensure_mirror(E, g, node, owner, lane);
+                if (m != RAZ_NO_NODE) node_P(node_ptr(E, g, m))[lane] = pn;
             }
         }
     } else {
         leaf_v = (double)E.leaf_term_v[g];
     }
-    const double vl = (double)c.virtual_loss;
-    for (int d = depth - 1; d >= 0; --d) {
-        const uint32_t node = uni(E.path_node[(size_t)g * 64 + d]);
-        const uint32_t pa = uni((uint32_t)E.path_act[(size_t)g * 64 + d]);
-        const uint32_t a = pa & 63u, npd = pa >> 6;
+    if (lane < depth) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
+        const double vl = (double)c.virtual_loss;
+        const uint32_t a = my_pa & 63u, npd = my_pa >> 6;
         const double vlw = npd == 1 ? vl : -vl;
-        unsigned char* p = node_ptr(E, g, node);
-        if (lane == 0) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
-            node_N(p)[a] += 1u;
-            const double w0 = node_W(p)[a];
-            node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
-        }
-        if (c.mirror_updates) {  // another_side_counter_key (:279-280)
-            const uint32_t m = mirror_node(E, g, uni(E.path_slot[(size_t)g * 64 + d]), owner, lane);
-            if (m != 0xffffffffu && lane == 0) {
-                unsigned char* q = node_ptr(E, g, m);
-                node_N(q)[a] += 1u;
-                node_W(q)[a] = node_W(q)[a] - leaf_v;
-            }
+        unsigned char* p = node_ptr(E, g, my_node);
+        uint32_t m = RAZ_NO_NODE;
+        if (c.mirror_updates) m = node_hdr(p)->mirror;
+        node_N(p)[a] += 1u;
+        const double w0 = node_W(p)[a];
+        node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
+        if (m != RAZ_NO_NODE) {  // another_side_counter_key (:279-280); exists since the node's expansion
+            unsigned char* q = node_ptr(E, g, m);
+            node_N(q)[a] += 1u;
+            node_W(q)[a] = node_W(q)[a] - leaf_v;
         }
     }
     if (lane == 0) {
@@ -378,14 +387,12 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
-    const uint32_t owner = c.share_mtcs_info ? 0u : pl;
     const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
     const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
     const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
     const uint32_t game_id = uni(E.g_game_id[g]);
-    const Found fr = node_get(E, g, own, enemy, 1, owner, bb_legal_moves(own, enemy), lane);
-    const uint32_t node = fr.node;
-    if (node == 0xffffffffu) {
+    const uint32_t node = uni(E.root_node[g]);
+    if (node == RAZ_NO_NODE) {
         if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
         return;
     }
@@ -487,25 +494,27 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     wave_sync();
 }
 
-// Start the mover's move: turn 0 -> bypass_first_move (:143-148), else arm a search.
+// Start the mover's move: find/create its root node; turn 0 -> bypass_first_move (:143-148),
+// else arm a search.
 __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
+    const uint32_t owner = c.share_mtcs_info ? 0u : pl;
     const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
     const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
     const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
+    const raz_bb legal = bb_legal_moves(own, enemy);
+    const uint32_t node = node_get(E, g, own, enemy, 1, owner, legal, lane);
+    if (lane == 0) E.root_node[g] = node;
     if (turn > 0) {
         if (lane == 0) {
             E.sims_left[g] = (int32_t)E.sims_per_move[g];
             E.g_phase[g] = RAZ_PHASE_SEARCH;
         }
     } else {
-        const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-        const raz_bb legal = bb_legal_moves(own, enemy);
-        const Found f = node_get(E, g, own, enemy, 1, owner, legal, lane);
-        if (f.node != 0xffffffffu) {
-            unsigned char* p = node_ptr(E, g, f.node);
+        if (node != RAZ_NO_NODE) {
+            unsigned char* p = node_ptr(E, g, node);
             const int first = __ffsll((long long)legal) - 1;
             const int cnt = bb_popcount(legal);
             node_P(p)[lane] = (float)((double)((legal >> lane) & 1ULL) / (double)cnt);
@@ -535,53 +544,84 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
     env.white = player == 1 ? rw : rb;
     env.np = 1;
     env.status = 0;
-    env.legal = 0;  // the root's mask comes from its table slot
+    env.legal = 0;
     int depth = 0;
-    uint32_t kind;
+    uint32_t kind = RAZ_LEAF_NONE;
+    uint32_t node = uni(E.root_node[g]);  // always exists (begin_move)
+    uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu;
+    raz_bb leaf_legal = 0;
+    if (node == RAZ_NO_NODE) {
+        if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
+        return;
+    }
     for (;;) {
+        // one round trip: header (broadcast) + the node's four vectors, lane i holding action i
+        unsigned char* p = node_ptr(E, g, node);
+        const raz_node_hdr* hp = node_hdr(p);
+        const raz_bb legal = hp->legal;
+        const uint32_t tag = hp->tag;
+        const double Wi = node_W(p)[lane];
+        const uint32_t Ni = node_N(p)[lane];
+        const float Pi = node_P(p)[lane];
+        const uint32_t Ci = node_child(p)[lane];
+        if (!((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
+            kind = RAZ_LEAF_EXPAND;
+            leaf_node = node;
+            leaf_legal = uni(legal);
+            break;
+        }
+        if (depth >= 64) {
+            if (lane == 0) E.g_error[g] |= RAZ_ERR_PATH_FULL;
+            break;
+        }
+        const int a = select_action(E, g, Wi, Ni, Pi, uni(legal), env.np, depth == 0, game_id, lane);
+        if (lane == 0) {
+            E.path_node[(size_t)g * 64 + depth] = node;
+            E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
+        }
+        ++depth;
+        env_step(env, a);
         if (env.status) {  // env.done (:226-232)
             kind = RAZ_LEAF_TERMINAL;
             if (lane == 0) E.leaf_term_v[g] = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
             break;
         }
-        const uint32_t tagkey = env.np | (owner << 2);
-        const Found f = table_find(E, g, env.black, env.white, tagkey, lane);
-        const bool expanded = f.found && ((f.tag >> (4 + pl)) & 1u) != 0;
-        if (!expanded) {  // leaf: expand_and_evaluate (:283-311), first half
-            kind = RAZ_LEAF_EXPAND;
-            const uint32_t ev = uni(E.ev_expand[g]);
-            double d0, d1;
-            raz_rng_pair(c.seed, game_id, RAZ_RNG_EXPAND, ev, 0, 0, d0, d1);
-            const int flip = d0 < 0.5 ? 1 : 0;   // random() < 0.5
-            const int rot = (int)(d1 * 4.0);     // int(random() * 4)
-            const raz_bb tb = bb_d4_apply(env.black, flip, rot), tw = bb_d4_apply(env.white, flip, rot);
-            raz_bb lg = f.found ? f.legal : env.legal;
-            if (depth == 0 && !f.found) lg = bb_legal_moves(env.black, env.white);
-            if (lane == 0) {
-                E.ev_expand[g] = ev + 1;
-                E.leaf_b[g] = env.black;
-                E.leaf_w[g] = env.white;
-                E.leaf_legal[g] = lg;
-                E.leaf_np[g] = (uint8_t)env.np;
-                E.leaf_sym[g] = (uint8_t)(flip * 4 + rot);
-                E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
-                E.nn_enemy[g] = env.np == 1 ? tw : tb;
-            }
-            break;
+        const uint32_t child = lane_u32(Ci, a);
+        if (child) {
+            node = child - 1;
+            continue;
         }
-        if (depth >= 64) {
-            kind = RAZ_LEAF_NONE;
-            if (lane == 0) E.g_error[g] |= RAZ_ERR_PATH_FULL;
-            break;
+        // first time along this edge: the position may still exist (transposition / mirror write)
+        const Found f = table_find(E, g, env.black, env.white, env.np | (owner << 2), lane);
+        if (f.found) {
+            if (lane == 0) node_child(p)[a] = f.node + 1;
+            node = f.node;
+            continue;
         }
-        const int a = select_action(E, g, f.node, f.legal, env.np, depth == 0, game_id, lane);
+        kind = RAZ_LEAF_EXPAND;  // brand-new position: created at backup time in the slot found here
+        leaf_slot = f.slot;
+        leaf_legal = env.legal;
+        break;
+    }
+    if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-311), first half
+        const uint32_t ev = uni(E.ev_expand[g]);
+        double d0, d1;
+        raz_rng_pair(c.seed, game_id, RAZ_RNG_EXPAND, ev, 0, 0, d0, d1);
+        const int flip = d0 < 0.5 ? 1 : 0;   // random() < 0.5
+        const int rot = (int)(d1 * 4.0);     // int(random() * 4)
+        const raz_bb tb = bb_d4_apply(env.black, flip, rot), tw = bb_d4_apply(env.white, flip, rot);
         if (lane == 0) {
-            E.path_node[(size_t)g * 64 + depth] = f.node;
-            E.path_slot[(size_t)g * 64 + depth] = f.slot;
-            E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
+            E.ev_expand[g] = ev + 1;
+            E.leaf_b[g] = env.black;
+            E.leaf_w[g] = env.white;
+            E.leaf_legal[g] = leaf_legal;
+            E.leaf_node[g] = leaf_node;
+            E.leaf_slot[g] = leaf_slot;
+            E.leaf_np[g] = (uint8_t)env.np;
+            E.leaf_sym[g] = (uint8_t)(flip * 4 + rot);
+            E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
+            E.nn_enemy[g] = env.np == 1 ? tw : tb;
         }
-        ++depth;
-        env_step(env, a);
     }
     if (lane == 0) {
         E.leaf_kind[g] = (uint8_t)kind;
@@ -683,6 +723,7 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     E.g_leaves[g] = 0;
     E.g_selections[g] = 0;
     E.leaf_kind[g] = RAZ_LEAF_NONE;
+    E.root_node[g] = RAZ_NO_NODE;
     E.nn_active[g] = 0;
     E.depth[g] = 0;
 }
@@ -718,9 +759,10 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.leaf_kind = take(B); d.leaf_sym = take(B); d.leaf_np = take(B); d.depth = take(B); d.nn_active = take(B);
     d.leaf_b = (unsigned long long*)take(B * 8); d.leaf_w = (unsigned long long*)take(B * 8);
     d.leaf_legal = (unsigned long long*)take(B * 8);
+    d.leaf_node = (uint32_t*)take(B * 4); d.leaf_slot = (uint32_t*)take(B * 4); d.root_node = (uint32_t*)take(B * 4);
     d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
     d.leaf_term_v = (float*)take(B * 4); d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
-    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_slot = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
+    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
     d.table = (raz_slot*)take(B * H * sizeof(raz_slot));
     d.nodes = take(B * C * RAZ_NODE_BYTES);
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
