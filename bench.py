@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=200, help="steps enqueued between completion polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=64)
+    ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
     args = ap.parse_args()
 
     import torch
@@ -101,7 +102,7 @@ def main():
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     cfg = bench_config(args)
     net = DeviceNet(blob, dev)
-    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims)
+    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile)
     first_id = rank * args.games
 
     # warm-up on a throw-away start (clocks, caches, code objects), then restart the same games
@@ -201,6 +202,10 @@ def main():
             "roofline": roof, "kernels": kern,
             "record_gather": {"seconds": gather_s, "bytes": gather_bytes, "collective": "gather (RCCL)" if world > 1 else "none (1 GPU): D2H read"},
         }
+        if args.phase_profile:
+            pp = eng.phase_profile()
+            launches = max(pp["active_launches"], 1)
+            out["phase_profile_ticks_per_active_game_launch"] = {k: v / launches for k, v in pp.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, blob, args.sims, args.cpu_games)
         print(json.dumps(out))

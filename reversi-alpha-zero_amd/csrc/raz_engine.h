@@ -103,4 +103,5 @@ struct raz_engine_dev {
     double* rec_w;                 // [B][max_plies][64] or NULL
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections
     unsigned long long* counters;
+    unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)
 };

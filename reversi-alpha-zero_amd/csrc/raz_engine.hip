@@ -137,6 +137,15 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return b;
 }
 
+// Optional phase profile (cfg.reserved & 1): shader-clock ticks (s_memtime) accumulated per game:
+// [0] backup, [1] controller, [2] select, [3] root-noise sampling, [4] first-arrival probes,
+// [5] launches in which the game did work, [6] node-vector load waits in select, [7] expansion part of backup.
+#define RAZ_PROF_ON(E) ((E).cfg.reserved & 1u)
+__device__ __forceinline__ unsigned long long prof_now() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ void prof_add(const raz_engine_dev& E, uint32_t g, int k, unsigned long long t0, int lane) {
+    if (RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + k] += prof_now() - t0;
+}
+
 // ------------------------------------------------------------------ tree storage
 __device__ __forceinline__ uint32_t key_hash(raz_bb b, raz_bb w, uint32_t tagkey) {
     unsigned long long x = b * 0x9E3779B97F4A7C15ULL ^ (w + tagkey) * 0xC2B2AE3D27D4EB4FULL;
@@ -281,6 +290,7 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
     const double Nd = (double)Ni;
     double u;
     if (is_root && c.noise_eps > 0.0) {  // (1-eps) p + eps Dir(alpha), fresh at every root visit (:415-417)
+        const unsigned long long tp = prof_now();
         const uint32_t ev = uni(E.ev_dirichlet[g]);
         const uint32_t rank = (uint32_t)__popcll(legal & ((1ULL << lane) - 1ULL));
         double gam = 0.0;
@@ -292,6 +302,7 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
         const double p64 = (double)(keep * p32) + c.noise_eps * noise;
         u = (c.c_puct * p64) * xx / (1.0 + Nd);
         if (lane == 0) E.ev_dirichlet[g] = ev + 1;
+        prof_add(E, g, 3, tp, lane);
     } else {
         const float cp = (float)c.c_puct;
         u = ((double)(cp * p32)) * xx / (1.0 + Nd);
@@ -324,6 +335,7 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
         my_pa = E.path_act[(size_t)g * 64 + lane];
     }
     double leaf_v;
+    const unsigned long long te = prof_now();
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-327), second half
         const uint32_t np = uni((uint32_t)E.leaf_np[g]);
         const raz_bb lg = uni(E.leaf_legal[g]);
@@ -354,6 +366,7 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
     } else {
         leaf_v = (double)E.leaf_term_v[g];
     }
+    prof_add(E, g, 7, te, lane);
     if (lane < depth) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
         const double vl = (double)c.virtual_loss;
         const uint32_t a = my_pa & 63u, npd = my_pa >> 6;
@@ -564,6 +577,11 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         const uint32_t Ni = node_N(p)[lane];
         const float Pi = node_P(p)[lane];
         const uint32_t Ci = node_child(p)[lane];
+        if (RAZ_PROF_ON(E)) {
+            const unsigned long long tl = prof_now();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prof_add(E, g, 6, tl, lane);
+        }
         if (!((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
             kind = RAZ_LEAF_EXPAND;
             leaf_node = node;
@@ -592,7 +610,9 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             continue;
         }
         // first time along this edge: the position may still exist (transposition / mirror write)
+        const unsigned long long tq = prof_now();
         const Found f = table_find(E, g, env.black, env.white, env.np | (owner << 2), lane);
+        prof_add(E, g, 4, tq, lane);
         if (f.found) {
             if (lane == 0) node_child(p)[a] = f.node + 1;
             node = f.node;
@@ -644,10 +664,14 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E) {
         uint32_t phase = E.g_phase[g];
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (E.g_error[g]) break;
+        unsigned long long t0 = prof_now();
+        if (it == 0 && RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
         if (E.leaf_kind[g] != RAZ_LEAF_NONE) {
             backup_leaf(E, g, (uint32_t)E.g_player[g] - 1, lane);
         }
         wave_sync();
+        prof_add(E, g, 0, t0, lane);
+        t0 = prof_now();
         // controller: loop because a decided move may immediately need another decision
         // (turn-0 bypass) before a search with simulations starts
         for (int guard = 0; guard < 8; ++guard) {
@@ -664,10 +688,13 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E) {
             break;
         }
         wave_sync();
+        prof_add(E, g, 1, t0, lane);
         phase = E.g_phase[g];
         if (phase != RAZ_PHASE_SEARCH || E.sims_left[g] <= 0 || E.g_error[g]) break;
+        t0 = prof_now();
         select_leaf(E, g, lane);
         wave_sync();
+        prof_add(E, g, 2, t0, lane);
         if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL) break;  // needs the net: end of this launch's work
     }
 }
@@ -769,6 +796,7 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
     d.counters = (unsigned long long*)take(8 * 8);
+    d.prof = (unsigned long long*)take(B * 8 * 8);
     if (E) *E = d;
     return off;
 }
@@ -840,6 +868,7 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
     RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_start: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(d.prof, 0, (size_t)d.B * 64, s), "raz_engine_start: clear profile");
     hipLaunchKernelGGL(k_start, dim3((d.B + 255) / 256), dim3(256), 0, s, d, first_game_id, e->d_sims, n_active);
     int rc = raz_check_launch("raz_engine_start");
     if (rc == RAZ_OK) e->started = true;
@@ -947,6 +976,7 @@ extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) {
         case 2: return e->dev.rec_w;
         case 3: return e->dev.n_plies;
         case 4: return e->dev.g_status;
+        case 5: return e->dev.prof;
         default: return nullptr;
     }
 }

@@ -65,7 +65,7 @@ class DeviceNet:
 
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
-                       record_root_w=False):
+                       record_root_w=False, phase_profile=False):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names)."""
     p = config.play
     if getattr(p, "parallel_search_num", 1) != 1:
@@ -86,13 +86,14 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         noise_eps=float(p.noise_eps), dirichlet_alpha=float(p.dirichlet_alpha),
         resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
-        nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed, reserved=0)
+        nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
+        reserved=1 if phase_profile else 0)
     return c
 
 
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
-                 max_plies=72, mirror_updates=None, record_root_w=False):
+                 max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False):
         import torch
         self.net = net
         self.device = net.device
@@ -105,7 +106,7 @@ class SelfPlayEngine:
             # every simulation adds at most one node (two with mirror keys); ~62 searched plies
             nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
-                                      record_root_w)
+                                      record_root_w, phase_profile)
         nbytes = lib.raz_engine_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("invalid engine config: " + N.last_error())
@@ -148,6 +149,17 @@ class SelfPlayEngine:
             check(lib.raz_engine_step_timed(self._h, n, ctypes.byref(a), ctypes.byref(b), _stream()),
                   "raz_engine_step_timed")
         return a.value, b.value
+
+    def phase_profile(self):
+        """Per-phase shader-clock ticks summed over games (engine created with phase_profile=True)."""
+        import torch
+        ptr = lib.raz_engine_device_ptr(self._h, 5)
+        off = ptr - self._ws.data_ptr()
+        torch.cuda.synchronize(self.device)
+        a = self._ws[off:off + self.n_games * 64].cpu().numpy().view(np.uint64).reshape(self.n_games, 8)
+        names = ["backup", "controller", "select", "root_noise", "first_arrival_probe", "active_launches",
+                 "node_load_wait", "expand_part_of_backup"]
+        return {n: int(a[:, i].sum()) for i, n in enumerate(names)}
 
     def stats(self):
         import torch
