@@ -71,20 +71,18 @@ double orc_det_log(double x) {
     double m = from_bits((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1,2) */
     if (m > 0x1.6a09e667f3bcdp+0) { m = m * 0.5; e += 1; }                     /* (0.707,1.414] */
     double s = (m - 1.0) / (m + 1.0), z = s * s;
-    /* atanh series: log m = 2 s (1 + z/3 + z^2/5 + ... + z^12/25) */
-    double p = 0x1.47ae147ae147bp-5;
-    p = p * z + 0x1.642c8590b2164p-5;
-    p = p * z + 0x1.8618618618618p-5;
-    p = p * z + 0x1.af286bca1af28p-5;
-    p = p * z + 0x1.e1e1e1e1e1e1ep-5;
-    p = p * z + 0x1.1111111111111p-4;
-    p = p * z + 0x1.3b13b13b13b14p-4;
-    p = p * z + 0x1.745d1745d1746p-4;
-    p = p * z + 0x1.c71c71c71c71cp-4;
-    p = p * z + 0x1.2492492492492p-3;
-    p = p * z + 0x1.999999999999ap-3;
-    p = p * z + 0x1.5555555555555p-2;
-    p = p * z + 1.0;
+    /* atanh series: log m = 2 s (1 + z/3 + z^2/5 + ... + z^12/25), Estrin association */
+    double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    double a0 = 1.0 + 0x1.5555555555555p-2 * z;
+    double a1 = 0x1.999999999999ap-3 + 0x1.2492492492492p-3 * z;
+    double a2 = 0x1.c71c71c71c71cp-4 + 0x1.745d1745d1746p-4 * z;
+    double a3 = 0x1.3b13b13b13b14p-4 + 0x1.1111111111111p-4 * z;
+    double a4 = 0x1.e1e1e1e1e1e1ep-5 + 0x1.af286bca1af28p-5 * z;
+    double a5 = 0x1.8618618618618p-5 + 0x1.642c8590b2164p-5 * z;
+    double a6 = 0x1.47ae147ae147bp-5;
+    double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2, b2 = a4 + a5 * z2;
+    double d0 = b0 + b1 * z4, d1 = b2 + a6 * z4;
+    double p = d0 + d1 * z8;
     double de = (double)e;
     return de * LN2_HI + (de * LN2_LO + (2.0 * s) * p);
 }
@@ -100,21 +98,19 @@ double orc_det_exp(double x) {
     if (x > 709.78) return 0x1.fffffffffffffp+1023;
     double k = floor_det(x * INV_LN2 + 0.5);
     double r = (x - k * LN2_HI) - k * LN2_LO;
-    double p = 0x1.93974a8c07c9dp-37;       /* 1/14! */
-    p = p * r + 0x1.6124613a86d09p-33;
-    p = p * r + 0x1.1eed8eff8d898p-29;
-    p = p * r + 0x1.ae64567f544e4p-26;
-    p = p * r + 0x1.27e4fb7789f5cp-22;
-    p = p * r + 0x1.71de3a556c734p-19;
-    p = p * r + 0x1.a01a01a01a01ap-16;
-    p = p * r + 0x1.a01a01a01a01ap-13;
-    p = p * r + 0x1.6c16c16c16c17p-10;
-    p = p * r + 0x1.1111111111111p-7;
-    p = p * r + 0x1.5555555555555p-5;
-    p = p * r + 0x1.5555555555555p-3;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    /* sum_{k=0..14} r^k/k!, Estrin association */
+    double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    double a0 = 1.0 + r;
+    double a1 = 0.5 + 0x1.5555555555555p-3 * r;
+    double a2 = 0x1.5555555555555p-5 + 0x1.1111111111111p-7 * r;
+    double a3 = 0x1.6c16c16c16c17p-10 + 0x1.a01a01a01a01ap-13 * r;
+    double a4 = 0x1.a01a01a01a01ap-16 + 0x1.71de3a556c734p-19 * r;
+    double a5 = 0x1.27e4fb7789f5cp-22 + 0x1.ae64567f544e4p-26 * r;
+    double a6 = 0x1.1eed8eff8d898p-29 + 0x1.6124613a86d09p-33 * r;
+    double a7 = 0x1.93974a8c07c9dp-37;
+    double b0 = a0 + a1 * r2, b1 = a2 + a3 * r2, b2 = a4 + a5 * r2, b3 = a6 + a7 * r2;
+    double d0 = b0 + b1 * r4, d1 = b2 + b3 * r4;
+    double p = d0 + d1 * r8;
     int ki = (int)k;
     if (ki >= -1021 && ki <= 1023) return p * from_bits((uint64_t)(ki + 1023) << 52);
     if (ki < -1021) return (p * from_bits((uint64_t)(ki + 1000 + 1023) << 52)) * 0x1p-1000;

@@ -97,13 +97,18 @@ RAZ_HD double raz_det_log(double x) {
     }
     const double s = (m - 1.0) / (m + 1.0);
     const double z = s * s;
-    const double c[12] = {0x1.642c8590b2164p-5, 0x1.8618618618618p-5, 0x1.af286bca1af28p-5,
-                          0x1.e1e1e1e1e1e1ep-5, 0x1.1111111111111p-4, 0x1.3b13b13b13b14p-4,
-                          0x1.745d1745d1746p-4, 0x1.c71c71c71c71cp-4, 0x1.2492492492492p-3,
-                          0x1.999999999999ap-3, 0x1.5555555555555p-2, 1.0};
-    double p = 0x1.47ae147ae147bp-5;  // 1/25
-#pragma unroll
-    for (int i = 0; i < 12; ++i) p = p * z + c[i];
+    // p(z) = sum_{k=0..12} z^k / (2k+1), Estrin scheme (fixed association: the oracle mirrors it)
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double a0 = 1.0 + 0x1.5555555555555p-2 * z;
+    const double a1 = 0x1.999999999999ap-3 + 0x1.2492492492492p-3 * z;
+    const double a2 = 0x1.c71c71c71c71cp-4 + 0x1.745d1745d1746p-4 * z;
+    const double a3 = 0x1.3b13b13b13b14p-4 + 0x1.1111111111111p-4 * z;
+    const double a4 = 0x1.e1e1e1e1e1e1ep-5 + 0x1.af286bca1af28p-5 * z;
+    const double a5 = 0x1.8618618618618p-5 + 0x1.642c8590b2164p-5 * z;
+    const double a6 = 0x1.47ae147ae147bp-5;
+    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2, b2 = a4 + a5 * z2;
+    const double d0 = b0 + b1 * z4, d1 = b2 + a6 * z4;
+    const double p = d0 + d1 * z8;
     const double de = (double)e;
     return de * 0x1.62e42fee00000p-1 + (de * 0x1.a39ef35793c76p-33 + (2.0 * s) * p);
 }
@@ -116,14 +121,19 @@ RAZ_HD double raz_det_exp(double x) {
     double k = (double)(long long)v;
     if (k > v) k = k - 1.0;
     const double r = (x - k * 0x1.62e42fee00000p-1) - k * 0x1.a39ef35793c76p-33;
-    const double c[14] = {0x1.6124613a86d09p-33, 0x1.1eed8eff8d898p-29, 0x1.ae64567f544e4p-26,
-                          0x1.27e4fb7789f5cp-22, 0x1.71de3a556c734p-19, 0x1.a01a01a01a01ap-16,
-                          0x1.a01a01a01a01ap-13, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7,
-                          0x1.5555555555555p-5,  0x1.5555555555555p-3,  0.5,
-                          1.0,                   1.0};
-    double p = 0x1.93974a8c07c9dp-37;  // 1/14!
-#pragma unroll
-    for (int i = 0; i < 14; ++i) p = p * r + c[i];
+    // sum_{k=0..14} r^k / k!, Estrin scheme (fixed association: the oracle mirrors it)
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = 1.0 + r;
+    const double a1 = 0.5 + 0x1.5555555555555p-3 * r;
+    const double a2 = 0x1.5555555555555p-5 + 0x1.1111111111111p-7 * r;
+    const double a3 = 0x1.6c16c16c16c17p-10 + 0x1.a01a01a01a01ap-13 * r;
+    const double a4 = 0x1.a01a01a01a01ap-16 + 0x1.71de3a556c734p-19 * r;
+    const double a5 = 0x1.27e4fb7789f5cp-22 + 0x1.ae64567f544e4p-26 * r;
+    const double a6 = 0x1.1eed8eff8d898p-29 + 0x1.6124613a86d09p-33 * r;
+    const double a7 = 0x1.93974a8c07c9dp-37;
+    const double b0 = a0 + a1 * r2, b1 = a2 + a3 * r2, b2 = a4 + a5 * r2, b3 = a6 + a7 * r2;
+    const double d0 = b0 + b1 * r4, d1 = b2 + b3 * r4;
+    const double p = d0 + d1 * r8;
     const int ki = (int)k;
     if (ki >= -1021 && ki <= 1023) return p * raz_bits_to_f64((uint64_t)(ki + 1023) << 52);
     if (ki < -1021) return (p * raz_bits_to_f64((uint64_t)(ki + 2023) << 52)) * 0x1p-1000;
@@ -161,27 +171,32 @@ RAZ_HD float raz_det_tanhf(float x) {
     return x < 0.0f ? -r : r;
 }
 
-// Gamma(alpha, 1) for 0 < alpha <= 1 (all shipped configs use dirichlet_alpha = 0.5,
-// config.py:138): alpha == 1 is an exponential; alpha < 1 is the rejection scheme of numpy's
-// legacy_standard_gamma for shape < 1, driven by (seed, game, DIRICHLET, event, sub, attempt).
-RAZ_HD double raz_gamma_sample(double alpha, uint32_t seed, uint32_t game, uint32_t event,
-                               uint32_t sub) {
+// One attempt `t` of the Gamma(alpha, 1) sampler for 0 < alpha <= 1 (all shipped configs use
+// dirichlet_alpha = 0.5, config.py:138): alpha == 1 is an exponential (always accepted); alpha < 1
+// is the rejection scheme of numpy's legacy_standard_gamma for shape < 1.  Attempt t of sample `sub`
+// of draw `event` uses the Philox block (seed, game, DIRICHLET, event, sub, t), so attempts can be
+// evaluated in any order or in parallel; the sample is the accepted attempt with the smallest t.
+RAZ_HD bool raz_gamma_attempt(double alpha, uint32_t seed, uint32_t game, uint32_t event, uint32_t sub,
+                              uint32_t t, double& X) {
     double d0, d1;
+    raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, sub, t, d0, d1);
     if (alpha == 1.0) {
-        raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, sub, 0, d0, d1);
-        return -raz_det_log(1.0 - d0);
+        X = -raz_det_log(1.0 - d0);
+        return true;
     }
     const double inv = 1.0 / alpha;
-    for (uint32_t t = 0;; ++t) {
-        raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, sub, t, d0, d1);
-        const double U = d0, V = -raz_det_log(1.0 - d1);
-        if (U <= 1.0 - alpha) {
-            const double X = raz_det_pow(U, inv);
-            if (X <= V) return X;
-        } else {
-            const double Y = -raz_det_log((1.0 - U) / alpha);
-            const double X = raz_det_pow(1.0 - alpha + alpha * Y, inv);
-            if (X <= V + Y) return X;
-        }
+    const double U = d0, V = -raz_det_log(1.0 - d1);
+    if (U <= 1.0 - alpha) {
+        X = raz_det_pow(U, inv);
+        return X <= V;
     }
+    const double Y = -raz_det_log((1.0 - U) / alpha);
+    X = raz_det_pow(1.0 - alpha + alpha * Y, inv);
+    return X <= V + Y;
+}
+
+RAZ_HD double raz_gamma_sample(double alpha, uint32_t seed, uint32_t game, uint32_t event, uint32_t sub) {
+    double X;
+    for (uint32_t t = 0;; ++t)
+        if (raz_gamma_attempt(alpha, seed, game, event, sub, t, X)) return X;
 }

@@ -292,9 +292,43 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
     if (is_root && c.noise_eps > 0.0) {  // (1-eps) p + eps Dir(alpha), fresh at every root visit (:415-417)
         const unsigned long long tp = prof_now();
         const uint32_t ev = uni(E.ev_dirichlet[g]);
+        // Gamma(alpha) sample j belongs to the j-th legal square.  Attempts of the rejection
+        // sampler are independent Philox blocks, so lane l evaluates attempt t = l / k of sample
+        // j = l % k (k legal moves, up to 8 attempts per sample per round) and each legal square
+        // takes its sample's first accepted attempt: one evaluation deep instead of the slowest
+        // lane's rejection count.
+        const int k = __popcll(legal);
+        int A = 64 / k;
+        if (A > 8) A = 8;
+        int myt = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) myt += (lane >= i * k) ? 1 : 0;
+        const int myj = lane - myt * k;
         const uint32_t rank = (uint32_t)__popcll(legal & ((1ULL << lane) - 1ULL));
         double gam = 0.0;
-        if (bit) gam = raz_gamma_sample(c.dirichlet_alpha, c.seed, game_id, ev, rank);
+        bool need = bit != 0;
+        for (uint32_t round = 0;; ++round) {
+            double X = 0.0;
+            bool ok = false;
+            if (lane < A * k) ok = raz_gamma_attempt(c.dirichlet_alpha, c.seed, game_id, ev, (uint32_t)myj, round * (uint32_t)A + (uint32_t)myt, X);
+            const unsigned long long am = __ballot(ok);
+            int src = -1;
+            if (need) {
+                for (int t = 0; t < A; ++t) {
+                    const int l = (int)rank + k * t;
+                    if ((am >> l) & 1ULL) {
+                        src = l;
+                        break;
+                    }
+                }
+            }
+            const double got = __shfl(X, src < 0 ? lane : src);
+            if (src >= 0) {
+                gam = got;
+                need = false;
+            }
+            if (__ballot(need) == 0ULL) break;
+        }
         double acc = 0.0;
         for (raz_bb m = legal; m; m &= m - 1) acc += lane_f64(gam, __ffsll((long long)m) - 1);
         const double noise = bit ? gam / acc : 0.0;
@@ -568,10 +602,12 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         return;
     }
     for (;;) {
-        // one round trip: header (broadcast) + the node's four vectors, lane i holding action i
+        // one round trip: header (broadcast) + the node's four vectors, lane i holding action i.
+        // The header carries the position itself, so following a linked edge needs no move
+        // generation: flips and legal moves are computed once, when an edge is first taken.
         unsigned char* p = node_ptr(E, g, node);
         const raz_node_hdr* hp = node_hdr(p);
-        const raz_bb legal = hp->legal;
+        const raz_bb hb = hp->black, hw = hp->white, legal = hp->legal;
         const uint32_t tag = hp->tag;
         const double Wi = node_W(p)[lane];
         const uint32_t Ni = node_N(p)[lane];
@@ -582,34 +618,48 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prof_add(E, g, 6, tl, lane);
         }
+        env.black = uni(hb);
+        env.white = uni(hw);
+        env.np = uni(tag) & 3u;
+        env.legal = uni(legal);
         if (!((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
             kind = RAZ_LEAF_EXPAND;
             leaf_node = node;
-            leaf_legal = uni(legal);
+            leaf_legal = env.legal;
             break;
         }
         if (depth >= 64) {
             if (lane == 0) E.g_error[g] |= RAZ_ERR_PATH_FULL;
             break;
         }
-        const int a = select_action(E, g, Wi, Ni, Pi, uni(legal), env.np, depth == 0, game_id, lane);
+        const int a = select_action(E, g, Wi, Ni, Pi, env.legal, env.np, depth == 0, game_id, lane);
         if (lane == 0) {
             E.path_node[(size_t)g * 64 + depth] = node;
             E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
         }
         ++depth;
-        env_step(env, a);
-        if (env.status) {  // env.done (:226-232)
+        const uint32_t child = lane_u32(Ci, a);
+        if (child & 0x80000000u) {  // edge known to end the game: env.done (:226-232)
+            const uint32_t w = child & 3u;
             kind = RAZ_LEAF_TERMINAL;
-            if (lane == 0) E.leaf_term_v[g] = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
+            if (lane == 0) E.leaf_term_v[g] = w == RAZ_WIN_BLACK ? 1.0f : (w == RAZ_WIN_WHITE ? -1.0f : 0.0f);
             break;
         }
-        const uint32_t child = lane_u32(Ci, a);
         if (child) {
             node = child - 1;
             continue;
         }
-        // first time along this edge: the position may still exist (transposition / mirror write)
+        // first time along this edge: play the move
+        env_step(env, a);
+        if (env.status) {  // env.done (:226-232); remember the result on the edge
+            kind = RAZ_LEAF_TERMINAL;
+            if (lane == 0) {
+                E.leaf_term_v[g] = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
+                node_child(p)[a] = 0x80000000u | env.status;
+            }
+            break;
+        }
+        // the position may already exist (transposition / mirror write)
         const unsigned long long tq = prof_now();
         const Found f = table_find(E, g, env.black, env.white, env.np | (owner << 2), lane);
         prof_add(E, g, 4, tq, lane);
