@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=200, help="steps enqueued between completion polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=64)
+    ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
     ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
     args = ap.parse_args()
 
@@ -102,7 +103,8 @@ def main():
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     cfg = bench_config(args)
     net = DeviceNet(blob, dev)
-    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile)
+    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile,
+                         single_stream=args.no_overlap)
     first_id = rank * args.games
 
     # warm-up on a throw-away start (clocks, caches, code objects), then restart the same games
@@ -167,21 +169,23 @@ def main():
 
     if rank == 0:
         macs = macs_per_position(F, R, V)
-        per_launch_tree_bytes = (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / max(steps, 1)
-        tree_avg_ms = tree_ms / max(timed_steps, 1)
-        net_avg_ms = net_ms / max(timed_steps, 1)
-        leaves_per_launch = leaves / world / max(steps, 1)
+        lps = 1 if (args.no_overlap or args.games < 256) else 2   # kernel launches per step (half batches)
+        per_launch_tree_bytes = (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / max(steps * lps, 1)
+        tree_avg_ms = tree_ms / max(timed_steps * lps, 1)
+        net_avg_ms = net_ms / max(timed_steps * lps, 1)
+        leaves_per_launch = leaves / world / max(steps * lps, 1)
+        net_kernel = "k_net_mfma" if F in (16, 32, 64) else "k_net_wave"
         kern = {
             "k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms, "algorithmic_bytes_per_launch": per_launch_tree_bytes,
                        "achieved": per_launch_tree_bytes / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s"},
-            "k_net_wave": {"bound": "mfma", "avg_ms": net_avg_ms, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
+            net_kernel: {"bound": "mfma", "avg_ms": net_avg_ms, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
                            "achieved": 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12 if net_avg_ms else None,
                            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"},
         }
         for k in kern.values():
             k["frac"] = (k["achieved"] / k["peak"]) if k["achieved"] else None
-        dom = "k_tree" if tree_avg_ms >= net_avg_ms else "k_net_wave"
+        dom = "k_tree" if tree_avg_ms >= net_avg_ms else net_kernel
         roof = dict(kern[dom], kernel=dom, traffic=None)
         roof.pop("avg_ms")
         roof["avg_kernel_ms"] = kern[dom]["avg_ms"]
@@ -194,7 +198,9 @@ def main():
                                    f"{args.sims} sims/move, mini.yml play settings, thinking_loop=1, solver off"
                                    + ("" if args.steps == 0 else f", first {args.steps} steps only"),
                        "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
-                       "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0},
+                       "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0,
+                       "kernel_launches_per_step": lps * 2,
+                       "overlap": "two half batches on two HIP streams" if lps == 2 else "single stream"},
             "sims_per_sec_per_gpu": total_sims / elapsed / world,
             "games_per_hour": finished / elapsed * 3600.0 if args.steps == 0 else None,
             "finished_games": finished, "total_sims": total_sims, "nn_leaves": leaves,

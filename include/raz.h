@@ -145,7 +145,7 @@ typedef struct {
     uint32_t table_slots;                     /* hash slots per game, power of two >= 2*nodes_per_game */
     uint32_t max_plies;                       /* record capacity per game (>= 64) */
     uint32_t seed;
-    uint32_t reserved;
+    uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream (no half-batch overlap) */
 } raz_engine_config;
 
 typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */
@@ -171,11 +171,15 @@ void raz_engine_destroy(raz_engine* e);
 int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
                      uint32_t n_active, raz_stream_t stream);
 /* Enqueue n_steps simulation steps (each: tree kernel = backup + move logic + select, then one
- * net batch over the gathered leaves).  Asynchronous. */
+ * net batch over the gathered leaves).  Asynchronous w.r.t. the host; all work is ordered after
+ * prior work on `stream` and before later work on it.  With n_games >= 256 the batch is stepped as
+ * two half batches on `stream` and an internal second stream so that one half's net kernel
+ * overlaps the other half's tree kernel. */
 int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
-/* Same as raz_engine_step, with HIP events recorded on `stream` around every kernel: the summed
- * durations (ms) of the tree kernel and the net kernel are ADDED to *tree_ms / *net_ms.
- * Synchronises the stream. */
+/* Same as raz_engine_step, with HIP events recorded around every kernel launch on the stream it runs
+ * on: the summed durations (ms) of the tree-kernel launches and of the net-kernel launches are
+ * ADDED to *tree_ms / *net_ms (with n_games >= 256 a step is 2 launches of each kernel, one per
+ * half batch, on two streams).  Synchronises the stream. */
 int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, double* net_ms,
                           raz_stream_t stream);
 /* Synchronise the stream and read the counters. */

@@ -704,8 +704,9 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
 }
 
 // ------------------------------------------------------------------ the tree kernel
-__global__ __launch_bounds__(64) void k_tree(raz_engine_dev E) {
-    const uint32_t g = blockIdx.x;
+__global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
+    if (blockIdx.x >= count) return;
+    const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
     if (lane == 0) E.nn_active[g] = 0;
@@ -872,9 +873,58 @@ struct raz_engine {
     raz_net net;
     void* net_scratch;
     size_t net_scratch_bytes;
-    uint32_t* d_sims;  // staging for sims_per_move (inside the workspace: reuse sims_left? no: own array)
+    uint32_t* d_sims;  // staging for sims_per_move
     bool started;
+    // The batch is stepped as two independent halves on two streams (the caller's and `aux`): while
+    // one half's leaves are in the net kernel (matrix pipe) the other half's tree kernel (scalar /
+    // f64 VALU, latency-bound) runs beside it instead of after it.
+    int halves;
+    hipStream_t aux;
+    hipEvent_t ev_fork, ev_join;
 };
+
+namespace {
+
+struct Half {
+    uint32_t g0, count;
+};
+inline Half half_of(const raz_engine* e, int h) {
+    const uint32_t B = e->dev.B;
+    if (e->halves == 1) return Half{0, B};
+    const uint32_t h0 = (B / 2 + 63) / 64 * 64 < B ? (B / 2 + 63) / 64 * 64 : B / 2;
+    return h == 0 ? Half{0, h0} : Half{h0, B - h0};
+}
+
+// one simulation step of one half on stream s; ev (nullable) = 3 events bracketing the two kernels
+int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
+    const raz_engine_dev& d = e->dev;
+    const Half hf = half_of(e, h);
+    if (ev) hipEventRecord(ev[0], s);
+    hipLaunchKernelGGL(k_tree, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
+    int rc = raz_check_launch("raz_engine_step: k_tree");
+    if (rc != RAZ_OK) return rc;
+    if (ev) hipEventRecord(ev[1], s);
+    rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + hf.g0, (const uint64_t*)d.nn_enemy + hf.g0,
+                         d.nn_active + hf.g0, d.nn_policy + (size_t)hf.g0 * 64, d.nn_value + hf.g0, hf.count,
+                         e->net_scratch, e->net_scratch_bytes, (raz_stream_t)s);
+    if (ev) hipEventRecord(ev[2], s);
+    return rc;
+}
+
+int fork_aux(raz_engine* e, hipStream_t s) {
+    if (e->halves == 1) return RAZ_OK;
+    RAZ_HIP_TRY(hipEventRecord(e->ev_fork, s), "raz_engine_step: fork record");
+    RAZ_HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), "raz_engine_step: fork wait");
+    return RAZ_OK;
+}
+int join_aux(raz_engine* e, hipStream_t s) {
+    if (e->halves == 1) return RAZ_OK;
+    RAZ_HIP_TRY(hipEventRecord(e->ev_join, e->aux), "raz_engine_step: join record");
+    RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), "raz_engine_step: join wait");
+    return RAZ_OK;
+}
+
+}  // namespace
 
 extern "C" size_t raz_engine_workspace_bytes(const raz_engine_config* cfg) {
     if (validate(cfg) != RAZ_OK) return 0;
@@ -902,11 +952,29 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     e->net_scratch = d_net_scratch;
     e->net_scratch_bytes = net_scratch_bytes;
     e->started = false;
+    e->halves = (cfg->n_games >= 256 && !(cfg->reserved & 2u)) ? 2 : 1;  // reserved bit 1: single stream
+    e->aux = nullptr;
+    e->ev_fork = e->ev_join = nullptr;
+    if (e->halves == 2) {
+        hipError_t err = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            delete e;
+            return raz_fail_hip(err, "raz_engine_create: stream/event creation");
+        }
+    }
     *out = e;
     return RAZ_OK;
 }
 
-extern "C" void raz_engine_destroy(raz_engine* e) { delete e; }
+extern "C" void raz_engine_destroy(raz_engine* e) {
+    if (!e) return;
+    if (e->aux) hipStreamDestroy(e->aux);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
+    delete e;
+}
 
 extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
                                 uint32_t n_active, raz_stream_t stream) {
@@ -929,16 +997,13 @@ extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t str
     if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_step: NULL engine");
     if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step: call raz_engine_start first");
     hipStream_t s = (hipStream_t)stream;
-    const raz_engine_dev& d = e->dev;
-    for (uint32_t i = 0; i < n_steps; ++i) {
-        hipLaunchKernelGGL(k_tree, dim3(d.B), dim3(64), 0, s, d);
-        int rc = raz_check_launch("raz_engine_step: k_tree");
-        if (rc != RAZ_OK) return rc;
-        rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own, (const uint64_t*)d.nn_enemy, d.nn_active,
-                             d.nn_policy, d.nn_value, d.B, e->net_scratch, e->net_scratch_bytes, stream);
-        if (rc != RAZ_OK) return rc;
+    int rc = fork_aux(e, s);
+    for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
+        rc = launch_half_step(e, 0, s, nullptr);
+        if (rc == RAZ_OK && e->halves == 2) rc = launch_half_step(e, 1, e->aux, nullptr);
     }
-    return RAZ_OK;
+    const int rj = join_aux(e, s);
+    return rc != RAZ_OK ? rc : rj;
 }
 
 extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
@@ -963,21 +1028,18 @@ extern "C" int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tr
     if (!e || !tree_ms || !net_ms) return raz_fail(RAZ_EINVAL, "raz_engine_step_timed: NULL argument");
     if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step_timed: call raz_engine_start first");
     hipStream_t s = (hipStream_t)stream;
-    const raz_engine_dev& d = e->dev;
-    std::vector<hipEvent_t> ev(3 * (size_t)n_steps);
+    const int H = e->halves;
+    std::vector<hipEvent_t> ev(3 * (size_t)n_steps * H);
     for (auto& x : ev) RAZ_HIP_TRY(hipEventCreate(&x), "raz_engine_step_timed: hipEventCreate");
-    int rc = RAZ_OK;
+    int rc = fork_aux(e, s);
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
-        hipEventRecord(ev[3 * i], s);
-        hipLaunchKernelGGL(k_tree, dim3(d.B), dim3(64), 0, s, d);
-        hipEventRecord(ev[3 * i + 1], s);
-        rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own, (const uint64_t*)d.nn_enemy, d.nn_active,
-                             d.nn_policy, d.nn_value, d.B, e->net_scratch, e->net_scratch_bytes, stream);
-        hipEventRecord(ev[3 * i + 2], s);
+        rc = launch_half_step(e, 0, s, &ev[3 * ((size_t)i * H)]);
+        if (rc == RAZ_OK && H == 2) rc = launch_half_step(e, 1, e->aux, &ev[3 * ((size_t)i * H + 1)]);
     }
+    const int rj = join_aux(e, s);
     hipError_t err = hipStreamSynchronize(s);
-    if (rc == RAZ_OK && err == hipSuccess) {
-        for (uint32_t i = 0; i < n_steps; ++i) {
+    if (rc == RAZ_OK && rj == RAZ_OK && err == hipSuccess) {
+        for (size_t i = 0; i < (size_t)n_steps * H; ++i) {
             float a = 0.f, b = 0.f;
             hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]);
             hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]);
@@ -987,7 +1049,7 @@ extern "C" int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tr
     }
     for (auto& x : ev) hipEventDestroy(x);
     if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step_timed: sync");
-    return rc;
+    return rc != RAZ_OK ? rc : rj;
 }
 
 extern "C" int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* root_n, double* root_w,
