@@ -90,6 +90,7 @@ struct raz_engine_dev {
     // in-flight simulation
     uint8_t *leaf_kind, *leaf_sym, *leaf_np, *depth, *nn_active;
     unsigned long long *leaf_b, *leaf_w, *leaf_legal, *nn_own, *nn_enemy;
+    uint32_t *leaf_tag, *leaf_mirror, *path_mirror /*[B][64]*/;
     uint32_t *leaf_node, *leaf_slot, *root_node;  // existing node of the leaf (or RAZ_NO_NODE) / empty slot found / root node
     float *leaf_term_v, *nn_policy /*[B][64]*/, *nn_value;
     uint32_t* path_node /*[B][64]*/;

@@ -35,9 +35,12 @@ constexpr int kInnerMax = 8;  // max simulations completed per game per launch (
 // ------------------------------------------------------------------ wave helpers
 // Lanes of the game's wave communicate through HBM (lane 0 writes game state, all lanes read it).
 // Each lane is a separate thread to the compiler, so such hand-offs need an acquire/release point
-// or an earlier load may be forwarded past another lane's store.  The workgroup IS one wave
-// (__launch_bounds__(64)), so this is a compiler/memory fence, not a real barrier.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// or an earlier load may be forwarded past another lane's store.  All communicating lanes belong
+// to ONE wavefront, whose vector-memory operations execute in program order, so a wavefront-scope
+// fence is sufficient: it constrains the compiler and emits no instruction (LLVM AMDGPU memory
+// model, gfx942 table: "fence acq_rel - wavefront: none") — in particular no s_waitcnt vmcnt(0)
+// that would stall the wave until its stores are acknowledged.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // Values every lane holds identically (game state, keys, node indices) are moved to SGPRs so the
 // 64-bit board arithmetic and the address math run on the scalar unit.
@@ -81,16 +84,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // exact, order-
 }
 
 // np.sum over float32[64] in numpy's pairwise order: 8 running partials r[j] += a[8i+j], then
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Only needed once per node (at expansion).
-__device__ __forceinline__ float wave_np_sum_f32(float a, int lane) {
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Once per node (at expansion).  The vector goes through
+// 256 B of LDS so that lane j can read its column a[j], a[8+j], ... with eight independent loads.
+__device__ __forceinline__ float wave_np_sum_f32(float a, int lane, float* lds64) {
+    lds64[lane] = a;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();  // single-wave workgroup: orders the LDS writes before the reads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int j = lane & 7;
-    float t = __shfl(a, j);
+    float t = lds64[j];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) t = t + __shfl(a, j + 8 * i);
-    t = t + __shfl_xor(t, 1);
-    t = t + __shfl_xor(t, 2);
-    t = t + __shfl_xor(t, 4);
-    return t;
+    for (int i = 1; i < 8; ++i) t = t + lds64[j + 8 * i];
+    t = t + raz_bits_to_f32(dpp32<RAZ_DPP_XOR1>(__float_as_uint(t)));
+    t = t + raz_bits_to_f32(dpp32<RAZ_DPP_XOR2>(__float_as_uint(t)));
+    t = t + raz_bits_to_f32(dpp32<RAZ_DPP_HALF_MIRROR>(__float_as_uint(t)));
+    return raz_bits_to_f32(lane_u32(__float_as_uint(t), 0));
 }
 
 // argmax with numpy's first-maximum rule; the result is wave-uniform.
@@ -348,57 +356,119 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
 }
 
 // P as select_action_q_and_u will use it: p = P * legal; if np.sum(p) > 0: p = p / np.sum(p)  (float32)
-__device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal, int lane) {
+__device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal, int lane, float* lds64) {
     float p32 = pol * (float)((legal >> lane) & 1ULL);
-    const float sp = wave_np_sum_f32(p32, lane);
+    const float sp = wave_np_sum_f32(p32, lane, lds64);
     if (sp > 0.0f) p32 = p32 / sp;
     return p32;
 }
 
 // ------------------------------------------------------------------ backup of the previous leaf
-__device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, int lane) {
+// Allocate node `idx` (the caller tracks the pool counter) for key (b, w, np, owner) in the EMPTY
+// table slot `slot`, with prior P already known.  Pure stores: nothing is read back.
+__device__ __forceinline__ void node_init(const raz_engine_dev& E, uint32_t g, uint32_t idx, uint32_t slot,
+                                          raz_bb b, raz_bb w, uint32_t tag, raz_bb legal, uint32_t mirror,
+                                          float prior, int lane) {
+    unsigned char* p = node_ptr(E, g, idx);
+    node_W(p)[lane] = 0.0;
+    node_N(p)[lane] = 0u;
+    node_P(p)[lane] = prior;
+    node_child(p)[lane] = 0u;
+    if (lane == 0) {
+        raz_node_hdr h;
+        h.black = b;
+        h.white = w;
+        h.legal = legal;
+        h.tag = tag;
+        h.mirror = mirror;
+        *node_hdr(p) = h;
+        raz_slot* s = E.table + (size_t)g * E.H + slot;
+        s->black = b;
+        s->white = w;
+        s->idx_tag = (idx << 8) | RAZ_SLOT_USED | (tag & RAZ_SLOT_KEYMASK);
+    }
+}
+
+// Everything the backup needs was written by select_leaf (leaf_* and path_* arrays), so all loads
+// are issued up front in ONE round trip; node creation is pure stores; the only other dependent
+// memory access is the table probe for the mirror key of a brand-new position.
+__device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, int lane, float* lds64) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t kind = uni((uint32_t)E.leaf_kind[g]);
+    // ---- load phase (independent loads)
+    const uint32_t kind_v = E.leaf_kind[g];
+    const uint32_t depth_v = E.depth[g];
+    const uint32_t np_v = E.leaf_np[g], sym_v = E.leaf_sym[g];
+    const raz_bb lg_v = E.leaf_legal[g], kb_v = E.leaf_b[g], kw_v = E.leaf_w[g];
+    const uint32_t lnode_v = E.leaf_node[g], lslot_v = E.leaf_slot[g], ltag_v = E.leaf_tag[g], lmir_v = E.leaf_mirror[g];
+    const uint32_t used_v = E.pool_used[g];
+    const float val_v = E.nn_value[g], term_v = E.leaf_term_v[g];
+    const float* polrow = E.nn_policy + (size_t)g * 64;
+    // every level of the path is an independent (node, action) cell: lane d handles level d
+    const uint32_t my_node = E.path_node[(size_t)g * 64 + lane];
+    const uint32_t my_mirror = E.path_mirror[(size_t)g * 64 + lane];
+    const uint32_t my_pa = E.path_act[(size_t)g * 64 + lane];
+    const uint32_t kind = uni(kind_v);
     if (kind == RAZ_LEAF_NONE) return;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const int depth = uni((int)E.depth[g]);
-    // every level of the path is an independent (node, action) cell: lane d handles level d
-    uint32_t my_node = 0, my_pa = 0;
-    if (lane < depth) {
-        my_node = E.path_node[(size_t)g * 64 + lane];
-        my_pa = E.path_act[(size_t)g * 64 + lane];
-    }
+    const int depth = uni((int)depth_v);
     double leaf_v;
     const unsigned long long te = prof_now();
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-327), second half
-        const uint32_t np = uni((uint32_t)E.leaf_np[g]);
-        const raz_bb lg = uni(E.leaf_legal[g]);
-        leaf_v = (double)E.nn_value[g];  // float(leaf_v)
+        const uint32_t np = uni(np_v), sym = uni(sym_v);
+        const raz_bb lg = uni(lg_v), kb = uni(kb_v), kw = uni(kw_v);
+        leaf_v = (double)val_v;          // float(leaf_v)
         if (np == 2) leaf_v = -leaf_v;   // :259-262
-        const uint32_t sym = uni((uint32_t)E.leaf_sym[g]);
         // the net saw T(board); its policy q is over T-squares, so p[s] = q[T(s)]
-        const float pol = E.nn_policy[(size_t)g * 64 + bb_d4_square(lane, (sym >> 2) & 1, sym & 3)];
-        const float pn = masked_normalised_prior(pol, lg, lane);
-        uint32_t node = uni(E.leaf_node[g]);
+        const float pol = polrow[bb_d4_square(lane, (sym >> 2) & 1, sym & 3)];
+        const float pn = masked_normalised_prior(pol, lg, lane, lds64);
+        uint32_t used = uni(used_v);
+        uint32_t node = uni(lnode_v), mirror = RAZ_NO_NODE;
+        const uint32_t tagkey = np | (owner << 2);
+        bool ok = true;
         if (node == RAZ_NO_NODE) {  // first arrival at this position: create it in the slot select found
-            node = node_create_at(E, g, uni(E.leaf_slot[g]), uni(E.leaf_b[g]), uni(E.leaf_w[g]), np, owner, lg, lane);
-            if (node != RAZ_NO_NODE && depth > 0) {  // link the parent's edge to it
-                const uint32_t parent = uni(E.path_node[(size_t)g * 64 + depth - 1]);
-                const uint32_t pa = uni((uint32_t)E.path_act[(size_t)g * 64 + depth - 1]);
-                if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
+            const uint32_t slot = uni(lslot_v);
+            if (slot == 0xffffffffu || used >= E.C) {
+                if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+                ok = false;
+            } else {
+                node = used++;
+                node_init(E, g, node, slot, kb, kw, tagkey | (16u << pl), lg, RAZ_NO_NODE, pn, lane);
+                if (depth > 0) {  // link the parent's edge to it
+                    const uint32_t parent = lane_u32(my_node, depth - 1);
+                    const uint32_t pa = lane_u32(my_pa, depth - 1);
+                    if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
+                }
             }
-        }
-        if (node != RAZ_NO_NODE) {
+        } else {  // existing, not yet expanded by this player: store the prior, set the flag
             unsigned char* p = node_ptr(E, g, node);
             node_P(p)[lane] = pn;
-            if (lane == 0) node_hdr(p)->tag |= (16u << pl);
-            if (c.mirror_updates) {
-                const uint32_t m = ensure_mirror(E, g, node, owner, lane);
-                if (m != RAZ_NO_NODE) node_P(node_ptr(E, g, m))[lane] = pn;
+            if (lane == 0) node_hdr(p)->tag = uni(ltag_v) | (16u << pl);
+            mirror = uni(lmir_v);
+        }
+        if (ok && c.mirror_updates) {  // var_p[another_side_key] = leaf_p (:324)
+            if (mirror == RAZ_NO_NODE) {
+                wave_sync();
+                const Found f = table_find(E, g, kw, kb, (3 - np) | (owner << 2), lane);
+                if (f.found) {
+                    mirror = f.node;
+                    node_P(node_ptr(E, g, mirror))[lane] = pn;
+                } else if (f.slot == 0xffffffffu || used >= E.C) {
+                    if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+                } else {
+                    mirror = used++;
+                    node_init(E, g, mirror, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, pn, lane);
+                }
+                if (mirror != RAZ_NO_NODE && lane == 0) {
+                    node_hdr(node_ptr(E, g, node))->mirror = mirror;
+                    node_hdr(node_ptr(E, g, mirror))->mirror = node;
+                }
+            } else {
+                node_P(node_ptr(E, g, mirror))[lane] = pn;
             }
         }
+        if (lane == 0 && used != uni(used_v)) E.pool_used[g] = used;
     } else {
-        leaf_v = (double)E.leaf_term_v[g];
+        leaf_v = (double)term_v;
     }
     prof_add(E, g, 7, te, lane);
     if (lane < depth) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
@@ -406,15 +476,17 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
         const uint32_t a = my_pa & 63u, npd = my_pa >> 6;
         const double vlw = npd == 1 ? vl : -vl;
         unsigned char* p = node_ptr(E, g, my_node);
-        uint32_t m = RAZ_NO_NODE;
-        if (c.mirror_updates) m = node_hdr(p)->mirror;
-        node_N(p)[a] += 1u;
+        const uint32_t m = c.mirror_updates ? my_mirror : RAZ_NO_NODE;
+        unsigned char* q = node_ptr(E, g, m == RAZ_NO_NODE ? my_node : m);
+        const uint32_t n0 = node_N(p)[a];
         const double w0 = node_W(p)[a];
+        const uint32_t n1 = node_N(q)[a];
+        const double w1 = node_W(q)[a];
+        node_N(p)[a] = n0 + 1u;
         node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
         if (m != RAZ_NO_NODE) {  // another_side_counter_key (:279-280); exists since the node's expansion
-            unsigned char* q = node_ptr(E, g, m);
-            node_N(q)[a] += 1u;
-            node_W(q)[a] = node_W(q)[a] - leaf_v;
+            node_N(q)[a] = n1 + 1u;
+            node_W(q)[a] = w1 - leaf_v;
         }
     }
     if (lane == 0) {
@@ -595,7 +667,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
     int depth = 0;
     uint32_t kind = RAZ_LEAF_NONE;
     uint32_t node = uni(E.root_node[g]);  // always exists (begin_move)
-    uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu;
+    uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu, leaf_tag = 0, leaf_mirror = RAZ_NO_NODE;
     raz_bb leaf_legal = 0;
     if (node == RAZ_NO_NODE) {
         if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
@@ -608,7 +680,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         unsigned char* p = node_ptr(E, g, node);
         const raz_node_hdr* hp = node_hdr(p);
         const raz_bb hb = hp->black, hw = hp->white, legal = hp->legal;
-        const uint32_t tag = hp->tag;
+        const uint32_t tag = hp->tag, hmirror = hp->mirror;
         const double Wi = node_W(p)[lane];
         const uint32_t Ni = node_N(p)[lane];
         const float Pi = node_P(p)[lane];
@@ -626,6 +698,8 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             kind = RAZ_LEAF_EXPAND;
             leaf_node = node;
             leaf_legal = env.legal;
+            leaf_tag = uni(tag);
+            leaf_mirror = uni(hmirror);
             break;
         }
         if (depth >= 64) {
@@ -635,6 +709,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         const int a = select_action(E, g, Wi, Ni, Pi, env.legal, env.np, depth == 0, game_id, lane);
         if (lane == 0) {
             E.path_node[(size_t)g * 64 + depth] = node;
+            E.path_mirror[(size_t)g * 64 + depth] = hmirror;
             E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
         }
         ++depth;
@@ -687,6 +762,8 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             E.leaf_legal[g] = leaf_legal;
             E.leaf_node[g] = leaf_node;
             E.leaf_slot[g] = leaf_slot;
+            E.leaf_tag[g] = leaf_tag;
+            E.leaf_mirror[g] = leaf_mirror;
             E.leaf_np[g] = (uint8_t)env.np;
             E.leaf_sym[g] = (uint8_t)(flip * 4 + rot);
             E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
@@ -706,6 +783,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
 // ------------------------------------------------------------------ the tree kernel
 __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
+    __shared__ float lds64[64];
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
@@ -718,7 +796,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
         unsigned long long t0 = prof_now();
         if (it == 0 && RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
         if (E.leaf_kind[g] != RAZ_LEAF_NONE) {
-            backup_leaf(E, g, (uint32_t)E.g_player[g] - 1, lane);
+            backup_leaf(E, g, (uint32_t)E.g_player[g] - 1, lane, lds64);
         }
         wave_sync();
         prof_add(E, g, 0, t0, lane);
@@ -838,6 +916,8 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.leaf_b = (unsigned long long*)take(B * 8); d.leaf_w = (unsigned long long*)take(B * 8);
     d.leaf_legal = (unsigned long long*)take(B * 8);
     d.leaf_node = (uint32_t*)take(B * 4); d.leaf_slot = (uint32_t*)take(B * 4); d.root_node = (uint32_t*)take(B * 4);
+    d.leaf_tag = (uint32_t*)take(B * 4); d.leaf_mirror = (uint32_t*)take(B * 4);
+    d.path_mirror = (uint32_t*)take(B * 64 * 4);
     d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
     d.leaf_term_v = (float*)take(B * 4); d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
     d.path_node = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
