@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=200, help="steps enqueued between completion polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=64)
+    ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = sized for whole games)")
     ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
     ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
     args = ap.parse_args()
@@ -104,6 +105,7 @@ def main():
     cfg = bench_config(args)
     net = DeviceNet(blob, dev)
     eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile,
+                         nodes_per_game=args.nodes_per_game or None,
                          single_stream=args.no_overlap)
     first_id = rank * args.games
 

@@ -10,8 +10,11 @@
  * Keras graph to 1e-5 (tests/test_net_oracle.py).
  *
  * "raznet-forward-v1":
- *   conv3x3 (same padding):  acc = b[oc]; for tap = ky*3+kx in 0..8: for ic in 0..Cin-1:
+ *   conv3x3 (same padding):  acc = b[oc]; for c in chunks of 16 input channels (one chunk if Cin <= 16):
+ *                              for tap = ky*3+kx in 0..8: for ic in chunk c:
  *                                acc = fmaf(x[ic][y+ky-1][x+kx-1] (0 off-board), w[oc][ic][ky][kx], acc)
+ *                            (chunk-major so a GEMM kernel can stage 16 channels of activations in LDS
+ *                             and reuse them for all nine taps; identical to tap-major for Cin <= 16)
  *   stem / first conv of a block: out = max(acc, 0);  second conv of a block: out = max(acc + skip, 0)
  *   conv1x1 heads:           acc = b[oc]; for ic: acc = fmaf(x[ic][sq], w[oc][ic], acc); out = max(acc,0)
  *   dense:                   acc = b[o];  for j:  acc = fmaf(h[j], W[j][o], acc)
@@ -55,9 +58,10 @@ static void conv3x3(const float* in, int cin, const float* w, const float* b, in
     for (int oc = 0; oc < cout; ++oc) {
         float acc[64];
         for (int s = 0; s < 64; ++s) acc[s] = b[oc];
+        for (int c0 = 0; c0 < cin; c0 += 16)
         for (int tap = 0; tap < 9; ++tap) {
             int ky = tap / 3, kx = tap % 3;
-            for (int ic = 0; ic < cin; ++ic) {
+            for (int ic = c0; ic < cin && ic < c0 + 16; ++ic) {
                 float wv = w[((size_t)oc * cin + ic) * 9 + tap];
                 const float* p = pad + ic * 100 + ky * 10 + kx;
                 for (int y = 0; y < 8; ++y)

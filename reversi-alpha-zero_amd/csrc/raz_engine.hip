@@ -984,9 +984,12 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
     int rc = raz_check_launch("raz_engine_step: k_tree");
     if (rc != RAZ_OK) return rc;
     if (ev) hipEventRecord(ev[1], s);
+    // the halves run concurrently: each gets its own slice of the net scratch (size is linear in n)
+    const size_t soff = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, hf.g0);
+    const size_t sbytes = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, hf.count);
     rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + hf.g0, (const uint64_t*)d.nn_enemy + hf.g0,
                          d.nn_active + hf.g0, d.nn_policy + (size_t)hf.g0 * 64, d.nn_value + hf.g0, hf.count,
-                         e->net_scratch, e->net_scratch_bytes, (raz_stream_t)s);
+                         e->net_scratch ? (unsigned char*)e->net_scratch + soff : nullptr, sbytes, (raz_stream_t)s);
     if (ev) hipEventRecord(ev[2], s);
     return rc;
 }

@@ -26,6 +26,10 @@
 #include "raz_net_layout.h"
 
 bool raz_net_mfma_supported(int F, int V);
+size_t raz_net_wide_scratch_bytes(int F, size_t n);
+int raz_net_forward_wide(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
+                         const uint8_t* active, float* policy, float* value, size_t n, void* scratch,
+                         size_t scratch_bytes, hipStream_t s);
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s);
 
@@ -94,23 +98,26 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
 #pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = bias[ocb * 16 + o];
             const float* wb = w + (size_t)ocb * 9 * cin * 16;
+            // k order of raznet-forward-v1: 16-channel chunks, then tap, then channel within the chunk
+            for (int c0 = 0; c0 < cin; c0 += 16) {
 #pragma unroll 1
-            for (int t = 0; t < 9; ++t) {
-                const float* wt = wb + (size_t)t * cin * 16;
-                if (l == 0) {
-                    const float x0 = ok[t] ? (float)((bo >> nbr[t]) & 1) : 0.0f;
-                    const float x1 = ok[t] ? (float)((be >> nbr[t]) & 1) : 0.0f;
+                for (int t = 0; t < 9; ++t) {
+                    const float* wt = wb + (size_t)t * cin * 16;
+                    if (l == 0) {
+                        const float x0 = ok[t] ? (float)((bo >> nbr[t]) & 1) : 0.0f;
+                        const float x1 = ok[t] ? (float)((be >> nbr[t]) & 1) : 0.0f;
 #pragma unroll
-                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(x0, wt[o], acc[o]);
+                        for (int o = 0; o < 16; ++o) acc[o] = fmaf(x0, wt[o], acc[o]);
 #pragma unroll
-                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(x1, wt[16 + o], acc[o]);
-                } else {
+                        for (int o = 0; o < 16; ++o) acc[o] = fmaf(x1, wt[16 + o], acc[o]);
+                    } else {
 #pragma unroll 4
-                    for (int ic = 0; ic < cin; ++ic) {
-                        const float xv = ok[t] ? in[ic * 64 + nbr[t]] : 0.0f;
-                        const float* w16 = wt + ic * 16;
+                        for (int ic = c0; ic < c0 + 16; ++ic) {
+                            const float xv = ok[t] ? in[ic * 64 + nbr[t]] : 0.0f;
+                            const float* w16 = wt + ic * 16;
 #pragma unroll
-                        for (int o = 0; o < 16; ++o) acc[o] = fmaf(xv, w16[o], acc[o]);
+                            for (int o = 0; o < 16; ++o) acc[o] = fmaf(xv, w16[o], acc[o]);
+                        }
                     }
                 }
             }
@@ -195,6 +202,10 @@ static bool use_lds(int F, int V) { return lds_bytes_for(F, V, true) <= 64 * 102
 
 extern "C" size_t raz_net_scratch_bytes(int filters, int value_fc, size_t n) {
     if (raz_net_mfma_supported(filters, value_fc) || use_lds(filters, value_fc)) return 0;
+    if (wide_supported(filters)) {  // the larger of the two paths (reserved==1 forces the VALU kernel)
+        const size_t a = raz_net_wide_scratch_bytes(filters, n), b = n * 3 * (size_t)filters * 64 * sizeof(float);
+        return a > b ? a : b;
+    }
     return n * 3 * (size_t)filters * 64 * sizeof(float);
 }
 
@@ -241,12 +252,31 @@ extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, v
                         const int k = 4 * st + (ln >> 4), oc = nt * 16 + (ln & 15);
                         float v = 0.0f;
                         if (k < 9 * cin) {
-                            const int t = k / cin, ic = k % cin;
+                            int t, ic;
+                            if (cin <= 16) { t = k / cin; ic = k % cin; }
+                            else { const int c = k / 144, r = k % 144; t = r / 16; ic = c * 16 + r % 16; }
                             v = lsrc[((size_t)oc * cin + ic) * 9 + t];
                         }
                         w[((size_t)nt * ks + st) * 64 + ln] = v;
                     }
             lsrc += (size_t)F * cin * 9 + F;
+        }
+    }
+    if (wide_supported(F)) {  // region 3: A operands of v_mfma_f32_32x32x2_f32 per (layer, chunk, 64-channel tile)
+        const float* lsrc = (const float*)((const char*)blob + 32) + ((size_t)F * 18 + F);
+        for (int l = 1; l < 2 * R + 1; ++l) {
+            for (int c = 0; c < F / 16; ++c)
+                for (int nt = 0; nt < F / 64; ++nt) {
+                    float* w = dst.data() + wide_tile_off(F, R, V, l, c, nt);
+                    for (int st = 0; st < 72; ++st)
+                        for (int mt = 0; mt < 2; ++mt)
+                            for (int ln = 0; ln < 64; ++ln) {
+                                const int kk = 2 * st + (ln >> 5), t = kk / 16, ic = c * 16 + kk % 16;
+                                const int oc = nt * 64 + mt * 32 + (ln & 31);
+                                w[(st * 2 + mt) * 64 + ln] = lsrc[((size_t)oc * F + ic) * 9 + t];
+                            }
+                }
+            lsrc += (size_t)F * F * 9 + F;
         }
     }
     RAZ_HIP_TRY(hipMemcpyAsync(d_weights, dst.data(), need, hipMemcpyHostToDevice, (hipStream_t)stream),
@@ -270,6 +300,9 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     if (raz_net_mfma_supported(F, V) && net->reserved != 1)  // reserved == 1: force the VALU kernel (tests)
         return raz_net_forward_mfma((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
                                     value, n, (hipStream_t)stream);
+    if (wide_supported(F) && net->reserved != 1)
+        return raz_net_forward_wide((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
+                                    value, n, scratch, scratch_bytes, (hipStream_t)stream);
     NetDims d = {F, net->res_layers, V};
     const bool lds = use_lds(F, V);
     if (!lds) {

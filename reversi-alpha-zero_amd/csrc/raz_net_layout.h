@@ -3,8 +3,8 @@
 //   then the heads exactly as in the blob.
 // Region 2 ("mfma" layout, used by k_net_mfma) at mfma_off(): per conv layer, per 16-channel N tile,
 //   per k-step s, 64 floats: the B operand of v_mfma_f32_16x16x4_f32 for lane l, i.e. the weight of
-//   out-channel nt*16 + (l&15) at reduction index k = 4s + (l>>4), where k runs tap-major then input
-//   channel (k = tap*Cin + ic) — the order raznet-forward-v1 fixes; k beyond 9*Cin (layer 0) is 0.
+//   out-channel nt*16 + (l&15) at reduction index k = 4s + (l>>4), where k enumerates (16-channel chunk,
+//   tap, channel in chunk) — the order raznet-forward-v1 fixes; k beyond 9*Cin (layer 0) is 0.
 #pragma once
 #include <stddef.h>
 
@@ -24,4 +24,16 @@ RAZ_HD_LAYOUT size_t mfma_off(int F, int R, int V) { return (wave_floats(F, R, V
 RAZ_HD_LAYOUT size_t mfma_layer_off(int F, int R, int V, int l) {
     return mfma_off(F, R, V) + (l == 0 ? 0 : mfma_layer_floats(F, 0) + (size_t)(l - 1) * mfma_layer_floats(F, 1));
 }
-RAZ_HD_LAYOUT size_t total_floats(int F, int R, int V) { return mfma_layer_off(F, R, V, 2 * R + 1); }
+// Region 3 ("wide" layout, used by k_conv3x3_wide, F % 64 == 0 and F >= 128): per conv layer l >= 1,
+//   per 16-channel input chunk c, per 64-channel output tile nt: the A operands of
+//   v_mfma_f32_32x32x2_f32 for the chunk's 72 k-steps: [s 72][mt 2][64 lanes], lane l holding the
+//   weight of out-channel nt*64 + mt*32 + (l&31) at k = 2s + (l>>5) within the chunk (k = tap*16 + ic).
+RAZ_HD_LAYOUT bool wide_supported(int F) { return F >= 128 && F % 64 == 0; }
+RAZ_HD_LAYOUT size_t wide_off(int F, int R, int V) { return (mfma_layer_off(F, R, V, 2 * R + 1) + 63) / 64 * 64; }
+RAZ_HD_LAYOUT size_t wide_layer_floats(int F) { return (size_t)F * F * 9; }
+RAZ_HD_LAYOUT size_t wide_tile_off(int F, int R, int V, int l, int c, int nt) {  // l >= 1
+    return wide_off(F, R, V) + (size_t)(l - 1) * wide_layer_floats(F) + ((size_t)c * (F / 64) + nt) * (72 * 128);
+}
+RAZ_HD_LAYOUT size_t total_floats(int F, int R, int V) {
+    return wide_supported(F) ? wide_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F) : mfma_layer_off(F, R, V, 2 * R + 1);
+}

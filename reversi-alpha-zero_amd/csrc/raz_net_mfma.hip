@@ -59,16 +59,20 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const f
             }
         } else {
             const float* base = in + kk * PS + pidx(i);  // M tile mt adds 24 floats (two board rows)
+            // k order of raznet-forward-v1: 16-channel chunks, then tap, then channel within the chunk
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int c = 0; c < CIN / 16; ++c) {
 #pragma unroll
-                for (int icg = 0; icg < CIN / 4; ++icg) {
-                    const int s = t * (CIN / 4) + icg;
-                    const int off = icg * 4 * PS + (t / 3 - 1) * 12 + (t % 3 - 1);
+                for (int t = 0; t < 9; ++t) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const float a = base[off + mt * 24];
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[s], acc[mt], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) {
+                        const int s = (c * 9 + t) * 4 + q;
+                        const int off = (c * 16 + q * 4) * PS + (t / 3 - 1) * 12 + (t % 3 - 1);
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const float a = base[off + mt * 24];
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[s], acc[mt], 0, 0, 0);
+                        }
                     }
                 }
             }

@@ -42,7 +42,22 @@ def test_net_mfma_kernel_equals_valu_kernel(shape):
     assert torch.equal(va.view(torch.int32), vb.view(torch.int32))
 
 
-@pytest.mark.parametrize("shape,n", [((16, 1, 16), 300), ((32, 2, 48), 40), ((64, 1, 32), 10), ((128, 1, 256), 3)])
+@pytest.mark.parametrize("shape,n", [((128, 1, 64), 37), ((256, 2, 256), 21)])
+def test_net_wide_kernel_equals_valu_kernel(shape, n):
+    """k_conv3x3_wide (implicit GEMM on v_mfma_f32_32x32x2) == k_net_wave (VALU) bit for bit, ragged n."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    blob = ReversiNet(*shape).keras_init_(8).randomize_bn_(9).to_blob()
+    own, enemy = _positions(n, 5)
+    o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
+    pa, va = DeviceNet(blob, DEV).predict_bitboards(o, e)
+    pb, vb = DeviceNet(blob, DEV, force_valu_kernel=True).predict_bitboards(o, e)
+    assert torch.equal(pa.view(torch.int32), pb.view(torch.int32))
+    assert torch.equal(va.view(torch.int32), vb.view(torch.int32))
+
+
+@pytest.mark.parametrize("shape,n", [((16, 1, 16), 300), ((32, 2, 48), 40), ((64, 1, 32), 10), ((128, 1, 256), 3),
+                                     ((256, 1, 64), 2)])
 def test_net_kernel_bitwise_vs_oracle_and_torch(shape, n):
     """HIP forward == oracle forward bit for bit; both within 1e-5 of the fp32 torch graph."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""tools/bench_net.py — MFMA roofline of the net forward alone (the "conv batch" leg of the north
+star): one raz_net_forward over n positions, repeated; prints one JSON line.
+    python tools/bench_net.py [--net ch5|mini] [--n 8192] [--iters 5]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--net", default="ch5", choices=["mini", "ch5"])
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    F, R, V = {"mini": (16, 1, 16), "ch5": (256, 10, 256)}[args.net]
+    dev = torch.device("cuda:0")
+    net = DeviceNet(ReversiNet(F, R, V).keras_init_(0).to_blob(), dev)
+    rng = np.random.default_rng(0)
+    own = rng.integers(0, 2**64, size=args.n, dtype=np.uint64)
+    enemy = rng.integers(0, 2**64, size=args.n, dtype=np.uint64) & ~own
+    o, e = torch.from_numpy(own.view(np.int64)).to(dev), torch.from_numpy(enemy.view(np.int64)).to(dev)
+    net.predict_bitboards(o, e)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+    ev[0].record()
+    for i in range(args.iters):
+        net.predict_bitboards(o, e)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters)]
+    flops = 2.0 * macs_per_position(F, R, V) * args.n
+    best = min(ms)
+    print(json.dumps({"net": args.net, "filters": F, "res_layers": R, "positions": args.n, "ms_per_forward": ms,
+                      "tflops_best": flops / (best * 1e-3) / 1e12, "peak_tflops_fp32_mfma": 157.3,
+                      "frac_of_peak": flops / (best * 1e-3) / 1e12 / 157.3, "flop_per_forward": flops}))
+
+
+if __name__ == "__main__":
+    main()
