@@ -176,7 +176,7 @@ def main():
         tree_avg_ms = tree_ms / max(timed_steps * lps, 1)
         net_avg_ms = net_ms / max(timed_steps * lps, 1)
         leaves_per_launch = leaves / world / max(steps * lps, 1)
-        net_kernel = "k_net_mfma" if F in (16, 32, 64) else "k_net_wave"
+        net_kernel = "k_net_mfma" if F in (16, 32, 64) else ("k_conv3x3_wide+heads" if F >= 128 and F % 64 == 0 else "k_net_wave")
         kern = {
             "k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms, "algorithmic_bytes_per_launch": per_launch_tree_bytes,
                        "achieved": per_launch_tree_bytes / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None,
