@@ -156,6 +156,10 @@ def load_ext():
         for n in ("orc_det_expf", "orc_det_tanhf"):
             getattr(lib, n).argtypes = [c_float]
             getattr(lib, n).restype = c_float
+        lib.orc_det_cos2.argtypes = [c_double]
+        lib.orc_det_cos2.restype = c_double
+        lib.orc_dirichlet_gammas.argtypes = [c_double, c_int, c_uint32, c_uint32, c_uint32, c_void_p]
+        lib.orc_dirichlet_gammas.restype = None
         lib.orc_gamma_sample.argtypes = [c_double] + [c_uint32] * 4
         lib.orc_gamma_sample.restype = c_double
         lib.orc_dirichlet_noise_of_mask.argtypes = [c_uint64, c_double, c_uint32, c_uint32, c_uint32, POINTER(c_double * 64)]

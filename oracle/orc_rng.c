@@ -179,21 +179,53 @@ double orc_gamma_sample(double alpha, uint32_t seed, uint32_t game, uint32_t eve
     }
 }
 
+/* cos^2(2 pi u), u in [0,1): exact octant reduction + 9-term Taylor sine on [0, pi/4] (Estrin). */
+double orc_det_cos2(double u) {
+    double w = 4.0 * u;
+    int q = (int)w;
+    double f = w - (double)q;
+    int swap = f > 0.5;
+    double gq = swap ? 1.0 - f : f;
+    double x = gq * 0x1.921fb54442d18p+0;
+    double z = x * x, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    double a0 = 1.0 + -0x1.5555555555555p-3 * z;
+    double a1 = 0x1.1111111111111p-7 + -0x1.a01a01a01a01ap-13 * z;
+    double a2 = 0x1.71de3a556c734p-19 + -0x1.ae64567f544e4p-26 * z;
+    double a3 = 0x1.6124613a86d09p-33 + -0x1.ae7f3e733b81fp-41 * z;
+    double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2;
+    double p = (b0 + b1 * z4) + 0x1.952c77030ad4ap-49 * z8;
+    double sn = x * p, s2 = sn * sn;
+    int use_s2 = ((q & 1) != 0) != swap;
+    return use_s2 ? s2 : 1.0 - s2;
+}
+
+/* The k Gamma(alpha,1) variates of one Dirichlet draw (raz-rng-v1 DIRICHLET).
+ * alpha == 0.5 (config.py:138, every shipped config): Box-Muller pairs — block m gives
+ * g[2m] = E cos^2(2 pi d1), g[2m+1] = E sin^2(2 pi d1) with E = -log(1 - d0) (Z^2/2 ~ Gamma(1/2)).
+ * Other alpha in (0,1]: orc_gamma_sample (exponential / numpy-legacy rejection). */
+void orc_dirichlet_gammas(double alpha, int k, uint32_t seed, uint32_t game, uint32_t event, double* g) {
+    if (alpha == 0.5) {
+        for (int m = 0; 2 * m < k; ++m) {
+            double d[2];
+            orc_rng_pair(seed, game, 2, event, (uint32_t)m, 0, d);
+            double E = -orc_det_log(1.0 - d[0]);
+            double c2 = orc_det_cos2(d[1]);
+            g[2 * m] = E * c2;
+            if (2 * m + 1 < k) g[2 * m + 1] = E * (1.0 - c2);
+        }
+        return;
+    }
+    for (int j = 0; j < k; ++j) g[j] = orc_gamma_sample(alpha, seed, game, event, (uint32_t)j);
+}
+
 /* dirichlet_noise_of_mask (lib/bitboard.py:162-171): noise[i] for the set bits of `mask` in
  * ascending order, 0 elsewhere.  Sum of the gammas is accumulated in ascending order. */
 void orc_dirichlet_noise_of_mask(u64 mask, double alpha, uint32_t seed, uint32_t game,
                                  uint32_t event, double out[64]) {
     double g[64], acc = 0.0;
-    int k = 0;
-    for (int i = 0; i < 64; ++i) {
-        out[i] = 0.0;
-        if (mask >> i & 1) {
-            g[k] = orc_gamma_sample(alpha, seed, game, event, (uint32_t)k);
-            acc += g[k];
-            ++k;
-        }
-    }
+    int k = orc_bit_count(mask);
+    orc_dirichlet_gammas(alpha, k, seed, game, event, g);
+    for (int j = 0; j < k; ++j) acc += g[j];
     k = 0;
-    for (int i = 0; i < 64; ++i)
-        if (mask >> i & 1) out[i] = g[k++] / acc;
+    for (int i = 0; i < 64; ++i) out[i] = (mask >> i & 1) ? g[k++] / acc : 0.0;
 }

@@ -13,6 +13,7 @@ names, no reference file is edited — SURVEY.md §7 hard part 2):
     numpy.random.random                     (self_play.py:182)             -> GAME d1
 """
 import contextlib
+import ctypes
 import json
 import os
 import tempfile
@@ -51,7 +52,10 @@ class GameStream:
         lib = O.load_ext()
         ev = self.ev_dirichlet
         self.ev_dirichlet += 1
-        g = [lib.orc_gamma_sample(float(al), self.seed, self.game_id, ev, j) for j, al in enumerate(alpha)]
+        alpha = list(alpha)
+        assert all(a == alpha[0] for a in alpha)
+        g = (ctypes.c_double * len(alpha))()
+        lib.orc_dirichlet_gammas(float(alpha[0]), len(alpha), self.seed, self.game_id, ev, g)
         acc = 0.0
         for x in g:
             acc += x

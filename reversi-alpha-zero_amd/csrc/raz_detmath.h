@@ -171,8 +171,43 @@ RAZ_HD float raz_det_tanhf(float x) {
     return x < 0.0f ? -r : r;
 }
 
-// One attempt `t` of the Gamma(alpha, 1) sampler for 0 < alpha <= 1 (all shipped configs use
-// dirichlet_alpha = 0.5, config.py:138): alpha == 1 is an exponential (always accepted); alpha < 1
+// cos^2(2 pi u) for u in [0,1): exact octant reduction (u is a dyadic rational), then the Taylor
+// series of sin on [0, pi/4] (9 terms, Estrin association), cos^2 = 1 - sin^2.
+RAZ_HD double raz_det_cos2(double u) {
+    const double w = 4.0 * u;            // exact
+    const int q = (int)w;                // quadrant 0..3
+    const double f = w - (double)q;      // exact, in [0,1)
+    const bool swap = f > 0.5;
+    const double gq = swap ? 1.0 - f : f;  // exact, in [0,0.5]
+    const double x = gq * 0x1.921fb54442d18p+0;  // angle in [0, pi/4]
+    const double z = x * x, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double a0 = 1.0 + -0x1.5555555555555p-3 * z;
+    const double a1 = 0x1.1111111111111p-7 + -0x1.a01a01a01a01ap-13 * z;
+    const double a2 = 0x1.71de3a556c734p-19 + -0x1.ae64567f544e4p-26 * z;
+    const double a3 = 0x1.6124613a86d09p-33 + -0x1.ae7f3e733b81fp-41 * z;
+    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2;
+    const double p = (b0 + b1 * z4) + 0x1.952c77030ad4ap-49 * z8;
+    const double sn = x * p, s2 = sn * sn;
+    const bool use_s2 = ((q & 1) != 0) != swap;
+    return use_s2 ? s2 : 1.0 - s2;
+}
+
+// Two independent Gamma(1/2, 1) variates from one Philox block (d0, d1): with E = -log(1 - d0) ~ Exp(1)
+// and theta = 2 pi d1, (sqrt(2E) cos theta, sqrt(2E) sin theta) are independent standard normals
+// (Box-Muller) and Z^2/2 ~ Gamma(1/2): g0 = E cos^2 theta, g1 = E sin^2 theta.  No rejection loop.
+// This is how dirichlet_alpha = 0.5 (config.py:138, every shipped config) is sampled: pair m
+// (sub = m, idx = 0) yields samples 2m and 2m+1.
+RAZ_HD void raz_gamma_half_pair(uint32_t seed, uint32_t game, uint32_t event, uint32_t m, double& g0, double& g1) {
+    double d0, d1;
+    raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, m, 0, d0, d1);
+    const double E = -raz_det_log(1.0 - d0);
+    const double c2 = raz_det_cos2(d1);
+    g0 = E * c2;
+    g1 = E * (1.0 - c2);
+}
+
+// One attempt `t` of the Gamma(alpha, 1) sampler for 0 < alpha <= 1, alpha != 0.5 (0.5 uses the pair
+// construction above): alpha == 1 is an exponential (always accepted); alpha < 1
 // is the rejection scheme of numpy's legacy_standard_gamma for shape < 1.  Attempt t of sample `sub`
 // of draw `event` uses the Philox block (seed, game, DIRICHLET, event, sub, t), so attempts can be
 // evaluated in any order or in parallel; the sample is the accepted attempt with the smallest t.

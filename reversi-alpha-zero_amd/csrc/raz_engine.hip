@@ -306,36 +306,49 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
         // takes its sample's first accepted attempt: one evaluation deep instead of the slowest
         // lane's rejection count.
         const int k = __popcll(legal);
-        int A = 64 / k;
-        if (A > 8) A = 8;
-        int myt = 0;
-#pragma unroll
-        for (int i = 1; i < 8; ++i) myt += (lane >= i * k) ? 1 : 0;
-        const int myj = lane - myt * k;
         const uint32_t rank = (uint32_t)__popcll(legal & ((1ULL << lane) - 1ULL));
         double gam = 0.0;
-        bool need = bit != 0;
-        for (uint32_t round = 0;; ++round) {
-            double X = 0.0;
-            bool ok = false;
-            if (lane < A * k) ok = raz_gamma_attempt(c.dirichlet_alpha, c.seed, game_id, ev, (uint32_t)myj, round * (uint32_t)A + (uint32_t)myt, X);
-            const unsigned long long am = __ballot(ok);
-            int src = -1;
-            if (need) {
-                for (int t = 0; t < A; ++t) {
-                    const int l = (int)rank + k * t;
-                    if ((am >> l) & 1ULL) {
-                        src = l;
-                        break;
+        if (c.dirichlet_alpha == 0.5) {
+            // Box-Muller pairs: lane m < ceil(k/2) turns one Philox block into the two Gamma(1/2)
+            // variates of legal moves 2m and 2m+1 (no rejection, no divergence).
+            double g0 = 0.0, g1 = 0.0;
+            if (2 * lane < k) raz_gamma_half_pair(c.seed, game_id, ev, (uint32_t)lane, g0, g1);
+            const double s0 = __shfl(g0, (int)(rank >> 1)), s1 = __shfl(g1, (int)(rank >> 1));
+            if (bit) gam = (rank & 1u) ? s1 : s0;
+        } else {
+            // Gamma(alpha) sample j belongs to the j-th legal square.  Attempts of the rejection
+            // sampler are independent Philox blocks, so lane l evaluates attempt t = l / k of sample
+            // j = l % k (up to 8 attempts per sample per round) and each legal square takes its
+            // sample's first accepted attempt.
+            int A = 64 / k;
+            if (A > 8) A = 8;
+            int myt = 0;
+#pragma unroll
+            for (int i = 1; i < 8; ++i) myt += (lane >= i * k) ? 1 : 0;
+            const int myj = lane - myt * k;
+            bool need = bit != 0;
+            for (uint32_t round = 0;; ++round) {
+                double X = 0.0;
+                bool ok = false;
+                if (lane < A * k) ok = raz_gamma_attempt(c.dirichlet_alpha, c.seed, game_id, ev, (uint32_t)myj, round * (uint32_t)A + (uint32_t)myt, X);
+                const unsigned long long am = __ballot(ok);
+                int src = -1;
+                if (need) {
+                    for (int t = 0; t < A; ++t) {
+                        const int l = (int)rank + k * t;
+                        if ((am >> l) & 1ULL) {
+                            src = l;
+                            break;
+                        }
                     }
                 }
+                const double got = __shfl(X, src < 0 ? lane : src);
+                if (src >= 0) {
+                    gam = got;
+                    need = false;
+                }
+                if (__ballot(need) == 0ULL) break;
             }
-            const double got = __shfl(X, src < 0 ? lane : src);
-            if (src >= 0) {
-                gam = got;
-                need = false;
-            }
-            if (__ballot(need) == 0ULL) break;
         }
         double acc = 0.0;
         for (raz_bb m = legal; m; m &= m - 1) acc += lane_f64(gam, __ffsll((long long)m) - 1);
