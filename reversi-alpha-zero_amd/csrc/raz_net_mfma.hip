@@ -28,32 +28,65 @@ constexpr int PS = 136;  // padded plane stride in floats (136 % 32 == 8 keeps b
 
 __device__ __forceinline__ int pidx(int sq) { return ((sq >> 3) + 1) * 12 + (sq & 7) + 4; }
 
-// One 3x3 conv layer over the zero-haloed planes `in` (CIN channels) -> `out` (F channels).
-// SKIP: out is also the residual input (updated in place).  FIRST: input planes from bitboards.
-template <int F, int CIN, bool FIRST, bool SKIP>
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lanef(float v, int l) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+}
+
+template <int F, int CIN, bool FIRST>
+struct LayerK {
+    static constexpr int KS = FIRST ? 5 : 9 * CIN / 4;
+};
+
+template <int KS>
+__device__ __forceinline__ void load_wregs(const float* __restrict__ Wl, int nt, int lane, float (&wreg)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[s] = Wl[((size_t)nt * KS + s) * 64 + lane];
+}
+
+// One 3x3 conv layer over the zero-haloed planes `in` (CIN channels; for FIRST the two input bit
+// planes) -> `out` (F channels).  SKIP: out is also the residual input (updated in place).
+// PRE: the layer's B operands are already in registers (`pre`, F == 16 only).
+// For F == 16 (one channel tile) `in` and `out` may be the SAME buffer: a single wave performs every
+// read of the layer (the MFMA operands) before the epilogue stores, and the residual input is the
+// lane's own D fragment of the previous block (`frag`, kept in registers), so one LDS buffer per
+// position is enough (16 workgroups per CU instead of 8).
+template <int F, int CIN, bool FIRST, bool SKIP, bool PRE>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const float* __restrict__ bias,
-                                           const float* in, float* out, raz_bb bo, raz_bb be, int lane) {
-    constexpr int KS = FIRST ? 5 : 9 * CIN / 4;
+                                           const float* in, float* out, int lane,
+                                           const float (&pre)[LayerK<F, CIN, FIRST>::KS], float preb,
+                                           f32x4 (&frag)[4], bool keep_frag) {
+    constexpr int KS = LayerK<F, CIN, FIRST>::KS;
     const int i = lane & 15, kk = lane >> 4;
     for (int nt = 0; nt < F / 16; ++nt) {
         float wreg[KS];
+        float b;
+        if (PRE) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wreg[s] = Wl[((size_t)nt * KS + s) * 64 + lane];
-        const float b = bias[nt * 16 + i];
+            for (int s = 0; s < KS; ++s) wreg[s] = pre[s];
+            b = preb;
+        } else {
+            load_wregs<KS>(Wl, nt, lane, wreg);
+            b = bias[nt * 16 + i];
+        }
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){b, b, b, b};
         if (FIRST) {
+            // k = tap*2 + plane: k-step s holds taps 2s (lanes 0..31) and 2s+1 (lanes 32..63); the
+            // padded k = 18, 19 carry zero weights, so any in-bounds address will do for them
+            const float* base = in + (kk & 1) * PS + pidx(i);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int k = 4 * s + kk, t = k >> 1;
-                const raz_bb board = (k & 1) ? be : bo;
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const int ta = 2 * s, tb = 2 * s + 1 > 8 ? 8 : 2 * s + 1;
+                const int offa = (ta / 3 - 1) * 12 + (ta % 3 - 1), offb = (tb / 3 - 1) * 12 + (tb % 3 - 1);
+                const int off = (kk < 2) ? offa : offb;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int y = mt * 2 + (i >> 3) + dy, x = (i & 7) + dx;
-                    const bool ok = (k < 18) && (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
-                    const float a = ok ? (float)((board >> ((y * 8 + x) & 63)) & 1ULL) : 0.0f;
+                    const float a = base[off + mt * 24];
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[s], acc[mt], 0, 0, 0);
                 }
             }
@@ -95,36 +128,32 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const f
     __syncthreads();
 }
 
-template <int F>
-__global__ __launch_bounds__(64) void k_net_mfma(const float* __restrict__ W, int R, int V,
+// PROF: lane 0 records s_memtime ticks at phase boundaries into prof[pos][8] (debug launches only:
+// RAZ_NET_PROF=1 + a scratch buffer).
+#define RAZ_NET_TICK(k) \
+    if (PROF && lane == 0) prof[(size_t)pos * 8 + (k)] = __builtin_amdgcn_s_memtime()
+
+// Persistent: min(n, 2048) single-wave workgroups (8 per CU = the LDS limit), each looping over
+// positions.  The LDS halos are zeroed once per workgroup; for the F = 16, R = 1 net (mini.yml) all
+// 77 weight registers of the three conv layers stay resident across positions.
+template <int F, bool PROF>
+__global__ __launch_bounds__(64, F == 16 ? 2 : 1) void k_net_mfma(const float* __restrict__ W, int R, int V,
                                                  const raz_bb* __restrict__ own,
                                                  const raz_bb* __restrict__ enemy,
                                                  const uint8_t* __restrict__ active,
-                                                 float* __restrict__ policy, float* __restrict__ value, int n) {
+                                                 float* __restrict__ policy, float* __restrict__ value, int n,
+                                                 unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int pos = blockIdx.x;
-    if (pos >= n) return;
-    if (active && !active[pos]) return;
     const int lane = threadIdx.x;
+    constexpr int NBUF = 2;   // (a single in-place buffer was tried for F == 16: registers, not LDS, bound the occupancy)
     float* bufA = smem;
-    float* bufT = smem + F * PS;
-    float* head = smem + 2 * F * PS;  // ph[128] vh[64] h1[V]
-    {  // zero both buffers: the halo must read as 0
+    float* bufT = smem + (NBUF - 1) * F * PS;
+    float* head = smem + NBUF * F * PS;  // ph[128] vh[64] h1[V]
+    {  // zero the buffers once: halos must read as 0, interiors are overwritten for every position
         f32x4* z = (f32x4*)smem;
-        for (int j = lane; j < 2 * F * PS / 4; j += 64) z[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < NBUF * F * PS / 4; j += 64) z[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    const raz_bb bo = own[pos], be = enemy[pos];
-    const float* Wm = W;  // mfma region offsets are absolute (raz_net_layout.h)
-    conv_layer<F, 2, true, false>(Wm + mfma_layer_off(F, R, V, 0), W + conv_off(F, 0) + (size_t)F * 9 * 2, nullptr,
-                                  bufA, bo, be, lane);
-    for (int r = 0; r < R; ++r) {
-        const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-        conv_layer<F, F, false, false>(Wm + mfma_layer_off(F, R, V, l1), W + conv_off(F, l1) + (size_t)F * 9 * F, bufA,
-                                       bufT, 0, 0, lane);
-        conv_layer<F, F, false, true>(Wm + mfma_layer_off(F, R, V, l2), W + conv_off(F, l2) + (size_t)F * 9 * F, bufT,
-                                      bufA, 0, 0, lane);
-    }
     const float* H = W + heads_off(F, R);
     const float* pol_w = H;
     const float* pol_b = pol_w + 2 * F;
@@ -139,57 +168,137 @@ __global__ __launch_bounds__(64) void k_net_mfma(const float* __restrict__ W, in
     float* ph = head;
     float* vh = head + 128;
     float* h1 = head + 192;
-    {
-        const float* a = bufA + pidx(lane);
-        float p0 = pol_b[0], p1 = pol_b[1], v0 = val_b[0];
-#pragma unroll 8
-        for (int ic = 0; ic < F; ++ic) {
-            const float xv = a[ic * PS];
-            p0 = fmaf(xv, pol_w[ic], p0);
-            p1 = fmaf(xv, pol_w[F + ic], p1);
-            v0 = fmaf(xv, val_w[ic], v0);
-        }
-        ph[lane] = p0 > 0.0f ? p0 : 0.0f;
-        ph[64 + lane] = p1 > 0.0f ? p1 : 0.0f;
-        vh[lane] = v0 > 0.0f ? v0 : 0.0f;
-    }
-    __syncthreads();
-    float logit = pfc_b[lane];
-#pragma unroll 16
-    for (int j = 0; j < 128; ++j) logit = fmaf(ph[j], pfc_w[j * 64 + lane], logit);
-    float m = logit;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
-    const float e = raz_det_expf(logit - m);
-    float sum = e;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) sum = sum + __shfl_xor(sum, s);
-    policy[(size_t)pos * 64 + lane] = e / sum;
-    for (int o0 = 0; o0 < V; o0 += 64) {
-        const int o = o0 + lane;
-        if (o < V) {
-            float acc = v1_b[o];
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) acc = fmaf(vh[j], v1_w[j * V + o], acc);
-            h1[o] = acc > 0.0f ? acc : 0.0f;
+    constexpr bool HOIST = (F == 16);
+    const bool pre = HOIST && R == 1;
+    float w0[5], w1[HOIST ? 36 : 1], w2[HOIST ? 36 : 1], pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;
+    if (HOIST) {
+        if (pre) {
+            load_wregs<5>(W + mfma_layer_off(F, R, V, 0), 0, lane, w0);
+            load_wregs<HOIST ? 36 : 1>(W + mfma_layer_off(F, R, V, 1), 0, lane, w1);
+            load_wregs<HOIST ? 36 : 1>(W + mfma_layer_off(F, R, V, 2), 0, lane, w2);
+            pb0 = (W + conv_off(F, 0) + (size_t)F * 9 * 2)[lane & 15];
+            pb1 = (W + conv_off(F, 1) + (size_t)F * 9 * F)[lane & 15];
+            pb2 = (W + conv_off(F, 2) + (size_t)F * 9 * F)[lane & 15];
         }
     }
-    __syncthreads();
-    float acc = v2_b[0];
-    for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
-    if (lane == 0) value[pos] = raz_det_tanhf(acc);
+    const float dummy5[5] = {0, 0, 0, 0, 0};
+    for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
+        if (active && !active[pos]) continue;
+        RAZ_NET_TICK(0);
+        const raz_bb bo = own[pos], be = enemy[pos];
+        // the two input bit planes go to planes 0/1 of bufT (overwritten again by the first block conv)
+        bufT[pidx(lane)] = (float)((bo >> lane) & 1ULL);
+        bufT[PS + pidx(lane)] = (float)((be >> lane) & 1ULL);
+        __syncthreads();
+        RAZ_NET_TICK(1);
+        f32x4 frag[4];  // the lane's D fragment of the last block output (residual input), F == 16
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) frag[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (HOIST && pre) {
+            if constexpr (HOIST) {
+                conv_layer<F, 2, true, false, true>(nullptr, nullptr, bufT, bufA, lane, w0, pb0, frag, true);
+                RAZ_NET_TICK(2);
+                conv_layer<F, F, false, false, true>(nullptr, nullptr, bufA, bufT, lane, w1, pb1, frag, false);
+                conv_layer<F, F, false, true, true>(nullptr, nullptr, bufT, bufA, lane, w2, pb2, frag, true);
+            }
+        } else {
+            float dummyK[LayerK<F, F, false>::KS];
+            conv_layer<F, 2, true, false, false>(W + mfma_layer_off(F, R, V, 0), W + conv_off(F, 0) + (size_t)F * 9 * 2, bufT,
+                                                 bufA, lane, dummy5, 0.f, frag, true);
+            RAZ_NET_TICK(2);
+            for (int r = 0; r < R; ++r) {
+                const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
+                conv_layer<F, F, false, false, false>(W + mfma_layer_off(F, R, V, l1), W + conv_off(F, l1) + (size_t)F * 9 * F,
+                                                      bufA, bufT, lane, dummyK, 0.f, frag, false);
+                conv_layer<F, F, false, true, false>(W + mfma_layer_off(F, R, V, l2), W + conv_off(F, l2) + (size_t)F * 9 * F,
+                                                     bufT, bufA, lane, dummyK, 0.f, frag, true);
+            }
+        }
+        RAZ_NET_TICK(3);
+        {
+            const float* a = bufA + pidx(lane);
+            float p0 = pol_b[0], p1 = pol_b[1], v0 = val_b[0];
+#pragma unroll 8
+            for (int ic = 0; ic < F; ++ic) {
+                const float xv = a[ic * PS];
+                p0 = fmaf(xv, pol_w[ic], p0);
+                p1 = fmaf(xv, pol_w[F + ic], p1);
+                v0 = fmaf(xv, val_w[ic], v0);
+            }
+            ph[lane] = p0 > 0.0f ? p0 : 0.0f;
+            ph[64 + lane] = p1 > 0.0f ? p1 : 0.0f;
+            vh[lane] = v0 > 0.0f ? v0 : 0.0f;
+        }
+        __syncthreads();
+        RAZ_NET_TICK(4);
+        // policy dense 128 -> 64, lane = output: all 128 weight loads are issued before the chain
+        float logit = pfc_b[lane];
+#pragma unroll 1
+        for (int j0 = 0; j0 < 128; j0 += 32) {  // 32 loads in flight, then their 32 chained fmas
+            float wv[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) wv[j] = pfc_w[(j0 + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) logit = fmaf(ph[j0 + j], wv[j], logit);
+        }
+        RAZ_NET_TICK(5);
+        // softmax: max (order-free) and the xor-butterfly sum (1,2,4,8 inside a row by DPP; the 16/32
+        // steps are (r0+r1)+(r2+r3) of the four row sums)
+        float m = logit;
+        m = fmaxf(m, dppf<0xB1>(m));
+        m = fmaxf(m, dppf<0x4E>(m));
+        m = fmaxf(m, dppf<0x141>(m));
+        m = fmaxf(m, dppf<0x140>(m));
+        m = fmaxf(fmaxf(lanef(m, 0), lanef(m, 16)), fmaxf(lanef(m, 32), lanef(m, 48)));
+        const float e = raz_det_expf(logit - m);
+        float sum = e;
+        sum = sum + dppf<0xB1>(sum);
+        sum = sum + dppf<0x4E>(sum);
+        sum = sum + dppf<0x141>(sum);
+        sum = sum + dppf<0x140>(sum);
+        sum = (lanef(sum, 0) + lanef(sum, 16)) + (lanef(sum, 32) + lanef(sum, 48));
+        policy[(size_t)pos * 64 + lane] = e / sum;
+        RAZ_NET_TICK(6);
+        for (int o0 = 0; o0 < V; o0 += 64) {
+            const int o = o0 + lane;
+            if (o < V) {
+                float acc = v1_b[o];
+#pragma unroll 1
+                for (int j0 = 0; j0 < 64; j0 += 32) {
+                    float wv[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) wv[j] = v1_w[(j0 + j) * V + o];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) acc = fmaf(vh[j0 + j], wv[j], acc);
+                }
+                h1[o] = acc > 0.0f ? acc : 0.0f;
+            }
+        }
+        __syncthreads();
+        float acc = v2_b[0];
+        for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
+        if (lane == 0) value[pos] = raz_det_tanhf(acc);
+        RAZ_NET_TICK(7);
+        __syncthreads();  // the next position overwrites bufT / head
+    }
 }
 
 template <int F>
 int launch(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy, const uint8_t* active,
-           float* policy, float* value, size_t n, hipStream_t s) {
+           float* policy, float* value, size_t n, hipStream_t s, unsigned long long* prof) {
     const size_t shm = ((size_t)2 * F * PS + 192 + V) * sizeof(float);
     if (shm > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_net_mfma<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)k_net_mfma<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
     }
-    hipLaunchKernelGGL(k_net_mfma<F>, dim3((unsigned)n), dim3(64), shm, s, W, R, V, own, enemy, active, policy, value,
-                       (int)n);
+    const unsigned maxgrid = 2048;  // LDS-limited residency: 16 (F=16) / 8 workgroups per CU
+    const unsigned grid = (unsigned)(n < maxgrid ? n : maxgrid);
+    if (prof)
+        hipLaunchKernelGGL((k_net_mfma<F, true>), dim3(grid), dim3(64), shm, s, W, R, V, own, enemy, active, policy,
+                           value, (int)n, prof);
+    else
+        hipLaunchKernelGGL((k_net_mfma<F, false>), dim3(grid), dim3(64), shm, s, W, R, V, own, enemy, active, policy,
+                           value, (int)n, prof);
     return raz_check_launch("raz_net_forward (mfma)");
 }
 
@@ -198,13 +307,14 @@ int launch(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy,
 bool raz_net_mfma_supported(int F, int V) { return (F == 16 || F == 32 || F == 64) && V <= 1024; }
 
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
-                         const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s) {
+                         const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
+                         unsigned long long* prof) {
     const raz_bb* o = (const raz_bb*)own;
     const raz_bb* e = (const raz_bb*)enemy;
     switch (F) {
-        case 16: return launch<16>(W, R, V, o, e, active, policy, value, n, s);
-        case 32: return launch<32>(W, R, V, o, e, active, policy, value, n, s);
-        case 64: return launch<64>(W, R, V, o, e, active, policy, value, n, s);
+        case 16: return launch<16>(W, R, V, o, e, active, policy, value, n, s, prof);
+        case 32: return launch<32>(W, R, V, o, e, active, policy, value, n, s, nullptr);
+        case 64: return launch<64>(W, R, V, o, e, active, policy, value, n, s, nullptr);
         default: return raz_fail(RAZ_EINVAL, "raz_net_forward_mfma: unsupported filter count");
     }
 }

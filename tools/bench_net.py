@@ -41,7 +41,22 @@ def main():
     ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters)]
     flops = 2.0 * macs_per_position(F, R, V) * args.n
     best = min(ms)
-    print(json.dumps({"net": args.net, "filters": F, "res_layers": R, "positions": args.n, "ms_per_forward": ms,
+    extra = {}
+    if os.environ.get("RAZ_NET_PROF") and args.net == "mini":
+        import ctypes
+        from reversi_alpha_zero_amd._native import lib, check
+        prof = torch.zeros(args.n * 8, dtype=torch.int64, device=dev)
+        pol = torch.empty((args.n, 64), dtype=torch.float32, device=dev)
+        val = torch.empty(args.n, dtype=torch.float32, device=dev)
+        check(lib.raz_net_forward(ctypes.byref(net.c), o.data_ptr(), e.data_ptr(), None, pol.data_ptr(), val.data_ptr(),
+                                  args.n, prof.data_ptr(), prof.numel() * 8, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        t = prof.cpu().numpy().reshape(args.n, 8).astype(np.float64)
+        d = np.diff(t, axis=1)
+        names = ["zero_lds", "layer0", "res_blocks", "head_convs", "policy_dense", "softmax", "value_head"]
+        extra["phase_ticks_mean"] = {k: float(v) for k, v in zip(names, d.mean(axis=0))}
+        extra["wave_ticks_mean"] = float((t[:, 7] - t[:, 0]).mean())
+    print(json.dumps({"net": args.net, **extra, "filters": F, "res_layers": R, "positions": args.n, "ms_per_forward": ms,
                       "tflops_best": flops / (best * 1e-3) / 1e12, "peak_tflops_fp32_mfma": 157.3,
                       "frac_of_peak": flops / (best * 1e-3) / 1e12 / 157.3, "flop_per_forward": flops}))
 
