@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=64)
     ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = sized for whole games)")
+    ap.add_argument("--parts", type=int, default=0, help="slices/streams the batch is stepped in (0 = engine default 3)")
+    ap.add_argument("--inner-max", type=int, default=0, help="max simulations completed per game per tree launch (0 = default 2)")
     ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
     ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
     args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
     net = DeviceNet(blob, dev)
     eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile,
                          nodes_per_game=args.nodes_per_game or None,
-                         single_stream=args.no_overlap)
+                         single_stream=args.no_overlap, parts=args.parts, inner_max=args.inner_max)
     first_id = rank * args.games
 
     # warm-up on a throw-away start (clocks, caches, code objects), then restart the same games
@@ -156,6 +158,20 @@ def main():
         elapsed = float(mx[4].item())
     total_sims, finished, leaves, selections = (float(tot[i].item()) for i in range(4))
 
+    # standalone kernel durations (whole batch, one stream, nothing overlapping) on the opening phase,
+    # for reference beside the in-run (overlapped) numbers
+    standalone = None
+    if rank == 0 and not args.no_overlap and args.games >= 256:
+        eng.start(first_id, args.sims)
+        eng.set_parts(1)
+        eng.step(300)
+        a, b = eng.step_timed(300)
+        st1 = eng.stats()
+        standalone = {"tree_ms": a / 300, "net_ms": b / 300, "steps_sampled": "300..600 of a fresh start",
+                      "sims_per_step": st1["total_sims"] / 600.0, "leaves_per_step": st1["nn_leaves"] / 600.0,
+                      "selections_per_step": st1["selections"] / 600.0}
+        eng.set_parts(args.parts or 3)
+
     # the single collective of the path: finished-game records -> rank 0 (timed separately)
     t1 = time.perf_counter()
     raw = eng.read_raw()
@@ -171,7 +187,7 @@ def main():
 
     if rank == 0:
         macs = macs_per_position(F, R, V)
-        lps = 1 if (args.no_overlap or args.games < 256) else 2   # kernel launches per step (half batches)
+        lps = 1 if (args.no_overlap or args.games < 256) else (args.parts or 3)   # launches of each kernel per step
         per_launch_tree_bytes = (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / max(steps * lps, 1)
         tree_avg_ms = tree_ms / max(timed_steps * lps, 1)
         net_avg_ms = net_ms / max(timed_steps * lps, 1)
@@ -202,7 +218,7 @@ def main():
                        "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
                        "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0,
                        "kernel_launches_per_step": lps * 2,
-                       "overlap": "two half batches on two HIP streams" if lps == 2 else "single stream"},
+                       "overlap": f"{lps} slices on {lps} HIP streams" if lps > 1 else "single stream"},
             "sims_per_sec_per_gpu": total_sims / elapsed / world,
             "games_per_hour": finished / elapsed * 3600.0 if args.steps == 0 else None,
             "finished_games": finished, "total_sims": total_sims, "nn_leaves": leaves,
@@ -210,6 +226,18 @@ def main():
             "roofline": roof, "kernels": kern,
             "record_gather": {"seconds": gather_s, "bytes": gather_bytes, "collective": "gather (RCCL)" if world > 1 else "none (1 GPU): D2H read"},
         }
+        if standalone:
+            sb = TREE_BYTES_PER_SELECTION * standalone["selections_per_step"] + TREE_BYTES_PER_SIM * standalone["sims_per_step"]
+            sf = 2.0 * macs * standalone["leaves_per_step"]
+            out["standalone_kernels"] = {
+                "note": "one launch over the whole batch on one stream, nothing overlapping (opening phase)",
+                "k_tree": {"avg_ms": standalone["tree_ms"], "achieved_GBps": sb / (standalone["tree_ms"] * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": sb / (standalone["tree_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                net_kernel: {"avg_ms": standalone["net_ms"], "achieved_TFLOPs": sf / (standalone["net_ms"] * 1e-3) / 1e12,
+                             "frac_of_f32_mfma_peak": sf / (standalone["net_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
+            out["sustained_in_timed_region"] = {
+                "net_TFLOPs": 2.0 * macs * leaves / world / elapsed / 1e12,
+                "tree_algorithmic_GBps": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / elapsed / 1e9}
         if args.phase_profile:
             pp = eng.phase_profile()
             launches = max(pp["active_launches"], 1)

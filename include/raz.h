@@ -145,7 +145,8 @@ typedef struct {
     uint32_t table_slots;                     /* hash slots per game, power of two >= 2*nodes_per_game */
     uint32_t max_plies;                       /* record capacity per game (>= 64) */
     uint32_t seed;
-    uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream (no half-batch overlap) */
+    uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream; bits 8-11: slices/streams (0 = 3);
+                                                 bits 12-15: max simulations per game per tree launch (0 = 2) */
 } raz_engine_config;
 
 typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */
@@ -173,8 +174,8 @@ int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims
 /* Enqueue n_steps simulation steps (each: tree kernel = backup + move logic + select, then one
  * net batch over the gathered leaves).  Asynchronous w.r.t. the host; all work is ordered after
  * prior work on `stream` and before later work on it.  With n_games >= 256 the batch is stepped as
- * two half batches on `stream` and an internal second stream so that one half's net kernel
- * overlaps the other half's tree kernel. */
+ * 3 slices on `stream` and two internal streams so that one slice's net kernel overlaps the
+ * other slices' tree kernels. */
 int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
 /* Same as raz_engine_step, with HIP events recorded around every kernel launch on the stream it runs
  * on: the summed durations (ms) of the tree-kernel launches and of the net-kernel launches are
@@ -182,6 +183,9 @@ int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
  * half batch, on two streams).  Synchronises the stream. */
 int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, double* net_ms,
                           raz_stream_t stream);
+/* Number of slices/streams a step is split into (1..8; 1 = one tree launch + one net launch over the
+ * whole batch).  Call with the stream idle. */
+int raz_engine_set_parts(raz_engine* e, int parts);
 /* Synchronise the stream and read the counters. */
 int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream);
 /* Copy finished-game records to host memory (synchronous).  headers: n_games*max_plies*48 bytes

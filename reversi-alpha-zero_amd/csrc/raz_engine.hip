@@ -30,7 +30,9 @@
 
 namespace {
 
-constexpr int kInnerMax = 8;  // max simulations completed per game per launch (terminal leaves)
+constexpr int kInnerMax = 2;  // max simulations completed per game per launch (terminal leaves need no net);
+                              // larger values make the few games with runs of terminal leaves stragglers
+                              // that set the launch's duration (8: 58.6M sims/s, 2: 62.2M on the bench config)
 
 // ------------------------------------------------------------------ wave helpers
 // Lanes of the game's wave communicate through HBM (lane 0 writes game state, all lanes read it).
@@ -802,7 +804,8 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
     if (g >= E.B) return;
     if (lane == 0) E.nn_active[g] = 0;
     wave_sync();
-    for (int it = 0; it < kInnerMax; ++it) {
+    const int inner_max = ((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax;
+    for (int it = 0; it < inner_max; ++it) {
         uint32_t phase = E.g_phase[g];
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (E.g_error[g]) break;
@@ -961,6 +964,8 @@ int validate(const raz_engine_config* cfg) {
 
 }  // namespace
 
+constexpr int kMaxParts = 8;
+
 struct raz_engine {
     raz_engine_dev dev;
     raz_net net;
@@ -968,12 +973,12 @@ struct raz_engine {
     size_t net_scratch_bytes;
     uint32_t* d_sims;  // staging for sims_per_move
     bool started;
-    // The batch is stepped as two independent halves on two streams (the caller's and `aux`): while
-    // one half's leaves are in the net kernel (matrix pipe) the other half's tree kernel (scalar /
-    // f64 VALU, latency-bound) runs beside it instead of after it.
-    int halves;
-    hipStream_t aux;
-    hipEvent_t ev_fork, ev_join;
+    // The batch is stepped as `parts` independent slices on as many streams (the caller's and
+    // parts-1 internal ones): while one slice's leaves are in the net kernel (matrix pipe) another
+    // slice's tree kernel (scalar / f64 VALU, latency-bound) runs beside it instead of after it.
+    int parts;
+    hipStream_t aux[kMaxParts];
+    hipEvent_t ev_fork, ev_join[kMaxParts];
 };
 
 namespace {
@@ -982,22 +987,25 @@ struct Half {
     uint32_t g0, count;
 };
 inline Half half_of(const raz_engine* e, int h) {
-    const uint32_t B = e->dev.B;
-    if (e->halves == 1) return Half{0, B};
-    const uint32_t h0 = (B / 2 + 63) / 64 * 64 < B ? (B / 2 + 63) / 64 * 64 : B / 2;
-    return h == 0 ? Half{0, h0} : Half{h0, B - h0};
+    const uint32_t B = e->dev.B, P = (uint32_t)e->parts;
+    const uint32_t per = ((B + P - 1) / P + 63) / 64 * 64;  // slice size, multiple of 64
+    const uint32_t g0 = per * (uint32_t)h < B ? per * (uint32_t)h : B;
+    const uint32_t g1 = g0 + per < B ? g0 + per : B;
+    return Half{g0, g1 - g0};
 }
+inline hipStream_t stream_of(const raz_engine* e, int h, hipStream_t s) { return h == 0 ? s : e->aux[h]; }
 
-// one simulation step of one half on stream s; ev (nullable) = 3 events bracketing the two kernels
+// one simulation step of one slice on stream s; ev (nullable) = 3 events bracketing the two kernels
 int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
     const raz_engine_dev& d = e->dev;
     const Half hf = half_of(e, h);
+    if (hf.count == 0) return RAZ_OK;
     if (ev) hipEventRecord(ev[0], s);
     hipLaunchKernelGGL(k_tree, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
     int rc = raz_check_launch("raz_engine_step: k_tree");
     if (rc != RAZ_OK) return rc;
     if (ev) hipEventRecord(ev[1], s);
-    // the halves run concurrently: each gets its own slice of the net scratch (size is linear in n)
+    // the slices run concurrently: each gets its own part of the net scratch (size is linear in n)
     const size_t soff = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, hf.g0);
     const size_t sbytes = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, hf.count);
     rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + hf.g0, (const uint64_t*)d.nn_enemy + hf.g0,
@@ -1008,19 +1016,23 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
 }
 
 int fork_aux(raz_engine* e, hipStream_t s) {
-    if (e->halves == 1) return RAZ_OK;
+    if (e->parts == 1) return RAZ_OK;
     RAZ_HIP_TRY(hipEventRecord(e->ev_fork, s), "raz_engine_step: fork record");
-    RAZ_HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), "raz_engine_step: fork wait");
+    for (int h = 1; h < e->parts; ++h)
+        RAZ_HIP_TRY(hipStreamWaitEvent(e->aux[h], e->ev_fork, 0), "raz_engine_step: fork wait");
     return RAZ_OK;
 }
 int join_aux(raz_engine* e, hipStream_t s) {
-    if (e->halves == 1) return RAZ_OK;
-    RAZ_HIP_TRY(hipEventRecord(e->ev_join, e->aux), "raz_engine_step: join record");
-    RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), "raz_engine_step: join wait");
+    for (int h = 1; h < e->parts; ++h) {
+        RAZ_HIP_TRY(hipEventRecord(e->ev_join[h], e->aux[h]), "raz_engine_step: join record");
+        RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_join[h], 0), "raz_engine_step: join wait");
+    }
     return RAZ_OK;
 }
 
 }  // namespace
+
+extern "C" void raz_engine_destroy(raz_engine* e);
 
 extern "C" size_t raz_engine_workspace_bytes(const raz_engine_config* cfg) {
     if (validate(cfg) != RAZ_OK) return 0;
@@ -1048,15 +1060,25 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     e->net_scratch = d_net_scratch;
     e->net_scratch_bytes = net_scratch_bytes;
     e->started = false;
-    e->halves = (cfg->n_games >= 256 && !(cfg->reserved & 2u)) ? 2 : 1;  // reserved bit 1: single stream
-    e->aux = nullptr;
-    e->ev_fork = e->ev_join = nullptr;
-    if (e->halves == 2) {
-        hipError_t err = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+    // reserved bit 1: single stream; bits 8..11: number of slices (default 3); bits 12..15: kInnerMax override
+    int parts = (int)((cfg->reserved >> 8) & 0xf);
+    if (parts == 0) parts = 3;
+    if (parts > kMaxParts) parts = kMaxParts;
+    if (cfg->n_games < 256 || (cfg->reserved & 2u)) parts = 1;
+    e->parts = parts;
+    e->ev_fork = nullptr;
+    for (int h = 0; h < kMaxParts; ++h) {
+        e->aux[h] = nullptr;
+        e->ev_join[h] = nullptr;
+    }
+    if (parts > 1) {
+        hipError_t err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        for (int h = 1; h < parts && err == hipSuccess; ++h) {
+            err = hipStreamCreateWithFlags(&e->aux[h], hipStreamNonBlocking);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
+        }
         if (err != hipSuccess) {
-            delete e;
+            raz_engine_destroy(e);
             return raz_fail_hip(err, "raz_engine_create: stream/event creation");
         }
     }
@@ -1064,11 +1086,29 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     return RAZ_OK;
 }
 
+// Change the number of slices/streams the batch is stepped in (1..8).  Takes effect at the next
+// raz_engine_step call; the caller must have synchronised the stream.
+extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
+    if (!e || parts < 1 || parts > kMaxParts) return raz_fail(RAZ_EINVAL, "raz_engine_set_parts: parts must be 1..8");
+    if (e->dev.B < 256) parts = 1;
+    hipError_t err = hipSuccess;
+    if (parts > 1 && !e->ev_fork) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    for (int h = 1; h < parts && err == hipSuccess; ++h) {
+        if (!e->aux[h]) err = hipStreamCreateWithFlags(&e->aux[h], hipStreamNonBlocking);
+        if (err == hipSuccess && !e->ev_join[h]) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
+    }
+    if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_set_parts");
+    e->parts = parts;
+    return RAZ_OK;
+}
+
 extern "C" void raz_engine_destroy(raz_engine* e) {
     if (!e) return;
-    if (e->aux) hipStreamDestroy(e->aux);
+    for (int h = 1; h < kMaxParts; ++h) {
+        if (e->aux[h]) hipStreamDestroy(e->aux[h]);
+        if (e->ev_join[h]) hipEventDestroy(e->ev_join[h]);
+    }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    if (e->ev_join) hipEventDestroy(e->ev_join);
     delete e;
 }
 
@@ -1095,8 +1135,7 @@ extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t str
     hipStream_t s = (hipStream_t)stream;
     int rc = fork_aux(e, s);
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
-        rc = launch_half_step(e, 0, s, nullptr);
-        if (rc == RAZ_OK && e->halves == 2) rc = launch_half_step(e, 1, e->aux, nullptr);
+        for (int h = 0; h < e->parts && rc == RAZ_OK; ++h) rc = launch_half_step(e, h, stream_of(e, h, s), nullptr);
     }
     const int rj = join_aux(e, s);
     return rc != RAZ_OK ? rc : rj;
@@ -1124,13 +1163,13 @@ extern "C" int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tr
     if (!e || !tree_ms || !net_ms) return raz_fail(RAZ_EINVAL, "raz_engine_step_timed: NULL argument");
     if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step_timed: call raz_engine_start first");
     hipStream_t s = (hipStream_t)stream;
-    const int H = e->halves;
+    const int H = e->parts;
     std::vector<hipEvent_t> ev(3 * (size_t)n_steps * H);
     for (auto& x : ev) RAZ_HIP_TRY(hipEventCreate(&x), "raz_engine_step_timed: hipEventCreate");
     int rc = fork_aux(e, s);
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
-        rc = launch_half_step(e, 0, s, &ev[3 * ((size_t)i * H)]);
-        if (rc == RAZ_OK && H == 2) rc = launch_half_step(e, 1, e->aux, &ev[3 * ((size_t)i * H + 1)]);
+        for (int h = 0; h < H && rc == RAZ_OK; ++h)
+            rc = launch_half_step(e, h, stream_of(e, h, s), &ev[3 * ((size_t)i * H + h)]);
     }
     const int rj = join_aux(e, s);
     hipError_t err = hipStreamSynchronize(s);

@@ -65,7 +65,7 @@ class DeviceNet:
 
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
-                       record_root_w=False, phase_profile=False, single_stream=False):
+                       record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names)."""
     p = config.play
     if getattr(p, "parallel_search_num", 1) != 1:
@@ -87,13 +87,13 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
-        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0))
+        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12))
     return c
 
 
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
-                 max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False):
+                 max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0):
         import torch
         self.net = net
         self.device = net.device
@@ -106,7 +106,7 @@ class SelfPlayEngine:
             # every simulation adds at most one node (two with mirror keys); ~62 searched plies
             nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
-                                      record_root_w, phase_profile, single_stream)
+                                      record_root_w, phase_profile, single_stream, parts, inner_max)
         nbytes = lib.raz_engine_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("invalid engine config: " + N.last_error())
@@ -140,6 +140,11 @@ class SelfPlayEngine:
         import torch
         with torch.cuda.device(self.device):
             check(lib.raz_engine_step(self._h, n, _stream()), "raz_engine_step")
+
+    def set_parts(self, parts):
+        import torch
+        torch.cuda.synchronize(self.device)
+        check(lib.raz_engine_set_parts(self._h, parts), "raz_engine_set_parts")
 
     def step_timed(self, n=1):
         """step(n) with HIP events around each kernel; returns (tree_ms, net_ms) summed over n."""
