@@ -157,6 +157,7 @@ typedef struct {
     uint64_t nn_leaves;       /* leaf positions sent to the net */
     uint64_t error_flags;     /* 0 = ok; 1 node pool full, 2 table full, 4 records full, 8 path overflow */
     uint64_t selections;      /* select_action_q_and_u calls (sum of descent depths) */
+    uint64_t max_pool_used;   /* largest node-pool fill over the running games */
 } raz_engine_stats;
 
 size_t raz_engine_workspace_bytes(const raz_engine_config* cfg);
@@ -183,6 +184,10 @@ int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
  * half batch, on two streams).  Synchronises the stream. */
 int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, double* net_ms,
                           raz_stream_t stream);
+/* Prune the nodes no future search can reach (positions with fewer discs than the current real
+ * position; the disc count only grows) in every game whose pool holds >= threshold nodes, compacting
+ * the pool and rebuilding that game's table.  Does not change any result.  Asynchronous. */
+int raz_engine_gc(raz_engine* e, uint32_t threshold, raz_stream_t stream);
 /* Number of slices/streams a step is split into (1..8; 1 = one tree launch + one net launch over the
  * whole batch).  Call with the stream idle. */
 int raz_engine_set_parts(raz_engine* e, int parts);

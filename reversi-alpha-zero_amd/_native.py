@@ -67,7 +67,7 @@ class RazEngineConfig(ctypes.Structure):
 
 class RazEngineStats(ctypes.Structure):
     _fields_ = [("finished_games", c_uint64), ("total_sims", c_uint64), ("nn_leaves", c_uint64),
-                ("error_flags", c_uint64), ("selections", c_uint64)]
+                ("error_flags", c_uint64), ("selections", c_uint64), ("max_pool_used", c_uint64)]
 
 
 SIGNATURES.update({
@@ -83,6 +83,7 @@ SIGNATURES.update({
     "raz_engine_start": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
     "raz_engine_step": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_step_timed": (c_int, [c_void_p, c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
+    "raz_engine_gc": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_set_parts": (c_int, [c_void_p, c_int]),
     "raz_engine_stats_sync": (c_int, [c_void_p, POINTER(RazEngineStats), c_void_p]),
     "raz_engine_read_records": (c_int, [c_void_p] * 11 + [c_void_p]),

@@ -102,7 +102,8 @@ struct raz_engine_dev {
     raz_ply_header* rec;           // [B][max_plies]
     uint32_t* rec_n;               // [B][max_plies][64]
     double* rec_w;                 // [B][max_plies][64] or NULL
-    // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections
+    // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games
+    uint32_t* gc_remap;            // [B][C] old -> new node index during k_gc
     unsigned long long* counters;
     unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)
 };

@@ -441,7 +441,8 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
         const uint32_t tagkey = np | (owner << 2);
         bool ok = true;
         if (node == RAZ_NO_NODE) {  // first arrival at this position: create it in the slot select found
-            const uint32_t slot = uni(lslot_v);
+            uint32_t slot = uni(lslot_v);
+            if (slot == 0xfffffffeu) slot = table_find(E, g, kb, kw, tagkey, lane).slot;  // table rebuilt by k_gc
             if (slot == 0xffffffffu || used >= E.C) {
                 if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
                 ok = false;
@@ -848,9 +849,11 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
 // global atomics: 4096 waves hitting one address cost ~90 us per launch (one word saturates at
 // ~88 atomics/us on this chip).
 __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
-    __shared__ unsigned long long sh[5][256];
-    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0;
+    __shared__ unsigned long long sh[6][256];
+    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0, maxpool = 0;
     for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
+        const unsigned long long pu = E.g_status[g] == 0 ? E.pool_used[g] : 0;
+        maxpool = pu > maxpool ? pu : maxpool;
         fin += E.g_status[g] != 0 ? 1 : 0;
         sims += E.g_sims[g];
         err |= E.g_error[g];
@@ -858,11 +861,14 @@ __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
         sel += E.g_selections[g];
     }
     sh[0][threadIdx.x] = fin; sh[1][threadIdx.x] = sims; sh[2][threadIdx.x] = err;
-    sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel;
+    sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel; sh[5][threadIdx.x] = maxpool;
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (threadIdx.x < 6) {
         unsigned long long a = 0;
-        for (int i = 0; i < 256; ++i) a = (threadIdx.x == 2) ? (a | sh[2][i]) : (a + sh[threadIdx.x][i]);
+        for (int i = 0; i < 256; ++i) {
+            const unsigned long long x = sh[threadIdx.x][i];
+            a = (threadIdx.x == 2) ? (a | x) : (threadIdx.x == 5 ? (x > a ? x : a) : a + x);
+        }
         E.counters[threadIdx.x] = a;
     }
 }
@@ -898,6 +904,123 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     E.root_node[g] = RAZ_NO_NODE;
     E.nn_active[g] = 0;
     E.depth[g] = 0;
+}
+
+// ------------------------------------------------------------------ node pruning
+// The disc count only grows, so once the real game has D discs every node whose position has fewer
+// is unreachable (SURVEY.md §7 hard part 5).  k_gc compacts the pool of every game whose usage is at
+// least `threshold`: kept nodes slide down in index order (so relative order, and with it nothing
+// observable, changes), child / mirror / root / in-flight path indices are renumbered and the hash
+// table is rebuilt.  One 256-thread workgroup per game; launched between simulation steps.
+__global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold) {
+    const uint32_t g = blockIdx.x;
+    if (g >= E.B) return;
+    const uint32_t used = E.pool_used[g];
+    if (E.g_status[g] != 0 || used < threshold) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_base;
+    uint32_t* remap = E.gc_remap + (size_t)g * E.C;
+    const int dmin = bb_popcount(E.root_black[g]) + bb_popcount(E.root_white[g]);
+    // pass 1: keep flags -> new indices (blocked exclusive scan, 256 nodes per round)
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < used; i0 += 256) {
+        const uint32_t i = i0 + tid;
+        uint32_t keep = 0;
+        if (i < used) {
+            const raz_node_hdr* h = node_hdr(node_ptr(E, g, i));
+            keep = (bb_popcount(h->black) + bb_popcount(h->white)) >= dmin ? 1u : 0u;
+        }
+        s_cnt[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+            const uint32_t v = tid >= off ? s_cnt[tid - off] : 0;
+            __syncthreads();
+            s_cnt[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t base = s_base;
+        if (i < used) remap[i] = keep ? base + s_cnt[tid] - 1 : RAZ_NO_NODE;
+        __syncthreads();
+        if (tid == 255) s_base = base + s_cnt[255];
+        __syncthreads();
+    }
+    const uint32_t kept = s_base;
+    // pass 2: slide kept nodes down, four per round (read all, barrier, write all: a destination
+    // never lies above its source, so later rounds' sources are untouched)
+    for (uint32_t i0 = 0; i0 < used; i0 += 4) {
+        const uint32_t i = i0 + wv;
+        const uint32_t dst = i < used ? remap[i] : RAZ_NO_NODE;
+        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+        const bool move = dst != RAZ_NO_NODE && dst != i;
+        if (move) {
+            const uint4* src = (const uint4*)node_ptr(E, g, i);
+            a = src[lane];
+            if (lane < 24) b = src[64 + lane];
+        }
+        __syncthreads();
+        if (move) {
+            uint4* d = (uint4*)node_ptr(E, g, dst);
+            d[lane] = a;
+            if (lane < 24) d[64 + lane] = b;
+        }
+        __syncthreads();
+    }
+    // pass 3: renumber links inside the kept nodes; clear the table
+    for (uint32_t n = wv; n < kept; n += 4) {
+        unsigned char* p = node_ptr(E, g, n);
+        const uint32_t c = node_child(p)[lane];
+        if (c && !(c & 0x80000000u)) {
+            const uint32_t r = remap[c - 1];
+            node_child(p)[lane] = r == RAZ_NO_NODE ? 0u : r + 1;
+        }
+        if (lane == 0) {
+            raz_node_hdr* h = node_hdr(p);
+            const uint32_t m = h->mirror;
+            if (m != RAZ_NO_NODE) h->mirror = remap[m];
+        }
+    }
+    raz_slot* tab = E.table + (size_t)g * E.H;
+    for (uint32_t sidx = tid; sidx < E.H; sidx += 256) tab[sidx].idx_tag = 0;
+    if (tid < 64) {  // in-flight simulation state
+        const uint32_t pn = E.path_node[(size_t)g * 64 + tid], pm = E.path_mirror[(size_t)g * 64 + tid];
+        const int depth = E.depth[g];
+        if (tid < depth) {
+            E.path_node[(size_t)g * 64 + tid] = remap[pn];
+            if (pm != RAZ_NO_NODE) E.path_mirror[(size_t)g * 64 + tid] = remap[pm];
+        }
+    }
+    if (tid == 0) {
+        const uint32_t rn = E.root_node[g];
+        if (rn != RAZ_NO_NODE) E.root_node[g] = remap[rn];
+        const uint32_t ln = E.leaf_node[g], lm = E.leaf_mirror[g];
+        if (E.leaf_kind[g] == RAZ_LEAF_EXPAND) {
+            if (ln != RAZ_NO_NODE) E.leaf_node[g] = remap[ln];
+            if (lm != RAZ_NO_NODE) E.leaf_mirror[g] = remap[lm];
+            E.leaf_slot[g] = 0xfffffffeu;  // the slot found by select is gone: backup probes again
+        }
+        E.pool_used[g] = kept;
+    }
+    __syncthreads();
+    __threadfence_block();
+    // pass 4: rebuild the table (parallel insertion, one thread per kept node)
+    const uint32_t mask = E.H - 1;
+    for (uint32_t n = tid; n < kept; n += 256) {
+        const raz_node_hdr* h = node_hdr(node_ptr(E, g, n));
+        const raz_bb kb = h->black, kw = h->white;
+        const uint32_t tagkey = h->tag & RAZ_SLOT_KEYMASK;
+        uint32_t si = key_hash(kb, kw, tagkey) & mask;
+        const uint32_t val = (n << 8) | RAZ_SLOT_USED | tagkey;
+        for (;;) {
+            if (atomicCAS(&tab[si].idx_tag, 0u, val) == 0u) {
+                tab[si].black = kb;
+                tab[si].white = kw;
+                break;
+            }
+            si = (si + 1) & mask;
+        }
+    }
 }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -942,6 +1065,7 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
     d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
+    d.gc_remap = (uint32_t*)take(B * C * 4);
     d.counters = (unsigned long long*)take(8 * 8);
     d.prof = (unsigned long long*)take(B * 8 * 8);
     if (E) *E = d;
@@ -1152,7 +1276,18 @@ extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_s
     out->error_flags = c[2];
     out->nn_leaves = c[3];
     out->selections = c[4];
+    out->max_pool_used = c[5];
     return RAZ_OK;
+}
+
+// Prune unreachable nodes (positions with fewer discs than the current real position) in every
+// game whose pool holds at least `threshold` nodes.  Asynchronous on `stream`; call between
+// raz_engine_step calls.  Results are unaffected (kept nodes keep their relative order).
+extern "C" int raz_engine_gc(raz_engine* e, uint32_t threshold, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_gc: NULL engine");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_gc: call raz_engine_start first");
+    hipLaunchKernelGGL(k_gc, dim3(e->dev.B), dim3(256), 0, (hipStream_t)stream, e->dev, threshold);
+    return raz_check_launch("raz_engine_gc");
 }
 
 // raz_engine_step with HIP events around every kernel launch on `stream` (the stream the kernels

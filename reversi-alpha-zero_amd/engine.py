@@ -175,15 +175,27 @@ class SelfPlayEngine:
             raise RuntimeError(f"engine error flags {st.error_flags:#x} (1 node pool full, 2 table full, "
                                f"4 records full, 8 path overflow): enlarge nodes_per_game/max_plies")
         return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves,
-                "selections": st.selections}
+                "selections": st.selections, "max_pool_used": st.max_pool_used}
+
+    def gc(self, threshold=0):
+        """Prune unreachable nodes in every game whose pool holds >= threshold nodes."""
+        import torch
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_gc(self._h, threshold, _stream()), "raz_engine_gc")
 
     def run(self, chunk=64, max_steps=10_000_000):
-        """Step until every active game has finished.  Returns the final stats."""
+        """Step until every active game has finished.  Returns the final stats.  Pools are pruned
+        whenever the fullest one could overflow before the next poll (<= 4 new nodes per step)."""
         steps = 0
+        cap = int(self.cfg.nodes_per_game)
+        self.gc_runs = 0
         while True:
             self.step(chunk)
             steps += chunk
             st = self.stats()
+            if st["max_pool_used"] + 4 * chunk + 64 > cap:
+                self.gc(threshold=cap // 4)
+                self.gc_runs += 1
             if st["finished_games"] >= self.n_active:
                 st["steps"] = steps
                 return st

@@ -157,3 +157,23 @@ def test_engine_mirror_off_equals_mirror_on_unshared(golden, blob):
         out.append(eng.records(save_policy_of_tau_1=False))
     for (pa, sa), (pb, sb) in zip(*out):
         assert pa == pb and sa == sb
+
+
+@pytest.mark.parametrize("variant,pool", [("mini_shared", 1024), ("agz", 512)])
+def test_engine_with_node_pruning_equals_oracle(golden, blob, variant, pool):
+    """A node pool far too small for whole games (forces several k_gc prunes per game) must not
+    change anything: 48 games == the oracle, bit for bit."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    g0 = next(g for g in golden["games"] if g["variant"] == variant)
+    cfg = config_of(g0)
+    n, sims = 48, 24
+    dnet = DeviceNet(blob, DEV)
+    eng = SelfPlayEngine(cfg, dnet, n_games=n, seed=31, nodes_per_game=pool, record_root_w=True)
+    eng.start(first_game_id=500, sims_per_move=sims)
+    eng.run(chunk=32)
+    assert eng.gc_runs >= 2
+    recs = eng.records(save_policy_of_tau_1=g0["resolved_play_data"]["save_policy_of_tau_1"])
+    ocfg = O.play_cfg_from_config(cfg)
+    for i in range(0, n, 2):
+        plies, summ = O.selfplay_game(ocfg, blob, 31, 500 + i, sims)
+        _compare_game(f"gc/{variant}/{500 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
