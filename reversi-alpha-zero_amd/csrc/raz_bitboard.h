@@ -89,24 +89,27 @@ RAZ_HD int bb_d4_square(int s, int flip, int rot) {
 }
 
 // One direction of the mobility fill, towards lower bit indices (lib/bitboard.py:95-104) and
-// towards higher ones (:107-116): seed = enemy discs adjacent to an own disc, five more
-// propagation steps (six flippable discs at most), then step once more onto an empty square.
+// towards higher ones (:107-116).  The reference seeds with the enemy discs adjacent to an own disc
+// and propagates five more single steps (a run of at most six flippable discs), then steps once
+// more onto an empty square.  Because the edge mask limits every run of `e` along a line to six
+// squares, propagating by 1, then 2, then 4 (parallel prefix) reaches exactly the same set for
+// every input, in three steps instead of five.
 RAZ_HD raz_bb bb_fill_down(raz_bb own, raz_bb e, int k) {
     raz_bb t = e & (own >> k);
     t |= e & (t >> k);
-    t |= e & (t >> k);
-    t |= e & (t >> k);
-    t |= e & (t >> k);
-    t |= e & (t >> k);
+    raz_bb e2 = e & (e >> k);
+    t |= e2 & (t >> (2 * k));
+    raz_bb e4 = e2 & (e2 >> (2 * k));
+    t |= e4 & (t >> (4 * k));
     return t >> k;
 }
 RAZ_HD raz_bb bb_fill_up(raz_bb own, raz_bb e, int k) {
     raz_bb t = e & (own << k);
     t |= e & (t << k);
-    t |= e & (t << k);
-    t |= e & (t << k);
-    t |= e & (t << k);
-    t |= e & (t << k);
+    raz_bb e2 = e & (e << k);
+    t |= e2 & (t << (2 * k));
+    raz_bb e4 = e2 & (e2 << (2 * k));
+    t |= e4 & (t << (4 * k));
     return t << k;
 }
 

@@ -82,33 +82,43 @@ __device__ __forceinline__ void step_one(raz_bb& b, raz_bb& w, uint8_t& pl, uint
     lg = r.legal;
 }
 
+// Four adjacent boards per thread: the u64 streams move as 2 x 16 B per lane and the u8 streams as
+// 4 B per lane, and the four independent flip/mobility computations give the VALU instruction-level
+// parallelism (the kernel sits near the crossover between the HBM and the integer-VALU bound).
 __global__ __launch_bounds__(kBlock) void k_step(raz_bb* __restrict__ black,
                                                  raz_bb* __restrict__ white,
                                                  uint8_t* __restrict__ player,
                                                  uint8_t* __restrict__ status,
                                                  raz_bb* __restrict__ legal,
                                                  const uint8_t* __restrict__ action, size_t n) {
-    const size_t pairs = n >> 1;
+    const size_t quads = n >> 2;
     const size_t stride = (size_t)gridDim.x * kBlock;
     ulonglong2* black2 = (ulonglong2*)black;
     ulonglong2* white2 = (ulonglong2*)white;
     ulonglong2* legal2 = (ulonglong2*)legal;
-    uchar2* player2 = (uchar2*)player;
-    uchar2* status2 = (uchar2*)status;
-    const uchar2* action2 = (const uchar2*)action;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += stride) {
-        ulonglong2 b = black2[i], w = white2[i], l;
-        uchar2 p = player2[i], s = status2[i], a = action2[i];
-        step_one(b.x, w.x, p.x, s.x, l.x, a.x);
-        step_one(b.y, w.y, p.y, s.y, l.y, a.y);
-        black2[i] = b;
-        white2[i] = w;
-        legal2[i] = l;
-        player2[i] = p;
-        status2[i] = s;
+    uchar4* player4 = (uchar4*)player;
+    uchar4* status4 = (uchar4*)status;
+    const uchar4* action4 = (const uchar4*)action;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < quads; i += stride) {
+        ulonglong2 b0 = black2[2 * i], b1 = black2[2 * i + 1], w0 = white2[2 * i], w1 = white2[2 * i + 1], l0, l1;
+        uchar4 p = player4[i], s = status4[i], a = action4[i];
+        step_one(b0.x, w0.x, p.x, s.x, l0.x, a.x);
+        step_one(b0.y, w0.y, p.y, s.y, l0.y, a.y);
+        step_one(b1.x, w1.x, p.z, s.z, l1.x, a.z);
+        step_one(b1.y, w1.y, p.w, s.w, l1.y, a.w);
+        black2[2 * i] = b0;
+        black2[2 * i + 1] = b1;
+        white2[2 * i] = w0;
+        white2[2 * i + 1] = w1;
+        legal2[2 * i] = l0;
+        legal2[2 * i + 1] = l1;
+        player4[i] = p;
+        status4[i] = s;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const size_t i = n - 1;
+    // ragged tail (n % 4 boards)
+    const size_t tail0 = quads << 2;
+    if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
+        const size_t i = tail0 + threadIdx.x;
         raz_bb b = black[i], w = white[i], l;
         uint8_t p = player[i], s = status[i];
         step_one(b, w, p, s, l, action[i]);
@@ -241,9 +251,9 @@ extern "C" int raz_step_batch(uint64_t* black, uint64_t* white, uint8_t* player,
     RAZ_REQUIRE(black && white && player && status && legal && action, "raz_step_batch: NULL array");
     RAZ_REQUIRE(aligned16(black) && aligned16(white) && aligned16(legal),
                 "raz_step_batch: u64 arrays must be 16-byte aligned");
-    RAZ_REQUIRE((((uintptr_t)player | (uintptr_t)status | (uintptr_t)action) & 1) == 0,
-                "raz_step_batch: u8 arrays must be 2-byte aligned");
-    hipLaunchKernelGGL(k_step, dim3(grid_for(n / 2 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
+    RAZ_REQUIRE((((uintptr_t)player | (uintptr_t)status | (uintptr_t)action) & 3) == 0,
+                "raz_step_batch: u8 arrays must be 4-byte aligned");
+    hipLaunchKernelGGL(k_step, dim3(grid_for(n / 4 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
                        (raz_bb*)black, (raz_bb*)white, player, status, (raz_bb*)legal, action, n);
     return raz_check_launch("raz_step_batch");
 }

@@ -126,6 +126,19 @@ def run_sweep(args, rank, world, dev):
                      "algorithmic_bytes_per_launch": STEP_BYTES_PER_BOARD * n},
     }
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+    # the mobility kernel alone (24 B/board)
+    lg = torch.empty(n, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        bb.legal_moves_batch(black, white, out=lg)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        bb.legal_moves_batch(black, white, out=lg)
+    e1.record()
+    torch.cuda.synchronize()
+    lm_ms = e0.elapsed_time(e1) / 10
+    out["k_legal_moves"] = {"avg_kernel_ms": lm_ms, "achieved": 24 * n / (lm_ms * 1e-3) / 1e9, "unit": "GB/s",
+                            "frac": 24 * n / (lm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "inputs (256 MiB) partly Infinity-Cache resident"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_sweep(black, white, player, action, args.cpu_budget)
     return out
