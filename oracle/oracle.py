@@ -112,7 +112,7 @@ class OrcPlayCfg(Structure):
 
 class OrcPlyRecord(Structure):
     _fields_ = [("player", c_int), ("turn", c_int), ("own", c_uint64), ("enemy", c_uint64),
-                ("action", c_int), ("has_row", c_int), ("sims", c_int), ("loops", c_int),
+                ("action", c_int), ("solved", c_int), ("has_row", c_int), ("sims", c_int), ("loops", c_int),
                 ("n", c_double), ("q", c_double), ("root_n", c_double * 64), ("root_w", c_double * 64),
                 ("saved_policy", c_double * 64)]
 
@@ -122,7 +122,7 @@ class OrcGameSummary(Structure):
                 ("resigned_black", c_int), ("resigned_white", c_int), ("black", c_uint64),
                 ("white", c_uint64), ("drop_draw_u", c_double), ("n_sims", c_longlong),
                 ("n_expand", c_longlong), ("n_mirror_hits", c_longlong), ("n_terminal", c_longlong),
-                ("n_nodes", c_longlong)]
+                ("n_nodes", c_longlong), ("n_solved_leaves", c_longlong), ("n_solver_nodes", c_longlong)]
 
 
 def play_cfg_from_config(config, parallel_search_num=1):
@@ -166,6 +166,11 @@ def load_ext():
         lib.orc_dirichlet_noise_of_mask.restype = None
         lib.orc_net_forward_planes.argtypes = [c_char_p, c_size_t, c_void_p, c_void_p, c_void_p]
         lib.orc_net_forward.argtypes = [c_char_p, c_size_t, c_uint64, c_uint64, c_void_p, c_void_p]
+        lib.orc_solver_new.restype = c_void_p
+        lib.orc_solver_free.argtypes = [c_void_p]
+        lib.orc_solver_nodes.argtypes = [c_void_p]
+        lib.orc_solver_nodes.restype = c_longlong
+        lib.orc_solver_solve.argtypes = [c_void_p, c_uint64, c_uint64, c_int, c_int, POINTER(c_int), POINTER(c_int)]
         lib.orc_selfplay_game.argtypes = [POINTER(OrcPlayCfg), c_char_p, c_size_t, c_uint32, c_uint32, c_int,
                                           POINTER(OrcPlyRecord), c_int, POINTER(OrcGameSummary)]
         _ext_done = True
@@ -206,7 +211,7 @@ def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128):
     for i in range(n):
         r = plies[i]
         out.append({"player": r.player, "turn": r.turn, "own": r.own, "enemy": r.enemy, "action": r.action,
-                    "has_row": bool(r.has_row), "sims": r.sims, "loops": r.loops, "n": r.n, "q": r.q,
+                    "solved": bool(r.solved), "has_row": bool(r.has_row), "sims": r.sims, "loops": r.loops, "n": r.n, "q": r.q,
                     "root_n": list(r.root_n), "root_w": list(r.root_w), "saved_policy": list(r.saved_policy)})
     s = {k: getattr(summ, k) for k, _ in OrcGameSummary._fields_}
     return out, s

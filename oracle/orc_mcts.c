@@ -89,6 +89,8 @@ typedef struct {
     uint32_t ev_expand, ev_choice, ev_dirichlet;
     otable tables[2];   /* tables[1] unused (aliased) when share_mtcs_info */
     int resigned[2];    /* ReversiPlayer.resigned (:58,125) */
+    orc_solver* solver[2]; /* one ReversiSolver per player (:60, 435-436) */
+    long long n_solved_leaves;
     long long n_sims, n_expand, n_mirror_hits, n_terminal;
 } ogame;
 
@@ -198,6 +200,26 @@ static double search_my_move(ogame* g, int pl, orc_env* env, int is_root) {
     otable* t = player_table(g, pl);
     const u64 kb = env->black, kw = env->white;
     const int knp = env->next_player;
+    if (c->use_solver_turn_in_simulation && env->turn >= c->use_solver_turn_in_simulation) { /* :237-251 */
+        int action, score;
+        int ok = orc_solver_solve(g->solver[pl], kb, kw, knp, 0, &action, &score);
+        if (ok && action) { /* `if action:` — square 0 is ignored like None */
+            if (knp != 1) score = -score;
+            double leaf_v = score > 0 ? 1.0 : (score < 0 ? -1.0 : 0.0);
+            onode* k = table_get(t, kb, kw, knp);
+            k->N[action] += 1;
+            k->W[action] += leaf_v;
+            for (int i = 0; i < 64; ++i) k->P[i] = 0.0f;
+            k->P[action] = 1.0f;
+            onode* m2 = table_get(t, kw, kb, 3 - knp);
+            m2->N[action] += 1;
+            m2->W[action] -= leaf_v;
+            for (int i = 0; i < 64; ++i) m2->P[i] = 0.0f;
+            m2->P[action] = 1.0f;
+            g->n_solved_leaves++;
+            return leaf_v;
+        }
+    }
     onode* n = table_find(t, kb, kw, knp);
     if (!(n && n->expanded[pl])) {
         if (n && !c->share_mtcs_info) g->n_mirror_hits++; /* reached a key only mirror writes created */
@@ -244,6 +266,24 @@ static int action_with_evaluation(ogame* g, int pl, u64 own, u64 enemy, int sims
     rec->own = root.black; /* after Board()'s `or default` quirk */
     rec->enemy = root.white;
     rec->turn = turn;
+    if (c->use_solver_turn && turn >= c->use_solver_turn) { /* action_by_searching (:100-103, 150-161) */
+        int a, score;
+        if (orc_solver_solve(g->solver[pl], root.black, root.white, 1, 1, &a, &score)) {
+            onode* n = table_get(t, root.black, root.white, 1);
+            double sg = score > 0 ? 1.0 : (score < 0 ? -1.0 : 0.0);
+            n->N[a] = 999;
+            n->W[a] = sg * 999;
+            for (int i = 0; i < 64; ++i) n->P[i] = 0.0f;
+            n->P[a] = 1.0f;
+            for (int i = 0; i < 64; ++i) { rec->root_n[i] = n->N[i]; rec->root_w[i] = n->W[i]; }
+            rec->action = a;
+            rec->solved = 1;
+            rec->has_row = 0;
+            rec->n = 999;
+            rec->q = sg;
+            return a;
+        }
+    }
     double policy[64];
     int action = 0;
     for (int tl = 0; tl < c->thinking_loop; ++tl) {
@@ -329,7 +369,9 @@ int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_byt
     ogame g;
     memset(&g, 0, sizeof g);
     g.cfg = cfg; g.blob = blob; g.blob_bytes = blob_bytes; g.seed = seed; g.game_id = game_id;
-    if (cfg->parallel_search_num != 1 || cfg->use_solver_turn || cfg->use_solver_turn_in_simulation) return -1;
+    if (cfg->parallel_search_num != 1) return -1;
+    g.solver[0] = orc_solver_new();
+    g.solver[1] = orc_solver_new();
     table_init(&g.tables[0]);
     if (!cfg->share_mtcs_info) table_init(&g.tables[1]);
     double d[2];
@@ -356,7 +398,11 @@ int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_byt
         sum->n_sims = g.n_sims; sum->n_expand = g.n_expand; sum->n_mirror_hits = g.n_mirror_hits;
         sum->n_terminal = g.n_terminal;
         sum->n_nodes = (long long)(g.tables[0].count + (cfg->share_mtcs_info ? 0 : g.tables[1].count));
+        sum->n_solved_leaves = g.n_solved_leaves;
+        sum->n_solver_nodes = orc_solver_nodes(g.solver[0]) + orc_solver_nodes(g.solver[1]);
     }
+    orc_solver_free(g.solver[0]);
+    orc_solver_free(g.solver[1]);
     table_free(&g.tables[0]);
     if (!cfg->share_mtcs_info) table_free(&g.tables[1]);
     return np;

@@ -141,6 +141,8 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
                       "n": float(res.n), "q": float(res.q),
                       "root_n": [float(v) for v in self.var_n[key]], "root_w": [float(v) for v in self.var_w[key]],
                       "has_row": len(new) == 8,
+                      "solved": (len(new) == 0 and res.action is not None and float(res.n) == 999.0
+                                 and not isinstance(res.q, float)),
                       "saved_policy": [float(v) for v in new[0][1]] if new else None})
         return res
 

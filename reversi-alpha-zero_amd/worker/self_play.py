@@ -84,7 +84,10 @@ def ggf_moves_of_game(plies):
             continue
         if (len(moves) % 2 == 0) != (p["player"] == 1):
             moves.append(convert_action_to_move(None))
-        moves.append(f"{convert_action_to_move(p['action'])}/{p['q'] * 10}/{p['n']}")
+        if p.get("solved"):  # action_by_searching returns n=999 (int) and q=np.sign(score) (integer): "10/999"
+            moves.append(f"{convert_action_to_move(p['action'])}/{int(p['q']) * 10}/{int(p['n'])}")
+        else:
+            moves.append(f"{convert_action_to_move(p['action'])}/{p['q'] * 10}/{p['n']}")
     return moves
 
 

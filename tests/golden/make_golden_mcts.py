@@ -33,6 +33,13 @@ VARIANTS = [
                                       "start_rethinking_turn": 6}, {}, 25, 15, [2]),
     ("eval_like_nonoise", "alpha_go_zero.yml", {"noise_eps": 0, "change_tau_turn": 0}, {"save_policy_of_tau_1": True}, 30, 16, [0, 9]),
     ("ch5_tau4_cpuct5", "ch5.yml", {"thinking_loop": 1}, {}, 30, 17, [3]),
+    # end-game solver ON (the reference's compiled Cython solver, lib/alt/reversi_solver_cython.pyx)
+    ("mini_solver_as_shipped", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
+                                            "use_solver_turn_in_simulation": 50}, {}, 20, 18, [0, 3]),
+    ("mini_solver_noresign", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
+                                          "use_solver_turn_in_simulation": 50, "resign_threshold": None}, {}, 16, 20, [2]),
+    ("agz_solver_52_50", "alpha_go_zero.yml", {"use_solver_turn": 52, "use_solver_turn_in_simulation": 50,
+                                               "resign_threshold": None}, {}, 25, 19, [1]),
 ]
 
 
@@ -49,7 +56,7 @@ def main():
            "games": []}
     for name, yml, play_over, pd_over, sims, seed, gids in VARIANTS:
         for gid in gids:
-            over = {"play": dict(NO_SOLVER, **play_over), "play_data": pd_over}
+            over = {"play": dict(NO_SOLVER, **play_over), "play_data": pd_over}   # variant keys win over NO_SOLVER
             cfg = rh.load_config(yml, over)
             ref = rs.run_reference_game(cfg, blob, seed, gid, sims)
             rows = ref.pop("play_rows")
@@ -57,6 +64,7 @@ def main():
             for p in ref.pop("plies"):
                 plies.append({"player": p["player"], "own": "0x%016x" % p["own"], "enemy": "0x%016x" % p["enemy"],
                               "action": p["action"], "n": p["n"], "q": p["q"], "has_row": p["has_row"],
+                              "solved": bool(p.get("solved", False)),
                               "root_n": sparse(p["root_n"]), "root_w": sparse(p["root_w"]),
                               "saved_policy": sparse(p["saved_policy"]) if p["saved_policy"] else None})
             keys = ["thinking_loop", "required_visit_to_decide_action", "start_rethinking_turn", "c_puct",

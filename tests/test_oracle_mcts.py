@@ -95,6 +95,7 @@ def test_games_bit_exact_vs_reference(golden, blob):
             assert a["root_n"] == dense(b["root_n"]), (tag, i)
             assert a["root_w"] == dense(b["root_w"]), (tag, i)
             assert a["has_row"] == b["has_row"], (tag, i)
+            assert a["solved"] == b.get("solved", False), (tag, i)
             if a["action"] >= 0:
                 assert a["n"] == b["n"] and a["q"] == b["q"], (tag, i)
             if b["has_row"]:
