@@ -147,6 +147,12 @@ typedef struct {
     uint32_t seed;
     uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream; bits 8-11: slices/streams (0 = 3);
                                                  bits 12-15: max simulations per game per tree launch (0 = 2) */
+    int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
+                                                 (agent/player.py:100-103,150-161; lib/alt/reversi_solver_cython.pyx) */
+    int32_t use_solver_turn_in_simulation;    /* config.py:155: 0 = off, else >= 46: win/loss solve inside simulations
+                                                 (agent/player.py:237-251) */
+    uint32_t solver_memo_slots;               /* per-game memo of solved positions, power of two (0 with the solver off) */
+    uint32_t reserved2;
 } raz_engine_config;
 
 typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */

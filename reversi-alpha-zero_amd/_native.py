@@ -62,7 +62,9 @@ class RazEngineConfig(ctypes.Structure):
                 ("c_puct", ctypes.c_double), ("noise_eps", ctypes.c_double), ("dirichlet_alpha", ctypes.c_double),
                 ("resign_threshold", ctypes.c_double), ("disable_resignation_rate", ctypes.c_double),
                 ("n_games", c_uint32), ("nodes_per_game", c_uint32), ("table_slots", c_uint32),
-                ("max_plies", c_uint32), ("seed", c_uint32), ("reserved", c_uint32)]
+                ("max_plies", c_uint32), ("seed", c_uint32), ("reserved", c_uint32),
+                ("use_solver_turn", ctypes.c_int32), ("use_solver_turn_in_simulation", ctypes.c_int32),
+                ("solver_memo_slots", c_uint32), ("reserved2", c_uint32)]
 
 
 class RazEngineStats(ctypes.Structure):

@@ -27,6 +27,7 @@
 #define RAZ_LEAF_NONE 0
 #define RAZ_LEAF_EXPAND 1
 #define RAZ_LEAF_TERMINAL 2
+#define RAZ_LEAF_SOLVED 3   // the in-simulation solver answered (agent/player.py:237-251)
 
 #define RAZ_PHASE_NEW_MOVE 0
 #define RAZ_PHASE_SEARCH 1
@@ -72,7 +73,7 @@ struct raz_ply_header {  // 48 bytes, one per recorded ply (== orc_ply_record mi
     uint8_t has_row;                // a training row is emitted for this ply
     uint32_t sims;                  // simulations run for this move (all thinking loops)
     uint32_t loops;
-    uint32_t pad;
+    uint32_t flags;                 // bit 0: move chosen by the exact solver (action_by_searching)
 };
 
 // Pointers into the caller-provided workspace + the play parameters.  Passed BY VALUE to kernels.
@@ -103,6 +104,9 @@ struct raz_engine_dev {
     uint32_t* rec_n;               // [B][max_plies][64]
     double* rec_w;                 // [B][max_plies][64] or NULL
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games
+    raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
+    uint32_t M;
+    uint8_t* leaf_action;          // [B] action of a RAZ_LEAF_SOLVED leaf
     uint32_t* gc_remap;            // [B][C] old -> new node index during k_gc
     unsigned long long* counters;
     unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)

@@ -378,6 +378,137 @@ __device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal
     return p32;
 }
 
+// ------------------------------------------------------------------ end-game solver
+// lib/alt/reversi_solver_cython.pyx:40-127.  The reference's explicit-stack DFS returns a function of
+// the position and the mode alone (see oracle/orc_solver.c): for the legal moves in ascending order
+// [non-exact: stop once the best score is > 0], value = -f(child) / +f(child after a pass) / final
+// disc difference, strict improvement keeps the first maximum.  Here: the same DFS, wave-uniform
+// (scalar unit), frames in LDS (depth <= empties <= 14), with a per-game memo in HBM (positions
+// with >= 4 empties; the memo only saves time, exactly as the reference's dict does).
+struct SolverLDS {
+    unsigned long long own[16], enemy[16], left[16];
+    int best_move[16], best_score[16], paction[16], flip[16], fresh[16];
+};
+
+__device__ bool memo_find(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int lane,
+                          int& move, int& score) {
+    const raz_slot* tab = E.memo + (size_t)g * E.M;
+    const uint32_t mask = E.M - 1;
+    const uint32_t h = key_hash(own, enemy, 8u + exact);
+    for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
+        const raz_slot* s = tab + ((h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask);
+        const raz_bb sb = s->black, sw = s->white;
+        const uint32_t it = s->idx_tag;
+        const bool used = (it >> 31) != 0;
+        const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact;
+        const unsigned long long mm = __ballot(match) & 0xffffULL;
+        const unsigned long long em = __ballot(!used) & 0xffffULL;
+        if (mm) {
+            const uint32_t v = lane_u32(it, __ffsll((long long)mm) - 1);
+            move = (int)((v >> 8) & 0xffu) - 1;
+            score = (int)(v & 0xffu) - 128;
+            return true;
+        }
+        if (em) return false;
+    }
+    return false;
+}
+
+__device__ void memo_put(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int move,
+                         int score, int lane) {
+    raz_slot* tab = E.memo + (size_t)g * E.M;
+    const uint32_t mask = E.M - 1;
+    const uint32_t h = key_hash(own, enemy, 8u + exact);
+    for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
+        const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
+        const bool used = (tab[si].idx_tag >> 31) != 0;
+        const unsigned long long em = __ballot(!used) & 0xffffULL;
+        if (em) {
+            if (lane == 0) {
+                raz_slot* s = tab + ((h + r + (uint32_t)(__ffsll((long long)em) - 1)) & mask);
+                s->black = own;
+                s->white = enemy;
+                s->idx_tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
+            }
+            wave_sync();
+            return;
+        }
+    }  // 64 occupied slots in a row: the memo is (locally) full; skipping the insert only costs time
+}
+
+// ReversiSolver.solve for the side to move (own, enemy).  Returns false for the reference's
+// (None, None) (no legal move at the root: never the case for a running game).
+__device__ bool solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                             SolverLDS* S, int& out_move, int& out_score) {
+    int depth = 0;
+    S->own[0] = own0;
+    S->enemy[0] = enemy0;
+    S->left[0] = bb_legal_moves(own0, enemy0);
+    S->best_move[0] = -1;
+    S->best_score[0] = -100;
+    S->paction[0] = -1;
+    S->flip[0] = 0;
+    S->fresh[0] = 1;
+    for (;;) {
+        wave_sync();
+        const raz_bb own = uni(S->own[depth]), enemy = uni(S->enemy[depth]);
+        raz_bb left = uni(S->left[depth]);
+        int best_move = uni(S->best_move[depth]), best_score = uni(S->best_score[depth]);
+        const bool big = bb_popcount(~(own | enemy)) >= 4;
+        int rm = 0, rs = 0;
+        bool done = false;
+        if (uni(S->fresh[depth])) {
+            S->fresh[depth] = 0;
+            if (big && memo_find(E, g, own, enemy, exact, lane, rm, rs)) done = true;
+        }
+        if (!done && (left == 0 || (!exact && best_score > 0))) {
+            if (big) memo_put(E, g, own, enemy, exact, best_move, best_score, lane);
+            rm = best_move;
+            rs = best_score;
+            done = true;
+        }
+        if (done) {
+            if (depth == 0) {
+                out_move = rm;
+                out_score = rs;
+                return rm >= 0;
+            }
+            const int pa = uni(S->paction[depth]);
+            const int v = uni(S->flip[depth]) ? -rs : rs;
+            --depth;
+            if (uni(S->best_score[depth]) < v) {
+                S->best_move[depth] = pa;
+                S->best_score[depth] = v;
+            }
+            continue;
+        }
+        const int a = __ffsll((long long)left) - 1;
+        left &= left - 1;
+        S->left[depth] = left;
+        const raz_bb flipped = bb_calc_flip(a, own, enemy);
+        const raz_bb nown = (own ^ flipped) | (1ULL << a), nenemy = enemy ^ flipped;
+        const raz_bb l1 = bb_legal_moves(nenemy, nown);
+        if (l1 || bb_legal_moves(nown, nenemy)) {
+            const bool turn_passes = l1 == 0;  // the opponent has no move: same side again
+            ++depth;
+            S->own[depth] = turn_passes ? nown : nenemy;
+            S->enemy[depth] = turn_passes ? nenemy : nown;
+            S->left[depth] = turn_passes ? bb_legal_moves(nown, nenemy) : l1;
+            S->best_move[depth] = -1;
+            S->best_score[depth] = -100;
+            S->paction[depth] = a;
+            S->flip[depth] = turn_passes ? 0 : 1;
+            S->fresh[depth] = 1;
+        } else {
+            const int score = bb_popcount(nown) - bb_popcount(nenemy);
+            if (best_score < score) {
+                S->best_move[depth] = a;
+                S->best_score[depth] = score;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ backup of the previous leaf
 // Allocate node `idx` (the caller tracks the pool counter) for key (b, w, np, owner) in the EMPTY
 // table slot `slot`, with prior P already known.  Pure stores: nothing is read back.
@@ -483,6 +614,70 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
             }
         }
         if (lane == 0 && used != uni(used_v)) E.pool_used[g] = used;
+    } else if (kind == RAZ_LEAF_SOLVED) {  // in-simulation solver hit (:239-251): the key and its mirror get
+        // N += 1, W +-= sign(score), P = one-hot; the key is NOT marked expanded
+        const uint32_t np = uni(np_v), act = uni((uint32_t)E.leaf_action[g]);
+        const raz_bb lg = uni(lg_v), kb = uni(kb_v), kw = uni(kw_v);
+        leaf_v = (double)term_v;  // sign(score) in the searching player's view
+        const float onehot = lane == (int)act ? 1.0f : 0.0f;
+        uint32_t used = uni(used_v);
+        uint32_t node = uni(lnode_v), mirror = RAZ_NO_NODE;
+        const uint32_t tagkey = np | (owner << 2);
+        bool ok = true;
+        if (node == RAZ_NO_NODE) {
+            uint32_t slot = uni(lslot_v);
+            if (slot == 0xfffffffeu) slot = table_find(E, g, kb, kw, tagkey, lane).slot;
+            if (slot == 0xffffffffu || used >= E.C) {
+                if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+                ok = false;
+            } else {
+                node = used++;
+                node_init(E, g, node, slot, kb, kw, tagkey, lg, RAZ_NO_NODE, onehot, lane);
+                if (depth > 0) {
+                    const uint32_t parent = lane_u32(my_node, depth - 1);
+                    const uint32_t pa = lane_u32(my_pa, depth - 1);
+                    if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
+                }
+            }
+        } else {
+            node_P(node_ptr(E, g, node))[lane] = onehot;
+            mirror = uni(lmir_v);
+        }
+        if (ok) {
+            if (!c.mirror_updates) {
+                mirror = RAZ_NO_NODE;  // (:248-250) writes to the mirror key are dead without a shared tree
+            } else if (mirror == RAZ_NO_NODE) {
+                wave_sync();
+                const Found f = table_find(E, g, kw, kb, (3 - np) | (owner << 2), lane);
+                if (f.found) {
+                    mirror = f.node;
+                    node_P(node_ptr(E, g, mirror))[lane] = onehot;
+                } else if (f.slot == 0xffffffffu || used >= E.C) {
+                    if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+                } else {
+                    mirror = used++;
+                    node_init(E, g, mirror, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, onehot, lane);
+                }
+                if (mirror != RAZ_NO_NODE && lane == 0) {
+                    node_hdr(node_ptr(E, g, node))->mirror = mirror;
+                    node_hdr(node_ptr(E, g, mirror))->mirror = node;
+                }
+            } else {
+                node_P(node_ptr(E, g, mirror))[lane] = onehot;
+            }
+            wave_sync();
+            if (lane == 0) {
+                unsigned char* p = node_ptr(E, g, node);
+                node_N(p)[act] += 1u;
+                node_W(p)[act] = node_W(p)[act] + leaf_v;
+                if (mirror != RAZ_NO_NODE) {
+                    unsigned char* q = node_ptr(E, g, mirror);
+                    node_N(q)[act] += 1u;
+                    node_W(q)[act] = node_W(q)[act] - leaf_v;
+                }
+            }
+        }
+        if (lane == 0 && used != uni(used_v)) E.pool_used[g] = used;
     } else {
         leaf_v = (double)term_v;
     }
@@ -510,6 +705,52 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
         E.sims_left[g] -= 1;
         E.move_sims[g] += 1;
         E.g_sims[g] += 1;
+    }
+    wave_sync();
+}
+
+// Record the chosen move and play it on the real board (worker/self_play.py:155-162).
+__device__ void finalize_move(const raz_engine_dev& E, uint32_t g, int lane, uint32_t player, raz_bb rb, raz_bb rw,
+                              raz_bb own, raz_bb enemy, int turn, int final_action, bool has_row, bool solved,
+                              double n_action, double q_action, uint32_t loops, uint32_t Ni, double Wi) {
+    // record the ply (rows + GGF are produced on the host from this)
+    const uint32_t ply = uni(E.n_plies[g]);
+    if (ply >= E.max_plies) {
+        if (lane == 0) {
+            E.g_error[g] |= RAZ_ERR_RECORDS_FULL;
+            E.g_phase[g] = RAZ_PHASE_DONE;
+        }
+        return;
+    }
+    const size_t ri = (size_t)g * E.max_plies + ply;
+    E.rec_n[ri * 64 + lane] = Ni;
+    if (E.rec_w) E.rec_w[ri * 64 + lane] = Wi;
+    if (lane == 0) {
+        raz_ply_header h;
+        h.own = own;
+        h.enemy = enemy;
+        h.n = final_action >= 0 ? n_action : 0.0;
+        h.q = final_action >= 0 ? q_action : 0.0;
+        h.action = (int8_t)final_action;
+        h.player = (uint8_t)player;
+        h.turn = (uint8_t)turn;
+        h.has_row = has_row ? 1 : 0;
+        h.sims = E.move_sims[g];
+        h.loops = loops;
+        h.flags = solved ? 1u : 0u;
+        E.rec[ri] = h;
+        E.n_plies[g] = ply + 1;
+    }
+    // env.step(action) on the real board (worker/self_play.py:162)
+    raz_step_result r = bb_env_step(rb, rw, (int)player, final_action < 0 ? RAZ_ACTION_RESIGN : final_action);
+    if (lane == 0) {
+        E.root_black[g] = r.black;
+        E.root_white[g] = r.white;
+        E.g_player[g] = r.player;
+        E.g_status[g] = r.status;
+        E.loops_done[g] = 0;
+        E.move_sims[g] = 0;
+        E.g_phase[g] = r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE;
     }
     wave_sync();
 }
@@ -587,51 +828,12 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
             }
         }
     }
-    // record the ply (rows + GGF are produced on the host from this)
-    const uint32_t ply = uni(E.n_plies[g]);
-    if (ply >= E.max_plies) {
-        if (lane == 0) {
-            E.g_error[g] |= RAZ_ERR_RECORDS_FULL;
-            E.g_phase[g] = RAZ_PHASE_DONE;
-        }
-        return;
-    }
-    const size_t ri = (size_t)g * E.max_plies + ply;
-    E.rec_n[ri * 64 + lane] = Ni;
-    if (E.rec_w) E.rec_w[ri * 64 + lane] = Wi;
-    if (lane == 0) {
-        raz_ply_header h;
-        h.own = own;
-        h.enemy = enemy;
-        h.n = final_action >= 0 ? n_action : 0.0;
-        h.q = final_action >= 0 ? q_action : 0.0;
-        h.action = (int8_t)final_action;
-        h.player = (uint8_t)player;
-        h.turn = (uint8_t)turn;
-        h.has_row = has_row ? 1 : 0;
-        h.sims = E.move_sims[g];
-        h.loops = loops;
-        h.pad = 0;
-        E.rec[ri] = h;
-        E.n_plies[g] = ply + 1;
-    }
-    // env.step(action) on the real board (worker/self_play.py:162)
-    raz_step_result r = bb_env_step(rb, rw, (int)player, final_action < 0 ? RAZ_ACTION_RESIGN : final_action);
-    if (lane == 0) {
-        E.root_black[g] = r.black;
-        E.root_white[g] = r.white;
-        E.g_player[g] = r.player;
-        E.g_status[g] = r.status;
-        E.loops_done[g] = 0;
-        E.move_sims[g] = 0;
-        E.g_phase[g] = r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE;
-    }
-    wave_sync();
+    finalize_move(E, g, lane, player, rb, rw, own, enemy, turn, final_action, has_row, false, n_action, q_action, loops, Ni, Wi);
 }
 
 // Start the mover's move: find/create its root node; turn 0 -> bypass_first_move (:143-148),
 // else arm a search.
-__device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
+__device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, SolverLDS* S) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
@@ -642,6 +844,25 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
     const raz_bb legal = bb_legal_moves(own, enemy);
     const uint32_t node = node_get(E, g, own, enemy, 1, owner, legal, lane);
     if (lane == 0) E.root_node[g] = node;
+    if (c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
+        int sm, ss;
+        if (solver_solve(E, g, lane, own, enemy, 1u, S, sm, ss)) {
+            unsigned char* p = node_ptr(E, g, node);
+            const double sg = ss > 0 ? 1.0 : (ss < 0 ? -1.0 : 0.0);
+            node_P(p)[lane] = lane == sm ? 1.0f : 0.0f;
+            uint32_t Ni = node_N(p)[lane];
+            double Wi = node_W(p)[lane];
+            if (lane == sm) {
+                Ni = 999u;
+                Wi = sg * 999.0;
+                node_N(p)[lane] = Ni;
+                node_W(p)[lane] = Wi;
+            }
+            wave_sync();
+            finalize_move(E, g, lane, player, rb, rw, own, enemy, turn, sm, false, true, 999.0, sg, 0u, Ni, Wi);
+            return;
+        }
+    }
     if (turn > 0) {
         if (lane == 0) {
             E.sims_left[g] = (int32_t)E.sims_per_move[g];
@@ -667,7 +888,7 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane) {
 }
 
 // ------------------------------------------------------------------ descent to the next leaf
-__device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
+__device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, SolverLDS* S) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = uni((uint32_t)E.g_player[g]);
     const uint32_t pl = player - 1;
@@ -685,6 +906,9 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
     uint32_t node = uni(E.root_node[g]);  // always exists (begin_move)
     uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu, leaf_tag = 0, leaf_mirror = RAZ_NO_NODE;
     raz_bb leaf_legal = 0;
+    int solved_action = 0;
+    float solved_v = 0.0f;
+    const int t_insim = c.use_solver_turn_in_simulation;
     if (node == RAZ_NO_NODE) {
         if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
         return;
@@ -710,6 +934,21 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
         env.white = uni(hw);
         env.np = uni(tag) & 3u;
         env.legal = uni(legal);
+        if (t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
+            const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
+            int sm, ss;
+            if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {  // `if action:` ignores square 0
+                if (env.np != 1) ss = -ss;
+                kind = RAZ_LEAF_SOLVED;
+                solved_action = sm;
+                solved_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
+                leaf_node = node;
+                leaf_legal = env.legal;
+                leaf_tag = uni(tag);
+                leaf_mirror = uni(hmirror);
+                break;
+            }
+        }
         if (!((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
             kind = RAZ_LEAF_EXPAND;
             leaf_node = node;
@@ -759,9 +998,19 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             node = f.node;
             continue;
         }
-        kind = RAZ_LEAF_EXPAND;  // brand-new position: created at backup time in the slot found here
-        leaf_slot = f.slot;
+        leaf_slot = f.slot;  // brand-new position: created at backup time in the slot found here
         leaf_legal = env.legal;
+        kind = RAZ_LEAF_EXPAND;
+        if (t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // (:237-251) on a first arrival
+            const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
+            int sm, ss;
+            if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {
+                if (env.np != 1) ss = -ss;
+                kind = RAZ_LEAF_SOLVED;
+                solved_action = sm;
+                solved_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
+            }
+        }
         break;
     }
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-311), first half
@@ -786,6 +1035,18 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
             E.nn_enemy[g] = env.np == 1 ? tw : tb;
         }
     }
+    if (kind == RAZ_LEAF_SOLVED && lane == 0) {
+        E.leaf_b[g] = env.black;
+        E.leaf_w[g] = env.white;
+        E.leaf_legal[g] = leaf_legal;
+        E.leaf_node[g] = leaf_node;
+        E.leaf_slot[g] = leaf_slot;
+        E.leaf_tag[g] = leaf_tag;
+        E.leaf_mirror[g] = leaf_mirror;
+        E.leaf_np[g] = (uint8_t)env.np;
+        E.leaf_action[g] = (uint8_t)solved_action;
+        E.leaf_term_v[g] = solved_v;
+    }
     if (lane == 0) {
         E.leaf_kind[g] = (uint8_t)kind;
         E.depth[g] = (uint8_t)depth;
@@ -800,6 +1061,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane) {
 __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
     __shared__ float lds64[64];
+    __shared__ SolverLDS slds;
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
@@ -824,7 +1086,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
             wave_sync();
             phase = E.g_phase[g];
             if (phase == RAZ_PHASE_NEW_MOVE) {
-                begin_move(E, g, lane);
+                begin_move(E, g, lane, &slds);
                 continue;
             }
             if (phase == RAZ_PHASE_SEARCH && E.sims_left[g] <= 0) {
@@ -838,10 +1100,10 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
         phase = E.g_phase[g];
         if (phase != RAZ_PHASE_SEARCH || E.sims_left[g] <= 0 || E.g_error[g]) break;
         t0 = prof_now();
-        select_leaf(E, g, lane);
+        select_leaf(E, g, lane, &slds);
         wave_sync();
         prof_add(E, g, 2, t0, lane);
-        if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL) break;  // needs the net: end of this launch's work
+        if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL && E.leaf_kind[g] != RAZ_LEAF_SOLVED) break;  // needs the net
     }
 }
 
@@ -995,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
         const uint32_t rn = E.root_node[g];
         if (rn != RAZ_NO_NODE) E.root_node[g] = remap[rn];
         const uint32_t ln = E.leaf_node[g], lm = E.leaf_mirror[g];
-        if (E.leaf_kind[g] == RAZ_LEAF_EXPAND) {
+        if (E.leaf_kind[g] == RAZ_LEAF_EXPAND || E.leaf_kind[g] == RAZ_LEAF_SOLVED) {
             if (ln != RAZ_NO_NODE) E.leaf_node[g] = remap[ln];
             if (lm != RAZ_NO_NODE) E.leaf_mirror[g] = remap[lm];
             E.leaf_slot[g] = 0xfffffffeu;  // the slot found by select is gone: backup probes again
@@ -1065,6 +1327,9 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
     d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
+    d.M = cfg.solver_memo_slots;
+    d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
+    d.leaf_action = take(B);
     d.gc_remap = (uint32_t*)take(B * C * 4);
     d.counters = (unsigned long long*)take(8 * 8);
     d.prof = (unsigned long long*)take(B * 8 * 8);
@@ -1081,6 +1346,11 @@ int validate(const raz_engine_config* cfg) {
     if (!(cfg->dirichlet_alpha > 0.0) || cfg->dirichlet_alpha > 1.0)
         return raz_fail(RAZ_EINVAL, "raz_engine: dirichlet_alpha must be in (0, 1] (all shipped configs use 0.5)");
     if (cfg->thinking_loop < 1) return raz_fail(RAZ_EINVAL, "raz_engine: thinking_loop must be >= 1");
+    if ((cfg->use_solver_turn && cfg->use_solver_turn < 46) || (cfg->use_solver_turn_in_simulation && cfg->use_solver_turn_in_simulation < 46))
+        return raz_fail(RAZ_EINVAL, "raz_engine: use_solver_turn(_in_simulation) must be 0 or >= 46 (<= 14 empties; the reference relies on a 30 s timeout below that)");
+    if ((cfg->use_solver_turn || cfg->use_solver_turn_in_simulation) &&
+        (cfg->solver_memo_slots < 1024 || (cfg->solver_memo_slots & (cfg->solver_memo_slots - 1))))
+        return raz_fail(RAZ_EINVAL, "raz_engine: solver_memo_slots must be a power of two >= 1024 when the solver is on");
     if (cfg->share_mtcs_info && !cfg->mirror_updates)
         return raz_fail(RAZ_EINVAL, "raz_engine: share_mtcs_info=1 requires mirror_updates=1 (player.py:279-280)");
     return RAZ_OK;
@@ -1245,6 +1515,7 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)d.B * 4, hipMemcpyHostToDevice, s), "raz_engine_start: copy sims");
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
+    if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_start: clear solver memo");
     RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_start: clear counters");
     RAZ_HIP_TRY(hipMemsetAsync(d.prof, 0, (size_t)d.B * 64, s), "raz_engine_start: clear profile");
     hipLaunchKernelGGL(k_start, dim3((d.B + 255) / 256), dim3(256), 0, s, d, first_game_id, e->d_sims, n_active);

@@ -15,7 +15,7 @@ from ._native import lib, check
 
 PLY_HEADER = np.dtype([("own", "<u8"), ("enemy", "<u8"), ("n", "<f8"), ("q", "<f8"), ("action", "i1"),
                        ("player", "u1"), ("turn", "u1"), ("has_row", "u1"), ("sims", "<u4"),
-                       ("loops", "<u4"), ("pad", "<u4")])
+                       ("loops", "<u4"), ("flags", "<u4")])
 assert PLY_HEADER.itemsize == 48
 
 
@@ -65,13 +65,13 @@ class DeviceNet:
 
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
-                       record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0):
+                       record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names)."""
     p = config.play
     if getattr(p, "parallel_search_num", 1) != 1:
         raise ValueError("the engine implements the reference's reproducible mode parallel_search_num=1")
-    if (getattr(p, "use_solver_turn", 0) or 0) or (getattr(p, "use_solver_turn_in_simulation", 0) or 0):
-        raise ValueError("end-game solver (use_solver_turn) is not built yet: set it to 0 (SURVEY §8(f) rank 1)")
+    ust = int(getattr(p, "use_solver_turn", 0) or 0)
+    usts = int(getattr(p, "use_solver_turn_in_simulation", 0) or 0)
     share = bool(p.share_mtcs_info_in_self_play)
     mirror = share if mirror_updates is None else bool(mirror_updates)
     slots = 16
@@ -87,7 +87,9 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
-        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12))
+        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
+        use_solver_turn=ust, use_solver_turn_in_simulation=usts,
+        solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), reserved2=0)
     return c
 
 
@@ -234,7 +236,7 @@ class SelfPlayEngine:
                 h = raw["headers"][g, i]
                 n = raw["root_n"][g, i].astype(np.float64)
                 plies.append({"player": int(h["player"]), "turn": int(h["turn"]), "own": int(h["own"]),
-                              "enemy": int(h["enemy"]), "action": int(h["action"]), "has_row": bool(h["has_row"]),
+                              "enemy": int(h["enemy"]), "action": int(h["action"]), "has_row": bool(h["has_row"]), "solved": bool(int(h["flags"]) & 1),
                               "sims": int(h["sims"]), "loops": int(h["loops"]), "n": float(h["n"]), "q": float(h["q"]),
                               "root_n": [float(v) for v in n],
                               "root_w": [float(v) for v in raw["root_w"][g, i]] if raw["root_w"] is not None else None,

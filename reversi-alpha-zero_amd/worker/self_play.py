@@ -256,7 +256,7 @@ def pack_records(records):
     summ = np.zeros((n, 8), dtype=np.int64)
     hdr = np.zeros((n, maxp, 6), dtype=np.float64)   # player turn action has_row n q  (+ own/enemy below)
     boards = np.zeros((n, maxp, 2), dtype=np.uint64)
-    sims = np.zeros((n, maxp, 2), dtype=np.int64)
+    sims = np.zeros((n, maxp, 3), dtype=np.int64)
     rootn = np.zeros((n, maxp, 64), dtype=np.float64)
     pol = np.zeros((n, maxp, 64), dtype=np.float64)
     for i, (plies, s) in enumerate(records):
@@ -266,7 +266,7 @@ def pack_records(records):
         for j, p in enumerate(plies):
             hdr[i, j] = [p["player"], p["turn"], p["action"], int(p["has_row"]), p["n"], p["q"]]
             boards[i, j] = [p["own"], p["enemy"]]
-            sims[i, j] = [p["sims"], p["loops"]]
+            sims[i, j] = [p["sims"], p["loops"], int(bool(p.get("solved", False)))]
             rootn[i, j] = p["root_n"]
             pol[i, j] = p["saved_policy"]
         summ[i, 7] = 0
@@ -283,7 +283,8 @@ def unpack_records(pk):
             pl, turn, act, hr, n, q = pk["hdr"][i, j]
             plies.append({"player": int(pl), "turn": int(turn), "own": int(pk["boards"][i, j, 0]),
                           "enemy": int(pk["boards"][i, j, 1]), "action": int(act), "has_row": bool(hr),
-                          "sims": int(pk["sims"][i, j, 0]), "loops": int(pk["sims"][i, j, 1]), "n": float(n),
+                          "sims": int(pk["sims"][i, j, 0]), "loops": int(pk["sims"][i, j, 1]),
+                          "solved": bool(pk["sims"][i, j, 2]), "n": float(n),
                           "q": float(q), "root_n": [float(v) for v in pk["rootn"][i, j]], "root_w": None,
                           "saved_policy": [float(v) for v in pk["pol"][i, j]]})
         out.append((plies, {"winner": w, "status": status, "plies": npl, "game_id": gid, "enable_resign": er,

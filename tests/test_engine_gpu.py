@@ -95,6 +95,7 @@ def _compare_game(tag, eng_plies, eng_sum, ref_plies, ref_winner, check_w=True):
         if check_w:
             assert a["root_w"] == b["root_w"], (tag, i)
         assert a["has_row"] == b["has_row"], (tag, i)
+        assert a["solved"] == b.get("solved", False), (tag, i)
         if a["action"] >= 0:
             assert a["n"] == b["n"] and a["q"] == b["q"], (tag, i)
         if b["has_row"]:
@@ -177,3 +178,23 @@ def test_engine_with_node_pruning_equals_oracle(golden, blob, variant, pool):
     for i in range(0, n, 2):
         plies, summ = O.selfplay_game(ocfg, blob, 31, 500 + i, sims)
         _compare_game(f"gc/{variant}/{500 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+
+
+def test_engine_with_solver_batch_vs_oracle(golden, blob):
+    """End-game solver on (mini.yml as shipped: exact at the root from turn 50, win/loss inside
+    simulations from turn 50), resignation off so every game reaches the solver: 24 games == oracle."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    g0 = next(g for g in golden["games"] if g["variant"] == "mini_solver_noresign")
+    cfg = config_of(g0)
+    n, sims = 24, 14
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, DEV), n_games=n, seed=41, sims_hint=sims, record_root_w=True)
+    eng.start(first_game_id=900, sims_per_move=sims)
+    eng.run(chunk=64)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg)
+    nsolved = 0
+    for i in range(0, n, 2):
+        plies, summ = O.selfplay_game(ocfg, blob, 41, 900 + i, sims)
+        _compare_game(f"solver/{900 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        nsolved += sum(p["solved"] for p in plies)
+    assert nsolved > 0

@@ -110,7 +110,7 @@ def _fake_records(rank, n):
             rn = [float(v) for v in rng.integers(0, 50, 64)]
             plies.append({"player": 1 + j % 2, "turn": j, "own": int(rng.integers(0, 2**63)) * 2 + 1,
                           "enemy": int(rng.integers(0, 2**63)), "action": int(rng.integers(-1, 64)),
-                          "has_row": bool(j % 3), "sims": 20, "loops": 1, "n": float(rng.integers(0, 9)),
+                          "has_row": bool(j % 3), "solved": bool(j % 5 == 4), "sims": 20, "loops": 1, "n": float(rng.integers(0, 9)),
                           "q": float(rng.random()), "root_n": rn, "root_w": None,
                           "saved_policy": [v / max(sum(rn), 1.0) for v in rn]})
         out.append((plies, {"winner": int(rng.integers(1, 4)), "status": 1, "plies": npl, "game_id": rank * 1000 + i,
