@@ -141,6 +141,8 @@ def main():
                 eng.step(args.chunk)
             steps += args.chunk
             st = eng.stats()
+            if st["max_pool_used"] + 4 * args.chunk + 64 > eng.cfg.nodes_per_game:   # prune before a pool can overflow
+                eng.gc(eng.cfg.nodes_per_game // 4)
             if st["finished_games"] >= args.games:
                 break
             if steps > 80 * args.sims * 4:

@@ -833,6 +833,7 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
 
 // Start the mover's move: find/create its root node; turn 0 -> bypass_first_move (:143-148),
 // else arm a search.
+template <bool SOLVER>
 __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, SolverLDS* S) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = uni((uint32_t)E.g_player[g]);
@@ -844,7 +845,7 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, Solver
     const raz_bb legal = bb_legal_moves(own, enemy);
     const uint32_t node = node_get(E, g, own, enemy, 1, owner, legal, lane);
     if (lane == 0) E.root_node[g] = node;
-    if (c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
+    if (SOLVER && c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
         int sm, ss;
         if (solver_solve(E, g, lane, own, enemy, 1u, S, sm, ss)) {
             unsigned char* p = node_ptr(E, g, node);
@@ -888,6 +889,7 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, Solver
 }
 
 // ------------------------------------------------------------------ descent to the next leaf
+template <bool SOLVER>
 __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, SolverLDS* S) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = uni((uint32_t)E.g_player[g]);
@@ -908,7 +910,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
     raz_bb leaf_legal = 0;
     int solved_action = 0;
     float solved_v = 0.0f;
-    const int t_insim = c.use_solver_turn_in_simulation;
+    const int t_insim = SOLVER ? c.use_solver_turn_in_simulation : 0;
     if (node == RAZ_NO_NODE) {
         if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
         return;
@@ -934,7 +936,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
         env.white = uni(hw);
         env.np = uni(tag) & 3u;
         env.legal = uni(legal);
-        if (t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
+        if (SOLVER && t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
             if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {  // `if action:` ignores square 0
@@ -1001,7 +1003,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
         leaf_slot = f.slot;  // brand-new position: created at backup time in the slot found here
         leaf_legal = env.legal;
         kind = RAZ_LEAF_EXPAND;
-        if (t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // (:237-251) on a first arrival
+        if (SOLVER && t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // (:237-251) on a first arrival
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
             if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {
@@ -1058,10 +1060,14 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
 }
 
 // ------------------------------------------------------------------ the tree kernel
+// SOLVER = false compiles the end-game solver (and its LDS frames) out: the common case, and the
+// bench configuration.
+template <bool SOLVER>
 __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
     __shared__ float lds64[64];
-    __shared__ SolverLDS slds;
+    __shared__ SolverLDS slds_store;
+    SolverLDS* slds_p = SOLVER ? &slds_store : nullptr;
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
@@ -1086,7 +1092,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
             wave_sync();
             phase = E.g_phase[g];
             if (phase == RAZ_PHASE_NEW_MOVE) {
-                begin_move(E, g, lane, &slds);
+                begin_move<SOLVER>(E, g, lane, slds_p);
                 continue;
             }
             if (phase == RAZ_PHASE_SEARCH && E.sims_left[g] <= 0) {
@@ -1100,7 +1106,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
         phase = E.g_phase[g];
         if (phase != RAZ_PHASE_SEARCH || E.sims_left[g] <= 0 || E.g_error[g]) break;
         t0 = prof_now();
-        select_leaf(E, g, lane, &slds);
+        select_leaf<SOLVER>(E, g, lane, slds_p);
         wave_sync();
         prof_add(E, g, 2, t0, lane);
         if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL && E.leaf_kind[g] != RAZ_LEAF_SOLVED) break;  // needs the net
@@ -1395,7 +1401,10 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
     const Half hf = half_of(e, h);
     if (hf.count == 0) return RAZ_OK;
     if (ev) hipEventRecord(ev[0], s);
-    hipLaunchKernelGGL(k_tree, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
+    if (d.cfg.use_solver_turn || d.cfg.use_solver_turn_in_simulation)
+        hipLaunchKernelGGL(k_tree<true>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
+    else
+        hipLaunchKernelGGL(k_tree<false>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
     int rc = raz_check_launch("raz_engine_step: k_tree");
     if (rc != RAZ_OK) return rc;
     if (ev) hipEventRecord(ev[1], s);

@@ -198,3 +198,24 @@ def test_engine_with_solver_batch_vs_oracle(golden, blob):
         _compare_game(f"solver/{900 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
         nsolved += sum(p["solved"] for p in plies)
     assert nsolved > 0
+
+
+def test_model_api_predict_contract():
+    """ReversiModelAPI.predict (agent/api.py:30-45 contract) on planes == the bitboard entry point."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.agent.api import ReversiModelAPI
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    net = ReversiNet(16, 1, 16).keras_init_(4)
+    api = ReversiModelAPI(None, net, DEV)
+    own, enemy = _positions(9, 12)
+    bits = lambda a: ((a[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8)
+    x = np.stack([bits(own), bits(enemy)], axis=1).reshape(9, 2, 8, 8)
+    p, v = api.predict(x)
+    assert p.shape == (9, 64) and v.shape == (9, 1) and p.dtype == np.float32
+    p1, v1 = api.predict(x[3])
+    assert p1.shape == (64,) and v1.shape == (1,) and np.array_equal(p1, p[3]) and v1[0] == v[3, 0]
+    pb, vb = DeviceNet(net.to_blob(), DEV).predict_bitboards(torch.from_numpy(own.view(np.int64)).to(DEV),
+                                                             torch.from_numpy(enemy.view(np.int64)).to(DEV))
+    assert np.array_equal(pb.cpu().numpy(), p) and np.array_equal(vb.cpu().numpy(), v[:, 0])
+    with pytest.raises(AssertionError):
+        api.predict(np.zeros((2, 8)))
