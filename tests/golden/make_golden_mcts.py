@@ -38,6 +38,10 @@ VARIANTS = [
                                             "use_solver_turn_in_simulation": 50}, {}, 20, 18, [0, 3]),
     ("mini_solver_noresign", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
                                           "use_solver_turn_in_simulation": 50, "resign_threshold": None}, {}, 16, 20, [2]),
+    # BASELINE.json configs[0]: config/mini.yml self worker, 1 game, 100 sims/move, as shipped (shared tree,
+    # thinking_loop 2, solver from turn 50) except parallel_search_num=1 (the reproducible mode)
+    ("config0_mini_yml_100sims", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
+                                              "use_solver_turn_in_simulation": 50}, {}, 100, 0, [0]),
     ("agz_solver_52_50", "alpha_go_zero.yml", {"use_solver_turn": 52, "use_solver_turn_in_simulation": 50,
                                                "resign_threshold": None}, {}, 25, 19, [1]),
 ]

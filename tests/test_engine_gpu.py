@@ -219,3 +219,75 @@ def test_model_api_predict_contract():
     assert np.array_equal(pb.cpu().numpy(), p) and np.array_equal(vb.cpu().numpy(), v[:, 0])
     with pytest.raises(AssertionError):
         api.predict(np.zeros((2, 8)))
+
+
+def test_worker_files_equal_oracle_rows(golden, blob, tmp_path):
+    """The `self` worker end to end on the GPU: play 6 games (mini.yml settings as shipped, solver on),
+    write play_*.json / GGF / game-idx the way worker/self_play.py does, and check the file content is
+    exactly what the reference's row construction yields for the oracle's games, and that it loads the
+    way the reference's trainer reads it (worker/optimize.py:214-231)."""
+    import json
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+    from reversi_alpha_zero_amd.lib.data_helper import get_game_data_filenames, read_game_data_from_file
+    from reversi_alpha_zero_amd.lib.bitboard import bit_to_array
+    from oracle_util import rows_of_game
+    g0 = next(g for g in golden["games"] if g["variant"] == "config0_mini_yml_100sims")
+    cfg = Config()
+    cfg.play.update(g0["resolved_play"])
+    cfg.play.schedule_of_simulation_num_per_move = [(0, 12)]
+    cfg.play_data.update(dict(g0["resolved_play_data"], nb_game_in_file=2, nb_game_in_ggf_file=3))
+    rc = cfg.resource
+    rc.data_dir = str(tmp_path)
+    rc.play_data_dir = str(tmp_path / "play_data")
+    rc.self_play_ggf_data_dir = str(tmp_path / "ggf")
+    rc.model_dir = str(tmp_path / "model")
+    rc.next_generation_model_dir = str(tmp_path / "model" / "next")
+    rc.log_dir = str(tmp_path / "logs")
+    rc.project_dir = str(tmp_path)
+    rc.force_simulation_num_file = str(tmp_path / ".force-sim")
+    rc.self_play_game_idx_file = str(tmp_path / ".self-play-game-idx")
+    rc.create_directories()
+    w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=6, seed=3, device=DEV)
+    recs = w.play_batch(first_game_idx=0)
+    paths = w.emit(recs, first_local_idx=1)
+    assert len(paths) == 3                                   # nb_game_in_file = 2
+    files = get_game_data_filenames(rc)
+    got = [row for f in files for row in read_game_data_from_file(f)]
+    ocfg = O.play_cfg_from_config(cfg)
+    exp = []
+    for i in range(6):
+        plies, summ = O.selfplay_game(ocfg, blob, 3, i, 12)
+        exp += rows_of_game(plies, summ["winner"])
+    assert json.dumps(got) == json.dumps(exp)
+    # the trainer's view of the data (worker/optimize.py:214-231)
+    state = np.array([[bit_to_array(r[0][0], 64).reshape(8, 8), bit_to_array(r[0][1], 64).reshape(8, 8)] for r in got])
+    policy = np.array([r[1] for r in got])
+    z = np.array([r[2] for r in got])
+    assert state.shape == (len(got), 2, 8, 8) and policy.shape == (len(got), 64) and z.shape == (len(got),)
+    assert np.allclose(policy.sum(axis=1), 1.0) and set(np.unique(z)) <= {-1, 0, 1}
+    assert len(list((tmp_path / "ggf").iterdir())) >= 1
+
+
+def test_engine_wide_net_vs_oracle():
+    """ch5-shaped path (wide-net implicit-GEMM kernels, per-slice activation scratch, 3 streams):
+    256 games with a 128-filter net; two of them replayed by the oracle, bit for bit."""
+    import types
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    blob = ReversiNet(128, 1, 32).keras_init_(21).randomize_bn_(22).to_blob()
+    play = types.SimpleNamespace(
+        share_mtcs_info_in_self_play=True, thinking_loop=1, required_visit_to_decide_action=400,
+        start_rethinking_turn=8, c_puct=5, noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=4,
+        virtual_loss=3, parallel_search_num=1, resign_threshold=-0.9, allowed_resign_turn=50,
+        disable_resignation_rate=0.1, use_solver_turn=0, use_solver_turn_in_simulation=0)   # ch5.yml, solver off
+    cfg = types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+    n, sims = 256, 8
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, DEV), n_games=n, seed=9, sims_hint=sims, record_root_w=True)
+    eng.start(first_game_id=0, sims_per_move=sims)
+    eng.run(chunk=128)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg)
+    for i in (0, 255):
+        plies, summ = O.selfplay_game(ocfg, blob, 9, i, sims)
+        _compare_game(f"wide/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
