@@ -164,6 +164,7 @@ typedef struct {
     uint64_t error_flags;     /* 0 = ok; 1 node pool full, 2 table full, 4 records full, 8 path overflow */
     uint64_t selections;      /* select_action_q_and_u calls (sum of descent depths) */
     uint64_t max_pool_used;   /* largest node-pool fill over the running games */
+    uint64_t idle_or_done;    /* slots that are idle (never started / one-move mode finished) or finished */
 } raz_engine_stats;
 
 size_t raz_engine_workspace_bytes(const raz_engine_config* cfg);
@@ -190,6 +191,27 @@ int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
  * half batch, on two streams).  Synchronises the stream. */
 int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, double* net_ms,
                           raz_stream_t stream);
+/* ReversiPlayer.action_with_evaluation(own, enemy) (agent/player.py:82-134) for the player that owns
+ * slot `slot`: put the slot on (black, white, player to move) keeping its tree (the reference keeps
+ * var_n/var_w/var_p across calls), its random-stream counters and its records, and arm one move of
+ * `sims` simulations.  one_move != 0: the slot idles once the move is decided (read it back with
+ * raz_engine_read_records: the last recorded ply); 0: the game simply continues from that position. */
+int raz_engine_set_position(raz_engine* e, uint32_t slot, uint64_t black, uint64_t white, int player,
+                            uint32_t sims, int enable_resign, int one_move, raz_stream_t stream);
+/* ReversiPlayer.stop_thinking (agent/player.py:163-164): the slot's running search ends at the next step
+ * and the move is decided from the tree as it is. */
+int raz_engine_stop_thinking(raz_engine* e, uint32_t slot, raz_stream_t stream);
+/* A ReversiPlayer constructed on a used MCTSInfo takes expanded = set(var_p.keys()) (agent/player.py:47):
+ * mark every key of the slot that holds a prior as expanded for player index 0/1. */
+int raz_engine_adopt_tree(raz_engine* e, uint32_t slot, int player_index, raz_stream_t stream);
+/* MCTSInfo introspection (agent/player.py:22,63-69: var_n[key], var_w[key], var_p[key] with
+ * key = CounterKey(black, white, next_player)): copies slot `slot`'s statistics of that key into host
+ * arrays of 64 (any may be NULL).  owner: 0 when share_mtcs_info, else the player index (0 black,
+ * 1 white) whose tree is read.  *found = 0 and zeros (the defaultdict default) when the key was never
+ * touched; the tree is not modified.  p64 is the masked, normalised prior the search uses
+ * (var_p after expand_and_evaluate, player.py:283-327).  Synchronises `stream`. */
+int raz_engine_read_node(raz_engine* e, uint32_t slot, uint64_t black, uint64_t white, int next_player,
+                         int owner, double* w64, uint32_t* n64, float* p64, int* found, raz_stream_t stream);
 /* Prune the nodes no future search can reach (positions with fewer discs than the current real
  * position; the disc count only grows) in every game whose pool holds >= threshold nodes, compacting
  * the pool and rebuilding that game's table.  Does not change any result.  Asynchronous. */

@@ -69,7 +69,7 @@ class RazEngineConfig(ctypes.Structure):
 
 class RazEngineStats(ctypes.Structure):
     _fields_ = [("finished_games", c_uint64), ("total_sims", c_uint64), ("nn_leaves", c_uint64),
-                ("error_flags", c_uint64), ("selections", c_uint64), ("max_pool_used", c_uint64)]
+                ("error_flags", c_uint64), ("selections", c_uint64), ("max_pool_used", c_uint64), ("idle_or_done", c_uint64)]
 
 
 SIGNATURES.update({
@@ -85,6 +85,11 @@ SIGNATURES.update({
     "raz_engine_start": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
     "raz_engine_step": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_step_timed": (c_int, [c_void_p, c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
+    "raz_engine_set_position": (c_int, [c_void_p, c_uint32, c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, c_void_p]),
+    "raz_engine_read_node": (c_int, [c_void_p, c_uint32, c_uint64, c_uint64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     POINTER(c_int), c_void_p]),
+    "raz_engine_stop_thinking": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "raz_engine_adopt_tree": (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
     "raz_engine_gc": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_set_parts": (c_int, [c_void_p, c_int]),
     "raz_engine_stats_sync": (c_int, [c_void_p, POINTER(RazEngineStats), c_void_p]),

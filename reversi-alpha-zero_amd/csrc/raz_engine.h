@@ -103,10 +103,12 @@ struct raz_engine_dev {
     raz_ply_header* rec;           // [B][max_plies]
     uint32_t* rec_n;               // [B][max_plies][64]
     double* rec_w;                 // [B][max_plies][64] or NULL
-    // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games
+    // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games, [6] idle or finished slots
     raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
     uint32_t M;
     uint8_t* leaf_action;          // [B] action of a RAZ_LEAF_SOLVED leaf
+    unsigned char* node_out;       // RAZ_NODE_BYTES + 64: staging of raz_engine_read_node
+    uint8_t* g_one_move;           // [B] 1: idle after the armed move (ReversiPlayer facade)
     uint32_t* gc_remap;            // [B][C] old -> new node index during k_gc
     unsigned long long* counters;
     unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)

@@ -750,7 +750,8 @@ __device__ void finalize_move(const raz_engine_dev& E, uint32_t g, int lane, uin
         E.g_status[g] = r.status;
         E.loops_done[g] = 0;
         E.move_sims[g] = 0;
-        E.g_phase[g] = r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE;
+        // one-move mode (ReversiPlayer facade): the slot idles after its move instead of playing on
+        E.g_phase[g] = E.g_one_move[g] ? RAZ_PHASE_IDLE : (r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE);
     }
     wave_sync();
 }
@@ -1117,21 +1118,22 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
 // global atomics: 4096 waves hitting one address cost ~90 us per launch (one word saturates at
 // ~88 atomics/us on this chip).
 __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
-    __shared__ unsigned long long sh[6][256];
-    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0, maxpool = 0;
+    __shared__ unsigned long long sh[7][256];
+    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0, maxpool = 0, idle = 0;
     for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
         const unsigned long long pu = E.g_status[g] == 0 ? E.pool_used[g] : 0;
         maxpool = pu > maxpool ? pu : maxpool;
         fin += E.g_status[g] != 0 ? 1 : 0;
+        idle += (E.g_phase[g] == RAZ_PHASE_IDLE || E.g_phase[g] == RAZ_PHASE_DONE) ? 1 : 0;
         sims += E.g_sims[g];
         err |= E.g_error[g];
         leaves += E.g_leaves[g];
         sel += E.g_selections[g];
     }
     sh[0][threadIdx.x] = fin; sh[1][threadIdx.x] = sims; sh[2][threadIdx.x] = err;
-    sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel; sh[5][threadIdx.x] = maxpool;
+    sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel; sh[5][threadIdx.x] = maxpool; sh[6][threadIdx.x] = idle;
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         unsigned long long a = 0;
         for (int i = 0; i < 256; ++i) {
             const unsigned long long x = sh[threadIdx.x][i];
@@ -1165,6 +1167,7 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     E.pool_used[g] = 0;
     E.n_plies[g] = 0;
     E.g_error[g] = 0;
+    E.g_one_move[g] = 0;
     E.g_sims[g] = 0;
     E.g_leaves[g] = 0;
     E.g_selections[g] = 0;
@@ -1336,8 +1339,10 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.M = cfg.solver_memo_slots;
     d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
     d.leaf_action = take(B);
+    d.g_one_move = take(B);
     d.gc_remap = (uint32_t*)take(B * C * 4);
     d.counters = (unsigned long long*)take(8 * 8);
+    d.node_out = take(RAZ_NODE_BYTES + 64);
     d.prof = (unsigned long long*)take(B * 8 * 8);
     if (E) *E = d;
     return off;
@@ -1557,7 +1562,128 @@ extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_s
     out->nn_leaves = c[3];
     out->selections = c[4];
     out->max_pool_used = c[5];
+    out->idle_or_done = c[6];
     return RAZ_OK;
+}
+
+namespace {
+__global__ void k_set_position(raz_engine_dev E, uint32_t g, unsigned long long black, unsigned long long white,
+                               uint32_t player, uint32_t sims, uint32_t enable_resign, uint32_t one_move) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    E.root_black[g] = black;
+    E.root_white[g] = white;
+    E.g_player[g] = (uint8_t)player;
+    E.g_status[g] = 0;
+    E.g_phase[g] = RAZ_PHASE_NEW_MOVE;
+    E.sims_per_move[g] = sims;
+    E.sims_left[g] = 0;
+    E.loops_done[g] = 0;
+    E.move_sims[g] = 0;
+    E.leaf_kind[g] = RAZ_LEAF_NONE;
+    E.nn_active[g] = 0;
+    E.g_enable_resign[g] = (uint8_t)enable_resign;
+    E.g_one_move[g] = (uint8_t)one_move;
+    E.root_node[g] = RAZ_NO_NODE;
+    if (one_move) E.n_plies[g] = 0;  // the facade reads each ply back right after it is decided
+}
+
+// var_n[key] / var_w[key] / var_p[key] of one slot: copy the node of (black, white, next_player)
+// owned by `owner` to node_out (found flag in the trailing word); never creates a node.
+__global__ __launch_bounds__(64) void k_read_node(raz_engine_dev E, uint32_t g, unsigned long long black,
+                                                  unsigned long long white, uint32_t np, uint32_t owner) {
+    const int lane = threadIdx.x;
+    const Found f = table_find(E, g, black, white, np | (owner << 2), lane);
+    uint32_t* flag = (uint32_t*)(E.node_out + RAZ_NODE_BYTES);
+    if (lane == 0) *flag = f.found ? 1u : 0u;
+    if (!f.found) return;
+    const uint32_t* src = (const uint32_t*)node_ptr(E, g, f.node);
+    uint32_t* dst = (uint32_t*)E.node_out;
+    for (int i = lane; i < RAZ_NODE_BYTES / 4; i += 64) dst[i] = src[i];
+}
+}  // namespace
+
+// Put slot `slot` on the position (black, white, `player` to move) WITHOUT touching its search tree,
+// random-stream counters or records, and arm a move with `sims` simulations.  one_move != 0: the slot
+// idles after deciding that move (ReversiPlayer.action_with_evaluation, agent/player.py:82-134, which
+// keeps var_n / var_w / var_p across calls); 0: the game continues from there.
+namespace {
+// ReversiPlayer.stop_thinking (agent/player.py:163-164,196-199): end the running search at the next
+// step and decide with what the tree holds (no further thinking loop).
+__global__ void k_stop_thinking(raz_engine_dev E, uint32_t g) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (E.g_phase[g] != RAZ_PHASE_SEARCH) return;
+    if (E.sims_left[g] > 0) E.sims_left[g] = 0;
+    E.loops_done[g] = (uint32_t)E.cfg.thinking_loop;
+}
+// A new ReversiPlayer built on a used MCTSInfo starts with expanded = set(var_p.keys())
+// (agent/player.py:47): every key that holds a prior counts as expanded for player index `pl`.
+__global__ __launch_bounds__(64) void k_adopt_tree(raz_engine_dev E, uint32_t g, uint32_t pl) {
+    const int lane = threadIdx.x;
+    const uint32_t used = E.pool_used[g];
+    for (uint32_t i = blockIdx.x; i < used; i += gridDim.x) {
+        unsigned char* p = node_ptr(E, g, i);
+        const bool has_p = __ballot(node_P(p)[lane] != 0.0f) != 0ULL;
+        raz_node_hdr* h = node_hdr(p);
+        if (lane == 0 && (has_p || ((h->tag >> 4) & 3u))) h->tag |= 1u << (4 + pl);
+    }
+}
+}  // namespace
+
+extern "C" int raz_engine_stop_thinking(raz_engine* e, uint32_t slot, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_stop_thinking: NULL engine");
+    if (!e->started || slot >= e->dev.B) return raz_fail(RAZ_EINVAL, "raz_engine_stop_thinking: not started / bad slot");
+    hipLaunchKernelGGL(k_stop_thinking, dim3(1), dim3(64), 0, (hipStream_t)stream, e->dev, slot);
+    return raz_check_launch("raz_engine_stop_thinking");
+}
+
+extern "C" int raz_engine_adopt_tree(raz_engine* e, uint32_t slot, int player_index, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_adopt_tree: NULL engine");
+    if (!e->started || slot >= e->dev.B || player_index < 0 || player_index > 1)
+        return raz_fail(RAZ_EINVAL, "raz_engine_adopt_tree: not started / bad slot / bad player index");
+    hipLaunchKernelGGL(k_adopt_tree, dim3(256), dim3(64), 0, (hipStream_t)stream, e->dev, slot, (uint32_t)player_index);
+    return raz_check_launch("raz_engine_adopt_tree");
+}
+
+extern "C" int raz_engine_read_node(raz_engine* e, uint32_t slot, uint64_t black, uint64_t white, int next_player,
+                                    int owner, double* w64, uint32_t* n64, float* p64, int* found,
+                                    raz_stream_t stream) {
+    if (!e || !found) return raz_fail(RAZ_EINVAL, "raz_engine_read_node: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_read_node: call raz_engine_start first");
+    if (slot >= e->dev.B || (next_player != 1 && next_player != 2) || owner < 0 || owner > 1)
+        return raz_fail(RAZ_EINVAL, "raz_engine_read_node: bad slot / next_player / owner");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_read_node, dim3(1), dim3(64), 0, s, e->dev, slot, (unsigned long long)black,
+                       (unsigned long long)white, (uint32_t)next_player, (uint32_t)owner);
+    int rc = raz_check_launch("raz_engine_read_node");
+    if (rc != RAZ_OK) return rc;
+    unsigned char host[RAZ_NODE_BYTES + 64];
+    RAZ_HIP_TRY(hipMemcpyAsync(host, e->dev.node_out, sizeof(host), hipMemcpyDeviceToHost, s), "raz_engine_read_node: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_read_node: sync");
+    uint32_t flag;
+    memcpy(&flag, host + RAZ_NODE_BYTES, 4);
+    *found = (int)flag;
+    if (flag) {
+        if (w64) memcpy(w64, host + RAZ_NODE_W, 64 * sizeof(double));
+        if (n64) memcpy(n64, host + RAZ_NODE_N, 64 * sizeof(uint32_t));
+        if (p64) memcpy(p64, host + RAZ_NODE_P, 64 * sizeof(float));
+    } else {
+        if (w64) memset(w64, 0, 64 * sizeof(double));
+        if (n64) memset(n64, 0, 64 * sizeof(uint32_t));
+        if (p64) memset(p64, 0, 64 * sizeof(float));
+    }
+    return RAZ_OK;
+}
+
+extern "C" int raz_engine_set_position(raz_engine* e, uint32_t slot, uint64_t black, uint64_t white, int player,
+                                       uint32_t sims, int enable_resign, int one_move, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_position: NULL engine");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_set_position: call raz_engine_start first");
+    if (slot >= e->dev.B || (player != 1 && player != 2) || sims == 0)
+        return raz_fail(RAZ_EINVAL, "raz_engine_set_position: bad slot / player / sims");
+    hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, (hipStream_t)stream, e->dev, slot,
+                       (unsigned long long)black, (unsigned long long)white, (uint32_t)player, sims,
+                       (uint32_t)(enable_resign != 0), (uint32_t)(one_move != 0));
+    return raz_check_launch("raz_engine_set_position");
 }
 
 // Prune unreachable nodes (positions with fewer discs than the current real position) in every

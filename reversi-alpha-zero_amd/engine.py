@@ -177,7 +177,37 @@ class SelfPlayEngine:
             raise RuntimeError(f"engine error flags {st.error_flags:#x} (1 node pool full, 2 table full, "
                                f"4 records full, 8 path overflow): enlarge nodes_per_game/max_plies")
         return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves,
-                "selections": st.selections, "max_pool_used": st.max_pool_used}
+                "selections": st.selections, "max_pool_used": st.max_pool_used, "idle_or_done": st.idle_or_done}
+
+    def set_position(self, slot, black, white, player, sims, enable_resign=True, one_move=True):
+        """Arm one move for `slot` on an arbitrary position, keeping the slot's tree (include/raz.h)."""
+        import torch
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_set_position(self._h, slot, black, white, player, sims, int(enable_resign),
+                                              int(one_move), _stream()), "raz_engine_set_position")
+
+    def stop_thinking(self, slot):
+        import torch
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_stop_thinking(self._h, slot, _stream()), "raz_engine_stop_thinking")
+
+    def adopt_tree(self, slot, player_index):
+        import torch
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_adopt_tree(self._h, slot, player_index, _stream()), "raz_engine_adopt_tree")
+
+    def read_node(self, slot, black, white, next_player=1, owner=0):
+        """(found, W f64[64], N u32[64], P f32[64]) of one key of one slot's tree (include/raz.h)."""
+        import torch
+        w = np.zeros(64, dtype=np.float64)
+        n = np.zeros(64, dtype=np.uint32)
+        p = np.zeros(64, dtype=np.float32)
+        found = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_read_node(self._h, slot, black, white, next_player, owner, w.ctypes.data,
+                                           n.ctypes.data, p.ctypes.data, ctypes.byref(found), _stream()),
+                  "raz_engine_read_node")
+        return bool(found.value), w, n, p
 
     def gc(self, threshold=0):
         """Prune unreachable nodes in every game whose pool holds >= threshold nodes."""

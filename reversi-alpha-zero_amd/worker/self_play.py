@@ -49,6 +49,24 @@ def decide_simulation_num_per_move(config, idx):
     return ret
 
 
+def symmetric_rows(own, enemy, policy):
+    """add_data_to_move_buffer_with_8_symmetries (agent/player.py:166-179): the 8 rows
+    [(own, enemy), policy64] of one searched ply, flip in {F,T} x rot_right in 0..3."""
+    policy = np.asarray(policy, dtype=np.float64)
+    rows = []
+    for flip in (False, True):
+        for rot in range(4):
+            o, e, pol = own, enemy, policy.reshape(8, 8)
+            if flip:
+                o, e, pol = bb.flip_vertical(o), bb.flip_vertical(e), np.flipud(pol)
+            for _ in range(rot):
+                o, e = bb.rotate90(o), bb.rotate90(e)
+            if rot:
+                pol = np.rot90(pol, k=-rot)
+            rows.append([(o, e), list(pol.reshape(64))])
+    return rows
+
+
 def rows_of_game(plies, winner):
     """The training rows of one finished game in file order: black.moves + white.moves
     (worker/self_play.py:183), each searched ply contributing its 8 symmetric rows
@@ -60,18 +78,8 @@ def rows_of_game(plies, winner):
     for p in plies:
         if not p["has_row"]:
             continue
-        policy = np.asarray(p["saved_policy"], dtype=np.float64)
         z = black_win if p["player"] == 1 else -black_win
-        for flip in (False, True):
-            for rot in range(4):
-                o, e, pol = p["own"], p["enemy"], policy.reshape(8, 8)
-                if flip:
-                    o, e, pol = bb.flip_vertical(o), bb.flip_vertical(e), np.flipud(pol)
-                for _ in range(rot):
-                    o, e = bb.rotate90(o), bb.rotate90(e)
-                if rot:
-                    pol = np.rot90(pol, k=-rot)
-                per_player[p["player"]].append([(o, e), list(pol.reshape(64)), z])
+        per_player[p["player"]] += [row + [z] for row in symmetric_rows(p["own"], p["enemy"], p["saved_policy"])]
     return per_player[1] + per_player[2]
 
 
