@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-games", type=int, default=64)
     ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = sized for whole games)")
     ap.add_argument("--parts", type=int, default=0, help="slices/streams the batch is stepped in (0 = engine default 3)")
+    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 steps instead of launching kernel by kernel")
     ap.add_argument("--inner-max", type=int, default=0, help="max simulations completed per game per tree launch (0 = default 2)")
     ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
     ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
@@ -92,12 +93,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is device-only; there is no CPU fallback)")
+    # RAZ_BENCH_SHARED_GPU=1 (test rig only): several ranks share the visible GPUs and rendezvous over
+    # gloo, to exercise the N > 1 code path on a 1-GPU box; the reported line says so.
+    shared_gpu = os.environ.get("RAZ_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if shared_gpu else dev   # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import __graft_entry__ as g
+    if world > 1:   # one rank builds (a no-op when the shipped .so files are current), the others wait
+        if local == 0:
+            g.build()
+        dist.barrier()
     g.build()
     from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
@@ -108,7 +122,8 @@ def main():
     net = DeviceNet(blob, dev)
     eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile,
                          nodes_per_game=args.nodes_per_game or None,
-                         single_stream=args.no_overlap, parts=args.parts, inner_max=args.inner_max)
+                         single_stream=args.no_overlap, parts=args.parts, inner_max=args.inner_max,
+                         use_graph=args.graph)
     first_id = rank * args.games
 
     # warm-up on a throw-away start (clocks, caches, code objects), then restart the same games
@@ -152,7 +167,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tot = torch.tensor([float(st["total_sims"]), float(st["finished_games"]), float(st["nn_leaves"]),
-                        float(st["selections"]), elapsed], dtype=torch.float64, device=dev)
+                        float(st["selections"]), elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -160,6 +175,20 @@ def main():
         elapsed = float(mx[4].item())
     total_sims, finished, leaves, selections = (float(tot[i].item()) for i in range(4))
 
+    # the single collective of the path: finished-game records -> rank 0 (timed separately)
+    t1 = time.perf_counter()
+    raw = eng.read_raw()
+    gather_bytes = 0
+    if world > 1:
+        for k in ("headers", "root_n", "n_plies", "status", "resigned", "game_id", "final_black", "final_white"):
+            t = torch.from_numpy(raw[k].view("u1").reshape(-1)).to(cdev)
+            lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, lst, dst=0)
+            gather_bytes += t.numel() * world
+        torch.cuda.synchronize()
+    gather_s = time.perf_counter() - t1
+
+    used_graph = eng.uses_graph()
     # standalone kernel durations (whole batch, one stream, nothing overlapping) on the opening phase,
     # for reference beside the in-run (overlapped) numbers
     standalone = None
@@ -174,18 +203,6 @@ def main():
                       "selections_per_step": st1["selections"] / 600.0}
         eng.set_parts(args.parts or 3)
 
-    # the single collective of the path: finished-game records -> rank 0 (timed separately)
-    t1 = time.perf_counter()
-    raw = eng.read_raw()
-    gather_bytes = 0
-    if world > 1:
-        for k in ("headers", "root_n", "n_plies", "status", "resigned", "game_id", "final_black", "final_white"):
-            t = torch.from_numpy(raw[k].view("u1").reshape(-1)).to(dev)
-            lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-            dist.gather(t, lst, dst=0)
-            gather_bytes += t.numel() * world
-        torch.cuda.synchronize()
-    gather_s = time.perf_counter() - t1
 
     if rank == 0:
         macs = macs_per_position(F, R, V)
@@ -220,13 +237,14 @@ def main():
                        "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
                        "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0,
                        "kernel_launches_per_step": lps * 2,
-                       "overlap": f"{lps} slices on {lps} HIP streams" if lps > 1 else "single stream"},
+                       "overlap": f"{lps} slices on {lps} HIP streams" if lps > 1 else "single stream",
+                       "launch": "hipGraph replay (16 steps per graph)" if used_graph else "kernel by kernel"},
             "sims_per_sec_per_gpu": total_sims / elapsed / world,
             "games_per_hour": finished / elapsed * 3600.0 if args.steps == 0 else None,
             "finished_games": finished, "total_sims": total_sims, "nn_leaves": leaves,
             "mean_selections_per_sim": selections / max(total_sims, 1.0),
             "roofline": roof, "kernels": kern,
-            "record_gather": {"seconds": gather_s, "bytes": gather_bytes, "collective": "gather (RCCL)" if world > 1 else "none (1 GPU): D2H read"},
+            "record_gather": {"seconds": gather_s, "bytes": gather_bytes, "collective": ("gather (gloo test rig, ranks share GPUs)" if shared_gpu else "gather (RCCL)") if world > 1 else "none (1 GPU): D2H read"},
         }
         if standalone:
             sb = TREE_BYTES_PER_SELECTION * standalone["selections_per_step"] + TREE_BYTES_PER_SIM * standalone["sims_per_step"]

@@ -16,9 +16,11 @@ def build(force=False):
     stale = force or not os.path.exists(LIB_PATH) or \
         any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
-        r = subprocess.run(["make", "-C", HERE, "-B", "liboracle.so"], capture_output=True, text=True)
+        tmp = f"liboracle.{os.getpid()}.tmp.so"   # private output + atomic rename: ranks may build concurrently
+        r = subprocess.run(["make", "-C", HERE, "-B", "liboracle.so", f"OUT={tmp}"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+        os.replace(os.path.join(HERE, tmp), LIB_PATH)
     return LIB_PATH
 
 

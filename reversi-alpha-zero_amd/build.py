@@ -30,13 +30,16 @@ def build_native(force=False, verbose=False):
     """Compile every .hip under csrc/ into libraz.so.  Returns the library path."""
     if not force and not _stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB + ".tmp"]
+    tmp = f"{LIB}.{os.getpid()}.tmp"   # several ranks may build at once: private output, atomic rename
+    cmd = [HIPCC] + FLAGS + sources() + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 

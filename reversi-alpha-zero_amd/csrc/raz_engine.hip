@@ -1384,9 +1384,20 @@ struct raz_engine {
     int parts;
     hipStream_t aux[kMaxParts];
     hipEvent_t ev_fork, ev_join[kMaxParts];
+    // kGraphSteps simulation steps (parts x 2 kernels each, fork/join included) captured once as a
+    // hipGraph and replayed: one host call per kGraphSteps * parts * 2 launches.
+    hipGraphExec_t graph_exec;
+    hipStream_t graph_stream;   // the caller stream the graph was captured on
+    int graph_parts;
+    bool graph_off;             // cfg.reserved bit 2 not set, or capture failed once
 };
 
 namespace {
+
+void drop_graph(raz_engine* e) {
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    e->graph_exec = nullptr;
+}
 
 struct Half {
     uint32_t g0, count;
@@ -1474,6 +1485,10 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     if (parts > kMaxParts) parts = kMaxParts;
     if (cfg->n_games < 256 || (cfg->reserved & 2u)) parts = 1;
     e->parts = parts;
+    e->graph_exec = nullptr;
+    e->graph_stream = nullptr;
+    e->graph_parts = 0;
+    e->graph_off = (cfg->reserved & 4u) == 0;   // reserved bit 2: replay captured hipGraphs (measured slower on ROCm 7.2: off by default)
     e->ev_fork = nullptr;
     for (int h = 0; h < kMaxParts; ++h) {
         e->aux[h] = nullptr;
@@ -1506,17 +1521,19 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
         if (err == hipSuccess && !e->ev_join[h]) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
     }
     if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_set_parts");
+    if (parts != e->parts) drop_graph(e);
     e->parts = parts;
     return RAZ_OK;
 }
 
 extern "C" void raz_engine_destroy(raz_engine* e) {
     if (!e) return;
-    for (int h = 1; h < kMaxParts; ++h) {
+    for (int h = 0; h < kMaxParts; ++h) {
         if (e->aux[h]) hipStreamDestroy(e->aux[h]);
         if (e->ev_join[h]) hipEventDestroy(e->ev_join[h]);
     }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     delete e;
 }
 
@@ -1538,10 +1555,10 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     return rc;
 }
 
-extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream) {
-    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_step: NULL engine");
-    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step: call raz_engine_start first");
-    hipStream_t s = (hipStream_t)stream;
+namespace {
+constexpr uint32_t kGraphSteps = 16;
+
+int launch_steps_direct(raz_engine* e, uint32_t n_steps, hipStream_t s) {
     int rc = fork_aux(e, s);
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
         for (int h = 0; h < e->parts && rc == RAZ_OK; ++h) rc = launch_half_step(e, h, stream_of(e, h, s), nullptr);
@@ -1549,6 +1566,80 @@ extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t str
     const int rj = join_aux(e, s);
     return rc != RAZ_OK ? rc : rj;
 }
+
+// Capture kGraphSteps steps on (s, aux streams).  On any failure the engine keeps launching directly.
+bool ensure_graph(raz_engine* e, hipStream_t s) {
+    if (e->graph_off) return false;
+    if (e->graph_exec && e->graph_stream == s && e->graph_parts == e->parts) return true;
+    drop_graph(e);
+    hipGraph_t g = nullptr;
+    hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (eb != hipSuccess) {
+        (void)hipGetLastError();
+        raz_fail_hip(eb, "raz_engine_step: hipStreamBeginCapture (falling back to direct launches)");
+        e->graph_off = true;
+        return false;
+    }
+    const int rc = launch_steps_direct(e, kGraphSteps, s);
+    const hipError_t ec = hipStreamEndCapture(s, &g);
+    if (rc != RAZ_OK || ec != hipSuccess || !g) {
+        (void)hipGetLastError();
+        if (ec != hipSuccess) raz_fail_hip(ec, "raz_engine_step: hipStreamEndCapture (falling back to direct launches)");
+        if (g) hipGraphDestroy(g);
+        e->graph_off = true;
+        return false;
+    }
+    const hipError_t ei = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ei != hipSuccess) {
+        (void)hipGetLastError();
+        raz_fail_hip(ei, "raz_engine_step: hipGraphInstantiate (falling back to direct launches)");
+        e->graph_exec = nullptr;
+        e->graph_off = true;
+        return false;
+    }
+    e->graph_stream = s;
+    e->graph_parts = e->parts;
+    return true;
+}
+}  // namespace
+
+extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_step: NULL engine");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step: call raz_engine_start first");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_steps < kGraphSteps || e->graph_off) return launch_steps_direct(e, n_steps, s);
+    // The legacy default stream cannot be captured: run on an internal stream ordered after / before it.
+    hipStream_t run = s;
+    if (s == nullptr) {
+        if (!e->aux[0]) {
+            hipError_t err = hipStreamCreateWithFlags(&e->aux[0], hipStreamNonBlocking);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming);
+            if (err == hipSuccess && !e->ev_fork) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+            if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step: internal stream");
+        }
+        run = e->aux[0];
+        RAZ_HIP_TRY(hipEventRecord(e->ev_join[0], s), "raz_engine_step: order after the caller stream");
+        RAZ_HIP_TRY(hipStreamWaitEvent(run, e->ev_join[0], 0), "raz_engine_step: order after the caller stream");
+    }
+    int rc = RAZ_OK;
+    if (ensure_graph(e, run)) {
+        while (n_steps >= kGraphSteps) {
+            hipError_t err = hipGraphLaunch(e->graph_exec, run);
+            if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step: hipGraphLaunch");
+            n_steps -= kGraphSteps;
+        }
+    }
+    if (n_steps) rc = launch_steps_direct(e, n_steps, run);
+    if (run != s) {
+        RAZ_HIP_TRY(hipEventRecord(e->ev_join[0], run), "raz_engine_step: order before the caller stream");
+        RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_join[0], 0), "raz_engine_step: order before the caller stream");
+    }
+    return rc;
+}
+
+// 1 when raz_engine_step replays a captured hipGraph, 0 when it launches kernel by kernel.
+extern "C" int raz_engine_uses_graph(const raz_engine* e) { return e && e->graph_exec ? 1 : 0; }
 
 extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
     if (!e || !out) return raz_fail(RAZ_EINVAL, "raz_engine_stats_sync: NULL argument");

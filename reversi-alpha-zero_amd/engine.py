@@ -65,7 +65,8 @@ class DeviceNet:
 
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
-                       record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16):
+                       record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
+                       use_graph=False):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names)."""
     p = config.play
     if getattr(p, "parallel_search_num", 1) != 1:
@@ -87,7 +88,7 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
-        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
+        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (4 if use_graph else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
         solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), reserved2=0)
     return c
@@ -95,7 +96,8 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
 
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
-                 max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0):
+                 max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
+                 use_graph=False):
         import torch
         self.net = net
         self.device = net.device
@@ -108,7 +110,7 @@ class SelfPlayEngine:
             # every simulation adds at most one node (two with mirror keys); ~62 searched plies
             nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
-                                      record_root_w, phase_profile, single_stream, parts, inner_max)
+                                      record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph)
         nbytes = lib.raz_engine_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("invalid engine config: " + N.last_error())
@@ -142,6 +144,9 @@ class SelfPlayEngine:
         import torch
         with torch.cuda.device(self.device):
             check(lib.raz_engine_step(self._h, n, _stream()), "raz_engine_step")
+
+    def uses_graph(self):
+        return bool(lib.raz_engine_uses_graph(self._h))
 
     def set_parts(self, parts):
         import torch
