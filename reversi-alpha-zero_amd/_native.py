@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int8, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libraz.so")
+LIB_PATH = os.environ.get("RAZ_LIB_PATH") or os.path.join(_HERE, "csrc", "libraz.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -10,7 +10,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 # -ffp-contract=off: the search arithmetic (PUCT, backup, softmax) is specified operation by
 # operation so that it is bit-identical to the CPU oracle; the compiler must not fuse a*b+c.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("RAZ_EXTRA_FLAGS", "").split()
 
 
 def sources():

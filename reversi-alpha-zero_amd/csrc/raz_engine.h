@@ -76,25 +76,38 @@ struct raz_ply_header {  // 48 bytes, one per recorded ply (== orc_ply_record mi
     uint32_t flags;                 // bit 0: move chosen by the exact solver (action_by_searching)
 };
 
+// One game slot's control state: 64 dwords.  k_tree loads it with one coalesced request (lane i =
+// dword i), keeps it in a single VGPR for the whole launch and stores it back once; the other
+// kernels and the host address the fields by name.
+struct raz_game {
+    unsigned long long root_black, root_white;      // the real board (SelfPlayWorker's env)
+    unsigned long long leaf_b, leaf_w, leaf_legal;  // in-flight leaf: position key (searching player's view), legal moves
+    unsigned long long sims, leaves, selections;    // statistics: simulations, leaves sent to the net, PUCT selections
+    uint32_t game_id, player, status, phase;        // player 1 black / 2 white to move; status = raz_env_step's
+    uint32_t enable_resign, resigned[2], one_move;  // resigned[p]: ReversiPlayer.resigned of black / white
+    uint32_t ev_expand, ev_choice, ev_dirichlet, sims_per_move;  // raz-rng-v1 event counters
+    int32_t sims_left;
+    uint32_t loops_done, move_sims, pool_used;
+    uint32_t n_plies, error, root_node, leaf_kind;
+    uint32_t leaf_sym, leaf_np, depth, leaf_action; // D4 transform shown to the net, side to move at the leaf, path length
+    uint32_t leaf_node, leaf_slot, leaf_tag, leaf_mirror;  // existing node of the leaf (or RAZ_NO_NODE) / empty slot found
+    uint32_t leaf_term_v;                           // f32 bits: value of a terminal / solved leaf
+    uint32_t pad[19];
+};
+#ifdef __cplusplus
+static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");
+#endif
+
 // Pointers into the caller-provided workspace + the play parameters.  Passed BY VALUE to kernels.
 struct raz_engine_dev {
     raz_engine_config cfg;
     uint32_t B, C, H, max_plies;
-    // game state
-    unsigned long long *root_black, *root_white;
-    uint8_t *g_player, *g_status, *g_phase, *g_enable_resign, *g_resigned /*[B][2]*/;
-    uint32_t *g_game_id, *ev_expand, *ev_choice, *ev_dirichlet;
-    uint32_t *sims_per_move, *loops_done, *move_sims, *pool_used, *n_plies, *g_error;
-    int32_t* sims_left;
-    unsigned long long* g_sims;  // simulations executed, per game
-    unsigned long long *g_leaves, *g_selections;  // leaves sent to the net / PUCT selections, per game
-    // in-flight simulation
-    uint8_t *leaf_kind, *leaf_sym, *leaf_np, *depth, *nn_active;
-    unsigned long long *leaf_b, *leaf_w, *leaf_legal, *nn_own, *nn_enemy;
-    uint32_t *leaf_tag, *leaf_mirror, *path_mirror /*[B][64]*/;
-    uint32_t *leaf_node, *leaf_slot, *root_node;  // existing node of the leaf (or RAZ_NO_NODE) / empty slot found / root node
-    float *leaf_term_v, *nn_policy /*[B][64]*/, *nn_value;
-    uint32_t* path_node /*[B][64]*/;
+    raz_game* game;                // [B]
+    // leaf exchange with the net kernel, and the path of the simulation in flight
+    uint8_t* nn_active;            // [B]
+    unsigned long long *nn_own, *nn_enemy;
+    float *nn_policy /*[B][64]*/, *nn_value;
+    uint32_t *path_node /*[B][64]*/, *path_mirror /*[B][64]*/;
     uint8_t* path_act /*[B][64]*/;
     // tree
     raz_slot* table;               // [B][H]
@@ -106,9 +119,7 @@ struct raz_engine_dev {
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games, [6] idle or finished slots
     raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
     uint32_t M;
-    uint8_t* leaf_action;          // [B] action of a RAZ_LEAF_SOLVED leaf
     unsigned char* node_out;       // RAZ_NODE_BYTES + 64: staging of raz_engine_read_node
-    uint8_t* g_one_move;           // [B] 1: idle after the armed move (ReversiPlayer facade)
     uint32_t* gc_remap;            // [B][C] old -> new node index during k_gc
     unsigned long long* counters;
     unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)

@@ -212,13 +212,56 @@ __device__ __forceinline__ float* node_P(unsigned char* p) { return (float*)(p +
 __device__ __forceinline__ uint32_t* node_child(unsigned char* p) { return (uint32_t*)(p + RAZ_NODE_CHILD); }
 __device__ __forceinline__ raz_node_hdr* node_hdr(unsigned char* p) { return (raz_node_hdr*)(p + RAZ_NODE_HDR); }
 
+// ------------------------------------------------------------------ the game's control block in registers
+// raz_game (raz_engine.h) is 64 dwords.  k_tree loads it with ONE coalesced request (lane i = dword
+// i) together with the in-flight path and the net's answer, keeps it in a single VGPR for the whole
+// launch — a field read is one v_readlane, a field write one v_writelane, no memory round trip, no
+// fence — and stores it back once at the end.  (The first version kept every field in its own
+// [B] array: ~40 dependent loads per simulation at 120-500 cycles each were 60 % of the kernel.)
+#define GW(field) ((int)(offsetof(raz_game, field) / 4))
+struct Regs {
+    uint32_t cw;                    // lane i = dword i of raz_game
+    uint32_t pnode, pmirror, pact;  // path of the simulation in flight: lane d = level d
+    float pol_raw, val;             // the net's policy row (lane = square of the TRANSFORMED board) and value
+    uint32_t nn;                    // this launch produced a leaf for the net
+    uint32_t path_dirty;
+};
+__device__ __forceinline__ uint32_t G32(const Regs& R, int i) { return (uint32_t)__builtin_amdgcn_readlane(R.cw, i); }
+__device__ __forceinline__ raz_bb G64(const Regs& R, int i) {  // (the builtin returns int: widen through uint32_t)
+    return (raz_bb)(uint32_t)__builtin_amdgcn_readlane(R.cw, i) | ((raz_bb)(uint32_t)__builtin_amdgcn_readlane(R.cw, i + 1) << 32);
+}
+// v_writelane_b32: this clang has no __builtin for it, so the LLVM intrinsic is bound by name; the
+// compiler then sees a VALU instruction and inserts the gfx950 wait states around it (VALU-written
+// SGPR -> VALU read: 2; VALU-written VGPR -> v_readlane: 1), which inline asm would hide from it.
+extern "C" __device__ uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+template <int I>
+__device__ __forceinline__ uint32_t writelane_c(uint32_t old, uint32_t v) {
+    static_assert(I >= 0 && I < 64, "lane");
+    return raz_llvm_writelane(__builtin_amdgcn_readfirstlane(v), (uint32_t)I, old);
+}
+__device__ __forceinline__ uint32_t writelane_r(uint32_t old, uint32_t v, int at, int lane) {
+    (void)lane;
+    return raz_llvm_writelane(__builtin_amdgcn_readfirstlane(v), __builtin_amdgcn_readfirstlane((uint32_t)at), old);
+}
+template <int I>
+__device__ __forceinline__ void set32(Regs& R, uint32_t v) { R.cw = writelane_c<I>(R.cw, v); }
+template <int I>
+__device__ __forceinline__ void set64(Regs& R, raz_bb v) {
+    R.cw = writelane_c<I>(R.cw, (uint32_t)v);
+    R.cw = writelane_c<I + 1>(R.cw, (uint32_t)(v >> 32));
+}
+#define S32(R, I, v) set32<(I)>((R), (uint32_t)(v))
+#define S64(R, I, v) set64<(I)>((R), (raz_bb)(v))
+#define ADD64(R, I, d) S64(R, I, G64(R, I) + (raz_bb)(d))
+__device__ __forceinline__ void flag_error(Regs& R, uint32_t f) { S32(R, GW(error), G32(R, GW(error)) | f); }
+
 // Allocate a zeroed node for key (b, w, np, owner) in the EMPTY table slot `slot`.
 // Returns RAZ_NO_NODE after flagging an error when out of space.
-__device__ uint32_t node_create_at(const raz_engine_dev& E, uint32_t g, uint32_t slot, raz_bb b, raz_bb w,
+__device__ uint32_t node_create_at(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t slot, raz_bb b, raz_bb w,
                                    uint32_t np, uint32_t owner, raz_bb legal, int lane) {
-    const uint32_t used = uni(E.pool_used[g]);
+    const uint32_t used = G32(R, GW(pool_used));
     if (slot == 0xffffffffu || used >= E.C) {
-        if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
+        flag_error(R, (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
         return RAZ_NO_NODE;
     }
     const uint32_t tagkey = np | (owner << 2);
@@ -239,35 +282,18 @@ __device__ uint32_t node_create_at(const raz_engine_dev& E, uint32_t g, uint32_t
         s->black = b;
         s->white = w;
         s->idx_tag = (used << 8) | RAZ_SLOT_USED | tagkey;
-        E.pool_used[g] = used + 1;
     }
+    S32(R, GW(pool_used), used + 1);
     wave_sync();
     return used;
 }
 
 // defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent.
-__device__ uint32_t node_get(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
+__device__ uint32_t node_get(const raz_engine_dev& E, Regs& R, uint32_t g, raz_bb b, raz_bb w, uint32_t np,
                              uint32_t owner, raz_bb legal, int lane) {
     const Found f = table_find(E, g, b, w, np | (owner << 2), lane);
     if (f.found) return f.node;
-    return node_create_at(E, g, f.slot, b, w, np, owner, legal, lane);
-}
-
-// Node of the colour-mirrored key (another_side_counter_key, player.py:391-393), created and
-// cross-linked on first use.
-__device__ uint32_t ensure_mirror(const raz_engine_dev& E, uint32_t g, uint32_t node, uint32_t owner, int lane) {
-    raz_node_hdr* h = node_hdr(node_ptr(E, g, node));
-    const uint32_t m0 = uni(h->mirror);
-    if (m0 != RAZ_NO_NODE) return m0;
-    const raz_bb kb = uni(h->black), kw = uni(h->white), lg = uni(h->legal);
-    const uint32_t np = uni(h->tag) & 3u;
-    const uint32_t m = node_get(E, g, kw, kb, 3 - np, owner, lg, lane);
-    if (m != RAZ_NO_NODE && lane == 0) {
-        h->mirror = m;
-        node_hdr(node_ptr(E, g, m))->mirror = node;
-    }
-    wave_sync();
-    return m;
+    return node_create_at(E, R, g, f.slot, b, w, np, owner, legal, lane);
 }
 
 // ------------------------------------------------------------------ search-space env (player's view)
@@ -290,7 +316,7 @@ __device__ __forceinline__ void env_step(Env& e, int action) {
 // ------------------------------------------------------------------ select (agent/player.py:395-428)
 // The node's P already holds normalize(P * legal) in float32 (player.py:404-413 gives the same
 // vector at every visit of a node, so it is computed once, when the net's policy is stored).
-__device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uint32_t Ni, float p32,
+__device__ int select_action(const raz_engine_dev& E, Regs& R, uint32_t g, double Wi, uint32_t Ni, float p32,
                              raz_bb legal, uint32_t np, bool is_root, uint32_t game_id, int lane) {
     const raz_engine_config& c = E.cfg;
     const uint32_t bit = (uint32_t)((legal >> lane) & 1ULL);
@@ -301,7 +327,7 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
     double u;
     if (is_root && c.noise_eps > 0.0) {  // (1-eps) p + eps Dir(alpha), fresh at every root visit (:415-417)
         const unsigned long long tp = prof_now();
-        const uint32_t ev = uni(E.ev_dirichlet[g]);
+        const uint32_t ev = G32(R, GW(ev_dirichlet));
         // Gamma(alpha) sample j belongs to the j-th legal square.  Attempts of the rejection
         // sampler are independent Philox blocks, so lane l evaluates attempt t = l / k of sample
         // j = l % k (k legal moves, up to 8 attempts per sample per round) and each legal square
@@ -358,7 +384,7 @@ __device__ int select_action(const raz_engine_dev& E, uint32_t g, double Wi, uin
         const float keep = (float)(1.0 - c.noise_eps);
         const double p64 = (double)(keep * p32) + c.noise_eps * noise;
         u = (c.c_puct * p64) * xx / (1.0 + Nd);
-        if (lane == 0) E.ev_dirichlet[g] = ev + 1;
+        S32(R, GW(ev_dirichlet), ev + 1);
         prof_add(E, g, 3, tp, lane);
     } else {
         const float cp = (float)c.c_puct;
@@ -535,164 +561,131 @@ __device__ __forceinline__ void node_init(const raz_engine_dev& E, uint32_t g, u
     }
 }
 
-// Everything the backup needs was written by select_leaf (leaf_* and path_* arrays), so all loads
-// are issued up front in ONE round trip; node creation is pure stores; the only other dependent
-// memory access is the table probe for the mirror key of a brand-new position.
-__device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, int lane, float* lds64) {
+// Leaf node + its colour-mirrored node for a leaf that is being expanded (prior = the net's policy)
+// or was solved (prior = one-hot): create / update them and cross-link.  Returns false when out of
+// space.  `used` is the running pool counter.
+__device__ bool place_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, uint32_t owner, uint32_t np,
+                           raz_bb kb, raz_bb kw, raz_bb lg, uint32_t new_tag_bits, float prior, bool with_mirror,
+                           int depth, uint32_t& node, uint32_t& mirror, uint32_t& used) {
+    node = G32(R, GW(leaf_node));
+    mirror = RAZ_NO_NODE;
+    const uint32_t tagkey = np | (owner << 2);
+    if (node == RAZ_NO_NODE) {  // first arrival at this position: create it in the slot select found
+        uint32_t slot = G32(R, GW(leaf_slot));
+        if (slot == 0xfffffffeu) slot = table_find(E, g, kb, kw, tagkey, lane).slot;  // table rebuilt by k_gc
+        if (slot == 0xffffffffu || used >= E.C) {
+            flag_error(R, (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
+            return false;
+        }
+        node = used++;
+        node_init(E, g, node, slot, kb, kw, tagkey | new_tag_bits, lg, RAZ_NO_NODE, prior, lane);
+        if (depth > 0) {  // link the parent's edge to it
+            const uint32_t parent = lane_u32(R.pnode, depth - 1);
+            const uint32_t pa = lane_u32(R.pact, depth - 1);
+            if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
+        }
+    } else {  // existing node: store the prior (and the expanded flag)
+        unsigned char* p = node_ptr(E, g, node);
+        node_P(p)[lane] = prior;
+        if (new_tag_bits && lane == 0) node_hdr(p)->tag = G32(R, GW(leaf_tag)) | new_tag_bits;
+        mirror = G32(R, GW(leaf_mirror));
+    }
+    if (!with_mirror) {
+        mirror = RAZ_NO_NODE;
+        return true;
+    }
+    if (mirror == RAZ_NO_NODE) {  // var_p[another_side_key] = leaf_p (:324): the mirror key may be new too
+        wave_sync();
+        const Found f = table_find(E, g, kw, kb, (3 - np) | (owner << 2), lane);
+        if (f.found) {
+            mirror = f.node;
+            node_P(node_ptr(E, g, mirror))[lane] = prior;
+        } else if (f.slot == 0xffffffffu || used >= E.C) {
+            flag_error(R, (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
+        } else {
+            mirror = used++;
+            node_init(E, g, mirror, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, prior, lane);
+        }
+        if (mirror != RAZ_NO_NODE && lane == 0) {
+            node_hdr(node_ptr(E, g, node))->mirror = mirror;
+            node_hdr(node_ptr(E, g, mirror))->mirror = node;
+        }
+    } else {
+        node_P(node_ptr(E, g, mirror))[lane] = prior;
+    }
+    return true;
+}
+
+// Everything the backup needs is in registers (control block, path, the net's answer), so its
+// memory work is: the (N, W) cells of the path levels (lane d = level d, issued first), the table
+// probe for the mirror key of a brand-new position, and stores.
+__device__ void backup_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t pl, int lane, float* lds64) {
     const raz_engine_config& c = E.cfg;
-    // ---- load phase (independent loads)
-    const uint32_t kind_v = E.leaf_kind[g];
-    const uint32_t depth_v = E.depth[g];
-    const uint32_t np_v = E.leaf_np[g], sym_v = E.leaf_sym[g];
-    const raz_bb lg_v = E.leaf_legal[g], kb_v = E.leaf_b[g], kw_v = E.leaf_w[g];
-    const uint32_t lnode_v = E.leaf_node[g], lslot_v = E.leaf_slot[g], ltag_v = E.leaf_tag[g], lmir_v = E.leaf_mirror[g];
-    const uint32_t used_v = E.pool_used[g];
-    const float val_v = E.nn_value[g], term_v = E.leaf_term_v[g];
-    const float* polrow = E.nn_policy + (size_t)g * 64;
-    // every level of the path is an independent (node, action) cell: lane d handles level d
-    const uint32_t my_node = E.path_node[(size_t)g * 64 + lane];
-    const uint32_t my_mirror = E.path_mirror[(size_t)g * 64 + lane];
-    const uint32_t my_pa = E.path_act[(size_t)g * 64 + lane];
-    const uint32_t kind = uni(kind_v);
+    const uint32_t kind = G32(R, GW(leaf_kind));
     if (kind == RAZ_LEAF_NONE) return;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const int depth = uni((int)depth_v);
+    const int depth = (int)G32(R, GW(depth));
+    // the path cells: every level is an independent (node, action) cell
+    const uint32_t my_node = R.pnode, my_mirror = R.pmirror, my_pa = R.pact;
+    const uint32_t a = my_pa & 63u;
+    const uint32_t m = c.mirror_updates ? my_mirror : RAZ_NO_NODE;
+    uint32_t n0 = 0, n1 = 0;
+    double w0 = 0.0, w1 = 0.0;
+    unsigned char *p = nullptr, *q = nullptr;
+    if (lane < depth) {  // issued first: in flight while the leaf is placed
+        p = node_ptr(E, g, my_node);
+        q = node_ptr(E, g, m == RAZ_NO_NODE ? my_node : m);
+        n0 = node_N(p)[a];
+        w0 = node_W(p)[a];
+        n1 = node_N(q)[a];
+        w1 = node_W(q)[a];
+    }
     double leaf_v;
     const unsigned long long te = prof_now();
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-327), second half
-        const uint32_t np = uni(np_v), sym = uni(sym_v);
-        const raz_bb lg = uni(lg_v), kb = uni(kb_v), kw = uni(kw_v);
-        leaf_v = (double)val_v;          // float(leaf_v)
+        const uint32_t np = G32(R, GW(leaf_np)), sym = G32(R, GW(leaf_sym));
+        const raz_bb lg = G64(R, GW(leaf_legal)), kb = G64(R, GW(leaf_b)), kw = G64(R, GW(leaf_w));
+        leaf_v = (double)R.val;          // float(leaf_v)
         if (np == 2) leaf_v = -leaf_v;   // :259-262
         // the net saw T(board); its policy q is over T-squares, so p[s] = q[T(s)]
-        const float pol = polrow[bb_d4_square(lane, (sym >> 2) & 1, sym & 3)];
+        const float pol = __shfl(R.pol_raw, bb_d4_square(lane, (sym >> 2) & 1, sym & 3));
         const float pn = masked_normalised_prior(pol, lg, lane, lds64);
-        uint32_t used = uni(used_v);
-        uint32_t node = uni(lnode_v), mirror = RAZ_NO_NODE;
-        const uint32_t tagkey = np | (owner << 2);
-        bool ok = true;
-        if (node == RAZ_NO_NODE) {  // first arrival at this position: create it in the slot select found
-            uint32_t slot = uni(lslot_v);
-            if (slot == 0xfffffffeu) slot = table_find(E, g, kb, kw, tagkey, lane).slot;  // table rebuilt by k_gc
-            if (slot == 0xffffffffu || used >= E.C) {
-                if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-                ok = false;
-            } else {
-                node = used++;
-                node_init(E, g, node, slot, kb, kw, tagkey | (16u << pl), lg, RAZ_NO_NODE, pn, lane);
-                if (depth > 0) {  // link the parent's edge to it
-                    const uint32_t parent = lane_u32(my_node, depth - 1);
-                    const uint32_t pa = lane_u32(my_pa, depth - 1);
-                    if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
-                }
-            }
-        } else {  // existing, not yet expanded by this player: store the prior, set the flag
-            unsigned char* p = node_ptr(E, g, node);
-            node_P(p)[lane] = pn;
-            if (lane == 0) node_hdr(p)->tag = uni(ltag_v) | (16u << pl);
-            mirror = uni(lmir_v);
-        }
-        if (ok && c.mirror_updates) {  // var_p[another_side_key] = leaf_p (:324)
-            if (mirror == RAZ_NO_NODE) {
-                wave_sync();
-                const Found f = table_find(E, g, kw, kb, (3 - np) | (owner << 2), lane);
-                if (f.found) {
-                    mirror = f.node;
-                    node_P(node_ptr(E, g, mirror))[lane] = pn;
-                } else if (f.slot == 0xffffffffu || used >= E.C) {
-                    if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-                } else {
-                    mirror = used++;
-                    node_init(E, g, mirror, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, pn, lane);
-                }
-                if (mirror != RAZ_NO_NODE && lane == 0) {
-                    node_hdr(node_ptr(E, g, node))->mirror = mirror;
-                    node_hdr(node_ptr(E, g, mirror))->mirror = node;
-                }
-            } else {
-                node_P(node_ptr(E, g, mirror))[lane] = pn;
-            }
-        }
-        if (lane == 0 && used != uni(used_v)) E.pool_used[g] = used;
+        uint32_t used = G32(R, GW(pool_used));
+        uint32_t node, mirror;
+        place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 16u << pl, pn, c.mirror_updates != 0, depth, node, mirror, used);
+        S32(R, GW(pool_used), used);
     } else if (kind == RAZ_LEAF_SOLVED) {  // in-simulation solver hit (:239-251): the key and its mirror get
         // N += 1, W +-= sign(score), P = one-hot; the key is NOT marked expanded
-        const uint32_t np = uni(np_v), act = uni((uint32_t)E.leaf_action[g]);
-        const raz_bb lg = uni(lg_v), kb = uni(kb_v), kw = uni(kw_v);
-        leaf_v = (double)term_v;  // sign(score) in the searching player's view
+        const uint32_t np = G32(R, GW(leaf_np)), act = G32(R, GW(leaf_action));
+        const raz_bb lg = G64(R, GW(leaf_legal)), kb = G64(R, GW(leaf_b)), kw = G64(R, GW(leaf_w));
+        leaf_v = (double)raz_bits_to_f32(G32(R, GW(leaf_term_v)));  // sign(score) in the searching player's view
         const float onehot = lane == (int)act ? 1.0f : 0.0f;
-        uint32_t used = uni(used_v);
-        uint32_t node = uni(lnode_v), mirror = RAZ_NO_NODE;
-        const uint32_t tagkey = np | (owner << 2);
-        bool ok = true;
-        if (node == RAZ_NO_NODE) {
-            uint32_t slot = uni(lslot_v);
-            if (slot == 0xfffffffeu) slot = table_find(E, g, kb, kw, tagkey, lane).slot;
-            if (slot == 0xffffffffu || used >= E.C) {
-                if (lane == 0) E.g_error[g] |= (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-                ok = false;
-            } else {
-                node = used++;
-                node_init(E, g, node, slot, kb, kw, tagkey, lg, RAZ_NO_NODE, onehot, lane);
-                if (depth > 0) {
-                    const uint32_t parent = lane_u32(my_node, depth - 1);
-                    const uint32_t pa = lane_u32(my_pa, depth - 1);
-                    if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
-                }
-            }
-        } else {
-            node_P(node_ptr(E, g, node))[lane] = onehot;
-            mirror = uni(lmir_v);
-        }
+        uint32_t used = G32(R, GW(pool_used));
+        uint32_t node, mirror;
+        // (:248-250) writes to the mirror key are dead without a shared tree
+        const bool ok = place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 0u, onehot, c.mirror_updates != 0, depth, node, mirror, used);
         if (ok) {
-            if (!c.mirror_updates) {
-                mirror = RAZ_NO_NODE;  // (:248-250) writes to the mirror key are dead without a shared tree
-            } else if (mirror == RAZ_NO_NODE) {
-                wave_sync();
-                const Found f = table_find(E, g, kw, kb, (3 - np) | (owner << 2), lane);
-                if (f.found) {
-                    mirror = f.node;
-                    node_P(node_ptr(E, g, mirror))[lane] = onehot;
-                } else if (f.slot == 0xffffffffu || used >= E.C) {
-                    if (lane == 0) E.g_error[g] |= (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL;
-                } else {
-                    mirror = used++;
-                    node_init(E, g, mirror, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, onehot, lane);
-                }
-                if (mirror != RAZ_NO_NODE && lane == 0) {
-                    node_hdr(node_ptr(E, g, node))->mirror = mirror;
-                    node_hdr(node_ptr(E, g, mirror))->mirror = node;
-                }
-            } else {
-                node_P(node_ptr(E, g, mirror))[lane] = onehot;
-            }
             wave_sync();
             if (lane == 0) {
-                unsigned char* p = node_ptr(E, g, node);
-                node_N(p)[act] += 1u;
-                node_W(p)[act] = node_W(p)[act] + leaf_v;
+                unsigned char* pp = node_ptr(E, g, node);
+                node_N(pp)[act] += 1u;
+                node_W(pp)[act] = node_W(pp)[act] + leaf_v;
                 if (mirror != RAZ_NO_NODE) {
-                    unsigned char* q = node_ptr(E, g, mirror);
-                    node_N(q)[act] += 1u;
-                    node_W(q)[act] = node_W(q)[act] - leaf_v;
+                    unsigned char* qq = node_ptr(E, g, mirror);
+                    node_N(qq)[act] += 1u;
+                    node_W(qq)[act] = node_W(qq)[act] - leaf_v;
                 }
             }
         }
-        if (lane == 0 && used != uni(used_v)) E.pool_used[g] = used;
+        S32(R, GW(pool_used), used);
     } else {
-        leaf_v = (double)term_v;
+        leaf_v = (double)raz_bits_to_f32(G32(R, GW(leaf_term_v)));
     }
     prof_add(E, g, 7, te, lane);
     if (lane < depth) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
         const double vl = (double)c.virtual_loss;
-        const uint32_t a = my_pa & 63u, npd = my_pa >> 6;
+        const uint32_t npd = my_pa >> 6;
         const double vlw = npd == 1 ? vl : -vl;
-        unsigned char* p = node_ptr(E, g, my_node);
-        const uint32_t m = c.mirror_updates ? my_mirror : RAZ_NO_NODE;
-        unsigned char* q = node_ptr(E, g, m == RAZ_NO_NODE ? my_node : m);
-        const uint32_t n0 = node_N(p)[a];
-        const double w0 = node_W(p)[a];
-        const uint32_t n1 = node_N(q)[a];
-        const double w1 = node_W(q)[a];
         node_N(p)[a] = n0 + 1u;
         node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
         if (m != RAZ_NO_NODE) {  // another_side_counter_key (:279-280); exists since the node's expansion
@@ -700,26 +693,22 @@ __device__ void backup_leaf(const raz_engine_dev& E, uint32_t g, uint32_t pl, in
             node_W(q)[a] = w1 - leaf_v;
         }
     }
-    if (lane == 0) {
-        E.leaf_kind[g] = RAZ_LEAF_NONE;
-        E.sims_left[g] -= 1;
-        E.move_sims[g] += 1;
-        E.g_sims[g] += 1;
-    }
+    S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
+    S32(R, GW(sims_left), G32(R, GW(sims_left)) - 1u);
+    S32(R, GW(move_sims), G32(R, GW(move_sims)) + 1u);
+    ADD64(R, GW(sims), 1ULL);
     wave_sync();
 }
 
 // Record the chosen move and play it on the real board (worker/self_play.py:155-162).
-__device__ void finalize_move(const raz_engine_dev& E, uint32_t g, int lane, uint32_t player, raz_bb rb, raz_bb rw,
+__device__ void finalize_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, uint32_t player, raz_bb rb, raz_bb rw,
                               raz_bb own, raz_bb enemy, int turn, int final_action, bool has_row, bool solved,
                               double n_action, double q_action, uint32_t loops, uint32_t Ni, double Wi) {
     // record the ply (rows + GGF are produced on the host from this)
-    const uint32_t ply = uni(E.n_plies[g]);
+    const uint32_t ply = G32(R, GW(n_plies));
     if (ply >= E.max_plies) {
-        if (lane == 0) {
-            E.g_error[g] |= RAZ_ERR_RECORDS_FULL;
-            E.g_phase[g] = RAZ_PHASE_DONE;
-        }
+        flag_error(R, RAZ_ERR_RECORDS_FULL);
+        S32(R, GW(phase), RAZ_PHASE_DONE);
         return;
     }
     const size_t ri = (size_t)g * E.max_plies + ply;
@@ -735,42 +724,39 @@ __device__ void finalize_move(const raz_engine_dev& E, uint32_t g, int lane, uin
         h.player = (uint8_t)player;
         h.turn = (uint8_t)turn;
         h.has_row = has_row ? 1 : 0;
-        h.sims = E.move_sims[g];
+        h.sims = G32(R, GW(move_sims));
         h.loops = loops;
         h.flags = solved ? 1u : 0u;
         E.rec[ri] = h;
-        E.n_plies[g] = ply + 1;
     }
+    S32(R, GW(n_plies), ply + 1);
     // env.step(action) on the real board (worker/self_play.py:162)
     raz_step_result r = bb_env_step(rb, rw, (int)player, final_action < 0 ? RAZ_ACTION_RESIGN : final_action);
-    if (lane == 0) {
-        E.root_black[g] = r.black;
-        E.root_white[g] = r.white;
-        E.g_player[g] = r.player;
-        E.g_status[g] = r.status;
-        E.loops_done[g] = 0;
-        E.move_sims[g] = 0;
-        // one-move mode (ReversiPlayer facade): the slot idles after its move instead of playing on
-        E.g_phase[g] = E.g_one_move[g] ? RAZ_PHASE_IDLE : (r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE);
-    }
-    wave_sync();
+    S64(R, GW(root_black), r.black);
+    S64(R, GW(root_white), r.white);
+    S32(R, GW(player), r.player);
+    S32(R, GW(status), r.status);
+    S32(R, GW(loops_done), 0);
+    S32(R, GW(move_sims), 0);
+    // one-move mode (ReversiPlayer facade): the slot idles after its move instead of playing on
+    S32(R, GW(phase), G32(R, GW(one_move)) ? RAZ_PHASE_IDLE : (r.status ? RAZ_PHASE_DONE : RAZ_PHASE_NEW_MOVE));
 }
 
 // ------------------------------------------------------------------ per-move controller
 // action_with_evaluation (:82-134) after a search (or the turn-0 bypass) has finished, then
 // SelfPlayWorker.start_game's env.step (worker/self_play.py:155-162).  Returns with the game either
 // searching again (phase SEARCH, sims_left > 0), waiting for a new move (phase NEW_MOVE) or DONE.
-__device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
+__device__ void decide_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lane) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t player = uni((uint32_t)E.g_player[g]);
+    const uint32_t player = G32(R, GW(player));
     const uint32_t pl = player - 1;
-    const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
+    const raz_bb rb = G64(R, GW(root_black)), rw = G64(R, GW(root_white));
     const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
     const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
-    const uint32_t game_id = uni(E.g_game_id[g]);
-    const uint32_t node = uni(E.root_node[g]);
+    const uint32_t game_id = G32(R, GW(game_id));
+    const uint32_t node = G32(R, GW(root_node));
     if (node == RAZ_NO_NODE) {
-        if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
+        S32(R, GW(phase), RAZ_PHASE_DONE);
         return;
     }
     unsigned char* p = node_ptr(E, g, node);
@@ -793,27 +779,25 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
         if (i == lane) cdf = acc;
     }
     cdf = cdf / acc;
-    const uint32_t ev = uni(E.ev_choice[g]);
+    const uint32_t ev = G32(R, GW(ev_choice));
     double d0, d1;
     raz_rng_pair(c.seed, game_id, RAZ_RNG_CHOICE, ev, 0, 0, d0, d1);
     int action = __popcll(__ballot(cdf <= d0));
     if (action > 63) action = 63;
-    if (lane == 0) E.ev_choice[g] = ev + 1;
+    S32(R, GW(ev_choice), ev + 1);
     // re-thinking rule (:113-118)
     const int abv = wave_argmax_f64(q + (Ni > 0 ? 100.0 : 0.0), lane);
     const double q_action = lane_f64(q, action), q_abv = lane_f64(q, abv);
     const double n_action = lane_f64(Nd, action);
     const double value_diff = q_action - q_abv;
-    const uint32_t loops = uni(E.loops_done[g]) + 1;
+    const uint32_t loops = G32(R, GW(loops_done)) + 1;
     const bool stop = (turn <= c.start_rethinking_turn) ||
                       (value_diff > -0.01 && n_action >= (double)c.required_visit_to_decide_action) ||
                       ((int)loops >= c.thinking_loop);
     if (!stop) {  // another thinking loop on the same root (tree and N are kept)
-        if (lane == 0) {
-            E.loops_done[g] = loops;
-            E.sims_left[g] = (int32_t)E.sims_per_move[g];
-            E.g_phase[g] = RAZ_PHASE_SEARCH;
-        }
+        S32(R, GW(loops_done), loops);
+        S32(R, GW(sims_left), G32(R, GW(sims_per_move)));
+        S32(R, GW(phase), RAZ_PHASE_SEARCH);
         return;
     }
     // resignation (:123-130)
@@ -822,30 +806,30 @@ __device__ void decide_move(const raz_engine_dev& E, uint32_t g, int lane) {
     if (c.has_resign_threshold) {
         const double mx = wave_max_f64(q - (Ni == 0 ? 10.0 : 0.0));
         if (mx <= c.resign_threshold) {
-            if (lane == 0) E.g_resigned[(size_t)g * 2 + pl] = 1;
-            if (uni((uint32_t)E.g_enable_resign[g]) && turn >= c.allowed_resign_turn) {
+            R.cw = writelane_r(R.cw, 1u, GW(resigned) + (int)pl, lane);
+            if (G32(R, GW(enable_resign)) && turn >= c.allowed_resign_turn) {
                 final_action = -1;
                 has_row = false;
             }
         }
     }
-    finalize_move(E, g, lane, player, rb, rw, own, enemy, turn, final_action, has_row, false, n_action, q_action, loops, Ni, Wi);
+    finalize_move(E, R, g, lane, player, rb, rw, own, enemy, turn, final_action, has_row, false, n_action, q_action, loops, Ni, Wi);
 }
 
 // Start the mover's move: find/create its root node; turn 0 -> bypass_first_move (:143-148),
 // else arm a search.
 template <bool SOLVER>
-__device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, SolverLDS* S) {
+__device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, SolverLDS* S) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t player = uni((uint32_t)E.g_player[g]);
+    const uint32_t player = G32(R, GW(player));
     const uint32_t pl = player - 1;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
+    const raz_bb rb = G64(R, GW(root_black)), rw = G64(R, GW(root_white));
     const raz_bb own = player == 1 ? rb : rw, enemy = player == 1 ? rw : rb;
     const int turn = bb_popcount(own) + bb_popcount(enemy) - 4;
     const raz_bb legal = bb_legal_moves(own, enemy);
-    const uint32_t node = node_get(E, g, own, enemy, 1, owner, legal, lane);
-    if (lane == 0) E.root_node[g] = node;
+    const uint32_t node = node_get(E, R, g, own, enemy, 1, owner, legal, lane);
+    S32(R, GW(root_node), node);
     if (SOLVER && c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
         int sm, ss;
         if (solver_solve(E, g, lane, own, enemy, 1u, S, sm, ss)) {
@@ -861,15 +845,13 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, Solver
                 node_W(p)[lane] = Wi;
             }
             wave_sync();
-            finalize_move(E, g, lane, player, rb, rw, own, enemy, turn, sm, false, true, 999.0, sg, 0u, Ni, Wi);
+            finalize_move(E, R, g, lane, player, rb, rw, own, enemy, turn, sm, false, true, 999.0, sg, 0u, Ni, Wi);
             return;
         }
     }
     if (turn > 0) {
-        if (lane == 0) {
-            E.sims_left[g] = (int32_t)E.sims_per_move[g];
-            E.g_phase[g] = RAZ_PHASE_SEARCH;
-        }
+        S32(R, GW(sims_left), G32(R, GW(sims_per_move)));
+        S32(R, GW(phase), RAZ_PHASE_SEARCH);
     } else {
         if (node != RAZ_NO_NODE) {
             unsigned char* p = node_ptr(E, g, node);
@@ -881,23 +863,21 @@ __device__ void begin_move(const raz_engine_dev& E, uint32_t g, int lane, Solver
                 node_W(p)[lane] = 0.0;
             }
         }
-        if (lane == 0) {
-            E.sims_left[g] = 0;
-            E.g_phase[g] = RAZ_PHASE_SEARCH;  // "search" of zero simulations: decide immediately
-        }
+        S32(R, GW(sims_left), 0u);
+        S32(R, GW(phase), RAZ_PHASE_SEARCH);  // "search" of zero simulations: decide immediately
     }
     wave_sync();
 }
 
 // ------------------------------------------------------------------ descent to the next leaf
 template <bool SOLVER>
-__device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, SolverLDS* S) {
+__device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, SolverLDS* S) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t player = uni((uint32_t)E.g_player[g]);
+    const uint32_t player = G32(R, GW(player));
     const uint32_t pl = player - 1;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
-    const uint32_t game_id = uni(E.g_game_id[g]);
-    const raz_bb rb = uni(E.root_black[g]), rw = uni(E.root_white[g]);
+    const uint32_t game_id = G32(R, GW(game_id));
+    const raz_bb rb = G64(R, GW(root_black)), rw = G64(R, GW(root_white));
     Env env;  // ReversiEnv().update(own, enemy, Player.black) (:209)
     env.black = player == 1 ? rb : rw;
     env.white = player == 1 ? rw : rb;
@@ -906,14 +886,14 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
     env.legal = 0;
     int depth = 0;
     uint32_t kind = RAZ_LEAF_NONE;
-    uint32_t node = uni(E.root_node[g]);  // always exists (begin_move)
+    uint32_t node = G32(R, GW(root_node));  // always exists (begin_move)
     uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu, leaf_tag = 0, leaf_mirror = RAZ_NO_NODE;
     raz_bb leaf_legal = 0;
     int solved_action = 0;
-    float solved_v = 0.0f;
+    float term_v = 0.0f;
     const int t_insim = SOLVER ? c.use_solver_turn_in_simulation : 0;
     if (node == RAZ_NO_NODE) {
-        if (lane == 0) E.g_phase[g] = RAZ_PHASE_DONE;
+        S32(R, GW(phase), RAZ_PHASE_DONE);
         return;
     }
     for (;;) {
@@ -944,7 +924,7 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
                 if (env.np != 1) ss = -ss;
                 kind = RAZ_LEAF_SOLVED;
                 solved_action = sm;
-                solved_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
+                term_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
                 leaf_node = node;
                 leaf_legal = env.legal;
                 leaf_tag = uni(tag);
@@ -961,21 +941,19 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
             break;
         }
         if (depth >= 64) {
-            if (lane == 0) E.g_error[g] |= RAZ_ERR_PATH_FULL;
+            flag_error(R, RAZ_ERR_PATH_FULL);
             break;
         }
-        const int a = select_action(E, g, Wi, Ni, Pi, env.legal, env.np, depth == 0, game_id, lane);
-        if (lane == 0) {
-            E.path_node[(size_t)g * 64 + depth] = node;
-            E.path_mirror[(size_t)g * 64 + depth] = hmirror;
-            E.path_act[(size_t)g * 64 + depth] = (uint8_t)(a | (env.np << 6));
-        }
+        const int a = select_action(E, R, g, Wi, Ni, Pi, env.legal, env.np, depth == 0, game_id, lane);
+        R.pnode = writelane_r(R.pnode, node, depth, lane);
+        R.pmirror = writelane_r(R.pmirror, hmirror, depth, lane);
+        R.pact = writelane_r(R.pact, (uint32_t)a | (env.np << 6), depth, lane);
         ++depth;
         const uint32_t child = lane_u32(Ci, a);
         if (child & 0x80000000u) {  // edge known to end the game: env.done (:226-232)
             const uint32_t w = child & 3u;
             kind = RAZ_LEAF_TERMINAL;
-            if (lane == 0) E.leaf_term_v[g] = w == RAZ_WIN_BLACK ? 1.0f : (w == RAZ_WIN_WHITE ? -1.0f : 0.0f);
+            term_v = w == RAZ_WIN_BLACK ? 1.0f : (w == RAZ_WIN_WHITE ? -1.0f : 0.0f);
             break;
         }
         if (child) {
@@ -986,10 +964,8 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
         env_step(env, a);
         if (env.status) {  // env.done (:226-232); remember the result on the edge
             kind = RAZ_LEAF_TERMINAL;
-            if (lane == 0) {
-                E.leaf_term_v[g] = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
-                node_child(p)[a] = 0x80000000u | env.status;
-            }
+            term_v = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
+            if (lane == 0) node_child(p)[a] = 0x80000000u | env.status;
             break;
         }
         // the position may already exist (transposition / mirror write)
@@ -1011,52 +987,43 @@ __device__ void select_leaf(const raz_engine_dev& E, uint32_t g, int lane, Solve
                 if (env.np != 1) ss = -ss;
                 kind = RAZ_LEAF_SOLVED;
                 solved_action = sm;
-                solved_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
+                term_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
             }
         }
         break;
     }
+    R.path_dirty = 1u;
+    if (kind == RAZ_LEAF_EXPAND || kind == RAZ_LEAF_SOLVED) {
+        S64(R, GW(leaf_b), env.black);
+        S64(R, GW(leaf_w), env.white);
+        S64(R, GW(leaf_legal), leaf_legal);
+        S32(R, GW(leaf_node), leaf_node);
+        S32(R, GW(leaf_slot), leaf_slot);
+        S32(R, GW(leaf_tag), leaf_tag);
+        S32(R, GW(leaf_mirror), leaf_mirror);
+        S32(R, GW(leaf_np), env.np);
+    }
     if (kind == RAZ_LEAF_EXPAND) {  // expand_and_evaluate (:283-311), first half
-        const uint32_t ev = uni(E.ev_expand[g]);
+        const uint32_t ev = G32(R, GW(ev_expand));
         double d0, d1;
         raz_rng_pair(c.seed, game_id, RAZ_RNG_EXPAND, ev, 0, 0, d0, d1);
         const int flip = d0 < 0.5 ? 1 : 0;   // random() < 0.5
         const int rot = (int)(d1 * 4.0);     // int(random() * 4)
         const raz_bb tb = bb_d4_apply(env.black, flip, rot), tw = bb_d4_apply(env.white, flip, rot);
+        S32(R, GW(ev_expand), ev + 1);
+        S32(R, GW(leaf_sym), (uint32_t)(flip * 4 + rot));
         if (lane == 0) {
-            E.ev_expand[g] = ev + 1;
-            E.leaf_b[g] = env.black;
-            E.leaf_w[g] = env.white;
-            E.leaf_legal[g] = leaf_legal;
-            E.leaf_node[g] = leaf_node;
-            E.leaf_slot[g] = leaf_slot;
-            E.leaf_tag[g] = leaf_tag;
-            E.leaf_mirror[g] = leaf_mirror;
-            E.leaf_np[g] = (uint8_t)env.np;
-            E.leaf_sym[g] = (uint8_t)(flip * 4 + rot);
             E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
             E.nn_enemy[g] = env.np == 1 ? tw : tb;
         }
+        ADD64(R, GW(leaves), 1ULL);
+        R.nn = 1u;
     }
-    if (kind == RAZ_LEAF_SOLVED && lane == 0) {
-        E.leaf_b[g] = env.black;
-        E.leaf_w[g] = env.white;
-        E.leaf_legal[g] = leaf_legal;
-        E.leaf_node[g] = leaf_node;
-        E.leaf_slot[g] = leaf_slot;
-        E.leaf_tag[g] = leaf_tag;
-        E.leaf_mirror[g] = leaf_mirror;
-        E.leaf_np[g] = (uint8_t)env.np;
-        E.leaf_action[g] = (uint8_t)solved_action;
-        E.leaf_term_v[g] = solved_v;
-    }
-    if (lane == 0) {
-        E.leaf_kind[g] = (uint8_t)kind;
-        E.depth[g] = (uint8_t)depth;
-        E.nn_active[g] = kind == RAZ_LEAF_EXPAND ? 1 : 0;
-        if (kind == RAZ_LEAF_EXPAND) E.g_leaves[g] += 1;
-        E.g_selections[g] += (unsigned long long)depth;
-    }
+    if (kind == RAZ_LEAF_SOLVED) S32(R, GW(leaf_action), (uint32_t)solved_action);
+    S32(R, GW(leaf_term_v), __float_as_uint(term_v));
+    S32(R, GW(leaf_kind), kind);
+    S32(R, GW(depth), (uint32_t)depth);
+    ADD64(R, GW(selections), (raz_bb)depth);
     wave_sync();
 }
 
@@ -1072,63 +1039,80 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
-    if (lane == 0) E.nn_active[g] = 0;
-    wave_sync();
+    // ONE round trip: control block, path, the net's answer for the leaf of the previous launch
+    uint32_t* gw = (uint32_t*)(E.game + g);
+    Regs R;
+    R.cw = gw[lane];
+    R.pnode = E.path_node[(size_t)g * 64 + lane];
+    R.pmirror = E.path_mirror[(size_t)g * 64 + lane];
+    R.pact = E.path_act[(size_t)g * 64 + lane];
+    R.pol_raw = E.nn_policy[(size_t)g * 64 + lane];
+    R.val = E.nn_value[g];
+    R.nn = 0u;
+    R.path_dirty = 0u;
+    {
+        const uint32_t phase = G32(R, GW(phase));
+        if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) return;  // nn_active is already 0
+    }
+    if (RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
     const int inner_max = ((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax;
     for (int it = 0; it < inner_max; ++it) {
-        uint32_t phase = E.g_phase[g];
+        uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
-        if (E.g_error[g]) break;
+        if (G32(R, GW(error))) break;
         unsigned long long t0 = prof_now();
-        if (it == 0 && RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
-        if (E.leaf_kind[g] != RAZ_LEAF_NONE) {
-            backup_leaf(E, g, (uint32_t)E.g_player[g] - 1, lane, lds64);
-        }
-        wave_sync();
+        if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
         prof_add(E, g, 0, t0, lane);
         t0 = prof_now();
         // controller: loop because a decided move may immediately need another decision
         // (turn-0 bypass) before a search with simulations starts
         for (int guard = 0; guard < 8; ++guard) {
-            wave_sync();
-            phase = E.g_phase[g];
+            phase = G32(R, GW(phase));
             if (phase == RAZ_PHASE_NEW_MOVE) {
-                begin_move<SOLVER>(E, g, lane, slds_p);
+                begin_move<SOLVER>(E, R, g, lane, slds_p);
                 continue;
             }
-            if (phase == RAZ_PHASE_SEARCH && E.sims_left[g] <= 0) {
-                decide_move(E, g, lane);
+            if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {
+                decide_move(E, R, g, lane);
                 continue;
             }
             break;
         }
-        wave_sync();
         prof_add(E, g, 1, t0, lane);
-        phase = E.g_phase[g];
-        if (phase != RAZ_PHASE_SEARCH || E.sims_left[g] <= 0 || E.g_error[g]) break;
+        phase = G32(R, GW(phase));
+        if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
         t0 = prof_now();
-        select_leaf<SOLVER>(E, g, lane, slds_p);
-        wave_sync();
+        select_leaf<SOLVER>(E, R, g, lane, slds_p);
         prof_add(E, g, 2, t0, lane);
-        if (E.leaf_kind[g] != RAZ_LEAF_TERMINAL && E.leaf_kind[g] != RAZ_LEAF_SOLVED) break;  // needs the net
+        const uint32_t lk = G32(R, GW(leaf_kind));
+        if (lk != RAZ_LEAF_TERMINAL && lk != RAZ_LEAF_SOLVED) break;  // needs the net
     }
+    // write the game back: one coalesced store (+ the path when a descent ran)
+    gw[lane] = R.cw;
+    if (R.path_dirty) {
+        E.path_node[(size_t)g * 64 + lane] = R.pnode;
+        E.path_mirror[(size_t)g * 64 + lane] = R.pmirror;
+        E.path_act[(size_t)g * 64 + lane] = (uint8_t)R.pact;
+    }
+    if (lane == 0) E.nn_active[g] = (uint8_t)R.nn;
 }
 
-// Reduce the per-game statistics into counters[0..4] (one block).  Per-game words instead of
+// Reduce the per-game statistics into counters[0..6] (one block).  Per-game words instead of
 // global atomics: 4096 waves hitting one address cost ~90 us per launch (one word saturates at
 // ~88 atomics/us on this chip).
 __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
     __shared__ unsigned long long sh[7][256];
     unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0, maxpool = 0, idle = 0;
     for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
-        const unsigned long long pu = E.g_status[g] == 0 ? E.pool_used[g] : 0;
+        const raz_game& G = E.game[g];
+        const unsigned long long pu = G.status == 0 ? G.pool_used : 0;
         maxpool = pu > maxpool ? pu : maxpool;
-        fin += E.g_status[g] != 0 ? 1 : 0;
-        idle += (E.g_phase[g] == RAZ_PHASE_IDLE || E.g_phase[g] == RAZ_PHASE_DONE) ? 1 : 0;
-        sims += E.g_sims[g];
-        err |= E.g_error[g];
-        leaves += E.g_leaves[g];
-        sel += E.g_selections[g];
+        fin += G.status != 0 ? 1 : 0;
+        idle += (G.phase == RAZ_PHASE_IDLE || G.phase == RAZ_PHASE_DONE) ? 1 : 0;
+        sims += G.sims;
+        err |= G.error;
+        leaves += G.leaves;
+        sel += G.selections;
     }
     sh[0][threadIdx.x] = fin; sh[1][threadIdx.x] = sims; sh[2][threadIdx.x] = err;
     sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel; sh[5][threadIdx.x] = maxpool; sh[6][threadIdx.x] = idle;
@@ -1148,33 +1132,23 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     const bool act = g < n_active;
-    E.root_black[g] = RAZ_INIT_BLACK;
-    E.root_white[g] = RAZ_INIT_WHITE;
-    E.g_player[g] = RAZ_PLAYER_BLACK;
-    E.g_status[g] = 0;
-    E.g_phase[g] = act ? RAZ_PHASE_NEW_MOVE : RAZ_PHASE_IDLE;
-    E.g_game_id[g] = first_game_id + g;
-    E.g_resigned[(size_t)g * 2] = 0;
-    E.g_resigned[(size_t)g * 2 + 1] = 0;
+    raz_game G;
+    memset(&G, 0, sizeof G);
+    G.root_black = RAZ_INIT_BLACK;
+    G.root_white = RAZ_INIT_WHITE;
+    G.player = RAZ_PLAYER_BLACK;
+    G.phase = act ? RAZ_PHASE_NEW_MOVE : RAZ_PHASE_IDLE;
+    G.game_id = first_game_id + g;
     double d0, d1;
     raz_rng_pair(E.cfg.seed, first_game_id + g, RAZ_RNG_GAME, 0, 0, 0, d0, d1);
-    E.g_enable_resign[g] = E.cfg.disable_resignation_rate <= d0 ? 1 : 0;  // worker/self_play.py:144
-    E.ev_expand[g] = E.ev_choice[g] = E.ev_dirichlet[g] = 0;
-    E.sims_per_move[g] = sims_per_move[g];
-    E.sims_left[g] = 0;
-    E.loops_done[g] = 0;
-    E.move_sims[g] = 0;
-    E.pool_used[g] = 0;
-    E.n_plies[g] = 0;
-    E.g_error[g] = 0;
-    E.g_one_move[g] = 0;
-    E.g_sims[g] = 0;
-    E.g_leaves[g] = 0;
-    E.g_selections[g] = 0;
-    E.leaf_kind[g] = RAZ_LEAF_NONE;
-    E.root_node[g] = RAZ_NO_NODE;
+    G.enable_resign = E.cfg.disable_resignation_rate <= d0 ? 1 : 0;  // worker/self_play.py:144
+    G.sims_per_move = sims_per_move[g];
+    G.leaf_kind = RAZ_LEAF_NONE;
+    G.root_node = RAZ_NO_NODE;
+    G.leaf_node = RAZ_NO_NODE;
+    G.leaf_mirror = RAZ_NO_NODE;
+    E.game[g] = G;
     E.nn_active[g] = 0;
-    E.depth[g] = 0;
 }
 
 // ------------------------------------------------------------------ node pruning
@@ -1186,13 +1160,14 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
 __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold) {
     const uint32_t g = blockIdx.x;
     if (g >= E.B) return;
-    const uint32_t used = E.pool_used[g];
-    if (E.g_status[g] != 0 || used < threshold) return;
+    raz_game& G = E.game[g];
+    const uint32_t used = G.pool_used;
+    if (G.status != 0 || used < threshold) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ uint32_t s_cnt[256];
     __shared__ uint32_t s_base;
     uint32_t* remap = E.gc_remap + (size_t)g * E.C;
-    const int dmin = bb_popcount(E.root_black[g]) + bb_popcount(E.root_white[g]);
+    const int dmin = bb_popcount(G.root_black) + bb_popcount(G.root_white);
     // pass 1: keep flags -> new indices (blocked exclusive scan, 256 nodes per round)
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -1256,22 +1231,22 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
     for (uint32_t sidx = tid; sidx < E.H; sidx += 256) tab[sidx].idx_tag = 0;
     if (tid < 64) {  // in-flight simulation state
         const uint32_t pn = E.path_node[(size_t)g * 64 + tid], pm = E.path_mirror[(size_t)g * 64 + tid];
-        const int depth = E.depth[g];
+        const int depth = (int)G.depth;
         if (tid < depth) {
             E.path_node[(size_t)g * 64 + tid] = remap[pn];
             if (pm != RAZ_NO_NODE) E.path_mirror[(size_t)g * 64 + tid] = remap[pm];
         }
     }
     if (tid == 0) {
-        const uint32_t rn = E.root_node[g];
-        if (rn != RAZ_NO_NODE) E.root_node[g] = remap[rn];
-        const uint32_t ln = E.leaf_node[g], lm = E.leaf_mirror[g];
-        if (E.leaf_kind[g] == RAZ_LEAF_EXPAND || E.leaf_kind[g] == RAZ_LEAF_SOLVED) {
-            if (ln != RAZ_NO_NODE) E.leaf_node[g] = remap[ln];
-            if (lm != RAZ_NO_NODE) E.leaf_mirror[g] = remap[lm];
-            E.leaf_slot[g] = 0xfffffffeu;  // the slot found by select is gone: backup probes again
+        const uint32_t rn = G.root_node;
+        if (rn != RAZ_NO_NODE) G.root_node = remap[rn];
+        const uint32_t ln = G.leaf_node, lm = G.leaf_mirror;
+        if (G.leaf_kind == RAZ_LEAF_EXPAND || G.leaf_kind == RAZ_LEAF_SOLVED) {
+            if (ln != RAZ_NO_NODE) G.leaf_node = remap[ln];
+            if (lm != RAZ_NO_NODE) G.leaf_mirror = remap[lm];
+            G.leaf_slot = 0xfffffffeu;  // the slot found by select is gone: backup probes again
         }
-        E.pool_used[g] = kept;
+        G.pool_used = kept;
     }
     __syncthreads();
     __threadfence_block();
@@ -1309,28 +1284,11 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     memset(&d, 0, sizeof d);
     d.cfg = cfg;
     d.B = (uint32_t)B; d.C = (uint32_t)C; d.H = (uint32_t)H; d.max_plies = (uint32_t)MP;
-    d.root_black = (unsigned long long*)take(B * 8);
-    d.root_white = (unsigned long long*)take(B * 8);
-    d.g_player = take(B); d.g_status = take(B); d.g_phase = take(B); d.g_enable_resign = take(B);
-    d.g_resigned = take(B * 2);
-    d.g_game_id = (uint32_t*)take(B * 4); d.ev_expand = (uint32_t*)take(B * 4);
-    d.ev_choice = (uint32_t*)take(B * 4); d.ev_dirichlet = (uint32_t*)take(B * 4);
-    d.sims_per_move = (uint32_t*)take(B * 4); d.loops_done = (uint32_t*)take(B * 4);
-    d.move_sims = (uint32_t*)take(B * 4); d.pool_used = (uint32_t*)take(B * 4);
-    d.n_plies = (uint32_t*)take(B * 4); d.g_error = (uint32_t*)take(B * 4);
-    d.sims_left = (int32_t*)take(B * 4);
-    d.g_sims = (unsigned long long*)take(B * 8);
-    d.g_leaves = (unsigned long long*)take(B * 8);
-    d.g_selections = (unsigned long long*)take(B * 8);
-    d.leaf_kind = take(B); d.leaf_sym = take(B); d.leaf_np = take(B); d.depth = take(B); d.nn_active = take(B);
-    d.leaf_b = (unsigned long long*)take(B * 8); d.leaf_w = (unsigned long long*)take(B * 8);
-    d.leaf_legal = (unsigned long long*)take(B * 8);
-    d.leaf_node = (uint32_t*)take(B * 4); d.leaf_slot = (uint32_t*)take(B * 4); d.root_node = (uint32_t*)take(B * 4);
-    d.leaf_tag = (uint32_t*)take(B * 4); d.leaf_mirror = (uint32_t*)take(B * 4);
-    d.path_mirror = (uint32_t*)take(B * 64 * 4);
+    d.game = (raz_game*)take(B * sizeof(raz_game));
+    d.nn_active = take(B);
     d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
-    d.leaf_term_v = (float*)take(B * 4); d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
-    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
+    d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
+    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_mirror = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
     d.table = (raz_slot*)take(B * H * sizeof(raz_slot));
     d.nodes = take(B * C * RAZ_NODE_BYTES);
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
@@ -1338,8 +1296,6 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
     d.M = cfg.solver_memo_slots;
     d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
-    d.leaf_action = take(B);
-    d.g_one_move = take(B);
     d.gc_remap = (uint32_t*)take(B * C * 4);
     d.counters = (unsigned long long*)take(8 * 8);
     d.node_out = take(RAZ_NODE_BYTES + 64);
@@ -1661,21 +1617,22 @@ namespace {
 __global__ void k_set_position(raz_engine_dev E, uint32_t g, unsigned long long black, unsigned long long white,
                                uint32_t player, uint32_t sims, uint32_t enable_resign, uint32_t one_move) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    E.root_black[g] = black;
-    E.root_white[g] = white;
-    E.g_player[g] = (uint8_t)player;
-    E.g_status[g] = 0;
-    E.g_phase[g] = RAZ_PHASE_NEW_MOVE;
-    E.sims_per_move[g] = sims;
-    E.sims_left[g] = 0;
-    E.loops_done[g] = 0;
-    E.move_sims[g] = 0;
-    E.leaf_kind[g] = RAZ_LEAF_NONE;
+    raz_game& G = E.game[g];
+    G.root_black = black;
+    G.root_white = white;
+    G.player = player;
+    G.status = 0;
+    G.phase = RAZ_PHASE_NEW_MOVE;
+    G.sims_per_move = sims;
+    G.sims_left = 0;
+    G.loops_done = 0;
+    G.move_sims = 0;
+    G.leaf_kind = RAZ_LEAF_NONE;
     E.nn_active[g] = 0;
-    E.g_enable_resign[g] = (uint8_t)enable_resign;
-    E.g_one_move[g] = (uint8_t)one_move;
-    E.root_node[g] = RAZ_NO_NODE;
-    if (one_move) E.n_plies[g] = 0;  // the facade reads each ply back right after it is decided
+    G.enable_resign = enable_resign;
+    G.one_move = one_move;
+    G.root_node = RAZ_NO_NODE;
+    if (one_move) G.n_plies = 0;  // the facade reads each ply back right after it is decided
 }
 
 // var_n[key] / var_w[key] / var_p[key] of one slot: copy the node of (black, white, next_player)
@@ -1702,15 +1659,16 @@ namespace {
 // step and decide with what the tree holds (no further thinking loop).
 __global__ void k_stop_thinking(raz_engine_dev E, uint32_t g) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (E.g_phase[g] != RAZ_PHASE_SEARCH) return;
-    if (E.sims_left[g] > 0) E.sims_left[g] = 0;
-    E.loops_done[g] = (uint32_t)E.cfg.thinking_loop;
+    raz_game& G = E.game[g];
+    if (G.phase != RAZ_PHASE_SEARCH) return;
+    if (G.sims_left > 0) G.sims_left = 0;
+    G.loops_done = (uint32_t)E.cfg.thinking_loop;
 }
 // A new ReversiPlayer built on a used MCTSInfo starts with expanded = set(var_p.keys())
 // (agent/player.py:47): every key that holds a prior counts as expanded for player index `pl`.
 __global__ __launch_bounds__(64) void k_adopt_tree(raz_engine_dev E, uint32_t g, uint32_t pl) {
     const int lane = threadIdx.x;
-    const uint32_t used = E.pool_used[g];
+    const uint32_t used = E.game[g].pool_used;
     for (uint32_t i = blockIdx.x; i < used; i += gridDim.x) {
         unsigned char* p = node_ptr(E, g, i);
         const bool has_p = __ballot(node_P(p)[lane] != 0.0f) != 0ULL;
@@ -1835,15 +1793,23 @@ extern "C" int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* r
         if (!d.rec_w) return raz_fail(RAZ_ESTATE, "raz_engine_read_records: engine created with record_root_w=0");
         RAZ_D2H(root_w, d.rec_w, B * MP * 64 * 8);
     }
-    RAZ_D2H(n_plies, d.n_plies, B * 4);
-    RAZ_D2H(status, d.g_status, B);
-    RAZ_D2H(resigned, d.g_resigned, B * 2);
-    RAZ_D2H(game_id, d.g_game_id, B * 4);
-    RAZ_D2H(enable_resign, d.g_enable_resign, B);
-    RAZ_D2H(final_black, d.root_black, B * 8);
-    RAZ_D2H(final_white, d.root_white, B * 8);
+    std::vector<raz_game> games(B);
+    RAZ_D2H(games.data(), d.game, B * sizeof(raz_game));
 #undef RAZ_D2H
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_read_records: sync");
+    for (size_t g = 0; g < B; ++g) {
+        const raz_game& G = games[g];
+        if (n_plies) n_plies[g] = G.n_plies;
+        if (status) status[g] = (uint8_t)G.status;
+        if (resigned) {
+            resigned[2 * g] = (uint8_t)G.resigned[0];
+            resigned[2 * g + 1] = (uint8_t)G.resigned[1];
+        }
+        if (game_id) game_id[g] = G.game_id;
+        if (enable_resign) enable_resign[g] = (uint8_t)G.enable_resign;
+        if (final_black) final_black[g] = G.root_black;
+        if (final_white) final_white[g] = G.root_white;
+    }
     return RAZ_OK;
 }
 
@@ -1853,8 +1819,7 @@ extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) {
         case 0: return e->dev.rec;
         case 1: return e->dev.rec_n;
         case 2: return e->dev.rec_w;
-        case 3: return e->dev.n_plies;
-        case 4: return e->dev.g_status;
+        case 3: return e->dev.game;
         case 5: return e->dev.prof;
         default: return nullptr;
     }
