@@ -132,6 +132,25 @@ __device__ __forceinline__ int wave_argmax_f64(double v, int lane) {
     }
     return bi;
 }
+// argmax of NON-NEGATIVE finite doubles (the PUCT scores: (+-Q + U + 1000) * legal >= 0): their IEEE
+// bit patterns order like unsigned integers, so the maximum is found with two u32 max-reductions
+// (high words, then low words among the lanes that hold the top high word) and the first maximum
+// with a ballot — a third of the instructions of the compare-and-select f64 reduction above.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp32<RAZ_DPP_XOR1>(v));
+    v = max(v, dpp32<RAZ_DPP_XOR2>(v));
+    v = max(v, dpp32<RAZ_DPP_HALF_MIRROR>(v));
+    v = max(v, dpp32<RAZ_DPP_MIRROR>(v));
+    return max(max(lane_u32(v, 0), lane_u32(v, 16)), max(lane_u32(v, 32), lane_u32(v, 48)));
+}
+__device__ __forceinline__ int wave_argmax_nonneg_f64(double v) {
+    const uint64_t b = raz_f64_to_bits(v);
+    const uint32_t hi = (uint32_t)(b >> 32), lo = (uint32_t)b;
+    const uint32_t mh = wave_max_u32(hi);
+    const bool top = hi == mh;
+    const uint32_t ml = wave_max_u32(top ? lo : 0u);
+    return __ffsll((long long)__ballot(top && lo == ml)) - 1;
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
     double o;
     o = dpp64<RAZ_DPP_XOR1>(v); v = o > v ? o : v;
@@ -393,7 +412,7 @@ __device__ int select_action(const raz_engine_dev& E, Regs& R, uint32_t g, doubl
     const double q = Wi / (Nd + 1e-5);
     double v = (np == 1) ? (q + u + 1000.0) : (-q + u + 1000.0);
     v = v * (double)bit;
-    return wave_argmax_f64(v, lane);
+    return wave_argmax_nonneg_f64(v);  // == wave_argmax_f64(v, lane): v >= 0, first maximum
 }
 
 // P as select_action_q_and_u will use it: p = P * legal; if np.sum(p) > 0: p = p / np.sum(p)  (float32)
