@@ -117,7 +117,12 @@ class ReversiPlayer:
             net = self.api._device_net()
         else:
             m = getattr(self.model, "model", self.model)
-            net = DeviceNet(m.to_blob(), info.device)
+            cache = getattr(m, "_raz_device_nets", None)
+            if cache is None:
+                cache = m._raz_device_nets = {}
+            net = cache.get(info.device)
+            if net is None:
+                net = cache[info.device] = DeviceNet(m.to_blob(), info.device)
         pc = copy.copy(self.play_config)
         pc.allowed_resign_turn = self.config.play.allowed_resign_turn   # player.py:127 reads config.play, not play_config
         shim = SimpleNamespace(play=pc, play_data=self.config.play_data)

@@ -98,6 +98,23 @@ class PlayConfig(_Section):
         self.use_newest_next_generation_model = True
 
 
+class EvaluateConfig(_Section):
+    """config.py:101-110.  parallel_search_num is pinned to 1: the engine implements the reference's
+    reproducible search mode (the reference's PlayConfig default is 8)."""
+
+    def __init__(self):
+        self.game_num = 200
+        self.replace_rate = 0.55
+        self.play_config = PlayConfig()
+        self.play_config.simulation_num_per_move = 400
+        self.play_config.thinking_loop = 1
+        self.play_config.change_tau_turn = 0
+        self.play_config.noise_eps = 0
+        self.play_config.disable_resignation_rate = 0
+        self.play_config.parallel_search_num = 1
+        self.evaluate_latest_first = True
+
+
 class ModelConfig(_Section):
     def __init__(self):  # config.py:187-193
         self.cnn_filter_num = 256
@@ -115,6 +132,7 @@ class Config(_Section):
         self.model = ModelConfig()
         self.play = PlayConfig()
         self.play_data = PlayDataConfig()
+        self.eval = EvaluateConfig()
 
 
 def load_config(yml_path=None, overrides=None):

@@ -384,3 +384,71 @@ def test_reversi_player_callback_and_stop_thinking(golden, blob):
     assert len(calls) >= 3 and calls[0] > 0
     assert sum(p.var_n[ReversiPlayer.counter_key(ReversiEnv().update(own, enemy, Player.black))]) < 400
     assert len(p.moves) == 8 and p.ask_thought_about(own, enemy).action == ae.action
+
+
+def test_evaluate_worker_end_to_end(tmp_path):
+    """The `eval` worker (worker/evaluate.py of the reference) on ReversiPlayer drop-ins: a best model and
+    one next-generation model on disk, 3 short games, the reference's file handling (challenger directory
+    removed; best model replaced iff the winning rate reaches replace_rate), deterministic for a seed."""
+    import os
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.agent.model import ReversiModel
+    from reversi_alpha_zero_amd.worker.evaluate import EvaluateWorker
+    from reversi_alpha_zero_amd.lib.model_helpler import save_as_best_model
+
+    def make_cfg(root):
+        cfg = Config()
+        cfg.model.update(dict(cnn_filter_num=16, res_layer_num=1, value_fc_size=16))
+        rc = cfg.resource
+        rc.model_dir = str(root / "model")
+        rc.model_best_config_path = str(root / "model" / "model_best_config.json")
+        rc.model_best_weight_path = str(root / "model" / "model_best_weight.h5")
+        rc.next_generation_model_dir = str(root / "model" / "next_generation")
+        os.makedirs(rc.next_generation_model_dir)
+        cfg.eval.game_num = 3
+        cfg.eval.play_config.simulation_num_per_move = 8
+        best = ReversiModel(cfg)
+        best.build(seed=1)
+        save_as_best_model(best)
+        ng = ReversiModel(cfg)
+        ng.build(seed=2)
+        d = os.path.join(rc.next_generation_model_dir, rc.next_generation_model_dirname_tmpl % "20260101-000000.000000")
+        os.makedirs(d)
+        ng.save(os.path.join(d, rc.next_generation_model_config_filename), os.path.join(d, rc.next_generation_model_weight_filename))
+        return cfg, best, ng
+
+    outcomes = []
+    for rep in range(2):
+        root = tmp_path / f"run{rep}"
+        os.makedirs(root)
+        cfg, best, ng = make_cfg(root)
+        w = EvaluateWorker(cfg, seed=11, device=DEV)
+        w.best_model = w.load_best_model()
+        ng_model, model_dir = w.load_next_generation_model()
+        results = [w.play_game(w.best_model, ng_model) for _ in range(2)]
+        for ng_win, best_is_black, (nb, nw) in results:
+            assert ng_win in (0, 1, None) and 0 < nb + nw <= 64
+        outcomes.append(results)
+        assert w.start(max_models=1) == 1
+        assert not os.path.exists(model_dir)                      # challenger consumed
+        kept = ReversiModel(cfg)
+        assert kept.load(cfg.resource.model_best_config_path, cfg.resource.model_best_weight_path)
+        assert kept.model.to_blob() in (best.model.to_blob(), ng.model.to_blob())
+    assert outcomes[0] == outcomes[1]                             # reproducible for a seed
+
+
+def test_training_tensors_on_device():
+    """lib/data_helper.training_tensors: packed bitboards -> float planes by raz_planes_batch == the
+    reference's bit_to_array recipe (worker/optimize.py:214-231)."""
+    from reversi_alpha_zero_amd.lib.data_helper import convert_to_training_data, training_tensors
+    rng = np.random.default_rng(5)
+    rows = []
+    for _ in range(257):
+        own = int(rng.integers(0, 2**64, dtype=np.uint64))
+        enemy = int(rng.integers(0, 2**64, dtype=np.uint64)) & ~own
+        p = rng.random(64)
+        rows.append([[own, enemy], list(p / p.sum()), int(rng.integers(-1, 2))])
+    state, policy, z = training_tensors(rows, DEV)
+    es, ep, ez = convert_to_training_data(rows)
+    assert np.array_equal(state.cpu().numpy(), es.astype(np.float32))
+    assert np.allclose(policy.cpu().numpy(), ep, atol=1e-7) and np.array_equal(z.cpu().numpy(), ez.astype(np.float32))

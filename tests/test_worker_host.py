@@ -150,3 +150,50 @@ def test_gather_records_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK 8" in r.stdout
+
+
+def test_convert_to_training_data_equals_reference_recipe():
+    """lib/data_helper.convert_to_training_data == the reference's per-row bit_to_array recipe
+    (worker/optimize.py:214-231) on golden rows, including boards with bit 63 set."""
+    import numpy as np
+    from reversi_alpha_zero_amd.lib.data_helper import convert_to_training_data, pack_game_data
+    from reversi_alpha_zero_amd.lib.bitboard import bit_to_array
+    rows = [[[0x0000000810000000, 0x0000001008000000], [1 / 64] * 64, 1],
+            [[0x8000000000000001, 0x7ffffffffffffffe], [0.0] * 63 + [1.0], -1],
+            [[0, 0xffffffffffffffff], [0.5, 0.5] + [0.0] * 62, 0]]
+    state, policy, z = convert_to_training_data(rows)
+    exp_state = np.array([[bit_to_array(r[0][0], 64).reshape(8, 8), bit_to_array(r[0][1], 64).reshape(8, 8)] for r in rows])
+    assert state.shape == (3, 2, 8, 8) and np.array_equal(state, exp_state)
+    assert np.array_equal(policy, np.array([r[1] for r in rows])) and list(z) == [1, -1, 0]
+    own, enemy, pol32, z8 = pack_game_data(rows)
+    assert own.dtype == np.uint64 and int(own[1]) == 0x8000000000000001 and pol32.dtype == np.float32 and z8.dtype == np.int8
+
+
+def test_evaluate_config_and_helpers(tmp_path):
+    """EvaluateConfig mirrors config.py:101-110; next-generation dir listing and best-model save/load helpers."""
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.lib.data_helper import get_next_generation_model_dirs
+    from reversi_alpha_zero_amd.lib.model_helpler import load_best_model_weight, save_as_best_model, reload_best_model_weight_if_changed
+    from reversi_alpha_zero_amd.agent.model import ReversiModel
+    cfg = Config()
+    assert (cfg.eval.game_num, cfg.eval.replace_rate, cfg.eval.play_config.simulation_num_per_move,
+            cfg.eval.play_config.noise_eps, cfg.eval.play_config.change_tau_turn) == (200, 0.55, 400, 0, 0)
+    rc = cfg.resource
+    rc.model_dir = str(tmp_path / "model")
+    rc.model_best_config_path = str(tmp_path / "model" / "model_best_config.json")
+    rc.model_best_weight_path = str(tmp_path / "model" / "model_best_weight.h5")
+    rc.next_generation_model_dir = str(tmp_path / "model" / "next_generation")
+    import os
+    os.makedirs(rc.next_generation_model_dir)
+    for name in ("model_20260101-000000.000000", "model_20260102-000000.000000"):
+        os.makedirs(os.path.join(rc.next_generation_model_dir, name))
+    assert [os.path.basename(d) for d in get_next_generation_model_dirs(rc)] == \
+        ["model_20260101-000000.000000", "model_20260102-000000.000000"]
+    cfg.model.update(dict(cnn_filter_num=16, res_layer_num=1, value_fc_size=16))
+    m = ReversiModel(cfg)
+    assert not load_best_model_weight(m)
+    m.build(seed=3)
+    save_as_best_model(m)
+    m2 = ReversiModel(cfg)
+    assert load_best_model_weight(m2) and m2.model.to_blob() == m.model.to_blob()
+    assert reload_best_model_weight_if_changed(m2) is False
