@@ -223,7 +223,21 @@ def main():
         for k in kern.values():
             k["frac"] = (k["achieved"] / k["peak"]) if k["achieved"] else None
         dom = "k_tree" if tree_avg_ms >= net_avg_ms else net_kernel
-        roof = dict(kern[dom], kernel=dom, traffic=None)
+        # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs,
+        # tools/run_profiles.sh -> tools/pmc_summary.py); only for the default workload they were collected on
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc", "final2_traffic.json")
+        default_workload = (args.games, args.sims, args.net, args.share, lps) == (4096, 200, "mini", 1, 3)
+        if default_workload and os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            for k in kern:
+                t = tj["kernels"].get(k)
+                if t:
+                    kern[k]["traffic"] = t["hbm_bytes_per_launch"]
+            traffic = kern[dom].get("traffic")
+            traffic_src = "profiles/r1_pmc/final2_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; per slice launch)"
+        roof = dict(kern[dom], kernel=dom, traffic=traffic, traffic_source=traffic_src)
         roof.pop("avg_ms")
         roof["avg_kernel_ms"] = kern[dom]["avg_ms"]
         out = {
