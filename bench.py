@@ -16,6 +16,10 @@ Without --steps the timed region runs the whole batch of games to completion and
 of steps that took; with --steps K exactly K steps are timed (from the opening position after W
 warm-up steps on a throw-away start).  metric = MCTS simulations/sec (start_search_my_move
 invocations / wall time, NN included, inputs resident in HBM), whole job over all GPUs.
+
+At N = 1 the same JSON line also carries "config2_8192x800_ch5": --config2-steps steps of BASELINE.json
+configs[2] (8192 games, 256x10 net, 800 sims/move - the shape the metric's "800 sims/move" names),
+whose dominant kernel is the MFMA convolution, with its own roofline object.
 """
 import argparse
 import json
@@ -46,6 +50,65 @@ def bench_config(args):
         resign_threshold=-0.9, allowed_resign_turn=10, disable_resignation_rate=0.1,
         use_solver_turn=0, use_solver_turn_in_simulation=0)
     return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+
+
+def ch5_config(sims):
+    """Play settings of config/ch5.yml:9-16 over config.py:128-166 (c_puct 5, change_tau_turn 4, shared
+    tree, resign from turn 50), with the declared overrides of SURVEY.md §8(d) "Config 3":
+    thinking_loop = 1 (ch5.yml:13 says 10), solver off, parallel_search_num = 1."""
+    play = types.SimpleNamespace(
+        simulation_num_per_move=sims, share_mtcs_info_in_self_play=True,
+        thinking_loop=1, required_visit_to_decide_action=400, start_rethinking_turn=8, c_puct=5,
+        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=4, virtual_loss=3, parallel_search_num=1,
+        resign_threshold=-0.9, allowed_resign_turn=50, disable_resignation_rate=0.1,
+        use_solver_turn=0, use_solver_turn_in_simulation=0)
+    return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+
+
+def config2_leg(dev, steps, games=8192, sims=800):
+    """BASELINE.json configs[2] (the shape the metric's "800 sims/move" is quoted on): 8192 concurrent
+    games on one GPU, 256x10 net (ch5.yml has no model section => config.py:187-193), 800 sims/move.
+    A whole batch of games is ~80 minutes at this size, so exactly `steps` steps are timed from the
+    opening (every game has one leaf in every step there, so the rate is if anything pessimistic:
+    later in the game terminal leaves cost no net evaluation).  Node pools are pruned by k_gc in
+    real runs (16*S nodes per game = 147 GB for the batch)."""
+    import torch
+    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    F, R, V = NETS["ch5"]
+    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
+    cfg = ch5_config(sims)
+    net = DeviceNet(blob, dev)
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, nodes_per_game=16 * sims)
+    eng.start(0, sims)
+    eng.step(2)
+    eng.stats()
+    eng.start(0, sims)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tree_ms, net_ms = eng.step_timed(steps)   # HIP events around every launch, on the launching streams
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    macs = macs_per_position(F, R, V)
+    parts = 3
+    leaves_per_launch = st["nn_leaves"] / (steps * parts)
+    net_avg_ms = net_ms / (steps * parts)
+    ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
+    out = {"workload": f"{games} concurrent self-play games/GPU, 256x10 net (F{F} R{R} V{V}), {sims} sims/move, ch5.yml play "
+                       f"settings, thinking_loop=1, solver off, first {steps} steps of the batch",
+           "value": st["total_sims"] / dt, "unit": "sims/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
+           "roofline": {"bound": "mfma", "kernel": "k_conv3x3_wide+k_conv0_wide+k_heads_wide (one net forward per slice)",
+                        "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch, "avg_kernel_ms": net_avg_ms,
+                        "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                        "traffic": None},
+           "k_tree_avg_ms": tree_ms / (steps * parts),
+           "sustained_net_TFLOPs": 2.0 * macs * st["nn_leaves"] / dt / 1e12,
+           "bound_sims_per_s_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs)}
+    del eng, net
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(cfg, blob, sims, budget_games):
@@ -84,6 +147,8 @@ def main():
     ap.add_argument("--inner-max", type=int, default=0, help="max simulations completed per game per tree launch (0 = default 2)")
     ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
     ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
+    ap.add_argument("--config2-steps", type=int, default=8,
+                    help="also time this many steps of BASELINE configs[2] (8192 games, 256x10 net, 800 sims/move) on rank 0 at N=1; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -276,6 +341,13 @@ def main():
             pp = eng.phase_profile()
             launches = max(pp["active_launches"], 1)
             out["phase_profile_ticks_per_active_game_launch"] = {k: v / launches for k, v in pp.items()}
+        if world == 1 and args.config2_steps > 0 and (args.games, args.sims, args.net) == (4096, 200, "mini"):
+            del eng, net   # the two workspaces do not fit in HBM together
+            torch.cuda.empty_cache()
+            try:
+                out["config2_8192x800_ch5"] = config2_leg(dev, args.config2_steps)
+            except Exception as ex:   # never lose the main line over the extra leg
+                out["config2_8192x800_ch5"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, blob, args.sims, args.cpu_games)
         print(json.dumps(out))
