@@ -124,7 +124,8 @@ class OrcGameSummary(Structure):
                 ("resigned_black", c_int), ("resigned_white", c_int), ("black", c_uint64),
                 ("white", c_uint64), ("drop_draw_u", c_double), ("n_sims", c_longlong),
                 ("n_expand", c_longlong), ("n_mirror_hits", c_longlong), ("n_terminal", c_longlong),
-                ("n_nodes", c_longlong), ("n_solved_leaves", c_longlong), ("n_solver_nodes", c_longlong)]
+                ("n_nodes", c_longlong), ("n_solved_leaves", c_longlong), ("n_solver_nodes", c_longlong),
+                ("n_parked", c_longlong)]
 
 
 def play_cfg_from_config(config, parallel_search_num=1):

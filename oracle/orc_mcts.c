@@ -1,8 +1,9 @@
 /* orc_mcts.c — CPU oracle: one self-play game of the reference's MCTS player, restated in plain C.
  * TEST INFRASTRUCTURE (see orc.h).  Follows agent/player.py and worker/self_play.py statement by
- * statement for the reproducible mode (parallel_search_num = 1: one simulation in flight, so the
- * asyncio machinery :189-215,329-355 degenerates to a plain loop and virtual loss only leaves its
- * floating-point rounding behind).  Storage is literally the reference's: per key
+ * statement.  parallel_search_num = 1 is the reference's reproducible mode (one simulation in
+ * flight: the asyncio machinery :189-215,329-355 degenerates to a plain loop and virtual loss only
+ * leaves its floating-point rounding behind); parallel_search_num > 1 follows the timer-free round
+ * schedule raz-sched-v1 defined at search_moves() below.  Storage is literally the reference's: per key
  * (black, white, next_player) three 64-vectors N (f64), W (f64), P (f32 once the net wrote it).
  *
  * Random draws come from raz-rng-v1 (orc_rng.c) at the reference's four call sites; the net is
@@ -24,6 +25,7 @@ typedef struct {
     double N[64], W[64];
     float P[64];
     uint8_t expanded[2]; /* per ReversiPlayer `expanded` set (:47, 325) */
+    uint8_t expanding[2]; /* per ReversiPlayer `now_expanding` set (:48, 294, 326) */
 } onode;
 
 typedef struct {
@@ -91,7 +93,7 @@ typedef struct {
     int resigned[2];    /* ReversiPlayer.resigned (:58,125) */
     orc_solver* solver[2]; /* one ReversiSolver per player (:60, 435-436) */
     long long n_solved_leaves;
-    long long n_sims, n_expand, n_mirror_hits, n_terminal;
+    long long n_sims, n_expand, n_mirror_hits, n_terminal, n_parked;
 } ogame;
 
 static otable* player_table(ogame* g, int pl) { return (g->cfg->share_mtcs_info) ? &g->tables[0] : &g->tables[pl]; }
@@ -164,83 +166,221 @@ static void flipud(float* m) {
     memcpy(m, o, sizeof o);
 }
 
-/* expand_and_evaluate (agent/player.py:283-327) */
-static double expand_and_evaluate(ogame* g, int pl, const orc_env* env) {
+/* ---------------- simulations in flight (agent/player.py:189-355) ----------------
+ * The reference runs `simulation_num_per_move` coroutines of search_my_move under
+ * asyncio.Semaphore(parallel_search_num) beside a prediction_worker coroutine that drains the
+ * prediction queue into ONE api.predict call (:329-349).  Here a simulation is an explicit record
+ * (the coroutine's frame: path so far, position, pending net answer) and the event loop is the
+ * round schedule raz-sched-v1 (search_moves below).  With parallel_search_num = 1 this is exactly
+ * the recursion of :217-281 unrolled - pinned bit for bit by tests/golden/mcts_games.json. */
+#define ORC_MAX_PAR 16 /* prediction_queue_size (config.py:141): put() would block beyond it */
+enum { SIM_FREE = 0, SIM_WAIT_NET = 1, SIM_WAIT_EXPAND = 2 };
+typedef struct {
+    int state;
+    int depth;
+    u64 kb[64], kw[64];   /* keys along the path (the frames of the recursion) */
+    int knp[64], act[64];
+    orc_env env;          /* position at the frontier */
+    float pol[64], val;   /* the net's answer for the leaf being expanded, policy already un-transformed */
+} osim;
+
+/* "on returning search path" (:273-281) for every frame of the simulation, deepest first */
+static void backup_path(ogame* g, int pl, const osim* s, double leaf_v) {
     otable* t = player_table(g, pl);
+    const double vl = (double)g->cfg->virtual_loss;
+    for (int d = s->depth - 1; d >= 0; --d) {
+        const int a = s->act[d];
+        const double vlw = s->knp[d] == 1 ? vl : -vl;
+        onode* n = table_get(t, s->kb[d], s->kw[d], s->knp[d]);
+        n->N[a] += -vl + 1.0;
+        n->W[a] += vlw + leaf_v;
+        onode* m = table_get(t, s->kw[d], s->kb[d], 3 - s->knp[d]);
+        m->N[a] += 1.0;
+        m->W[a] -= leaf_v;
+    }
+}
+
+/* expand_and_evaluate (:283-327) up to `await future`: now_expanding.add(key), the random D4, the
+ * request to the net (its answer is position-determined, so it is computed here and kept in the
+ * simulation's record until the event loop resumes it) */
+static void expand_begin(ogame* g, int pl, osim* s) {
+    otable* t = player_table(g, pl);
+    const orc_env* env = &s->env;
     u64 black = env->black, white = env->white;
+    onode* n = table_get(t, env->black, env->white, env->next_player);
+    n->expanding[pl] = 1;
     double d[2];
     orc_rng_pair(g->seed, g->game_id, 0, g->ev_expand++, 0, 0, d);
     int is_flip = d[0] < 0.5;
     int rot = (int)(d[1] * 4);
     if (is_flip) { black = orc_flip_vertical(black); white = orc_flip_vertical(white); }
     for (int i = 0; i < rot; ++i) { black = orc_rotate90(black); white = orc_rotate90(white); }
-    float pol[64], val;
     if (env->next_player == 1)
-        orc_net_forward(g->blob, g->blob_bytes, black, white, pol, &val);
+        orc_net_forward(g->blob, g->blob_bytes, black, white, s->pol, &s->val);
     else
-        orc_net_forward(g->blob, g->blob_bytes, white, black, pol, &val);
-    for (int i = 0; i < rot; ++i) rot90_left(pol);
-    if (is_flip) flipud(pol);
-    onode* n = table_get(t, env->black, env->white, env->next_player);
-    memcpy(n->P, pol, sizeof pol);
-    n->expanded[pl] = 1;
-    onode* m = table_get(t, env->white, env->black, 3 - env->next_player); /* mirror key (:324) */
-    memcpy(m->P, pol, sizeof pol);
-    g->n_expand++;
-    return (double)val; /* float(leaf_v) */
+        orc_net_forward(g->blob, g->blob_bytes, white, black, s->pol, &s->val);
+    for (int i = 0; i < rot; ++i) rot90_left(s->pol);
+    if (is_flip) flipud(s->pol);
 }
 
-/* search_my_move (agent/player.py:217-281); returns leaf_v from the searching player's view */
-static double search_my_move(ogame* g, int pl, orc_env* env, int is_root) {
-    const orc_play_cfg* c = g->cfg;
-    if (env->done) {
-        g->n_terminal++;
-        return env->winner == 1 ? 1.0 : (env->winner == 2 ? -1.0 : 0.0);
-    }
+/* ... and after it: var_p[key] = var_p[another_side_key] = leaf_p, expanded.add, now_expanding.remove,
+ * then the returns of search_my_move up the path */
+static void expand_finish(ogame* g, int pl, osim* s) {
     otable* t = player_table(g, pl);
-    const u64 kb = env->black, kw = env->white;
-    const int knp = env->next_player;
-    if (c->use_solver_turn_in_simulation && env->turn >= c->use_solver_turn_in_simulation) { /* :237-251 */
-        int action, score;
-        int ok = orc_solver_solve(g->solver[pl], kb, kw, knp, 0, &action, &score);
-        if (ok && action) { /* `if action:` — square 0 is ignored like None */
-            if (knp != 1) score = -score;
-            double leaf_v = score > 0 ? 1.0 : (score < 0 ? -1.0 : 0.0);
-            onode* k = table_get(t, kb, kw, knp);
-            k->N[action] += 1;
-            k->W[action] += leaf_v;
-            for (int i = 0; i < 64; ++i) k->P[i] = 0.0f;
-            k->P[action] = 1.0f;
-            onode* m2 = table_get(t, kw, kb, 3 - knp);
-            m2->N[action] += 1;
-            m2->W[action] -= leaf_v;
-            for (int i = 0; i < 64; ++i) m2->P[i] = 0.0f;
-            m2->P[action] = 1.0f;
-            g->n_solved_leaves++;
-            return leaf_v;
+    const orc_env* env = &s->env;
+    onode* n = table_get(t, env->black, env->white, env->next_player);
+    memcpy(n->P, s->pol, sizeof s->pol);
+    n->expanded[pl] = 1;
+    n->expanding[pl] = 0;
+    onode* m = table_get(t, env->white, env->black, 3 - env->next_player); /* mirror key (:324) */
+    memcpy(m->P, s->pol, sizeof s->pol);
+    g->n_expand++;
+    double leaf_v = (double)s->val; /* float(leaf_v) */
+    backup_path(g, pl, s, env->next_player == 1 ? leaf_v : -leaf_v);
+}
+
+/* search_my_move (:217-281) from the simulation's frontier until it finishes (returns SIM_FREE,
+ * statistics backed up) or blocks: SIM_WAIT_NET (a leaf went to the net) / SIM_WAIT_EXPAND (the
+ * key is in now_expanding, :253-254) */
+static int descend(ogame* g, int pl, osim* s, int polling) {
+    const orc_play_cfg* c = g->cfg;
+    otable* t = player_table(g, pl);
+    orc_env* env = &s->env;
+    for (;;) {
+        if (env->done) {
+            g->n_terminal++;
+            backup_path(g, pl, s, env->winner == 1 ? 1.0 : (env->winner == 2 ? -1.0 : 0.0));
+            return SIM_FREE;
         }
+        const u64 kb = env->black, kw = env->white;
+        const int knp = env->next_player;
+        /* a simulation woken from the now_expanding sleep stands behind the solver look already */
+        if (!polling && c->use_solver_turn_in_simulation && env->turn >= c->use_solver_turn_in_simulation) { /* :237-251 */
+            int action, score;
+            int ok = orc_solver_solve(g->solver[pl], kb, kw, knp, 0, &action, &score);
+            if (ok && action) { /* `if action:` — square 0 is ignored like None */
+                if (knp != 1) score = -score;
+                double leaf_v = score > 0 ? 1.0 : (score < 0 ? -1.0 : 0.0);
+                onode* k = table_get(t, kb, kw, knp);
+                k->N[action] += 1;
+                k->W[action] += leaf_v;
+                for (int i = 0; i < 64; ++i) k->P[i] = 0.0f;
+                k->P[action] = 1.0f;
+                onode* m2 = table_get(t, kw, kb, 3 - knp);
+                m2->N[action] += 1;
+                m2->W[action] -= leaf_v;
+                for (int i = 0; i < 64; ++i) m2->P[i] = 0.0f;
+                m2->P[action] = 1.0f;
+                g->n_solved_leaves++;
+                backup_path(g, pl, s, leaf_v);
+                return SIM_FREE;
+            }
+        }
+        polling = 0;
+        onode* n = table_find(t, kb, kw, knp);
+        if (n && n->expanding[pl]) return SIM_WAIT_EXPAND; /* while key in self.now_expanding: await asyncio.sleep(...) */
+        if (!(n && n->expanded[pl])) {
+            if (n && !c->share_mtcs_info) g->n_mirror_hits++; /* reached a key only mirror writes created */
+            expand_begin(g, pl, s);
+            return SIM_WAIT_NET;
+        }
+        if (s->depth >= 64) return -1;
+        const double vl = (double)c->virtual_loss;
+        const double vlw = knp == 1 ? vl : -vl;
+        const int a = select_action(g, pl, env, s->depth == 0);
+        orc_env_step(env, a);
+        n = table_get(t, kb, kw, knp);
+        n->N[a] += vl;
+        n->W[a] -= vlw;
+        s->kb[s->depth] = kb; s->kw[s->depth] = kw; s->knp[s->depth] = knp; s->act[s->depth] = a;
+        s->depth++;
     }
-    onode* n = table_find(t, kb, kw, knp);
-    if (!(n && n->expanded[pl])) {
-        if (n && !c->share_mtcs_info) g->n_mirror_hits++; /* reached a key only mirror writes created */
-        double leaf_v = expand_and_evaluate(g, pl, env);
-        return knp == 1 ? leaf_v : -leaf_v;
+}
+
+/* search_moves (:189-200) under raz-sched-v1: the asyncio event loop in EXACT VIRTUAL TIME - the
+ * clock only moves when no coroutine is runnable, and then to the earliest timer; timers with equal
+ * deadlines fire in the order they were set.  (The reference's real interleaving at
+ * parallel_search_num > 1 depends on how long Python takes between its 100 us / 10 us sleeps and is
+ * not reproducible run to run; raz-sched-v1 is that loop with computation taking no time.  The
+ * UNMODIFIED reference player run on such a loop - oracle/ref_harness.py VirtualTimeLoop - produces
+ * the goldens this function is pinned to, tests/golden/mcts_par_games.json.)  What the loop then
+ * does between two wake-ups of prediction_worker (every prediction_worker_sleep_sec = 10 ticks of
+ * wait_for_expanding_sleep_sec) is one round:
+ *   B  the worker drained the queue into one api.predict call and resolved the futures: every
+ *      simulation waiting for the net finishes its expansion and returns up its path, in the order
+ *      the leaves were queued (:343-349); each return releases the semaphore, waking the next
+ *      waiting simulation BEHIND the remaining resumptions;
+ *   C  the woken simulations run in turn, each until it blocks (a simulation that ends on a
+ *      finished game releases its slot to the next one at once);
+ *   D  one tick later the simulations sleeping on now_expanding poll (:253-254) in the order they
+ *      went to sleep: those whose key has been expanded in B go on from where they stood, the
+ *      others (blocked by a leaf queued in C) sleep on; slots released here are refilled after
+ *      the whole batch of sleepers has polled (C').
+ * The first round of a search has an empty B: the worker's first look at the queue comes right
+ * after the initial `parallel_search_num` simulations have blocked. */
+typedef struct {
+    osim* sims;
+    osim* queue[ORC_MAX_PAR];    /* prediction_queue, put order */
+    osim* sleepers[ORC_MAX_PAR]; /* simulations sleeping on now_expanding, poll order */
+    int nq, ns, K, to_start, inflight;
+} osched;
+
+static int sched_fill(ogame* g, int pl, osched* sc, u64 own, u64 enemy, int* sims_done) {
+    while (sc->inflight < sc->K && sc->to_start > 0) {
+        int j = 0;
+        while (sc->sims[j].state != SIM_FREE) ++j;
+        osim* s = &sc->sims[j];
+        s->depth = 0;
+        orc_env_update(&s->env, own, enemy, 1); /* ReversiEnv().update(own, enemy, Player.black) (:209) */
+        --sc->to_start;
+        const int r = descend(g, pl, s, 0);
+        if (r < 0) return -1;
+        s->state = r;
+        if (r == SIM_FREE) { g->n_sims++; ++*sims_done; continue; }
+        ++sc->inflight;
+        if (r == SIM_WAIT_NET) sc->queue[sc->nq++] = s;
+        else { sc->sleepers[sc->ns++] = s; g->n_parked++; }
     }
-    double vl = (double)c->virtual_loss;
-    double vlw = knp == 1 ? vl : -vl;
-    int a = select_action(g, pl, env, is_root);
-    orc_env_step(env, a);
-    n = table_get(t, kb, kw, knp);
-    n->N[a] += vl;
-    n->W[a] -= vlw;
-    double leaf_v = search_my_move(g, pl, env, 0);
-    n = table_get(t, kb, kw, knp); /* table may have grown */
-    n->N[a] += -vl + 1.0;
-    n->W[a] += vlw + leaf_v;
-    onode* m = table_get(t, kw, kb, 3 - knp);
-    m->N[a] += 1.0;
-    m->W[a] -= leaf_v;
-    return leaf_v;
+    return 0;
+}
+
+static int search_moves(ogame* g, int pl, u64 own, u64 enemy, int sims_per_move, int* sims_done) {
+    osched sc;
+    memset(&sc, 0, sizeof sc);
+    sc.K = g->cfg->parallel_search_num;
+    sc.sims = (osim*)calloc((size_t)sc.K, sizeof(osim));
+    sc.to_start = sims_per_move;
+    int rc = 0;
+    while (rc == 0 && (sc.to_start > 0 || sc.inflight > 0)) {
+        /* B */
+        osim* batch[ORC_MAX_PAR];
+        const int nb = sc.nq;
+        memcpy(batch, sc.queue, sizeof batch);
+        sc.nq = 0;
+        for (int i = 0; i < nb; ++i) {
+            expand_finish(g, pl, batch[i]);
+            batch[i]->state = SIM_FREE; --sc.inflight; g->n_sims++; ++*sims_done;
+        }
+        /* C */
+        if ((rc = sched_fill(g, pl, &sc, own, enemy, sims_done)) != 0) break;
+        /* D: every sleeper polls once, in order; one that sleeps on keeps its place */
+        osim* poll[ORC_MAX_PAR];
+        const int np = sc.ns;
+        memcpy(poll, sc.sleepers, sizeof poll);
+        sc.ns = 0;
+        for (int i = 0; i < np && rc == 0; ++i) {
+            const int r = descend(g, pl, poll[i], 1);
+            if (r < 0) { rc = -1; break; }
+            poll[i]->state = r;
+            if (r == SIM_WAIT_EXPAND) sc.sleepers[sc.ns++] = poll[i];
+            else if (r == SIM_WAIT_NET) sc.queue[sc.nq++] = poll[i];
+            else { --sc.inflight; g->n_sims++; ++*sims_done; }
+        }
+        /* C' */
+        if (rc == 0) rc = sched_fill(g, pl, &sc, own, enemy, sims_done);
+    }
+    free(sc.sims);
+    return rc;
 }
 
 /* np.random.choice(range(64), p=policy) with the injected uniform (agent/player.py:112): cdf =
@@ -288,13 +428,7 @@ static int action_with_evaluation(ogame* g, int pl, u64 own, u64 enemy, int sims
     int action = 0;
     for (int tl = 0; tl < c->thinking_loop; ++tl) {
         if (turn > 0) {
-            for (int s = 0; s < sims_per_move; ++s) { /* search_moves (:189-215) */
-                orc_env env;
-                orc_env_update(&env, own, enemy, 1);
-                search_my_move(g, pl, &env, 1);
-                g->n_sims++;
-                rec->sims++;
-            }
+            if (search_moves(g, pl, own, enemy, sims_per_move, &rec->sims) != 0) return -2; /* :189-215 */
         } else { /* bypass_first_move (:143-148) */
             onode* n = table_get(t, root.black, root.white, 1);
             u64 legal = orc_find_correct_moves(root.black, root.white);
@@ -369,7 +503,7 @@ int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_byt
     ogame g;
     memset(&g, 0, sizeof g);
     g.cfg = cfg; g.blob = blob; g.blob_bytes = blob_bytes; g.seed = seed; g.game_id = game_id;
-    if (cfg->parallel_search_num != 1) return -1;
+    if (cfg->parallel_search_num < 1 || cfg->parallel_search_num > ORC_MAX_PAR) return -1;
     g.solver[0] = orc_solver_new();
     g.solver[1] = orc_solver_new();
     table_init(&g.tables[0]);
@@ -385,6 +519,7 @@ int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_byt
         int pl = env.next_player == 1 ? 0 : 1;
         u64 own = pl == 0 ? env.black : env.white, enemy = pl == 0 ? env.white : env.black;
         int a = action_with_evaluation(&g, pl, own, enemy, sims_per_move, enable_resign, &plies[np]);
+        if (a == -2) { np = -1; break; }
         plies[np].player = env.next_player;
         ++np;
         orc_env_step(&env, a);
@@ -400,6 +535,7 @@ int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_byt
         sum->n_nodes = (long long)(g.tables[0].count + (cfg->share_mtcs_info ? 0 : g.tables[1].count));
         sum->n_solved_leaves = g.n_solved_leaves;
         sum->n_solver_nodes = orc_solver_nodes(g.solver[0]) + orc_solver_nodes(g.solver[1]);
+        sum->n_parked = g.n_parked;
     }
     orc_solver_free(g.solver[0]);
     orc_solver_free(g.solver[1]);

@@ -100,6 +100,60 @@ def install():
     _installed = True
 
 
+class _FifoTimerHandle(asyncio.TimerHandle):
+    """TimerHandle ordered by (deadline, scheduling sequence): equal deadlines fire first-set-first."""
+    __slots__ = ("_seq",)
+
+    def __lt__(self, other):
+        return (self._when, self._seq) < (other._when, other._seq)
+
+
+class VirtualTimeLoop(asyncio.SelectorEventLoop):
+    """asyncio event loop in EXACT VIRTUAL TIME, the deterministic stage on which the unmodified
+    reference player is run with parallel_search_num > 1 (raz-sched-v1, oracle/orc_mcts.c):
+      * time() is a Fraction that never moves while a callback is runnable; when nothing is
+        runnable it jumps to the earliest timer (so computation takes no time and
+        prediction_worker_sleep_sec / wait_for_expanding_sleep_sec only order events);
+      * delays are taken as exact decimals (1e-05 is 1/100000), so ten 10-us sleeps end exactly
+        when one 100-us sleep does, and equal deadlines fire in the order they were set.
+    Nothing of the reference is edited: ReversiPlayer.__init__ picks the loop up through
+    asyncio.get_event_loop() (agent/player.py:53)."""
+
+    def __init__(self):
+        super().__init__()
+        from fractions import Fraction
+        self._F = Fraction
+        self._vnow = Fraction(0)
+        self._vseq = 0
+
+    def time(self):
+        return self._vnow
+
+    def call_later(self, delay, callback, *args, context=None):
+        return self.call_at(self._vnow + self._F(repr(float(delay))), callback, *args, context=context)
+
+    def call_at(self, when, callback, *args, context=None):
+        import heapq
+        self._check_closed()
+        timer = _FifoTimerHandle(when, callback, args, self, context)
+        timer._seq = self._vseq
+        self._vseq += 1
+        heapq.heappush(self._scheduled, timer)
+        timer._scheduled = True
+        return timer
+
+    def _run_once(self):
+        import heapq
+        if not self._ready:
+            while self._scheduled and self._scheduled[0]._cancelled:
+                self._timer_cancelled_count -= 1
+                h = heapq.heappop(self._scheduled)
+                h._scheduled = False
+            if self._scheduled and self._scheduled[0]._when > self._vnow:
+                self._vnow = self._scheduled[0]._when
+        super()._run_once()
+
+
 class _Releaser:
     def __init__(self, sem):
         self._sem = sem

@@ -108,7 +108,7 @@ def injected(stream):
          rp.ReversiPlayer.__init__) = saved
 
 
-def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None):
+def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False):
     """One game through the reference's SelfPlayWorker.start_game.  Returns a dict with per-ply
     captures (root N/W, action, n, q, emitted rows) and the play_*.json content the reference wrote."""
     rh.install()
@@ -146,6 +146,11 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
                       "saved_policy": [float(v) for v in new[0][1]] if new else None})
         return res
 
+    old_loop = None
+    if virtual_time:   # parallel_search_num > 1: the deterministic stage of raz-sched-v1 (ref_harness.VirtualTimeLoop)
+        import asyncio
+        old_loop = asyncio.get_event_loop_policy().get_event_loop()
+        asyncio.set_event_loop(rh.VirtualTimeLoop())
     with injected(stream):
         rp.ReversiPlayer.action_with_evaluation = capture
         try:
@@ -154,6 +159,10 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
             env = worker.start_game(1, 0, mtcs_info)
         finally:
             rp.ReversiPlayer.action_with_evaluation = orig_awe
+            if old_loop is not None:
+                import asyncio
+                asyncio.get_event_loop().close()
+                asyncio.set_event_loop(old_loop)
     files = sorted(os.listdir(rc.play_data_dir))
     play_rows = None
     if files:

@@ -47,22 +47,45 @@ VARIANTS = [
 ]
 
 
+# parallel_search_num > 1: the unmodified reference player on the exact-virtual-time event loop
+# (oracle/ref_harness.py VirtualTimeLoop = the stage raz-sched-v1 is defined on) -> mcts_par_games.json
+PAR_VARIANTS = [
+    ("mini_par4_as_shipped", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
+                                          "use_solver_turn_in_simulation": 50, "parallel_search_num": 4}, {}, 20, 31, [0, 1]),
+    ("mini_par2_nosolver", "mini.yml", {"reset_mtcs_info_per_game": 1, "parallel_search_num": 2}, {}, 24, 35, [4]),
+    ("default_par8_rethink", None, {"thinking_loop": 3, "required_visit_to_decide_action": 60, "start_rethinking_turn": 6,
+                                    "parallel_search_num": 8}, {}, 30, 32, [0]),
+    ("agz_par8_unshared", "alpha_go_zero.yml", {"parallel_search_num": 8}, {}, 40, 33, [2]),
+    ("ch5_par8_cpuct5", "ch5.yml", {"thinking_loop": 1, "parallel_search_num": 8}, {}, 30, 34, [1]),
+    ("agz_par16_resign", "alpha_go_zero.yml", {"resign_threshold": -0.02, "allowed_resign_turn": 12,
+                                               "disable_resignation_rate": 0.0, "parallel_search_num": 16}, {}, 32, 36, [0]),
+    ("agz_par3_solver_52_50", "alpha_go_zero.yml", {"use_solver_turn": 52, "use_solver_turn_in_simulation": 50,
+                                                    "resign_threshold": None, "parallel_search_num": 3}, {}, 25, 37, [1]),
+]
+
+
 def sparse(v):
     return {str(i): x for i, x in enumerate(v) if x != 0}
 
 
 def main():
+    generate(VARIANTS, "mcts_games.json", virtual_time=False)
+    generate(PAR_VARIANTS, "mcts_par_games.json", virtual_time=True)
+
+
+def generate(variants, fname, virtual_time):
     net = ReversiNet(16, 1, 16).keras_init_(0).randomize_bn_(3)
     blob = net.to_blob()
     out = {"_generator": "tests/golden/make_golden_mcts.py",
+           "event_loop": "ref_harness.VirtualTimeLoop (exact virtual time, FIFO ties)" if virtual_time else "asyncio default (parallel_search_num=1: order-free)",
            "net": {"filters": 16, "res_layers": 1, "value_fc": 16, "keras_init_seed": 0, "randomize_bn_seed": 3,
                    "blob_sha256": hashlib.sha256(blob).hexdigest()},
            "games": []}
-    for name, yml, play_over, pd_over, sims, seed, gids in VARIANTS:
+    for name, yml, play_over, pd_over, sims, seed, gids in variants:
         for gid in gids:
             over = {"play": dict(NO_SOLVER, **play_over), "play_data": pd_over}   # variant keys win over NO_SOLVER
             cfg = rh.load_config(yml, over)
-            ref = rs.run_reference_game(cfg, blob, seed, gid, sims)
+            ref = rs.run_reference_game(cfg, blob, seed, gid, sims, virtual_time=virtual_time)
             rows = ref.pop("play_rows")
             plies = []
             for p in ref.pop("plies"):
@@ -86,7 +109,7 @@ def main():
             out["games"].append(g)
             print(name, gid, "plies", len(plies), "winner", ref["winner"], "resigned", ref["resigned_black"],
                   ref["resigned_white"], "rows", g["play_rows_count"], "nn", ref["nn_positions"])
-    path = os.path.join(HERE, "mcts_games.json")
+    path = os.path.join(HERE, fname)
     with open(path, "wt") as f:
         json.dump(out, f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -9,9 +9,20 @@ import oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load_mcts_golden():
-    with open(os.path.join(GOLDEN, "mcts_games.json")) as f:
+def load_mcts_golden(name="mcts_games.json"):
+    with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
+
+
+def load_par_golden():
+    """Games of the unmodified reference at parallel_search_num > 1 on the exact-virtual-time event
+    loop (raz-sched-v1; tests/golden/make_golden_mcts.py PAR_VARIANTS)."""
+    return load_mcts_golden("mcts_par_games.json")
+
+
+def orc_cfg_of(game):
+    """OrcPlayCfg of a golden game, with the parallel_search_num the reference ran it at."""
+    return O.play_cfg_from_config(config_of(game), parallel_search_num=game["resolved_play"]["parallel_search_num"])
 
 
 def golden_net_blob(meta):

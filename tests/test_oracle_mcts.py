@@ -8,7 +8,7 @@ import json
 import pytest
 
 import oracle as O
-from oracle_util import load_mcts_golden, golden_net_blob, config_of, dense, rows_of_game
+from oracle_util import load_mcts_golden, load_par_golden, orc_cfg_of, golden_net_blob, config_of, dense, rows_of_game
 
 
 @pytest.fixture(scope="module")
@@ -80,8 +80,23 @@ def test_numpy_pairwise_sum_restatement():
 
 def test_games_bit_exact_vs_reference(golden, blob):
     assert len(golden["games"]) >= 10
+    check_games_bit_exact(golden, blob)
+
+
+def test_parallel_search_games_bit_exact_vs_reference_on_virtual_time_loop(blob):
+    """parallel_search_num = 2..16 (raz-sched-v1): the oracle's round schedule against the unmodified
+    reference player run on the exact-virtual-time event loop - same bit-exact bar as above."""
+    par = load_par_golden()
+    assert par["net"] == load_mcts_golden()["net"]
+    ks = {g["resolved_play"]["parallel_search_num"] for g in par["games"]}
+    assert ks >= {2, 3, 4, 8, 16}
+    check_games_bit_exact(par, blob)
+    check_play_rows(par, blob)
+
+
+def check_games_bit_exact(golden, blob):
     for g in golden["games"]:
-        cfg = O.play_cfg_from_config(config_of(g))
+        cfg = orc_cfg_of(g)
         plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"])
         tag = f'{g["variant"]}/{g["game_id"]}'
         assert [p["action"] for p in plies] == [p["action"] for p in g["plies"]], tag
@@ -105,8 +120,12 @@ def test_games_bit_exact_vs_reference(golden, blob):
 
 
 def test_play_rows_identical_to_reference_files(golden, blob):
+    check_play_rows(golden, blob)
+
+
+def check_play_rows(golden, blob):
     for g in golden["games"]:
-        cfg = O.play_cfg_from_config(config_of(g))
+        cfg = orc_cfg_of(g)
         plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"])
         rows = rows_of_game(plies, summ["winner"])
         dropped = summ["winner"] == 3 and not (g["resolved_play_data"]["drop_draw_game_rate"] <= summ["drop_draw_u"])
@@ -131,3 +150,19 @@ def test_live_reference_game_matches_oracle(blob):
     for a, b in zip(plies, ref["plies"]):
         assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"]
     assert summ["winner"] == ref["winner"]
+
+
+@pytest.mark.needs_reference
+def test_live_reference_parallel_search_matches_oracle(blob):
+    """Fresh differential runs at parallel_search_num 5 and 7 (not in the goldens), container only."""
+    import ref_harness as rh
+    import ref_selfplay as rs
+    for k, yml, seed in ((5, "mini.yml", 77), (7, "alpha_go_zero.yml", 78)):
+        cfg = rh.load_config(yml, {"play": {"parallel_search_num": k, "reset_mtcs_info_per_game": 1,
+                                            "use_solver_turn": 0, "use_solver_turn_in_simulation": 0}})
+        ref = rs.run_reference_game(cfg, blob, seed=seed, game_id=4242, sims_per_move=18, virtual_time=True)
+        plies, summ = O.selfplay_game(O.play_cfg_from_config(cfg, parallel_search_num=k), blob, seed, 4242, 18)
+        assert [p["action"] for p in plies] == [p["action"] for p in ref["plies"]]
+        for a, b in zip(plies, ref["plies"]):
+            assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"]
+        assert summ["n_expand"] == ref["nn_positions"] and summ["winner"] == ref["winner"]
