@@ -221,7 +221,7 @@ def main():
                 eng.step(args.chunk)
             steps += args.chunk
             st = eng.stats()
-            if st["max_pool_used"] + 4 * args.chunk + 64 > eng.cfg.nodes_per_game:   # prune before a pool can overflow
+            if st["max_pool_used"] + eng.nodes_per_step * args.chunk + 64 > eng.cfg.nodes_per_game:   # prune before a pool can overflow
                 eng.gc(eng.cfg.nodes_per_game // 4)
             if st["finished_games"] >= args.games:
                 break

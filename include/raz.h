@@ -145,14 +145,18 @@ typedef struct {
     uint32_t table_slots;                     /* hash slots per game, power of two >= 2*nodes_per_game */
     uint32_t max_plies;                       /* record capacity per game (>= 64) */
     uint32_t seed;
-    uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream; bits 8-11: slices/streams (0 = 3);
-                                                 bits 12-15: max simulations per game per tree launch (0 = 2) */
+    uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream; bit 3: drive even
+                                                 parallel_search_num <= 1 with the slot kernel (tests); bits 8-11: slices/streams
+                                                 (0 = 3); bits 12-15: max simulations per game per tree launch (0 = 2; slot
+                                                 kernel: simulations STARTED per launch beyond parallel_search_num) */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
                                                  (agent/player.py:100-103,150-161; lib/alt/reversi_solver_cython.pyx) */
     int32_t use_solver_turn_in_simulation;    /* config.py:155: 0 = off, else >= 46: win/loss solve inside simulations
                                                  (agent/player.py:237-251) */
     uint32_t solver_memo_slots;               /* per-game memo of solved positions, power of two (0 with the solver off) */
-    uint32_t reserved2;
+    uint32_t parallel_search_num;             /* config.py:142: simulations in flight per game; 0/1 = one (the reference's
+                                                 reproducible mode), 2..16 = the asyncio loop in exact virtual time
+                                                 (raz-sched-v1), bit-exact vs the reference on such a loop */
 } raz_engine_config;
 
 typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */

@@ -64,7 +64,7 @@ class RazEngineConfig(ctypes.Structure):
                 ("n_games", c_uint32), ("nodes_per_game", c_uint32), ("table_slots", c_uint32),
                 ("max_plies", c_uint32), ("seed", c_uint32), ("reserved", c_uint32),
                 ("use_solver_turn", ctypes.c_int32), ("use_solver_turn_in_simulation", ctypes.c_int32),
-                ("solver_memo_slots", c_uint32), ("reserved2", c_uint32)]
+                ("solver_memo_slots", c_uint32), ("parallel_search_num", c_uint32)]
 
 
 class RazEngineStats(ctypes.Structure):

@@ -28,6 +28,12 @@
 #define RAZ_LEAF_EXPAND 1
 #define RAZ_LEAF_TERMINAL 2
 #define RAZ_LEAF_SOLVED 3   // the in-simulation solver answered (agent/player.py:237-251)
+#define RAZ_LEAF_PARKED 4   // parallel_search_num > 1: the key is in now_expanding (agent/player.py:253-254)
+
+// State of one of the parallel_search_num simulation slots of a game (k_tree_par)
+#define RAZ_SIM_FREE 0
+#define RAZ_SIM_WAIT_NET 1     // its leaf is in the prediction queue (expand_and_evaluate awaits the future)
+#define RAZ_SIM_WAIT_EXPAND 2  // sleeping on now_expanding at node sim_parked
 
 #define RAZ_PHASE_NEW_MOVE 0
 #define RAZ_PHASE_SEARCH 1
@@ -55,6 +61,7 @@ struct raz_node_hdr {
     unsigned long long black, white;  // key
     unsigned long long legal;         // legal moves of the side to move (computed once)
     uint32_t tag;                     // next_player | owner<<2 | expanded_by_black<<4 | expanded_by_white<<5
+                                      // | being expanded by black<<6 / white<<7 (now_expanding, parallel_search_num > 1)
     uint32_t mirror;                  // node index of the colour-mirrored key, 0xffffffff = none yet
 };
 #define RAZ_NODE_W 0
@@ -92,7 +99,12 @@ struct raz_game {
     uint32_t leaf_sym, leaf_np, depth, leaf_action; // D4 transform shown to the net, side to move at the leaf, path length
     uint32_t leaf_node, leaf_slot, leaf_tag, leaf_mirror;  // existing node of the leaf (or RAZ_NO_NODE) / empty slot found
     uint32_t leaf_term_v;                           // f32 bits: value of a terminal / solved leaf
-    uint32_t pad[19];
+    // parallel_search_num > 1 (k_tree_par).  Every simulation slot owns a 64-dword block with THIS layout in
+    // which only the in-flight-simulation fields (leaf_*, depth, sim_*) are meaningful, so that moving a slot
+    // into / out of the register-resident control block is one masked select / one masked store.
+    uint32_t sim_state, sim_seq, sim_parked;        // per slot: RAZ_SIM_*, order number (queue put order / sleep order), node slept on
+    uint32_t par_seq_next, par_stage;               // per game: next order number; 0 = round boundary, 1 = filling (C), 2 = refilling (C')
+    uint32_t pad[14];
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");
@@ -102,13 +114,17 @@ static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");
 struct raz_engine_dev {
     raz_engine_config cfg;
     uint32_t B, C, H, max_plies;
+    uint32_t K;                    // simulation slots per game: parallel_search_num (1 for the classic one-in-flight kernel)
+    uint32_t par;                  // 1: k_tree_par drives the games (per-slot state in `sim`), 0: k_tree
+    uint32_t* sim;                 // [B][K][64] slot blocks (raz_game layout), par only
     raz_game* game;                // [B]
-    // leaf exchange with the net kernel, and the path of the simulation in flight
-    uint8_t* nn_active;            // [B]
+    // leaf exchange with the net kernel, and the path of the simulation in flight; one entry per
+    // simulation slot: index g * K + slot
+    uint8_t* nn_active;            // [B*K]
     unsigned long long *nn_own, *nn_enemy;
-    float *nn_policy /*[B][64]*/, *nn_value;
-    uint32_t *path_node /*[B][64]*/, *path_mirror /*[B][64]*/;
-    uint8_t* path_act /*[B][64]*/;
+    float *nn_policy /*[B*K][64]*/, *nn_value;
+    uint32_t *path_node /*[B*K][64]*/, *path_mirror /*[B*K][64]*/;
+    uint8_t* path_act /*[B*K][64]*/;
     // tree
     raz_slot* table;               // [B][H]
     unsigned char* nodes;          // [B][C][1024]

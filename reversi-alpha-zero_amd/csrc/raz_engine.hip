@@ -638,6 +638,9 @@ __device__ bool place_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
 // Everything the backup needs is in registers (control block, path, the net's answer), so its
 // memory work is: the (N, W) cells of the path levels (lane d = level d, issued first), the table
 // probe for the mirror key of a brand-new position, and stores.
+// PAR (parallel_search_num > 1): the virtual loss was STORED when the edge was taken (other simulations
+// of the game read it meanwhile), so the return path only adds "-vl + 1" / "vlw + leaf_v" (:276-277).
+template <bool PAR>
 __device__ void backup_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t pl, int lane, float* lds64) {
     const raz_engine_config& c = E.cfg;
     const uint32_t kind = G32(R, GW(leaf_kind));
@@ -705,8 +708,13 @@ __device__ void backup_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, uint32
         const double vl = (double)c.virtual_loss;
         const uint32_t npd = my_pa >> 6;
         const double vlw = npd == 1 ? vl : -vl;
-        node_N(p)[a] = n0 + 1u;
-        node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
+        if (PAR) {
+            node_N(p)[a] = n0 + 1u - (uint32_t)c.virtual_loss;
+            node_W(p)[a] = w0 + (vlw + leaf_v);
+        } else {
+            node_N(p)[a] = n0 + 1u;
+            node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
+        }
         if (m != RAZ_NO_NODE) {  // another_side_counter_key (:279-280); exists since the node's expansion
             node_N(q)[a] = n1 + 1u;
             node_W(q)[a] = w1 - leaf_v;
@@ -889,8 +897,14 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
 }
 
 // ------------------------------------------------------------------ descent to the next leaf
-template <bool SOLVER>
-__device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, SolverLDS* S) {
+// PAR (k_tree_par): the descent may start at the node a sleeping simulation stood on (start_node /
+// start_depth, `polling`: the solver look of :237-251 lies behind it), every edge taken gets its virtual
+// loss stored at once (:270-271), a leaf being expanded is flagged in its node's tag (now_expanding,
+// :294) - a brand-new position gets its node right here for that - and a descent that meets such a
+// flag stops there (RAZ_LEAF_PARKED, :253-254).  nn_index: the slot of the leaf exchange arrays.
+template <bool SOLVER, bool PAR>
+__device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, SolverLDS* S, uint32_t nn_index,
+                            uint32_t start_node, int start_depth, bool polling) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = G32(R, GW(player));
     const uint32_t pl = player - 1;
@@ -903,9 +917,9 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
     env.np = 1;
     env.status = 0;
     env.legal = 0;
-    int depth = 0;
+    int depth = PAR ? start_depth : 0;
     uint32_t kind = RAZ_LEAF_NONE;
-    uint32_t node = G32(R, GW(root_node));  // always exists (begin_move)
+    uint32_t node = PAR ? start_node : G32(R, GW(root_node));  // always exists (begin_move)
     uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu, leaf_tag = 0, leaf_mirror = RAZ_NO_NODE;
     raz_bb leaf_legal = 0;
     int solved_action = 0;
@@ -936,7 +950,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         env.white = uni(hw);
         env.np = uni(tag) & 3u;
         env.legal = uni(legal);
-        if (SOLVER && t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
+        if (SOLVER && t_insim && !(PAR && polling) && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
             if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {  // `if action:` ignores square 0
@@ -951,12 +965,21 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
                 break;
             }
         }
+        if (PAR) {
+            polling = false;
+            if ((uni(tag) >> (6 + pl)) & 1u) {  // while key in self.now_expanding: await asyncio.sleep(...) (:253-254)
+                kind = RAZ_LEAF_PARKED;
+                leaf_node = node;
+                break;
+            }
+        }
         if (!((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
             kind = RAZ_LEAF_EXPAND;
             leaf_node = node;
             leaf_legal = env.legal;
             leaf_tag = uni(tag);
             leaf_mirror = uni(hmirror);
+            if (PAR && lane == 0) node_hdr(p)->tag = uni(tag) | (64u << pl);  // now_expanding.add(key) (:294)
             break;
         }
         if (depth >= 64) {
@@ -964,6 +987,11 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
             break;
         }
         const int a = select_action(E, R, g, Wi, Ni, Pi, env.legal, env.np, depth == 0, game_id, lane);
+        if (PAR && lane == a) {  // var_n[key][action_t] += virtual_loss; var_w[key][action_t] -= virtual_loss_for_w (:270-271)
+            const double vl = (double)c.virtual_loss;
+            node_N(p)[a] = Ni + (uint32_t)c.virtual_loss;
+            node_W(p)[a] = Wi - (env.np == 1 ? vl : -vl);
+        }
         R.pnode = writelane_r(R.pnode, node, depth, lane);
         R.pmirror = writelane_r(R.pmirror, hmirror, depth, lane);
         R.pact = writelane_r(R.pact, (uint32_t)a | (env.np << 6), depth, lane);
@@ -1009,6 +1037,20 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
                 term_v = ss > 0 ? 1.0f : (ss < 0 ? -1.0f : 0.0f);
             }
         }
+        if (PAR && kind == RAZ_LEAF_EXPAND) {  // the key enters now_expanding: it needs a node to carry the flag
+            const uint32_t used = G32(R, GW(pool_used));
+            if (f.slot == 0xffffffffu || used >= E.C) {
+                flag_error(R, (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
+                kind = RAZ_LEAF_NONE;
+                break;
+            }
+            const uint32_t tagkey = env.np | (owner << 2);
+            node_init(E, g, used, f.slot, env.black, env.white, tagkey | (64u << pl), env.legal, RAZ_NO_NODE, 0.0f, lane);
+            if (lane == 0) node_child(p)[a] = used + 1;
+            S32(R, GW(pool_used), used + 1);
+            leaf_node = used;
+            leaf_tag = tagkey;
+        }
         break;
     }
     R.path_dirty = 1u;
@@ -1032,17 +1074,18 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         S32(R, GW(ev_expand), ev + 1);
         S32(R, GW(leaf_sym), (uint32_t)(flip * 4 + rot));
         if (lane == 0) {
-            E.nn_own[g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
-            E.nn_enemy[g] = env.np == 1 ? tw : tb;
+            E.nn_own[PAR ? nn_index : g] = env.np == 1 ? tb : tw;   // planes from the side to move's view (:309)
+            E.nn_enemy[PAR ? nn_index : g] = env.np == 1 ? tw : tb;
         }
         ADD64(R, GW(leaves), 1ULL);
         R.nn = 1u;
     }
     if (kind == RAZ_LEAF_SOLVED) S32(R, GW(leaf_action), (uint32_t)solved_action);
+    if (PAR && kind == RAZ_LEAF_PARKED) S32(R, GW(sim_parked), leaf_node);
     S32(R, GW(leaf_term_v), __float_as_uint(term_v));
     S32(R, GW(leaf_kind), kind);
     S32(R, GW(depth), (uint32_t)depth);
-    ADD64(R, GW(selections), (raz_bb)depth);
+    ADD64(R, GW(selections), (raz_bb)(depth - (PAR ? start_depth : 0)));
     wave_sync();
 }
 
@@ -1080,7 +1123,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (G32(R, GW(error))) break;
         unsigned long long t0 = prof_now();
-        if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+        if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf<false>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
         prof_add(E, g, 0, t0, lane);
         t0 = prof_now();
         // controller: loop because a decided move may immediately need another decision
@@ -1101,7 +1144,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
         phase = G32(R, GW(phase));
         if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
         t0 = prof_now();
-        select_leaf<SOLVER>(E, R, g, lane, slds_p);
+        select_leaf<SOLVER, false>(E, R, g, lane, slds_p, g, 0u, 0, false);
         prof_add(E, g, 2, t0, lane);
         const uint32_t lk = G32(R, GW(leaf_kind));
         if (lk != RAZ_LEAF_TERMINAL && lk != RAZ_LEAF_SOLVED) break;  // needs the net
@@ -1114,6 +1157,216 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
         E.path_act[(size_t)g * 64 + lane] = (uint8_t)R.pact;
     }
     if (lane == 0) E.nn_active[g] = (uint8_t)R.nn;
+}
+
+// ------------------------------------------------------------------ parallel_search_num > 1: k_tree_par
+// The reference runs simulation_num_per_move coroutines under asyncio.Semaphore(parallel_search_num)
+// beside a prediction_worker that turns the queued leaves into one api.predict call
+// (agent/player.py:189-215, 329-355).  raz-sched-v1 (oracle/orc_mcts.c search_moves)
+// is that event loop in exact virtual time; one ROUND of it is
+//   B   the batch came back: the simulations waiting for the net finish their expansion and return up
+//       their paths, in the order their leaves were queued;
+//   C   freed semaphore slots are taken by the next simulations, each running until it blocks;
+//   D   the simulations sleeping on now_expanding whose key was expanded in B go on, in sleep order;
+//   C'  slots freed in D are refilled.
+// A game keeps parallel_search_num simulation SLOTS (block = raz_game layout, only the leaf_* / depth
+// lanes meaningful; path and leaf-exchange rows indexed g * K + slot); lane j of three VGPRs holds
+// slot j's state, order number and node slept on.  One launch = at most one round; a fill that runs
+// out of its per-launch budget (games whose simulations all end on finished positions would otherwise
+// be the launch's stragglers) continues at the next launch WITHOUT an intervening B, so the result
+// does not depend on the budget.
+#define LB(f) (1ULL << GW(f))
+constexpr unsigned long long kSimLanes =
+    LB(leaf_b) | (LB(leaf_b) << 1) | LB(leaf_w) | (LB(leaf_w) << 1) | LB(leaf_legal) | (LB(leaf_legal) << 1) |
+    LB(leaf_kind) | LB(leaf_sym) | LB(leaf_np) | LB(depth) | LB(leaf_action) | LB(leaf_node) | LB(leaf_slot) |
+    LB(leaf_tag) | LB(leaf_mirror) | LB(leaf_term_v);
+#undef LB
+
+struct Slots {
+    uint32_t st, sq, pk;  // lane j = slot j: RAZ_SIM_*, order number, node slept on
+};
+
+__device__ __forceinline__ void slot_load(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t j, int lane, bool with_net) {
+    const size_t gi = (size_t)g * E.K + j;
+    const uint32_t v = E.sim[gi * 64 + lane];
+    R.pnode = E.path_node[gi * 64 + lane];
+    R.pmirror = E.path_mirror[gi * 64 + lane];
+    R.pact = E.path_act[gi * 64 + lane];
+    if (with_net) {
+        R.pol_raw = E.nn_policy[gi * 64 + lane];
+        R.val = E.nn_value[gi];
+    }
+    R.cw = ((kSimLanes >> lane) & 1ULL) ? v : R.cw;
+}
+__device__ __forceinline__ void slot_store(const raz_engine_dev& E, const Regs& R, uint32_t g, uint32_t j, int lane) {
+    const size_t gi = (size_t)g * E.K + j;
+    if ((kSimLanes >> lane) & 1ULL) E.sim[gi * 64 + lane] = R.cw;
+    E.path_node[gi * 64 + lane] = R.pnode;
+    E.path_mirror[gi * 64 + lane] = R.pmirror;
+    E.path_act[gi * 64 + lane] = (uint8_t)R.pact;
+}
+// the slot of `mask` with the smallest order number (K <= 16: a scalar scan)
+__device__ __forceinline__ int pick_min_seq(uint32_t sq, unsigned long long mask) {
+    int best = -1;
+    uint32_t bs = 0;
+    for (unsigned long long m = mask; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const uint32_t q = lane_u32(sq, j);
+        if (best < 0 || q < bs) {
+            bs = q;
+            best = j;
+        }
+    }
+    return best;
+}
+
+// What became of slot j's simulation after a descent: it ended on a finished game / a solved position
+// (returns up its path at once, the slot is free), queued a leaf, or fell asleep on now_expanding.
+__device__ void par_after(const raz_engine_dev& E, Regs& R, Slots& T, uint32_t g, int lane, int j, bool was_sleeper,
+                          uint32_t& nnmask, float* lds64) {
+    const uint32_t kind = G32(R, GW(leaf_kind));
+    if (kind == RAZ_LEAF_TERMINAL || kind == RAZ_LEAF_SOLVED) {
+        backup_leaf<true>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+        T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
+        return;
+    }
+    if (kind == RAZ_LEAF_EXPAND) {
+        const uint32_t seq = G32(R, GW(par_seq_next));
+        S32(R, GW(par_seq_next), seq + 1);
+        T.st = writelane_r(T.st, RAZ_SIM_WAIT_NET, j, lane);
+        T.sq = writelane_r(T.sq, seq, j, lane);
+        nnmask |= 1u << j;
+    } else if (kind == RAZ_LEAF_PARKED) {
+        if (!was_sleeper) {  // a sleeper that goes back to sleep keeps its place among the sleepers
+            const uint32_t seq = G32(R, GW(par_seq_next));
+            S32(R, GW(par_seq_next), seq + 1);
+            T.sq = writelane_r(T.sq, seq, j, lane);
+        }
+        T.st = writelane_r(T.st, RAZ_SIM_WAIT_EXPAND, j, lane);
+        T.pk = writelane_r(T.pk, G32(R, GW(sim_parked)), j, lane);
+    } else {
+        return;  // an error was flagged
+    }
+    slot_store(E, R, g, (uint32_t)j, lane);
+    S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
+}
+
+// C / C': the per-move controller, then new simulations into the free slots.  Returns false when the
+// launch's budget ran out before the fill was complete.
+template <bool SOLVER>
+__device__ bool par_fill(const raz_engine_dev& E, Regs& R, Slots& T, uint32_t g, int lane, uint32_t K,
+                         unsigned long long kmask, int& budget, uint32_t& nnmask, SolverLDS* S, float* lds64) {
+    for (;;) {
+        for (int guard = 0; guard < 8; ++guard) {
+            const uint32_t phase = G32(R, GW(phase));
+            if (phase == RAZ_PHASE_NEW_MOVE) {
+                begin_move<SOLVER>(E, R, g, lane, S);
+                continue;
+            }
+            if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {  // every simulation has returned
+                decide_move(E, R, g, lane);
+                continue;
+            }
+            break;
+        }
+        if (G32(R, GW(phase)) != RAZ_PHASE_SEARCH || G32(R, GW(error))) return true;
+        const unsigned long long busy = __ballot(T.st != RAZ_SIM_FREE) & kmask;
+        const int inflight = __popcll(busy);
+        const int to_start = (int32_t)G32(R, GW(sims_left)) - inflight;
+        if (inflight >= (int)K || to_start <= 0) return true;
+        if (budget <= 0) return false;
+        --budget;
+        const int j = __ffsll((long long)(~busy & kmask)) - 1;
+        select_leaf<SOLVER, true>(E, R, g, lane, S, g * K + (uint32_t)j, G32(R, GW(root_node)), 0, false);
+        par_after(E, R, T, g, lane, j, false, nnmask, lds64);
+    }
+}
+
+template <bool SOLVER>
+__global__ __launch_bounds__(64) void k_tree_par(raz_engine_dev E, uint32_t g0, uint32_t count) {
+    if (blockIdx.x >= count) return;
+    __shared__ float lds64[64];
+    __shared__ SolverLDS slds_store;
+    SolverLDS* slds_p = SOLVER ? &slds_store : nullptr;
+    const uint32_t g = g0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    if (g >= E.B) return;
+    const uint32_t K = E.K;
+    const unsigned long long kmask = (1ULL << K) - 1ULL;  // K <= 16
+    uint32_t* gw = (uint32_t*)(E.game + g);
+    Regs R;
+    R.cw = gw[lane];
+    R.pnode = R.pmirror = R.pact = 0u;
+    R.pol_raw = 0.0f;
+    R.val = 0.0f;
+    R.nn = 0u;
+    R.path_dirty = 0u;
+    Slots T;
+    T.st = T.sq = T.pk = 0u;
+    uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
+    if (lane < (int)K) {
+        T.st = myblk[GW(sim_state)];
+        T.sq = myblk[GW(sim_seq)];
+        T.pk = myblk[GW(sim_parked)];
+    }
+    uint32_t nnmask = 0u;
+    {
+        const uint32_t phase = G32(R, GW(phase));
+        if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) {
+            if (lane < (int)K) E.nn_active[(size_t)g * K + lane] = 0;
+            return;
+        }
+    }
+    if (RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
+    int budget = (int)K + (((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax);
+    uint32_t stage = G32(R, GW(par_stage));
+    if (stage == 0u) {  // B
+        const unsigned long long t0 = prof_now();
+        for (;;) {
+            const unsigned long long m = __ballot(T.st == RAZ_SIM_WAIT_NET) & kmask;
+            if (!m || G32(R, GW(error))) break;
+            const int j = pick_min_seq(T.sq, m);
+            slot_load(E, R, g, (uint32_t)j, lane, true);
+            backup_leaf<true>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+            T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
+        }
+        prof_add(E, g, 0, t0, lane);
+        stage = 1u;
+    }
+    for (;;) {
+        const unsigned long long t0 = prof_now();
+        const bool complete = par_fill<SOLVER>(E, R, T, g, lane, K, kmask, budget, nnmask, slds_p, lds64);
+        prof_add(E, g, 2, t0, lane);
+        if (!complete || G32(R, GW(error))) break;
+        if (stage == 2u) {
+            stage = 0u;  // the round is complete: the next launch starts with B
+            break;
+        }
+        {  // D: sleepers whose key is still in now_expanding sleep on (their nodes' tags are read in one go)
+            const uint32_t pl = G32(R, GW(player)) - 1;
+            const bool sl = lane < (int)K && T.st == RAZ_SIM_WAIT_EXPAND;
+            uint32_t tg = 0u;
+            if (sl) tg = node_hdr(node_ptr(E, g, T.pk))->tag;
+            unsigned long long m = __ballot(sl && !((tg >> (6 + pl)) & 1u)) & kmask;
+            while (m && !G32(R, GW(error))) {
+                const int j = pick_min_seq(T.sq, m);
+                m &= ~(1ULL << j);
+                slot_load(E, R, g, (uint32_t)j, lane, false);
+                select_leaf<SOLVER, true>(E, R, g, lane, slds_p, g * K + (uint32_t)j, lane_u32(T.pk, j),
+                                          (int)G32(R, GW(depth)), true);
+                par_after(E, R, T, g, lane, j, true, nnmask, lds64);
+            }
+        }
+        stage = 2u;
+    }
+    S32(R, GW(par_stage), stage);
+    gw[lane] = R.cw;
+    if (lane < (int)K) {
+        myblk[GW(sim_state)] = T.st;
+        myblk[GW(sim_seq)] = T.sq;
+        myblk[GW(sim_parked)] = T.pk;
+        E.nn_active[(size_t)g * K + lane] = (uint8_t)((nnmask >> lane) & 1u);
+    }
 }
 
 // Reduce the per-game statistics into counters[0..6] (one block).  Per-game words instead of
@@ -1167,7 +1420,7 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     G.leaf_node = RAZ_NO_NODE;
     G.leaf_mirror = RAZ_NO_NODE;
     E.game[g] = G;
-    E.nn_active[g] = 0;
+    if (!E.par) E.nn_active[g] = 0;   // (slot kernel: cleared by raz_engine_start, one flag per slot)
 }
 
 // ------------------------------------------------------------------ node pruning
@@ -1248,23 +1501,33 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
     }
     raz_slot* tab = E.table + (size_t)g * E.H;
     for (uint32_t sidx = tid; sidx < E.H; sidx += 256) tab[sidx].idx_tag = 0;
-    if (tid < 64) {  // in-flight simulation state
-        const uint32_t pn = E.path_node[(size_t)g * 64 + tid], pm = E.path_mirror[(size_t)g * 64 + tid];
-        const int depth = (int)G.depth;
-        if (tid < depth) {
-            E.path_node[(size_t)g * 64 + tid] = remap[pn];
-            if (pm != RAZ_NO_NODE) E.path_mirror[(size_t)g * 64 + tid] = remap[pm];
+    // in-flight simulation state: of the game block (k_tree) or of every busy simulation slot (k_tree_par)
+    const uint32_t nslots = E.par ? E.K : 1u;
+    for (uint32_t j = 0; j < nslots; ++j) {
+        uint32_t* blk = E.par ? E.sim + ((size_t)g * E.K + j) * 64 : (uint32_t*)&G;
+        const size_t pi = E.par ? (size_t)g * E.K + j : (size_t)g;
+        if (E.par && blk[GW(sim_state)] == RAZ_SIM_FREE) continue;
+        if (tid < 64) {
+            const uint32_t pn = E.path_node[pi * 64 + tid], pm = E.path_mirror[pi * 64 + tid];
+            const int depth = (int)blk[GW(depth)];
+            if (tid < depth) {
+                E.path_node[pi * 64 + tid] = remap[pn];
+                if (pm != RAZ_NO_NODE) E.path_mirror[pi * 64 + tid] = remap[pm];
+            }
+        }
+        if (tid == 0) {
+            const uint32_t ln = blk[GW(leaf_node)], lm = blk[GW(leaf_mirror)], lk = blk[GW(leaf_kind)];
+            if (lk == RAZ_LEAF_EXPAND || lk == RAZ_LEAF_SOLVED) {
+                if (ln != RAZ_NO_NODE) blk[GW(leaf_node)] = remap[ln];
+                if (lm != RAZ_NO_NODE) blk[GW(leaf_mirror)] = remap[lm];
+                blk[GW(leaf_slot)] = 0xfffffffeu;  // the slot found by select is gone: backup probes again
+            }
+            if (E.par && blk[GW(sim_state)] == RAZ_SIM_WAIT_EXPAND) blk[GW(sim_parked)] = remap[blk[GW(sim_parked)]];
         }
     }
     if (tid == 0) {
         const uint32_t rn = G.root_node;
         if (rn != RAZ_NO_NODE) G.root_node = remap[rn];
-        const uint32_t ln = G.leaf_node, lm = G.leaf_mirror;
-        if (G.leaf_kind == RAZ_LEAF_EXPAND || G.leaf_kind == RAZ_LEAF_SOLVED) {
-            if (ln != RAZ_NO_NODE) G.leaf_node = remap[ln];
-            if (lm != RAZ_NO_NODE) G.leaf_mirror = remap[lm];
-            G.leaf_slot = 0xfffffffeu;  // the slot found by select is gone: backup probes again
-        }
         G.pool_used = kept;
     }
     __syncthreads();
@@ -1290,6 +1553,11 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// parallel_search_num (config.py:142): simulation slots per game; 0 means 1.
+inline size_t slots_of(const raz_engine_config& cfg) { return cfg.parallel_search_num ? cfg.parallel_search_num : 1; }
+// k_tree_par drives the games when more than one simulation is in flight (or when reserved bit 3 asks for it)
+inline bool uses_slot_kernel(const raz_engine_config& cfg) { return slots_of(cfg) > 1 || (cfg.reserved & 8u); }
+
 // Carve the workspace; with base == nullptr only the total size is computed.
 size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* E) {
     size_t off = 0;
@@ -1303,11 +1571,16 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     memset(&d, 0, sizeof d);
     d.cfg = cfg;
     d.B = (uint32_t)B; d.C = (uint32_t)C; d.H = (uint32_t)H; d.max_plies = (uint32_t)MP;
+    const size_t K = slots_of(cfg);
+    d.K = (uint32_t)K;
+    d.par = uses_slot_kernel(cfg) ? 1u : 0u;
     d.game = (raz_game*)take(B * sizeof(raz_game));
-    d.nn_active = take(B);
-    d.nn_own = (unsigned long long*)take(B * 8); d.nn_enemy = (unsigned long long*)take(B * 8);
-    d.nn_policy = (float*)take(B * 64 * 4); d.nn_value = (float*)take(B * 4);
-    d.path_node = (uint32_t*)take(B * 64 * 4); d.path_mirror = (uint32_t*)take(B * 64 * 4); d.path_act = take(B * 64);
+    d.sim = d.par ? (uint32_t*)take(B * K * sizeof(raz_game)) : nullptr;
+    const size_t BK = B * K;   // one leaf-exchange row and one path per simulation slot
+    d.nn_active = take(BK);
+    d.nn_own = (unsigned long long*)take(BK * 8); d.nn_enemy = (unsigned long long*)take(BK * 8);
+    d.nn_policy = (float*)take(BK * 64 * 4); d.nn_value = (float*)take(BK * 4);
+    d.path_node = (uint32_t*)take(BK * 64 * 4); d.path_mirror = (uint32_t*)take(BK * 64 * 4); d.path_act = take(BK * 64);
     d.table = (raz_slot*)take(B * H * sizeof(raz_slot));
     d.nodes = take(B * C * RAZ_NODE_BYTES);
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
@@ -1332,6 +1605,8 @@ int validate(const raz_engine_config* cfg) {
     if (!(cfg->dirichlet_alpha > 0.0) || cfg->dirichlet_alpha > 1.0)
         return raz_fail(RAZ_EINVAL, "raz_engine: dirichlet_alpha must be in (0, 1] (all shipped configs use 0.5)");
     if (cfg->thinking_loop < 1) return raz_fail(RAZ_EINVAL, "raz_engine: thinking_loop must be >= 1");
+    if (cfg->parallel_search_num > 16)
+        return raz_fail(RAZ_EINVAL, "raz_engine: parallel_search_num must be <= 16 (prediction_queue_size, config.py:141: the reference's queue would block beyond it)");
     if ((cfg->use_solver_turn && cfg->use_solver_turn < 46) || (cfg->use_solver_turn_in_simulation && cfg->use_solver_turn_in_simulation < 46))
         return raz_fail(RAZ_EINVAL, "raz_engine: use_solver_turn(_in_simulation) must be 0 or >= 46 (<= 14 empties; the reference relies on a 30 s timeout below that)");
     if ((cfg->use_solver_turn || cfg->use_solver_turn_in_simulation) &&
@@ -1392,18 +1667,26 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
     const Half hf = half_of(e, h);
     if (hf.count == 0) return RAZ_OK;
     if (ev) hipEventRecord(ev[0], s);
-    if (d.cfg.use_solver_turn || d.cfg.use_solver_turn_in_simulation)
+    const bool solver = d.cfg.use_solver_turn || d.cfg.use_solver_turn_in_simulation;
+    if (d.par) {
+        if (solver)
+            hipLaunchKernelGGL(k_tree_par<true>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
+        else
+            hipLaunchKernelGGL(k_tree_par<false>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
+    } else if (solver)
         hipLaunchKernelGGL(k_tree<true>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
     else
         hipLaunchKernelGGL(k_tree<false>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
     int rc = raz_check_launch("raz_engine_step: k_tree");
     if (rc != RAZ_OK) return rc;
     if (ev) hipEventRecord(ev[1], s);
-    // the slices run concurrently: each gets its own part of the net scratch (size is linear in n)
-    const size_t soff = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, hf.g0);
-    const size_t sbytes = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, hf.count);
-    rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + hf.g0, (const uint64_t*)d.nn_enemy + hf.g0,
-                         d.nn_active + hf.g0, d.nn_policy + (size_t)hf.g0 * 64, d.nn_value + hf.g0, hf.count,
+    // the slices run concurrently: each gets its own part of the net scratch (size is linear in n);
+    // a game contributes one leaf-exchange row per simulation slot
+    const size_t p0 = (size_t)hf.g0 * d.K, pn = (size_t)hf.count * d.K;
+    const size_t soff = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, p0);
+    const size_t sbytes = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, pn);
+    rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + p0, (const uint64_t*)d.nn_enemy + p0,
+                         d.nn_active + p0, d.nn_policy + p0 * 64, d.nn_value + p0, pn,
                          e->net_scratch ? (unsigned char*)e->net_scratch + soff : nullptr, sbytes, (raz_stream_t)s);
     if (ev) hipEventRecord(ev[2], s);
     return rc;
@@ -1444,7 +1727,7 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     if (!d_workspace || ((uintptr_t)d_workspace & 255)) return raz_fail(RAZ_EINVAL, "raz_engine_create: workspace must be 256-byte aligned");
     const size_t need = raz_engine_workspace_bytes(cfg);
     if (workspace_bytes < need) return raz_fail(RAZ_ENOMEM, "raz_engine_create: workspace too small (raz_engine_workspace_bytes)");
-    if (net_scratch_bytes < raz_net_scratch_bytes(net->filters, net->value_fc, cfg->n_games))
+    if (net_scratch_bytes < raz_net_scratch_bytes(net->filters, net->value_fc, (size_t)cfg->n_games * slots_of(*cfg)))
         return raz_fail(RAZ_ENOMEM, "raz_engine_create: net scratch too small (raz_net_scratch_bytes)");
     raz_engine* e = new (std::nothrow) raz_engine;
     if (!e) return raz_fail(RAZ_ENOMEM, "raz_engine_create: host allocation failed");
@@ -1523,6 +1806,10 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_start: clear solver memo");
     RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_start: clear counters");
+    if (d.par) {
+        RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_start: clear simulation slots");
+        RAZ_HIP_TRY(hipMemsetAsync(d.nn_active, 0, (size_t)d.B * d.K, s), "raz_engine_start: clear leaf flags");
+    }
     RAZ_HIP_TRY(hipMemsetAsync(d.prof, 0, (size_t)d.B * 64, s), "raz_engine_start: clear profile");
     hipLaunchKernelGGL(k_start, dim3((d.B + 255) / 256), dim3(256), 0, s, d, first_game_id, e->d_sims, n_active);
     int rc = raz_check_launch("raz_engine_start");
@@ -1647,7 +1934,8 @@ __global__ void k_set_position(raz_engine_dev E, uint32_t g, unsigned long long 
     G.loops_done = 0;
     G.move_sims = 0;
     G.leaf_kind = RAZ_LEAF_NONE;
-    E.nn_active[g] = 0;
+    if (!E.par) E.nn_active[g] = 0;   // (slot kernel: no simulation is in flight between two moves of a slot)
+    G.par_stage = 0;
     G.enable_resign = enable_resign;
     G.one_move = one_move;
     G.root_node = RAZ_NO_NODE;
@@ -1680,7 +1968,10 @@ __global__ void k_stop_thinking(raz_engine_dev E, uint32_t g) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     raz_game& G = E.game[g];
     if (G.phase != RAZ_PHASE_SEARCH) return;
-    if (G.sims_left > 0) G.sims_left = 0;
+    int inflight = 0;   // simulations already started return first (requested_stop_thinking only stops new ones, :206-208)
+    if (E.par)
+        for (uint32_t j = 0; j < E.K; ++j) inflight += E.sim[((size_t)g * E.K + j) * 64 + GW(sim_state)] != RAZ_SIM_FREE;
+    if (G.sims_left > inflight) G.sims_left = inflight;
     G.loops_done = (uint32_t)E.cfg.thinking_loop;
 }
 // A new ReversiPlayer built on a used MCTSInfo starts with expanded = set(var_p.keys())

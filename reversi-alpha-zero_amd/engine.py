@@ -66,11 +66,14 @@ class DeviceNet:
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
                        record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
-                       use_graph=False):
-    """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names)."""
+                       use_graph=False, force_slot_kernel=False):
+    """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
+    play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
+    that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par)."""
     p = config.play
-    if getattr(p, "parallel_search_num", 1) != 1:
-        raise ValueError("the engine implements the reference's reproducible mode parallel_search_num=1")
+    par = int(getattr(p, "parallel_search_num", 1) or 1)
+    if not 1 <= par <= 16:
+        raise ValueError("parallel_search_num must be 1..16 (prediction_queue_size, config.py:141)")
     ust = int(getattr(p, "use_solver_turn", 0) or 0)
     usts = int(getattr(p, "use_solver_turn_in_simulation", 0) or 0)
     share = bool(p.share_mtcs_info_in_self_play)
@@ -88,16 +91,17 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
-        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (4 if use_graph else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
+        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (4 if use_graph else 0) | (8 if force_slot_kernel else 0)
+        | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
-        solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), reserved2=0)
+        solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par)
     return c
 
 
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 use_graph=False):
+                 use_graph=False, force_slot_kernel=False):
         import torch
         self.net = net
         self.device = net.device
@@ -110,14 +114,21 @@ class SelfPlayEngine:
             # every simulation adds at most one node (two with mirror keys); ~62 searched plies
             nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
-                                      record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph)
+                                      record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph,
+                                      force_slot_kernel=force_slot_kernel)
+        self.slots = int(self.cfg.parallel_search_num) or 1   # simulation slots (leaf-exchange rows) per game
+        # most nodes one step can add to a game's pool: k_tree completes <= inner_max (default 2) simulations,
+        # each adding a leaf and its mirror; k_tree_par starts <= slots + inner_max simulations, wakes <= slots
+        # sleepers (a leaf node each) and finishes <= slots expansions (a mirror node each)
+        self.nodes_per_step = 2 * (inner_max or 2) if (self.slots == 1 and not force_slot_kernel) \
+            else 3 * self.slots + (inner_max or 2)
         nbytes = lib.raz_engine_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("invalid engine config: " + N.last_error())
         self.workspace_bytes = nbytes
         self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         base = (self._ws.data_ptr() + 255) // 256 * 256
-        sp, sb = net.scratch(n_games)
+        sp, sb = net.scratch(n_games * self.slots)
         self._h = ctypes.c_void_p()
         check(lib.raz_engine_create(ctypes.byref(self.cfg), ctypes.byref(net.c), base, nbytes, sp, sb,
                                     ctypes.byref(self._h)), "raz_engine_create")
@@ -222,7 +233,7 @@ class SelfPlayEngine:
 
     def run(self, chunk=64, max_steps=10_000_000):
         """Step until every active game has finished.  Returns the final stats.  Pools are pruned
-        whenever the fullest one could overflow before the next poll (<= 4 new nodes per step)."""
+        whenever the fullest one could overflow before the next poll (<= nodes_per_step new nodes per step)."""
         steps = 0
         cap = int(self.cfg.nodes_per_game)
         self.gc_runs = 0
@@ -230,7 +241,7 @@ class SelfPlayEngine:
             self.step(chunk)
             steps += chunk
             st = self.stats()
-            if st["max_pool_used"] + 4 * chunk + 64 > cap:
+            if st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
                 self.gc(threshold=cap // 4)
                 self.gc_runs += 1
             if st["finished_games"] >= self.n_active:
