@@ -17,9 +17,10 @@ of steps that took; with --steps K exactly K steps are timed (from the opening p
 warm-up steps on a throw-away start).  metric = MCTS simulations/sec (start_search_my_move
 invocations / wall time, NN included, inputs resident in HBM), whole job over all GPUs.
 
-At N = 1 the same JSON line also carries "config2_8192x800_ch5": --config2-steps steps of BASELINE.json
+At N = 1 the same JSON line also carries "mini_yml_parallel_search_num_4" (the same workload at mini.yml's own
+parallel_search_num = 4, whole games) and "config2_8192x800_ch5": --config2-steps steps of BASELINE.json
 configs[2] (8192 games, 256x10 net, 800 sims/move - the shape the metric's "800 sims/move" names),
-whose dominant kernel is the MFMA convolution, with its own roofline object.
+whose dominant kernel is the MFMA convolution, with its own roofline object.  --config2-steps 0 skips both.
 """
 import argparse
 import json
@@ -46,7 +47,7 @@ def bench_config(args):
     play = types.SimpleNamespace(
         simulation_num_per_move=args.sims, share_mtcs_info_in_self_play=bool(args.share),
         thinking_loop=1, required_visit_to_decide_action=40, start_rethinking_turn=10, c_puct=5,
-        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3, parallel_search_num=1,
+        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3, parallel_search_num=args.par,
         resign_threshold=-0.9, allowed_resign_turn=10, disable_resignation_rate=0.1,
         use_solver_turn=0, use_solver_turn_in_simulation=0)
     return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
@@ -65,6 +66,47 @@ def ch5_config(sims):
     return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
 
 
+def mini_par_leg(dev, args, par):
+    """The configs[1] workload at config/mini.yml's own parallel_search_num (4): that many simulations in
+    flight per game on the deterministic raz-sched-v1 schedule (bit-exact vs the reference run on a
+    virtual-time event loop, tests/golden/mcts_par_games.json).  Whole games, same settings otherwise."""
+    import copy
+    import torch
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    a = copy.copy(args)
+    a.par = par
+    cfg = bench_config(a)
+    F, R, V = NETS[args.net]
+    net = DeviceNet(ReversiNet(F, R, V).keras_init_(0).to_blob(), dev)
+    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims)
+    eng.start(0, args.sims)
+    eng.step(20)
+    eng.stats()
+    eng.start(0, args.sims)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        eng.step(args.chunk)
+        steps += args.chunk
+        st = eng.stats()
+        if st["max_pool_used"] + eng.nodes_per_step * args.chunk + 64 > eng.cfg.nodes_per_game:
+            eng.gc(eng.cfg.nodes_per_game // 4)
+        if st["finished_games"] >= args.games or steps > 80 * args.sims * 4:
+            break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"{args.games} concurrent self-play games/GPU, {args.net} net, {args.sims} sims/move, mini.yml play settings, "
+                       f"thinking_loop=1, solver off, parallel_search_num={par} (mini.yml:19), whole games",
+           "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
+           "finished_games": st["finished_games"]}
+    del eng, net
+    torch.cuda.empty_cache()
+    return out
+
+
 def config2_leg(dev, steps, games=8192, sims=800):
     """BASELINE.json configs[2] (the shape the metric's "800 sims/move" is quoted on): 8192 concurrent
     games on one GPU, 256x10 net (ch5.yml has no model section => config.py:187-193), 800 sims/move.
@@ -79,25 +121,28 @@ def config2_leg(dev, steps, games=8192, sims=800):
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     cfg = ch5_config(sims)
     net = DeviceNet(blob, dev)
-    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, nodes_per_game=16 * sims)
+    # one slice: the net forward (~95 ms for 8192 positions) dwarfs the tree kernel, so there is nothing to
+    # overlap, and the per-launch duration of the convolution is then its stand-alone duration
+    parts = 1
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, nodes_per_game=16 * sims, parts=parts)
     eng.start(0, sims)
     eng.step(2)
     eng.stats()
     eng.start(0, sims)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tree_ms, net_ms = eng.step_timed(steps)   # HIP events around every launch, on the launching streams
+    tree_ms, net_ms = eng.step_timed(steps)   # HIP events around every launch, on the launching stream
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = eng.stats()
     macs = macs_per_position(F, R, V)
-    parts = 3
     leaves_per_launch = st["nn_leaves"] / (steps * parts)
     net_avg_ms = net_ms / (steps * parts)
     ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
     out = {"workload": f"{games} concurrent self-play games/GPU, 256x10 net (F{F} R{R} V{V}), {sims} sims/move, ch5.yml play "
                        f"settings, thinking_loop=1, solver off, first {steps} steps of the batch",
-           "value": st["total_sims"] / dt, "unit": "sims/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "value": st["total_sims"] / dt, "unit": "sims/s", "leaves_per_s": st["nn_leaves"] / dt,
+           "steps": steps, "ms_per_step": 1e3 * dt / steps,
            "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
            "roofline": {"bound": "mfma", "kernel": "k_conv3x3_wide+k_conv0_wide+k_heads_wide (one net forward per slice)",
                         "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch, "avg_kernel_ms": net_avg_ms,
@@ -116,7 +161,7 @@ def cpu_baseline(cfg, blob, sims, budget_games):
     the host cores (ctypes releases the GIL), same settings.  Reported, not optimised."""
     import concurrent.futures as cf
     import oracle as O
-    ocfg = O.play_cfg_from_config(cfg)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=cfg.play.parallel_search_num)
     cores = min(os.cpu_count() or 1, budget_games)
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(max_workers=cores) as ex:
@@ -147,7 +192,10 @@ def main():
     ap.add_argument("--inner-max", type=int, default=0, help="max simulations completed per game per tree launch (0 = default 2)")
     ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
     ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
-    ap.add_argument("--config2-steps", type=int, default=8,
+    ap.add_argument("--par", type=int, default=1,
+                    help="play.parallel_search_num: simulations in flight per game (1 = the reference's reproducible mode, the headline; "
+                         "mini.yml ships 4, the other configs 8: raz-sched-v1)")
+    ap.add_argument("--config2-steps", type=int, default=12,
                     help="also time this many steps of BASELINE configs[2] (8192 games, 256x10 net, 800 sims/move) on rank 0 at N=1; 0 = skip")
     args = ap.parse_args()
 
@@ -225,7 +273,7 @@ def main():
                 eng.gc(eng.cfg.nodes_per_game // 4)
             if st["finished_games"] >= args.games:
                 break
-            if steps > 80 * args.sims * 4:
+            if steps > 80 * args.sims * 4 + 4000:
                 raise SystemExit("engine did not finish")
     torch.cuda.synchronize()
     if world > 1:
@@ -292,7 +340,7 @@ def main():
         # tools/run_profiles.sh -> tools/pmc_summary.py); only for the default workload they were collected on
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc", "final2_traffic.json")
-        default_workload = (args.games, args.sims, args.net, args.share, lps) == (4096, 200, "mini", 1, 3)
+        default_workload = (args.games, args.sims, args.net, args.share, lps, args.par) == (4096, 200, "mini", 1, 3, 1)
         if default_workload and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
@@ -311,10 +359,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 tree statistics + f32 net",
             "data": "synthetic (random-init net of the named architecture, games from the initial position)",
             "config": {"workload": f"{args.games} concurrent self-play games/GPU, {args.net} net (F{F} R{R} V{V}), "
-                                   f"{args.sims} sims/move, mini.yml play settings, thinking_loop=1, solver off"
+                                   f"{args.sims} sims/move, mini.yml play settings, thinking_loop=1, solver off, parallel_search_num={args.par}"
                                    + ("" if args.steps == 0 else f", first {args.steps} steps only"),
                        "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
                        "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0,
+                       "parallel_search_num": args.par,
                        "kernel_launches_per_step": lps * 2,
                        "overlap": f"{lps} slices on {lps} HIP streams" if lps > 1 else "single stream",
                        "launch": "hipGraph replay (16 steps per graph)" if used_graph else "kernel by kernel"},
@@ -341,13 +390,15 @@ def main():
             pp = eng.phase_profile()
             launches = max(pp["active_launches"], 1)
             out["phase_profile_ticks_per_active_game_launch"] = {k: v / launches for k, v in pp.items()}
-        if world == 1 and args.config2_steps > 0 and (args.games, args.sims, args.net) == (4096, 200, "mini"):
-            del eng, net   # the two workspaces do not fit in HBM together
+        if world == 1 and args.config2_steps > 0 and (args.games, args.sims, args.net, args.par) == (4096, 200, "mini", 1):
+            del eng, net   # the workspaces do not fit in HBM together
             torch.cuda.empty_cache()
-            try:
-                out["config2_8192x800_ch5"] = config2_leg(dev, args.config2_steps)
-            except Exception as ex:   # never lose the main line over the extra leg
-                out["config2_8192x800_ch5"] = {"error": repr(ex)}
+            for key, leg in (("mini_yml_parallel_search_num_4", lambda: mini_par_leg(dev, args, 4)),
+                             ("config2_8192x800_ch5", lambda: config2_leg(dev, args.config2_steps))):
+                try:
+                    out[key] = leg()
+                except Exception as ex:   # never lose the main line over an extra leg
+                    out[key] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, blob, args.sims, args.cpu_games)
         print(json.dumps(out))

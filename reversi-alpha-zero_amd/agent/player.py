@@ -94,8 +94,8 @@ class ReversiPlayer:
         self.play_config = play_config or self.config.play
         self.enable_resign = enable_resign
         self.api = api
-        if getattr(self.play_config, "parallel_search_num", 1) != 1:
-            raise ValueError("ReversiPlayer: parallel_search_num must be 1 (the reference's reproducible mode)")
+        if not 1 <= int(getattr(self.play_config, "parallel_search_num", 1) or 1) <= 16:
+            raise ValueError("ReversiPlayer: parallel_search_num must be 1..16 (prediction_queue_size, config.py:141)")
         mtcs_info = mtcs_info or self.create_mtcs_info()
         self.mtcs_info = mtcs_info
         self.var_n, self.var_w, self.var_p = mtcs_info
@@ -164,7 +164,7 @@ class ReversiPlayer:
             st = eng.stats()   # raises on engine error flags (node pool / table / record overflow)
             if st["idle_or_done"] >= eng.n_games:
                 break
-            if st["max_pool_used"] + 4 * chunk + 64 > cap:
+            if st["max_pool_used"] + eng.nodes_per_step * chunk + 64 > cap:
                 eng.gc(threshold=cap // 4)
             if callback_in_mtcs and callback_in_mtcs.callback:
                 callback_in_mtcs.callback(list(self.var_q(key)), list(self.var_n[key]))

@@ -99,8 +99,8 @@ class PlayConfig(_Section):
 
 
 class EvaluateConfig(_Section):
-    """config.py:101-110.  parallel_search_num is pinned to 1: the engine implements the reference's
-    reproducible search mode (the reference's PlayConfig default is 8)."""
+    """config.py:101-110.  play_config.parallel_search_num stays at the PlayConfig default (8), as in the
+    reference; the engine plays it on the deterministic raz-sched-v1 schedule."""
 
     def __init__(self):
         self.game_num = 200
@@ -111,7 +111,6 @@ class EvaluateConfig(_Section):
         self.play_config.change_tau_turn = 0
         self.play_config.noise_eps = 0
         self.play_config.disable_resignation_rate = 0
-        self.play_config.parallel_search_num = 1
         self.evaluate_latest_first = True
 
 

@@ -102,3 +102,71 @@ def test_engine_parallel_search_with_node_pruning_equals_oracle(blob, variant, p
     for i in range(0, n, 2):
         plies, summ = O.selfplay_game(ocfg, blob, 61, 700 + i, sims)
         _compare_game(f"gc/{variant}/k{k}/{700 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+
+
+def test_reversi_player_facade_parallel_search_equals_oracle(blob):
+    """A whole game through the ReversiPlayer drop-in with mini.yml's play settings as shipped
+    (parallel_search_num 4, thinking_loop 2, solver from turn 50) == the oracle's game at the same setting:
+    actions, n, q, resign flags and the training rows black.moves + white.moves."""
+    import json
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from oracle_util import rows_of_game
+    from test_engine_gpu import _facade_game
+    par = load_par_golden()
+    g0 = next(g for g in par["games"] if g["variant"] == "mini_par4_as_shipped")
+    cfg = Config()
+    cfg.play.update(g0["resolved_play"])
+    cfg.play_data.update(g0["resolved_play_data"])
+    assert cfg.play.parallel_search_num == 4
+    meta = par["net"]
+    net = ReversiNet(meta["filters"], meta["res_layers"], meta["value_fc"]).keras_init_(meta["keras_init_seed"])
+    net.randomize_bn_(meta["randomize_bn_seed"])
+    seed, gid, sims = 6, 41, 18
+    env, black, white, evals = _facade_game(cfg, net, seed, gid, sims)
+    plies, summ = O.selfplay_game(O.play_cfg_from_config(cfg, parallel_search_num=4), blob, seed, gid, sims)
+    assert len(evals) == len(plies)
+    for (pl, ae), p in zip(evals, plies):
+        assert pl == p["player"]
+        assert (ae.action if ae.action is not None else -1) == p["action"]
+        if ae.action is not None:
+            assert float(ae.n) == p["n"] and float(ae.q) == p["q"]
+    assert {"black": 1, "white": 2, "draw": 3}[env.winner.name] == summ["winner"]
+    assert (black.resigned, white.resigned) == (bool(summ["resigned_black"]), bool(summ["resigned_white"]))
+    assert json.dumps(black.moves + white.moves) == json.dumps(rows_of_game(plies, summ["winner"]))
+
+
+def test_reversi_player_stop_thinking_with_simulations_in_flight(blob):
+    """stop_thinking() at parallel_search_num 8: simulations already started return (their virtual losses
+    are taken back), no new one starts, and the move is decided from the tree as it is."""
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.agent.player import ReversiPlayer, CallbackInMCTS
+    from reversi_alpha_zero_amd.lib.bitboard import find_correct_moves
+    from reversi_alpha_zero_amd.env.reversi_env import ReversiEnv, Player
+    par = load_par_golden()
+    g0 = next(g for g in par["games"] if g["variant"] == "agz_par8_unshared")
+    cfg = Config()
+    cfg.play.update(g0["resolved_play"])
+    cfg.play_data.update(g0["resolved_play_data"])
+    cfg.play.simulation_num_per_move = 400
+    meta = par["net"]
+    net = ReversiNet(meta["filters"], meta["res_layers"], meta["value_fc"]).keras_init_(meta["keras_init_seed"])
+    p = ReversiPlayer(cfg, net, enable_resign=False)
+    calls = []
+
+    def cb(q, n):
+        calls.append(sum(n))
+        if len(calls) == 3:
+            p.stop_thinking()
+
+    env = ReversiEnv().reset()
+    env.step(19)
+    own, enemy = env.board.white, env.board.black
+    ae = p.action_with_evaluation(own, enemy, callback_in_mtcs=CallbackInMCTS(5, cb))
+    assert ae.action is not None and (find_correct_moves(own, enemy) >> ae.action) & 1
+    key = ReversiPlayer.counter_key(ReversiEnv().update(own, enemy, Player.black))
+    n, w = p.var_n[key], p.var_w[key]
+    assert len(calls) >= 3 and 0 < sum(n) < 400
+    assert float(sum(n)) == float(int(sum(n))) and abs(float(ae.q)) <= 1.0   # no virtual loss left behind
+    assert all(abs(wi) <= ni + 1e-9 for wi, ni in zip(w, n))
