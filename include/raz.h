@@ -117,8 +117,9 @@ int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* ene
  * driving two ReversiPlayer objects (agent/player.py:28-428) through ReversiEnv, with the leaf
  * evaluations of ALL live games gathered into one raz_net_forward batch per simulation step
  * (the reference batches at most prediction_queue_size=16 leaves per worker, player.py:329-355,
- * plus Pipe fan-in, api.py:75-100).  One simulation is in flight per game, i.e. the reference's
- * reproducible mode parallel_search_num=1 (SURVEY.md §7 hard part 1).
+ * plus Pipe fan-in, api.py:75-100).  parallel_search_num simulations are in flight per game: 1 is the
+ * reference's reproducible mode (SURVEY.md §7 hard part 1); 2..16 follow the reference's asyncio event
+ * loop in exact virtual time (raz-sched-v1), each in-flight leaf being one row of the batch.
  *
  * Field names follow PlayConfig (config.py:128-166).  Randomness: raz-rng-v1 keyed by
  * (seed, global game id), so results do not depend on n_games, slot order or GPU count. */
@@ -127,7 +128,7 @@ typedef struct {
     int32_t required_visit_to_decide_action;  /* :134 */
     int32_t start_rethinking_turn;            /* :135 */
     int32_t change_tau_turn;                  /* :139 */
-    int32_t virtual_loss;                     /* :140 (parallel_search_num=1: only its rounding is observable) */
+    int32_t virtual_loss;                     /* :140 (with parallel_search_num=1 only its rounding is observable) */
     int32_t allowed_resign_turn;              /* :146 */
     int32_t has_resign_threshold;             /* resign_threshold is not None */
     int32_t share_mtcs_info;                  /* share_mtcs_info_in_self_play :131 */
