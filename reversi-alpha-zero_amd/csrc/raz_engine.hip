@@ -1220,70 +1220,13 @@ __device__ __forceinline__ int pick_min_seq(uint32_t sq, unsigned long long mask
     return best;
 }
 
-// What became of slot j's simulation after a descent: it ended on a finished game / a solved position
-// (returns up its path at once, the slot is free), queued a leaf, or fell asleep on now_expanding.
-__device__ void par_after(const raz_engine_dev& E, Regs& R, Slots& T, uint32_t g, int lane, int j, bool was_sleeper,
-                          uint32_t& nnmask, float* lds64) {
-    const uint32_t kind = G32(R, GW(leaf_kind));
-    if (kind == RAZ_LEAF_TERMINAL || kind == RAZ_LEAF_SOLVED) {
-        backup_leaf<true>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
-        T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
-        return;
-    }
-    if (kind == RAZ_LEAF_EXPAND) {
-        const uint32_t seq = G32(R, GW(par_seq_next));
-        S32(R, GW(par_seq_next), seq + 1);
-        T.st = writelane_r(T.st, RAZ_SIM_WAIT_NET, j, lane);
-        T.sq = writelane_r(T.sq, seq, j, lane);
-        nnmask |= 1u << j;
-    } else if (kind == RAZ_LEAF_PARKED) {
-        if (!was_sleeper) {  // a sleeper that goes back to sleep keeps its place among the sleepers
-            const uint32_t seq = G32(R, GW(par_seq_next));
-            S32(R, GW(par_seq_next), seq + 1);
-            T.sq = writelane_r(T.sq, seq, j, lane);
-        }
-        T.st = writelane_r(T.st, RAZ_SIM_WAIT_EXPAND, j, lane);
-        T.pk = writelane_r(T.pk, G32(R, GW(sim_parked)), j, lane);
-    } else {
-        return;  // an error was flagged
-    }
-    slot_store(E, R, g, (uint32_t)j, lane);
-    S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
-}
-
-// C / C': the per-move controller, then new simulations into the free slots.  Returns false when the
-// launch's budget ran out before the fill was complete.
+// The kernel is ONE loop with a single call site each for the controller, the descent and the return
+// path (the three large inlined bodies): duplicating them per phase doubled the code to 66 KB, more
+// than the instruction cache two CUs share.  Each iteration picks the next operation of the round -
+// resume the oldest queued leaf (B), start a simulation in a free slot (C, C'), wake the next sleeper
+// (D) - then runs at most one slot load, one descent, one return.
 template <bool SOLVER>
-__device__ bool par_fill(const raz_engine_dev& E, Regs& R, Slots& T, uint32_t g, int lane, uint32_t K,
-                         unsigned long long kmask, int& budget, uint32_t& nnmask, SolverLDS* S, float* lds64) {
-    for (;;) {
-        for (int guard = 0; guard < 8; ++guard) {
-            const uint32_t phase = G32(R, GW(phase));
-            if (phase == RAZ_PHASE_NEW_MOVE) {
-                begin_move<SOLVER>(E, R, g, lane, S);
-                continue;
-            }
-            if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {  // every simulation has returned
-                decide_move(E, R, g, lane);
-                continue;
-            }
-            break;
-        }
-        if (G32(R, GW(phase)) != RAZ_PHASE_SEARCH || G32(R, GW(error))) return true;
-        const unsigned long long busy = __ballot(T.st != RAZ_SIM_FREE) & kmask;
-        const int inflight = __popcll(busy);
-        const int to_start = (int32_t)G32(R, GW(sims_left)) - inflight;
-        if (inflight >= (int)K || to_start <= 0) return true;
-        if (budget <= 0) return false;
-        --budget;
-        const int j = __ffsll((long long)(~busy & kmask)) - 1;
-        select_leaf<SOLVER, true>(E, R, g, lane, S, g * K + (uint32_t)j, G32(R, GW(root_node)), 0, false);
-        par_after(E, R, T, g, lane, j, false, nnmask, lds64);
-    }
-}
-
-template <bool SOLVER>
-__global__ __launch_bounds__(64) void k_tree_par(raz_engine_dev E, uint32_t g0, uint32_t count) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree_par(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
     __shared__ float lds64[64];
     __shared__ SolverLDS slds_store;
@@ -1319,47 +1262,100 @@ __global__ __launch_bounds__(64) void k_tree_par(raz_engine_dev E, uint32_t g0, 
     }
     if (RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
     int budget = (int)K + (((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax);
+    constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D never outlives a launch
     uint32_t stage = G32(R, GW(par_stage));
-    if (stage == 0u) {  // B
-        const unsigned long long t0 = prof_now();
-        for (;;) {
-            const unsigned long long m = __ballot(T.st == RAZ_SIM_WAIT_NET) & kmask;
-            if (!m || G32(R, GW(error))) break;
-            const int j = pick_min_seq(T.sq, m);
-            slot_load(E, R, g, (uint32_t)j, lane, true);
-            backup_leaf<true>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
-            T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
-        }
-        prof_add(E, g, 0, t0, lane);
-        stage = 1u;
-    }
+    unsigned long long dmask = 0ULL;  // sleepers still to poll in D
     for (;;) {
-        const unsigned long long t0 = prof_now();
-        const bool complete = par_fill<SOLVER>(E, R, T, g, lane, K, kmask, budget, nnmask, slds_p, lds64);
-        prof_add(E, g, 2, t0, lane);
-        if (!complete || G32(R, GW(error))) break;
-        if (stage == 2u) {
-            stage = 0u;  // the round is complete: the next launch starts with B
-            break;
+        if (G32(R, GW(error))) break;
+        // ---- the next operation of the round
+        int j = -1;
+        bool resume = false, wake = false;
+        if (stage == kStageB) {
+            const unsigned long long m = __ballot(T.st == RAZ_SIM_WAIT_NET) & kmask;
+            if (!m) {
+                stage = kStageC;
+                continue;
+            }
+            j = pick_min_seq(T.sq, m);
+            resume = true;
+        } else if (stage == kStageD) {
+            if (!dmask) {
+                stage = kStageC2;
+                continue;
+            }
+            j = pick_min_seq(T.sq, dmask);
+            dmask &= ~(1ULL << j);
+            wake = true;
+        } else {  // C / C': the per-move controller, then a new simulation into a free slot
+            for (int guard = 0; guard < 8; ++guard) {
+                const uint32_t phase = G32(R, GW(phase));
+                if (phase == RAZ_PHASE_NEW_MOVE) {
+                    begin_move<SOLVER>(E, R, g, lane, slds_p);
+                    continue;
+                }
+                if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {  // every simulation has returned
+                    decide_move(E, R, g, lane);
+                    continue;
+                }
+                break;
+            }
+            const unsigned long long busy = __ballot(T.st != RAZ_SIM_FREE) & kmask;
+            const int inflight = __popcll(busy);
+            const int to_start = (int32_t)G32(R, GW(sims_left)) - inflight;
+            if (G32(R, GW(phase)) != RAZ_PHASE_SEARCH || G32(R, GW(error)) || inflight >= (int)K || to_start <= 0) {
+                if (stage == kStageC2) {
+                    stage = kStageB;  // the round is complete: the next launch starts with B
+                    break;
+                }
+                // D: sleepers whose key is still in now_expanding sleep on (their nodes' tags are read in one go)
+                const uint32_t pl = G32(R, GW(player)) - 1;
+                const bool sl = lane < (int)K && T.st == RAZ_SIM_WAIT_EXPAND;
+                uint32_t tg = 0u;
+                if (sl) tg = node_hdr(node_ptr(E, g, T.pk))->tag;
+                dmask = __ballot(sl && !((tg >> (6 + pl)) & 1u)) & kmask;
+                stage = kStageD;
+                continue;
+            }
+            if (budget <= 0) break;  // the fill goes on at the next launch, without a B in between
+            --budget;
+            j = __ffsll((long long)(~busy & kmask)) - 1;
         }
-        {  // D: sleepers whose key is still in now_expanding sleep on (their nodes' tags are read in one go)
-            const uint32_t pl = G32(R, GW(player)) - 1;
-            const bool sl = lane < (int)K && T.st == RAZ_SIM_WAIT_EXPAND;
-            uint32_t tg = 0u;
-            if (sl) tg = node_hdr(node_ptr(E, g, T.pk))->tag;
-            unsigned long long m = __ballot(sl && !((tg >> (6 + pl)) & 1u)) & kmask;
-            while (m && !G32(R, GW(error))) {
-                const int j = pick_min_seq(T.sq, m);
-                m &= ~(1ULL << j);
-                slot_load(E, R, g, (uint32_t)j, lane, false);
-                select_leaf<SOLVER, true>(E, R, g, lane, slds_p, g * K + (uint32_t)j, lane_u32(T.pk, j),
-                                          (int)G32(R, GW(depth)), true);
-                par_after(E, R, T, g, lane, j, true, nnmask, lds64);
+        // ---- at most one slot load, one descent, one return
+        bool back = resume;
+        if (resume || wake) slot_load(E, R, g, (uint32_t)j, lane, resume);
+        if (!resume) {
+            const unsigned long long t0 = prof_now();
+            select_leaf<SOLVER, true>(E, R, g, lane, slds_p, g * K + (uint32_t)j,
+                                      wake ? lane_u32(T.pk, j) : G32(R, GW(root_node)), wake ? (int)G32(R, GW(depth)) : 0, wake);
+            prof_add(E, g, 2, t0, lane);
+            const uint32_t kind = G32(R, GW(leaf_kind));
+            if (kind == RAZ_LEAF_TERMINAL || kind == RAZ_LEAF_SOLVED) {
+                back = true;  // ended on a finished game / a solved position: returns up its path at once
+            } else if (kind == RAZ_LEAF_EXPAND || kind == RAZ_LEAF_PARKED) {
+                if (kind == RAZ_LEAF_EXPAND || !wake) {  // a sleeper that goes back to sleep keeps its place
+                    const uint32_t seq = G32(R, GW(par_seq_next));
+                    S32(R, GW(par_seq_next), seq + 1);
+                    T.sq = writelane_r(T.sq, seq, j, lane);
+                }
+                if (kind == RAZ_LEAF_EXPAND) {
+                    T.st = writelane_r(T.st, RAZ_SIM_WAIT_NET, j, lane);
+                    nnmask |= 1u << j;
+                } else {
+                    T.st = writelane_r(T.st, RAZ_SIM_WAIT_EXPAND, j, lane);
+                    T.pk = writelane_r(T.pk, G32(R, GW(sim_parked)), j, lane);
+                }
+                slot_store(E, R, g, (uint32_t)j, lane);
+                S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
             }
         }
-        stage = 2u;
+        if (back) {
+            const unsigned long long t0 = prof_now();
+            backup_leaf<true>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+            T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
+            prof_add(E, g, 0, t0, lane);
+        }
     }
-    S32(R, GW(par_stage), stage);
+    S32(R, GW(par_stage), stage == kStageD ? kStageC2 : stage);
     gw[lane] = R.cw;
     if (lane < (int)K) {
         myblk[GW(sim_state)] = T.st;
