@@ -176,6 +176,9 @@ def load_ext():
         lib.orc_solver_solve.argtypes = [c_void_p, c_uint64, c_uint64, c_int, c_int, POINTER(c_int), POINTER(c_int)]
         lib.orc_selfplay_game.argtypes = [POINTER(OrcPlayCfg), c_char_p, c_size_t, c_uint32, c_uint32, c_int,
                                           POINTER(OrcPlyRecord), c_int, POINTER(OrcGameSummary)]
+        lib.orc_tree_new.restype = c_void_p
+        lib.orc_tree_free.argtypes = [c_void_p]
+        lib.orc_selfplay_game_on.argtypes = [c_void_p] + lib.orc_selfplay_game.argtypes
         _ext_done = True
     return lib
 
@@ -201,13 +204,27 @@ def net_forward_planes(blob, planes):
     return pol, val
 
 
-def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128):
+class Tree:
+    """The MCTSInfo one worker carries across `reset_mtcs_info_per_game` games (worker/self_play.py:109-111,
+    132-134): pass the same Tree to consecutive selfplay_game calls."""
+
+    def __init__(self):
+        self._lib = load_ext()
+        self.h = self._lib.orc_tree_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.orc_tree_free(self.h)
+            self.h = None
+
+
+def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128, tree=None):
     """Run one oracle self-play game.  Returns (list of ply dicts, summary dict)."""
     lib = load_ext()
     plies = (OrcPlyRecord * max_plies)()
     summ = OrcGameSummary()
-    n = lib.orc_selfplay_game(ctypes.byref(cfg), blob, len(blob), seed, game_id, sims_per_move, plies,
-                              max_plies, ctypes.byref(summ))
+    n = lib.orc_selfplay_game_on(tree.h if tree is not None else None, ctypes.byref(cfg), blob, len(blob), seed, game_id,
+                                 sims_per_move, plies, max_plies, ctypes.byref(summ))
     if n < 0:
         raise RuntimeError("orc_selfplay_game failed (unsupported config or too many plies)")
     out = []

@@ -26,6 +26,7 @@ typedef struct {
     float P[64];
     uint8_t expanded[2]; /* per ReversiPlayer `expanded` set (:47, 325) */
     uint8_t expanding[2]; /* per ReversiPlayer `now_expanding` set (:48, 294, 326) */
+    uint8_t has_p;        /* key in var_p (what a new ReversiPlayer on a used MCTSInfo takes as `expanded`, :47) */
 } onode;
 
 typedef struct {
@@ -230,10 +231,12 @@ static void expand_finish(ogame* g, int pl, osim* s) {
     const orc_env* env = &s->env;
     onode* n = table_get(t, env->black, env->white, env->next_player);
     memcpy(n->P, s->pol, sizeof s->pol);
+    n->has_p = 1;
     n->expanded[pl] = 1;
     n->expanding[pl] = 0;
     onode* m = table_get(t, env->white, env->black, 3 - env->next_player); /* mirror key (:324) */
     memcpy(m->P, s->pol, sizeof s->pol);
+    m->has_p = 1;
     g->n_expand++;
     double leaf_v = (double)s->val; /* float(leaf_v) */
     backup_path(g, pl, s, env->next_player == 1 ? leaf_v : -leaf_v);
@@ -266,11 +269,13 @@ static int descend(ogame* g, int pl, osim* s, int polling) {
                 k->W[action] += leaf_v;
                 for (int i = 0; i < 64; ++i) k->P[i] = 0.0f;
                 k->P[action] = 1.0f;
+                k->has_p = 1;
                 onode* m2 = table_get(t, kw, kb, 3 - knp);
                 m2->N[action] += 1;
                 m2->W[action] -= leaf_v;
                 for (int i = 0; i < 64; ++i) m2->P[i] = 0.0f;
                 m2->P[action] = 1.0f;
+                m2->has_p = 1;
                 g->n_solved_leaves++;
                 backup_path(g, pl, s, leaf_v);
                 return SIM_FREE;
@@ -415,6 +420,7 @@ static int action_with_evaluation(ogame* g, int pl, u64 own, u64 enemy, int sims
             n->W[a] = sg * 999;
             for (int i = 0; i < 64; ++i) n->P[i] = 0.0f;
             n->P[a] = 1.0f;
+            n->has_p = 1;
             for (int i = 0; i < 64; ++i) { rec->root_n[i] = n->N[i]; rec->root_w[i] = n->W[i]; }
             rec->action = a;
             rec->solved = 1;
@@ -437,6 +443,7 @@ static int action_with_evaluation(ogame* g, int pl, u64 own, u64 enemy, int sims
             n->N[first] = 1;
             n->W[first] = 0;
             for (int i = 0; i < 64; ++i) n->P[i] = (float)((double)((legal >> i) & 1) / (double)cnt);
+            n->has_p = 1;
         }
         onode* n = table_get(t, root.black, root.white, 1);
         /* calc_policy (:366-385) */
@@ -495,18 +502,48 @@ static int action_with_evaluation(ogame* g, int pl, u64 own, u64 enemy, int sims
     return action;
 }
 
+/* MCTSInfo carried from game to game by one worker (worker/self_play.py:109-111: created when None
+ * and share_mtcs_info_in_self_play; :132-134: dropped every reset_mtcs_info_per_game games). */
+struct orc_tree {
+    otable table;
+};
+orc_tree* orc_tree_new(void) {
+    orc_tree* t = (orc_tree*)calloc(1, sizeof *t);
+    table_init(&t->table);
+    return t;
+}
+void orc_tree_free(orc_tree* t) {
+    if (!t) return;
+    table_free(&t->table);
+    free(t);
+}
+
 /* SelfPlayWorker.start_game (worker/self_play.py:139-175) for one game; plies[] needs room for
- * max_plies records.  Returns the number of plies recorded, or -1 on error. */
-int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,
-                      uint32_t game_id, int sims_per_move, orc_ply_record* plies, int max_plies,
-                      orc_game_summary* sum) {
+ * max_plies records.  Returns the number of plies recorded, or -1 on error.
+ * tree (nullable): the worker's MCTSInfo; used - and left holding this game's statistics too - when
+ * share_mtcs_info.  The game's two new ReversiPlayers start with expanded = set(var_p.keys())
+ * (agent/player.py:47) and an empty now_expanding. */
+int orc_selfplay_game_on(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,
+                         uint32_t game_id, int sims_per_move, orc_ply_record* plies, int max_plies,
+                         orc_game_summary* sum) {
     ogame g;
     memset(&g, 0, sizeof g);
     g.cfg = cfg; g.blob = blob; g.blob_bytes = blob_bytes; g.seed = seed; g.game_id = game_id;
     if (cfg->parallel_search_num < 1 || cfg->parallel_search_num > ORC_MAX_PAR) return -1;
+    const int carried = tree && cfg->share_mtcs_info;
     g.solver[0] = orc_solver_new();
     g.solver[1] = orc_solver_new();
-    table_init(&g.tables[0]);
+    if (carried) {
+        g.tables[0] = tree->table;
+        for (size_t i = 0; i < g.tables[0].cap; ++i) {
+            onode* n = &g.tables[0].nodes[i];
+            if (!n->used) continue;
+            n->expanded[0] = n->expanded[1] = n->has_p;
+            n->expanding[0] = n->expanding[1] = 0;
+        }
+    } else {
+        table_init(&g.tables[0]);
+    }
     if (!cfg->share_mtcs_info) table_init(&g.tables[1]);
     double d[2];
     orc_rng_pair(seed, game_id, 3, 0, 0, 0, d);
@@ -539,7 +576,14 @@ int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_byt
     }
     orc_solver_free(g.solver[0]);
     orc_solver_free(g.solver[1]);
-    table_free(&g.tables[0]);
+    if (carried) tree->table = g.tables[0]; /* (the table may have been re-allocated while growing) */
+    else table_free(&g.tables[0]);
     if (!cfg->share_mtcs_info) table_free(&g.tables[1]);
     return np;
+}
+
+int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,
+                      uint32_t game_id, int sims_per_move, orc_ply_record* plies, int max_plies,
+                      orc_game_summary* sum) {
+    return orc_selfplay_game_on(NULL, cfg, blob, blob_bytes, seed, game_id, sims_per_move, plies, max_plies, sum);
 }

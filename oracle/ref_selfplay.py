@@ -108,9 +108,11 @@ def injected(stream):
          rp.ReversiPlayer.__init__) = saved
 
 
-def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False):
+def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False, carry=None):
     """One game through the reference's SelfPlayWorker.start_game.  Returns a dict with per-ply
-    captures (root N/W, action, n, q, emitted rows) and the play_*.json content the reference wrote."""
+    captures (root N/W, action, n, q, emitted rows) and the play_*.json content the reference wrote.
+    carry (dict, optional): holds the worker's MCTSInfo from call to call, the way SelfPlayWorker.start
+    keeps `mtcs_info` for reset_mtcs_info_per_game games (worker/self_play.py:109-111,132-134)."""
     rh.install()
     import reversi_zero.agent.player as rp
     from reversi_zero.env.reversi_env import ReversiEnv, Player
@@ -155,7 +157,11 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
         rp.ReversiPlayer.action_with_evaluation = capture
         try:
             worker = SelfPlayWorker(config, env=ReversiEnv(), api=api, shared_var=None, worker_index=0)
-            mtcs_info = rp.ReversiPlayer.create_mtcs_info() if config.play.share_mtcs_info_in_self_play else None
+            mtcs_info = carry.get("mtcs_info") if carry is not None else None
+            if mtcs_info is None and config.play.share_mtcs_info_in_self_play:   # self_play.py:109-111
+                mtcs_info = rp.ReversiPlayer.create_mtcs_info()
+            if carry is not None:
+                carry["mtcs_info"] = mtcs_info
             env = worker.start_game(1, 0, mtcs_info)
         finally:
             rp.ReversiPlayer.action_with_evaluation = orig_awe

@@ -64,6 +64,16 @@ PAR_VARIANTS = [
 ]
 
 
+# reset_mtcs_info_per_game > 1 (mini.yml ships 3): the worker's MCTSInfo is carried from game to game
+# (worker/self_play.py:109-111,132-134); the game ids of a variant are played in order on ONE tree
+# -> mcts_series_games.json.  mini.yml exactly as shipped (parallel_search_num 4, thinking_loop 2,
+# solver from turn 50, reset every 3 games) and the same at parallel_search_num 1.
+SERIES_VARIANTS = [
+    ("mini_yml_as_shipped_3_games", "mini.yml", {}, {}, 16, 41, [0, 1, 2]),
+    ("mini_yml_par1_3_games", "mini.yml", {"parallel_search_num": 1}, {}, 14, 42, [7, 8, 9]),
+]
+
+
 def sparse(v):
     return {str(i): x for i, x in enumerate(v) if x != 0}
 
@@ -71,9 +81,10 @@ def sparse(v):
 def main():
     generate(VARIANTS, "mcts_games.json", virtual_time=False)
     generate(PAR_VARIANTS, "mcts_par_games.json", virtual_time=True)
+    generate(SERIES_VARIANTS, "mcts_series_games.json", virtual_time=True, series=True)
 
 
-def generate(variants, fname, virtual_time):
+def generate(variants, fname, virtual_time, series=False):
     net = ReversiNet(16, 1, 16).keras_init_(0).randomize_bn_(3)
     blob = net.to_blob()
     out = {"_generator": "tests/golden/make_golden_mcts.py",
@@ -82,10 +93,12 @@ def generate(variants, fname, virtual_time):
                    "blob_sha256": hashlib.sha256(blob).hexdigest()},
            "games": []}
     for name, yml, play_over, pd_over, sims, seed, gids in variants:
-        for gid in gids:
-            over = {"play": dict(NO_SOLVER, **play_over), "play_data": pd_over}   # variant keys win over NO_SOLVER
+        carry = {} if series else None   # one MCTSInfo for the variant's games, like one worker's `mtcs_info`
+        for gi, gid in enumerate(gids):
+            over = {"play": play_over if series else dict(NO_SOLVER, **play_over), "play_data": pd_over}   # variant keys win over NO_SOLVER
             cfg = rh.load_config(yml, over)
-            ref = rs.run_reference_game(cfg, blob, seed, gid, sims, virtual_time=virtual_time)
+            ref = rs.run_reference_game(cfg, blob, seed, gid, sims, virtual_time=virtual_time, carry=carry)
+            ref["series_index"] = gi if series else None
             rows = ref.pop("play_rows")
             plies = []
             for p in ref.pop("plies"):
@@ -97,7 +110,7 @@ def generate(variants, fname, virtual_time):
             keys = ["thinking_loop", "required_visit_to_decide_action", "start_rethinking_turn", "c_puct",
                     "noise_eps", "dirichlet_alpha", "change_tau_turn", "virtual_loss", "parallel_search_num",
                     "resign_threshold", "allowed_resign_turn", "disable_resignation_rate", "use_solver_turn",
-                    "use_solver_turn_in_simulation", "share_mtcs_info_in_self_play"]
+                    "use_solver_turn_in_simulation", "share_mtcs_info_in_self_play", "reset_mtcs_info_per_game"]
             ref["resolved_play"] = {k: getattr(cfg.play, k) for k in keys}
             ref["resolved_play_data"] = {"save_policy_of_tau_1": cfg.play_data.save_policy_of_tau_1,
                                          "drop_draw_game_rate": cfg.play_data.drop_draw_game_rate}

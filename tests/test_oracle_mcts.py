@@ -94,10 +94,26 @@ def test_parallel_search_games_bit_exact_vs_reference_on_virtual_time_loop(blob)
     check_play_rows(par, blob)
 
 
-def check_games_bit_exact(golden, blob):
+def test_tree_carried_across_games_bit_exact_vs_reference(blob):
+    """reset_mtcs_info_per_game = 3 (config/mini.yml as shipped, incl. parallel_search_num 4, solver, re-thinking):
+    three consecutive games of one worker on ONE MCTSInfo (worker/self_play.py:109-111,132-134; each game's new
+    players start with expanded = set(var_p.keys()), agent/player.py:47) == the reference's three games."""
+    ser = load_mcts_golden("mcts_series_games.json")
+    assert {g["resolved_play"]["reset_mtcs_info_per_game"] for g in ser["games"]} == {3}
+    assert {g["resolved_play"]["parallel_search_num"] for g in ser["games"]} == {1, 4}
+    check_games_bit_exact(ser, blob, series=True)
+
+
+def check_games_bit_exact(golden, blob, series=False):
+    trees = {}
     for g in golden["games"]:
         cfg = orc_cfg_of(g)
-        plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"])
+        tree = None
+        if series:   # the games of a variant were played in order by one worker: one MCTSInfo
+            assert g["series_index"] == (0 if g["variant"] not in trees else trees[g["variant"]][1] + 1)
+            tree = trees[g["variant"]][0] if g["variant"] in trees else O.Tree()
+            trees[g["variant"]] = (tree, g["series_index"])
+        plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"], tree=tree)
         tag = f'{g["variant"]}/{g["game_id"]}'
         assert [p["action"] for p in plies] == [p["action"] for p in g["plies"]], tag
         assert summ["winner"] == g["winner"] and summ["turn"] == g["turn"], tag
