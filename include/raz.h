@@ -184,6 +184,14 @@ void raz_engine_destroy(raz_engine* e);
  * per game from the schedule, worker/self_play.py:145,262-272).  Slots i >= n_active stay idle. */
 int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
                      uint32_t n_active, raz_stream_t stream);
+/* The next game of every slot ON THE SLOT'S TREE: SelfPlayWorker.start keeps its MCTSInfo for
+ * reset_mtcs_info_per_game games (worker/self_play.py:109-111,132-134; mini.yml ships 3).  Boards, records,
+ * random-stream counters and statistics start afresh for global game ids first_game_id + i; nodes, tables and
+ * pools stay, and every key that holds a prior counts as expanded for the new game's players
+ * (agent/player.py:47).  All games of the previous round must have finished and their records been read.
+ * Without share_mtcs_info the reference carries nothing over and this is raz_engine_start. */
+int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
+                         uint32_t n_active, raz_stream_t stream);
 /* Enqueue n_steps simulation steps (each: tree kernel = backup + move logic + select, then one
  * net batch over the gathered leaves).  Asynchronous w.r.t. the host; all work is ordered after
  * prior work on `stream` and before later work on it.  With n_games >= 256 the batch is stepped as

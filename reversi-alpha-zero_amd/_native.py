@@ -83,6 +83,7 @@ SIGNATURES.update({
                                   c_size_t, POINTER(c_void_p)]),
     "raz_engine_destroy": (None, [c_void_p]),
     "raz_engine_start": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
+    "raz_engine_next_game": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
     "raz_engine_step": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_step_timed": (c_int, [c_void_p, c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
     "raz_engine_set_position": (c_int, [c_void_p, c_uint32, c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, c_void_p]),

@@ -1419,6 +1419,51 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     if (!E.par) E.nn_active[g] = 0;   // (slot kernel: cleared by raz_engine_start, one flag per slot)
 }
 
+// The next game of every slot ON THE SLOT'S TREE: what SelfPlayWorker.start does when it keeps `mtcs_info`
+// for reset_mtcs_info_per_game games (worker/self_play.py:109-111,132-134).  Board, records, random-stream
+// counters and statistics start afresh (global game id first_game_id + g); nodes, table and pool stay.
+__global__ void k_next_game(raz_engine_dev E, uint32_t first_game_id, const uint32_t* sims_per_move, uint32_t n_active) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    const bool act = g < n_active;
+    raz_game G;
+    memset(&G, 0, sizeof G);
+    G.root_black = RAZ_INIT_BLACK;
+    G.root_white = RAZ_INIT_WHITE;
+    G.player = RAZ_PLAYER_BLACK;
+    G.phase = act ? RAZ_PHASE_NEW_MOVE : RAZ_PHASE_IDLE;
+    G.game_id = first_game_id + g;
+    double d0, d1;
+    raz_rng_pair(E.cfg.seed, first_game_id + g, RAZ_RNG_GAME, 0, 0, 0, d0, d1);
+    G.enable_resign = E.cfg.disable_resignation_rate <= d0 ? 1 : 0;  // worker/self_play.py:144
+    G.sims_per_move = sims_per_move[g];
+    G.leaf_kind = RAZ_LEAF_NONE;
+    G.root_node = RAZ_NO_NODE;
+    G.leaf_node = RAZ_NO_NODE;
+    G.leaf_mirror = RAZ_NO_NODE;
+    G.pool_used = E.game[g].pool_used;
+    G.error = E.game[g].error;
+    E.game[g] = G;
+    if (!E.par) E.nn_active[g] = 0;
+}
+// The game's two new ReversiPlayers take expanded = set(var_p.keys()) (agent/player.py:47) and an empty
+// now_expanding: every node that holds a prior counts as expanded for both.  grid (B, y).
+__global__ __launch_bounds__(64) void k_adopt_all(raz_engine_dev E) {
+    const uint32_t g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t used = E.game[g].pool_used;
+    for (uint32_t i = blockIdx.y; i < used; i += gridDim.y) {
+        unsigned char* p = node_ptr(E, g, i);
+        const bool has_p = __ballot(node_P(p)[lane] != 0.0f) != 0ULL;
+        raz_node_hdr* h = node_hdr(p);
+        if (lane == 0) {
+            uint32_t t = h->tag & ~0xC0u;
+            if (has_p || ((t >> 4) & 3u)) t |= 0x30u;
+            h->tag = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ node pruning
 // The disc count only grows, so once the real game has D discs every node whose position has fewer
 // is unreachable (SURVEY.md §7 hard part 5).  k_gc compacts the pool of every game whose usage is at
@@ -1811,6 +1856,32 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     int rc = raz_check_launch("raz_engine_start");
     if (rc == RAZ_OK) e->started = true;
     return rc;
+}
+
+// SelfPlayWorker.start keeps its MCTSInfo for reset_mtcs_info_per_game games (worker/self_play.py:109-111,
+// 132-134): start the NEXT game of every slot on the slot's tree (share_mtcs_info only - without it the
+// reference gives every game's players fresh trees, and this is raz_engine_start).
+extern "C" int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const uint32_t* sims_per_move,
+                                    uint32_t n_active, raz_stream_t stream) {
+    if (!e || !sims_per_move) return raz_fail(RAZ_EINVAL, "raz_engine_next_game: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_next_game: call raz_engine_start first");
+    if (!e->dev.cfg.share_mtcs_info) return raz_engine_start(e, first_game_id, sims_per_move, n_active, stream);
+    if (n_active > e->dev.B) return raz_fail(RAZ_EINVAL, "raz_engine_next_game: n_active > n_games");
+    hipStream_t s = (hipStream_t)stream;
+    const raz_engine_dev& d = e->dev;
+    RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)d.B * 4, hipMemcpyHostToDevice, s), "raz_engine_next_game: copy sims");
+    RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_next_game: sync");  // host array may be transient
+    if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_next_game: clear solver memo");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_next_game: clear counters");
+    if (d.par) {
+        RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_next_game: clear simulation slots");
+        RAZ_HIP_TRY(hipMemsetAsync(d.nn_active, 0, (size_t)d.B * d.K, s), "raz_engine_next_game: clear leaf flags");
+    }
+    hipLaunchKernelGGL(k_adopt_all, dim3(d.B, 8), dim3(64), 0, s, d);
+    int rc = raz_check_launch("raz_engine_next_game: adopt");
+    if (rc != RAZ_OK) return rc;
+    hipLaunchKernelGGL(k_next_game, dim3((d.B + 255) / 256), dim3(256), 0, s, d, first_game_id, e->d_sims, n_active);
+    return raz_check_launch("raz_engine_next_game");
 }
 
 namespace {

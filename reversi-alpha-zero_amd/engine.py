@@ -151,6 +151,17 @@ class SelfPlayEngine:
                                        self.n_games if n_active is None else n_active, _stream()), "raz_engine_start")
         self.n_active = self.n_games if n_active is None else n_active
 
+    def next_game(self, first_game_id, sims_per_move, n_active=None):
+        """The next game of every slot on the slot's tree (reset_mtcs_info_per_game > 1, include/raz.h)."""
+        import torch
+        sims = np.full(self.n_games, sims_per_move, dtype=np.uint32) if np.isscalar(sims_per_move) \
+            else np.ascontiguousarray(sims_per_move, dtype=np.uint32)
+        assert sims.size == self.n_games
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_next_game(self._h, first_game_id, sims.ctypes.data,
+                                           self.n_games if n_active is None else n_active, _stream()), "raz_engine_next_game")
+        self.n_active = self.n_games if n_active is None else n_active
+
     def step(self, n=1):
         import torch
         with torch.cuda.device(self.device):
@@ -231,9 +242,11 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             check(lib.raz_engine_gc(self._h, threshold, _stream()), "raz_engine_gc")
 
-    def run(self, chunk=64, max_steps=10_000_000):
+    def run(self, chunk=64, max_steps=10_000_000, allow_gc=True):
         """Step until every active game has finished.  Returns the final stats.  Pools are pruned
-        whenever the fullest one could overflow before the next poll (<= nodes_per_step new nodes per step)."""
+        whenever the fullest one could overflow before the next poll (<= nodes_per_step new nodes per step).
+        allow_gc=False: never prune (a tree that the NEXT game of the slot will search again must keep its
+        early positions: reset_mtcs_info_per_game > 1); a pool that fills up then raises from stats()."""
         steps = 0
         cap = int(self.cfg.nodes_per_game)
         self.gc_runs = 0
@@ -241,7 +254,7 @@ class SelfPlayEngine:
             self.step(chunk)
             steps += chunk
             st = self.stats()
-            if st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
+            if allow_gc and st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
                 self.gc(threshold=cap // 4)
                 self.gc_runs += 1
             if st["finished_games"] >= self.n_active:

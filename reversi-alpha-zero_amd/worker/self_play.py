@@ -122,8 +122,22 @@ class BatchedSelfPlayWorker:
         self._engine = None
         self._net = None
         self._engine_key = None
+        # worker/self_play.py:109-111,132-134: with share_mtcs_info_in_self_play the worker keeps one MCTSInfo for
+        # reset_mtcs_info_per_game consecutive games (mini.yml: 3).  Here a "worker" is a game slot: the games a
+        # slot plays in consecutive play_batch calls form such a series on the slot's device tree.
+        self._series_pos = 0
 
     # -- engine life cycle -------------------------------------------------------------------
+    def _series_length(self):
+        p = self.config.play
+        if not p.share_mtcs_info_in_self_play:
+            return 1   # mtcs_info stays None: every game's players get fresh trees (self_play.py:109, player.py:43)
+        r = getattr(p, "reset_mtcs_info_per_game", 1)
+        if not r or int(r) < 1:
+            raise ValueError("play.reset_mtcs_info_per_game must be >= 1: 0/None never resets the shared tree "
+                             "(worker/self_play.py:132), which a fixed device node pool cannot hold")
+        return int(r)
+
     def _get_engine(self, max_sims):
         from ..engine import DeviceNet, SelfPlayEngine
         key = (max_sims, self.config.play.resign_threshold, self.config.play.thinking_loop)
@@ -131,8 +145,14 @@ class BatchedSelfPlayWorker:
             self._net = DeviceNet(self.net_blob, self.device)
         if self._engine is None or self._engine_key != key:
             self._engine = None
+            self._series_pos = 0   # a new engine starts from empty trees
+            r = self._series_length()
+            nodes = None
+            if r > 1:   # the tree of a series is never pruned (its early positions are searched again): room for r games
+                p = self.config.play
+                nodes = r * (max_sims * max(1, p.thinking_loop) * 62 + 128) * 2
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
-                                          sims_hint=max_sims)
+                                          sims_hint=max_sims, nodes_per_game=nodes)
             self._engine_key = key
         return self._engine
 
@@ -143,8 +163,13 @@ class BatchedSelfPlayWorker:
         sims = np.array([decide_simulation_num_per_move(self.config, base + i) for i in range(self.games_in_flight)],
                         dtype=np.uint32)
         eng = self._get_engine(int(sims.max()))
-        eng.start(base, sims, n_active=n)
-        stats = eng.run()
+        r = self._series_length()
+        if self._series_pos == 0:
+            eng.start(base, sims, n_active=n)
+        else:
+            eng.next_game(base, sims, n_active=n)   # the slots' trees are kept (reset_mtcs_info_per_game > 1)
+        stats = eng.run(allow_gc=(r == 1))
+        self._series_pos = (self._series_pos + 1) % r
         recs = eng.records(save_policy_of_tau_1=self.config.play_data.save_policy_of_tau_1)
         self.last_stats = stats
         return recs

@@ -170,3 +170,60 @@ def test_reversi_player_stop_thinking_with_simulations_in_flight(blob):
     assert len(calls) >= 3 and 0 < sum(n) < 400
     assert float(sum(n)) == float(int(sum(n))) and abs(float(ae.q)) <= 1.0   # no virtual loss left behind
     assert all(abs(wi) <= ni + 1e-9 for wi, ni in zip(w, n))
+
+
+# ---- reset_mtcs_info_per_game > 1: the slot's tree carried from game to game (raz_engine_next_game) ----------
+def test_engine_tree_carried_across_games_reproduces_reference_series(blob):
+    """config/mini.yml as shipped (reset_mtcs_info_per_game 3, parallel_search_num 4, thinking_loop 2, solver from
+    turn 50) and the same at parallel_search_num 1: three consecutive games of one reference worker on one
+    MCTSInfo == three raz_engine_next_game rounds of one slot, every root N and W."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    ser = load_mcts_golden("mcts_series_games.json")
+    dnet = DeviceNet(blob, DEV)
+    eng, cur = None, None
+    for g in ser["games"]:
+        cfg = config_of(g)
+        if g["variant"] != cur:
+            assert g["series_index"] == 0
+            cur = g["variant"]
+            eng = SelfPlayEngine(cfg, dnet, n_games=1, seed=g["seed"], record_root_w=True,
+                                 nodes_per_game=3 * (g["sims_per_move"] * cfg.play.thinking_loop * 62 + 128) * 2)
+            eng.start(first_game_id=g["game_id"], sims_per_move=g["sims_per_move"])
+        else:
+            eng.next_game(first_game_id=g["game_id"], sims_per_move=g["sims_per_move"])
+        st = eng.run(chunk=256, allow_gc=False)
+        (plies, summ), = eng.records(save_policy_of_tau_1=g["resolved_play_data"]["save_policy_of_tau_1"])
+        tag = f'{g["variant"]}/{g["game_id"]}'
+        _compare_game(tag, plies, summ, _ref_plies(g), g["winner"])
+        assert st["nn_leaves"] == g["nn_positions"], tag
+        assert (bool(summ["resigned_black"]), bool(summ["resigned_white"])) == (g["resigned_black"], g["resigned_white"]), tag
+
+
+def test_worker_series_of_three_rounds_equals_oracle(blob, tmp_path):
+    """The `self` worker with mini.yml's play settings as shipped: three play_batch rounds of 12 slots = 12 series
+    of 3 games on carried trees; every game == the oracle's game on the series' tree, and the next round (a new
+    series) starts from empty trees again."""
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+    g0 = next(g for g in load_mcts_golden("mcts_series_games.json")["games"] if g["variant"] == "mini_yml_as_shipped_3_games")
+    cfg = Config()
+    cfg.play.update(g0["resolved_play"])
+    cfg.play.schedule_of_simulation_num_per_move = [(0, 10)]
+    cfg.play_data.update(g0["resolved_play_data"])
+    rc = cfg.resource
+    rc.data_dir = str(tmp_path)
+    rc.force_simulation_num_file = str(tmp_path / ".force-sim")
+    n = 12
+    w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=n, seed=9, device=DEV)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=cfg.play.parallel_search_num)
+    trees = [O.Tree() for _ in range(n)]
+    for rnd in range(4):
+        if rnd == 3:
+            trees = [O.Tree() for _ in range(n)]   # reset_mtcs_info_per_game = 3: the 4th round starts a new series
+        recs = w.play_batch(first_game_idx=100 + rnd * n)
+        for i in range(0, n, 2 if rnd else 1):
+            plies, summ = O.selfplay_game(ocfg, blob, 9, 100 + rnd * n + i, 10, tree=trees[i])
+            _compare_game(f"series/round{rnd}/slot{i}", recs[i][0], recs[i][1], plies, summ["winner"], check_w=False)
+        if rnd:   # the slots skipped above still have to advance their oracle trees
+            for i in range(1, n, 2):
+                O.selfplay_game(ocfg, blob, 9, 100 + rnd * n + i, 10, tree=trees[i])
