@@ -59,6 +59,9 @@ PAR_VARIANTS = [
     ("ch5_par8_cpuct5", "ch5.yml", {"thinking_loop": 1, "parallel_search_num": 8}, {}, 30, 34, [1]),
     ("agz_par16_resign", "alpha_go_zero.yml", {"resign_threshold": -0.02, "allowed_resign_turn": 12,
                                                "disable_resignation_rate": 0.0, "parallel_search_num": 16}, {}, 32, 36, [0]),
+    # BASELINE.json configs[0] with nothing overridden but the tree reset: config/mini.yml, 1 game, 100 sims/move
+    ("config0_mini_yml_100sims_as_shipped", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
+                                                         "use_solver_turn_in_simulation": 50, "parallel_search_num": 4}, {}, 100, 0, [0]),
     ("agz_par3_solver_52_50", "alpha_go_zero.yml", {"use_solver_turn": 52, "use_solver_turn_in_simulation": 50,
                                                     "resign_threshold": None, "parallel_search_num": 3}, {}, 25, 37, [1]),
 ]
