@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-SHORT = {"k_tree": "k_tree", "k_net_mfma": "k_net_mfma", "k_conv3x3_wide": "k_conv3x3_wide", "k_heads_wide": "k_heads_wide",
+SHORT = {"k_tree_par": "k_tree_par", "k_tree": "k_tree", "k_net_mfma": "k_net_mfma", "k_conv3x3_wide": "k_conv3x3_wide", "k_heads_wide": "k_heads_wide",
          "k_conv0_wide": "k_conv0_wide", "k_stats": "k_stats", "k_start": "k_start", "k_gc": "k_gc"}
 
 
@@ -51,7 +51,7 @@ def main(src, out):
                              "average per dispatch; FETCH_SIZE under-reports wide coalesced reads on gfx950 (guide)",
                    "kernels": traffic}, f, indent=1, sort_keys=True)
     print(json.dumps({k: {c: (round(v, 1) if isinstance(v, float) else v) for c, v in res[k].items()}
-                      for k in ("k_tree", "k_net_mfma") if k in res}, indent=1))
+                      for k in ("k_tree", "k_tree_par", "k_net_mfma") if k in res}, indent=1))
 
 
 if __name__ == "__main__":

@@ -1,23 +1,30 @@
 #!/bin/bash
 # Evidence run on the GPU box (gpurun): rocprofv3 kernel statistics and the PMC passes of
 # /opt/skills/guides/MI355X_MICROARCH.md (one counter set per pass, --kernel-trace only) for the
-# self-play bench, written under gpurun_out/prof_final/.  Summarise afterwards with tools/pmc_summary.py.
-#   usage: tools/run_profiles.sh [steps]
+# self-play bench, written under gpurun_out/<name>/.  Summarise afterwards with tools/pmc_summary.py.
+#   usage: tools/run_profiles.sh [steps] [name] [passes: "stats 1 2 3 4"] [extra bench.py args...]
 set -u
 STEPS=${1:-600}
+NAME=${2:-prof_final}
+PASSES=${3:-"stats 1 2 3 4"}
+shift; shift; shift
+EXTRA="$*"
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_final
+OUT=$ROOT/gpurun_out/$NAME
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline"
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
-echo "stats rc=$?"
-i=0
-for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32" \
-           "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  timeout 240 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc$i" -- $BENCH < /dev/null > "$OUT/pmc$i.log" 2>&1
-  echo "pmc$i rc=$?"
+BENCH="python $ROOT/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --config2-steps 0 $EXTRA"
+SETS=("" \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32" \
+  "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES" \
+  "FETCH_SIZE" "WRITE_SIZE")
+for P in $PASSES; do
+  if [ "$P" = "stats" ]; then
+    timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
+    echo "stats rc=$?"
+  else
+    timeout 240 rocprofv3 --pmc ${SETS[$P]} --kernel-trace --output-format csv -d "$OUT/pmc$P" -- $BENCH < /dev/null > "$OUT/pmc$P.log" 2>&1
+    echo "pmc$P rc=$?"
+  fi
 done
 find "$OUT" -name "*.csv" | head -40
