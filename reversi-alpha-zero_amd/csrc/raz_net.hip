@@ -32,7 +32,7 @@ int raz_net_forward_wide(const float* W, int F, int R, int V, const uint64_t* ow
                          size_t scratch_bytes, hipStream_t s);
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
-                         unsigned long long* prof);
+                         unsigned long long* prof, int variant);
 
 namespace {
 
@@ -298,13 +298,14 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     if (!net || !net->d_weights || !own || !enemy || !policy || !value)
         return raz_fail(RAZ_EINVAL, "raz_net_forward: NULL argument");
     const int F = net->filters, V = net->value_fc;
-    if (raz_net_mfma_supported(F, V) && net->reserved != 1)  // reserved == 1: force the VALU kernel (tests)
+    // reserved (tests): 1 forces the VALU kernel, 2 / 3 the one-wave / the eight-wave MFMA kernel whatever n is
+    if (raz_net_mfma_supported(F, V) && net->reserved != 1)
     {
         // debug: RAZ_NET_PROF=1 and a caller scratch of >= n*64 bytes -> per-position phase ticks
         unsigned long long* prof = nullptr;
         if (scratch && scratch_bytes >= n * 64 && getenv("RAZ_NET_PROF")) prof = (unsigned long long*)scratch;
         return raz_net_forward_mfma((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
-                                    value, n, (hipStream_t)stream, prof);
+                                    value, n, (hipStream_t)stream, prof, net->reserved == 2 || net->reserved == 3 ? net->reserved : 0);
     }
     if (wide_supported(F) && net->reserved != 1)
         return raz_net_forward_wide((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,

@@ -27,7 +27,9 @@ def _stream():
 class DeviceNet:
     """The policy/value net resident in HBM (agent/api.py ReversiModelAPI role, device side)."""
 
-    def __init__(self, blob: bytes, device="cuda:0", force_valu_kernel=False):
+    def __init__(self, blob: bytes, device="cuda:0", force_valu_kernel=False, kernel=None):
+        """kernel (tests): None = chosen by shape and batch size; "valu" = k_net_wave; "mfma_wave" = one single-wave
+        workgroup per position; "mfma_wg" = eight-wave workgroups sharing the dense weights in LDS (F == 16)."""
         import torch
         import struct
         magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -38,7 +40,8 @@ class DeviceNet:
         self.filters, self.res_layers, self.value_fc = F, R, V
         self._weights = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.c = N.RazNet()
-        self.c.reserved = 1 if force_valu_kernel else 0   # 1: wave-per-position VALU kernel even where MFMA applies
+        kernel = "valu" if force_valu_kernel else kernel
+        self.c.reserved = {None: 0, "valu": 1, "mfma_wave": 2, "mfma_wg": 3}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")
@@ -51,15 +54,18 @@ class DeviceNet:
             self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         return (self._scratch.data_ptr(), self._scratch.numel()) if need else (None, 0)
 
-    def predict_bitboards(self, own, enemy):
-        """own/enemy: int64 device tensors (side to move's view).  -> (policy (n,64), value (n,))"""
+    def predict_bitboards(self, own, enemy, active=None):
+        """own/enemy: int64 device tensors (side to move's view).  -> (policy (n,64), value (n,)).
+        active (uint8 device tensor, optional): positions with 0 are skipped, their outputs stay 0."""
         import torch
         n = own.numel()
-        policy = torch.empty((n, 64), dtype=torch.float32, device=self.device)
-        value = torch.empty((n,), dtype=torch.float32, device=self.device)
+        alloc = torch.zeros if active is not None else torch.empty
+        policy = alloc((n, 64), dtype=torch.float32, device=self.device)
+        value = alloc((n,), dtype=torch.float32, device=self.device)
         sp, sb = self.scratch(n)
         with torch.cuda.device(self.device):
-            check(lib.raz_net_forward(ctypes.byref(self.c), own.data_ptr(), enemy.data_ptr(), None,
+            check(lib.raz_net_forward(ctypes.byref(self.c), own.data_ptr(), enemy.data_ptr(),
+                                      active.data_ptr() if active is not None else None,
                                       policy.data_ptr(), value.data_ptr(), n, sp, sb, _stream()), "raz_net_forward")
         return policy, value
 

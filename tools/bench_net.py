@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--net", default="ch5", choices=["mini", "ch5"])
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--kernel", default=None, choices=["valu", "mfma_wave", "mfma_wg"], help="force a kernel variant (default: by shape and n)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -25,7 +26,7 @@ def main():
     from reversi_alpha_zero_amd.engine import DeviceNet
     F, R, V = {"mini": (16, 1, 16), "ch5": (256, 10, 256)}[args.net]
     dev = torch.device("cuda:0")
-    net = DeviceNet(ReversiNet(F, R, V).keras_init_(0).to_blob(), dev)
+    net = DeviceNet(ReversiNet(F, R, V).keras_init_(0).to_blob(), dev, kernel=args.kernel)
     rng = np.random.default_rng(0)
     own = rng.integers(0, 2**64, size=args.n, dtype=np.uint64)
     enemy = rng.integers(0, 2**64, size=args.n, dtype=np.uint64) & ~own
@@ -56,7 +57,7 @@ def main():
         names = ["zero_lds", "layer0", "res_blocks", "head_convs", "policy_dense", "softmax", "value_head"]
         extra["phase_ticks_mean"] = {k: float(v) for k, v in zip(names, d.mean(axis=0))}
         extra["wave_ticks_mean"] = float((t[:, 7] - t[:, 0]).mean())
-    print(json.dumps({"net": args.net, **extra, "filters": F, "res_layers": R, "positions": args.n, "ms_per_forward": ms,
+    print(json.dumps({"net": args.net, "kernel": args.kernel or "auto", **extra, "filters": F, "res_layers": R, "positions": args.n, "ms_per_forward": ms,
                       "tflops_best": flops / (best * 1e-3) / 1e12, "peak_tflops_fp32_mfma": 157.3,
                       "frac_of_peak": flops / (best * 1e-3) / 1e12 / 157.3, "flop_per_forward": flops}))
 
