@@ -86,3 +86,35 @@ def test_batched_ops_refuse_cpu_tensors():
     t = torch.zeros(4, dtype=torch.int64)
     with pytest.raises(ValueError):
         bb.legal_moves_batch(t, t)
+
+
+def test_engine_workspace_scales_with_parallel_search_num():
+    """Host-only part of the engine ABI: raz_engine_workspace_bytes validates the config and sizes the
+    per-slot arrays (simulation slots, paths, leaf-exchange rows) by parallel_search_num (config.py:142)."""
+    import ctypes
+    import types
+    from reversi_alpha_zero_amd import _native as N
+    from reversi_alpha_zero_amd.engine import engine_config_from
+    play = types.SimpleNamespace(
+        share_mtcs_info_in_self_play=True, thinking_loop=1, required_visit_to_decide_action=40,
+        start_rethinking_turn=10, c_puct=5, noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10,
+        virtual_loss=3, parallel_search_num=1, resign_threshold=-0.9, allowed_resign_turn=10,
+        disable_resignation_rate=0.1, use_solver_turn=0, use_solver_turn_in_simulation=0)
+    cfg = types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+    sizes = {}
+    for k in (1, 4, 16):
+        play.parallel_search_num = k
+        c = engine_config_from(cfg, n_games=64, seed=0, nodes_per_game=256)
+        assert c.parallel_search_num == k
+        sizes[k] = N.lib.raz_engine_workspace_bytes(ctypes.byref(c))
+        assert sizes[k] > 0
+    per_slot = 256 + 64 * 9 + 1 + 16 + 260     # slot block, path (node, mirror, action), flag, leaf in, leaf out
+    assert sizes[4] - sizes[1] >= 64 * (3 * per_slot)                  # the slot kernel's arrays for 4 slots ...
+    assert sizes[16] - sizes[4] >= 64 * (12 * per_slot)                # ... and 12 more
+    play.parallel_search_num = 17                                      # prediction_queue_size (config.py:141)
+    with pytest.raises(ValueError):
+        engine_config_from(cfg, n_games=64, seed=0, nodes_per_game=256)
+    c = engine_config_from(types.SimpleNamespace(play=types.SimpleNamespace(**dict(vars(play), parallel_search_num=16)),
+                                                 play_data=cfg.play_data), n_games=64, seed=0, nodes_per_game=256)
+    c.parallel_search_num = 17
+    assert N.lib.raz_engine_workspace_bytes(ctypes.byref(c)) == 0 and b"parallel_search_num" in N.lib.raz_last_error()
