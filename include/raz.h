@@ -247,6 +247,19 @@ int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* root_n, doub
                             uint32_t* n_plies, uint8_t* status, uint8_t* resigned,
                             uint32_t* game_id, uint8_t* enable_resign, uint64_t* final_black,
                             uint64_t* final_white, raz_stream_t stream);
+/* The play_*.json text of ONE finished game, natively: the rows SelfPlayWorker.save_play_data appends for it
+ * (worker/self_play.py:180-194: black.moves + white.moves; agent/player.py:166-179: 8 symmetric rows
+ * [[own, enemy], [64 floats]] per searched ply, :357-364: z appended; saved policy per :132,366-385), as the
+ * exact bytes json.dump would write for them - rows joined by ", ", WITHOUT the enclosing "[" "]" of the file
+ * (a file is "[" + the fragments of its games joined by ", " + "]").  headers / root_n: n_plies records as
+ * raz_engine_read_records returns them for that game; winner: status & 0x0f.  Host function, thread-safe.
+ * Returns the number of bytes written (0 for a game without rows), negative on error (RAZ_ENOMEM: cap too
+ * small - 8 x 2048 bytes per ply always suffice); *n_rows (nullable) receives the number of rows. */
+long long raz_emit_game_rows_json(const void* headers, const uint32_t* root_n, int n_plies, int winner,
+                                  int change_tau_turn, int save_policy_of_tau_1, char* out, size_t cap,
+                                  int* n_rows);
+/* float.__repr__(x) (the number format of json.dump) into out32 (>= 32 bytes, NUL-terminated); returns its length. */
+int raz_format_float_repr(double x, char* out32);
 /* Device pointers of the record arrays, for a caller that gathers them itself (e.g. RCCL):
  * which = 0 headers, 1 root_n, 2 root_w, 3 n_plies, 4 status. */
 void* raz_engine_device_ptr(raz_engine* e, int which);

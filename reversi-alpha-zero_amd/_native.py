@@ -83,6 +83,9 @@ SIGNATURES.update({
                                   c_size_t, POINTER(c_void_p)]),
     "raz_engine_destroy": (None, [c_void_p]),
     "raz_engine_start": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
+    "raz_emit_game_rows_json": (ctypes.c_longlong, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                                    POINTER(c_int)]),
+    "raz_format_float_repr": (c_int, [ctypes.c_double, ctypes.c_char_p]),
     "raz_engine_next_game": (c_int, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
     "raz_engine_step": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_step_timed": (c_int, [c_void_p, c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),

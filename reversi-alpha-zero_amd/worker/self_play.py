@@ -105,6 +105,55 @@ def drop_draw_uniform(seed, game_id):
     return rng_pair(seed, game_id, 3, 0)[1]
 
 
+def game_rows_json(headers, root_n, n_plies, winner, change_tau_turn, save_policy_of_tau_1):
+    """The JSON text of one finished game's rows (rows joined by ", ", no enclosing brackets) and their number,
+    produced by libraz (csrc/raz_emit.hip) from the engine's raw records: byte for byte what
+    json.dumps(rows_of_game(plies, winner)) yields minus the outer "[" "]"."""
+    import ctypes
+    from .._native import lib, last_error
+    n_plies = int(n_plies)
+    hdr = np.ascontiguousarray(headers[:n_plies])
+    rn = np.ascontiguousarray(root_n[:n_plies], dtype=np.uint32)
+    cap = max(1, n_plies) * 8 * 2048
+    buf = ctypes.create_string_buffer(cap)
+    nrows = ctypes.c_int(0)
+    n = lib.raz_emit_game_rows_json(hdr.ctypes.data, rn.ctypes.data, n_plies, int(winner), int(change_tau_turn),
+                                    int(bool(save_policy_of_tau_1)), buf, cap, ctypes.byref(nrows))
+    if n < 0:
+        raise RuntimeError("raz_emit_game_rows_json: " + last_error())
+    return buf.raw[:n].decode("ascii"), nrows.value
+
+
+def plies_for_ggf(headers, n_plies):
+    """The per-ply facts MoveHistory needs (worker/self_play.py:279-296) from raw ply headers."""
+    return [{"action": int(h["action"]), "player": int(h["player"]), "solved": bool(int(h["flags"]) & 1),
+             "q": float(h["q"]), "n": float(h["n"])} for h in headers[:int(n_plies)]]
+
+
+RAW_KEYS = ("headers", "root_n", "n_plies", "status", "resigned", "game_id", "enable_resign", "final_black", "final_white")
+
+
+def gather_raw(raw, rank, world, device=None):
+    """The single collective of the path on the engine's own record arrays: every rank's arrays (same shapes
+    on all ranks) gathered on rank 0 and concatenated in rank order = global game id order.  Returns None
+    on the other ranks."""
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    dev = torch.device(device) if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    out = {}
+    for k in RAW_KEYS:
+        a = np.ascontiguousarray(raw[k])
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
+        lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, lst, dst=0)
+        if rank == 0:
+            parts = [x.cpu().numpy().view(a.dtype).reshape(a.shape) for x in lst]
+            out[k] = np.concatenate(parts, axis=0)
+    return out if rank == 0 else None
+
+
 class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
@@ -116,6 +165,7 @@ class BatchedSelfPlayWorker:
         self.device = device
         self.rank, self.world = rank, world
         self.buffer = []
+        self.buffer_json = []          # the same rows as JSON text fragments, one per game (emit_raw)
         self.move_history_buffer = []
         self.false_positive_count_of_resign = 0
         self.resign_test_game_count = 0
@@ -173,6 +223,61 @@ class BatchedSelfPlayWorker:
         recs = eng.records(save_policy_of_tau_1=self.config.play_data.save_policy_of_tau_1)
         self.last_stats = stats
         return recs
+
+    def play_batch_raw(self, first_game_idx, n_games=None):
+        """play_batch without the per-ply Python objects: the engine's record arrays (SelfPlayEngine.read_raw),
+        cut to the n games played."""
+        n = self.games_in_flight if n_games is None else n_games
+        base = first_game_idx + self.rank * self.games_in_flight
+        sims = np.array([decide_simulation_num_per_move(self.config, base + i) for i in range(self.games_in_flight)],
+                        dtype=np.uint32)
+        eng = self._get_engine(int(sims.max()))
+        r = self._series_length()
+        if self._series_pos == 0:
+            eng.start(base, sims, n_active=n)
+        else:
+            eng.next_game(base, sims, n_active=n)
+        self.last_stats = eng.run(allow_gc=(r == 1))
+        self._series_pos = (self._series_pos + 1) % r
+        raw = eng.read_raw()
+        return {k: raw[k][:n] for k in RAW_KEYS}
+
+    def emit_raw(self, raw, first_local_idx=1, threads=None):
+        """emit() on raw record arrays: the same files, with the rows' JSON text produced natively
+        (csrc/raz_emit.hip; one call per game, spread over host threads - ctypes releases the GIL)."""
+        import concurrent.futures as cf
+        pd, pc = self.config.play_data, self.config.play
+        n = len(raw["n_plies"])
+        winners = [int(s) & 0x0f for s in raw["status"]]
+
+        def frag(g):
+            return game_rows_json(raw["headers"][g], raw["root_n"][g], raw["n_plies"][g], winners[g],
+                                  pc.change_tau_turn, pd.save_policy_of_tau_1)
+        with cf.ThreadPoolExecutor(max_workers=threads or min(32, os.cpu_count() or 1)) as ex:
+            frags = list(ex.map(frag, range(n)))
+        paths = []
+        for g in range(n):
+            local_idx = first_local_idx + g
+            gid = int(raw["game_id"][g])
+            self.finish_game({"winner": winners[g], "resigned_black": int(raw["resigned"][g, 0]),
+                              "resigned_white": int(raw["resigned"][g, 1]), "enable_resign": int(raw["enable_resign"][g])})
+            text, nrows = frags[g]
+            is_draw = nrows > 0 and winners[g] == 3          # rows[0][-1] == 0 (self_play.py:181)
+            if nrows and (not is_draw or pd.drop_draw_game_rate <= drop_draw_uniform(self.seed, gid)):
+                self.buffer_json.append(text)
+            if local_idx % pd.nb_game_in_file == 0 and self.buffer_json:
+                rc = self.config.resource
+                stamp = datetime.now().strftime("%Y%m%d-%H%M%S.%f")
+                path = os.path.join(rc.play_data_dir, rc.play_data_filename_tmpl % stamp)
+                with open(path, "wt") as f:
+                    f.write("[" + ", ".join(self.buffer_json) + "]")
+                self.buffer_json = []
+                paths.append(path)
+            self.remove_play_data()
+            if pd.enable_ggf_data:
+                self.save_ggf_data(plies_for_ggf(raw["headers"][g], raw["n_plies"][g]),
+                                   write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
+        return paths
 
     # -- bookkeeping identical to the reference worker ---------------------------------------------
     def finish_game(self, summary):
@@ -266,11 +371,11 @@ class BatchedSelfPlayWorker:
         game_idx = read_as_int(rc.self_play_game_idx_file) or 0
         local_idx = 1
         while total_games is None or local_idx <= total_games:
-            recs = self.play_batch(game_idx)
-            allrecs = gather_records(recs, self.rank, self.world) if self.world > 1 else recs
+            raw = self.play_batch_raw(game_idx)
+            allraw = gather_raw(raw, self.rank, self.world) if self.world > 1 else raw
             if self.rank == 0:
-                self.emit(allrecs, local_idx)
-                game_idx += len(allrecs)
+                self.emit_raw(allraw, local_idx)
+                game_idx += len(allraw["n_plies"])
                 with open(rc.self_play_game_idx_file, "wt") as f:
                     f.write(str(game_idx))
             if self.world > 1:

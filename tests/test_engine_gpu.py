@@ -245,8 +245,11 @@ def test_model_api_predict_contract():
         api.predict(np.zeros((2, 8)))
 
 
-def test_worker_files_equal_oracle_rows(golden, blob, tmp_path):
-    """The `self` worker end to end on the GPU: play 6 games (mini.yml settings as shipped, solver on),
+@pytest.mark.parametrize("raw_path", [False, True])
+def test_worker_files_equal_oracle_rows(golden, blob, tmp_path, raw_path):
+    """(raw_path: the worker's production path - engine record arrays, JSON text written natively by
+    raz_emit_game_rows_json - instead of per-ply Python objects and json.dump; same files.)
+    The `self` worker end to end on the GPU: play 6 games (mini.yml settings as shipped, solver on),
     write play_*.json / GGF / game-idx the way worker/self_play.py does, and check the file content is
     exactly what the reference's row construction yields for the oracle's games, and that it loads the
     way the reference's trainer reads it (worker/optimize.py:214-231)."""
@@ -273,8 +276,10 @@ def test_worker_files_equal_oracle_rows(golden, blob, tmp_path):
     rc.self_play_game_idx_file = str(tmp_path / ".self-play-game-idx")
     rc.create_directories()
     w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=6, seed=3, device=DEV)
-    recs = w.play_batch(first_game_idx=0)
-    paths = w.emit(recs, first_local_idx=1)
+    if raw_path:
+        paths = w.emit_raw(w.play_batch_raw(first_game_idx=0), first_local_idx=1)
+    else:
+        paths = w.emit(w.play_batch(first_game_idx=0), first_local_idx=1)
     assert len(paths) == 3                                   # nb_game_in_file = 2
     files = get_game_data_filenames(rc)
     got = [row for f in files for row in read_game_data_from_file(f)]

@@ -197,3 +197,154 @@ def test_evaluate_config_and_helpers(tmp_path):
     m2 = ReversiModel(cfg)
     assert load_best_model_weight(m2) and m2.model.to_blob() == m.model.to_blob()
     assert reload_best_model_weight_if_changed(m2) is False
+
+
+# ---- native row emission (csrc/raz_emit.hip) and the raw-array path of the worker -------------------------
+def _raw_of_games(games, max_plies=72):
+    """Engine-style record arrays (SelfPlayEngine.read_raw) of oracle / golden games: [(plies, summary)]."""
+    from reversi_alpha_zero_amd.engine import PLY_HEADER
+    n = len(games)
+    raw = {"headers": np.zeros((n, max_plies), dtype=PLY_HEADER), "root_n": np.zeros((n, max_plies, 64), dtype=np.uint32),
+           "n_plies": np.zeros(n, dtype=np.uint32), "status": np.zeros(n, dtype=np.uint8),
+           "resigned": np.zeros((n, 2), dtype=np.uint8), "game_id": np.zeros(n, dtype=np.uint32),
+           "enable_resign": np.zeros(n, dtype=np.uint8), "final_black": np.zeros(n, dtype=np.uint64),
+           "final_white": np.zeros(n, dtype=np.uint64)}
+    for g, (plies, s) in enumerate(games):
+        raw["n_plies"][g] = len(plies)
+        raw["status"][g] = s["winner"]
+        raw["resigned"][g] = [s.get("resigned_black", 0), s.get("resigned_white", 0)]
+        raw["game_id"][g] = s.get("game_id", g)
+        raw["enable_resign"][g] = s.get("enable_resign", 1)
+        for j, p in enumerate(plies):
+            h = raw["headers"][g, j]
+            h["own"], h["enemy"], h["n"], h["q"] = p["own"], p["enemy"], p["n"], p["q"]
+            h["action"], h["player"], h["turn"], h["has_row"] = p["action"], p["player"], p.get("turn", 0), int(p["has_row"])
+            h["flags"] = int(bool(p.get("solved", False)))
+            raw["root_n"][g, j] = np.asarray(p["root_n"], dtype=np.float64).astype(np.uint32)
+    return raw
+
+
+def test_float_repr_matches_python():
+    """raz_format_float_repr == float.__repr__ (what json.dump writes): visit-count ratios, random bit
+    patterns, subnormals, the exponent / fixed notation switch points."""
+    import ctypes
+    import math
+    import random
+    import struct
+    from reversi_alpha_zero_amd._native import lib
+    buf = ctypes.create_string_buffer(32)
+    rng = random.Random(3)
+    xs = [0.0, 1.0, 0.1, 1e-5, 0.0001, 1e16, 1e15, 123456789012345678.0, 1e22, 1.5e-7, 2 / 3, 0.1 + 0.2, 5e-324,
+          1.7976931348623157e308, -0.0, -2.5, 9999999999999998.0, 0.30000000000000004]
+    xs += [rng.randint(0, 3200) / rng.randint(1, 200000) for _ in range(20000)]
+    xs += [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0] for _ in range(20000)]
+    xs += [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(52)))[0] for _ in range(2000)]
+    for x in xs:
+        if math.isnan(x) or math.isinf(x):
+            continue
+        assert lib.raz_format_float_repr(x, buf) == len(repr(x)) and buf.value.decode() == repr(x), repr(x)
+
+
+def test_native_rows_json_equals_reference_play_files():
+    """raz_emit_game_rows_json on engine-style records == json.dumps(rows) byte for byte: the sha256 of the files the
+    unmodified reference worker wrote (all golden sets: tau-1 and one-hot saved policies, resignations, solver moves
+    without rows, draws), and == the Python row builder on every game."""
+    from reversi_alpha_zero_amd.worker.self_play import rows_of_game, game_rows_json
+    from oracle_util import load_par_golden
+    n_files = 0
+    for gold in (load_mcts_golden(), load_par_golden(), load_mcts_golden("mcts_series_games.json")):
+        for g in gold["games"]:
+            plies = _plies_of(g)
+            raw = _raw_of_games([(plies, {"winner": g["winner"]})])
+            ctt = g["resolved_play"]["change_tau_turn"]
+            tau1 = g["resolved_play_data"]["save_policy_of_tau_1"]
+            for j, p in enumerate(plies):   # the golden plies do not store the turn: recover it like the env does
+                raw["headers"][0, j]["turn"] = bin(p["own"]).count("1") + bin(p["enemy"]).count("1") - 4
+            text, nrows = game_rows_json(raw["headers"][0], raw["root_n"][0], raw["n_plies"][0], g["winner"], ctt, tau1)
+            rows = rows_of_game(plies, g["winner"])
+            assert nrows == len(rows) and "[" + text + "]" == json.dumps(rows), g["variant"]
+            if g["play_rows_sha256"] is not None:
+                assert hashlib.sha256(("[" + text + "]").encode()).hexdigest() == g["play_rows_sha256"], g["variant"]
+                n_files += 1
+    assert n_files >= 20
+
+
+def test_emit_raw_writes_the_same_files_as_emit(tmp_path):
+    """BatchedSelfPlayWorker.emit_raw (native text, raw arrays) and .emit (Python rows, json.dump) produce identical
+    play_*.json contents and GGF files for the same games, incl. file grouping, dropped draws and resign bookkeeping."""
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.engine import saved_policy
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+    rng = np.random.default_rng(12)
+    games = []
+    for i in range(11):
+        plies = []
+        for j in range(int(rng.integers(3, 12))):
+            own = int(rng.integers(0, 2**63)) * 2 + 1
+            enemy = int(rng.integers(0, 2**63)) & ~own
+            rn = [float(v) for v in rng.integers(0, 40, 64) * (rng.random(64) < 0.3)]
+            if sum(rn) == 0:
+                rn[5] = 3.0
+            turn = int(rng.integers(0, 40))
+            plies.append({"player": 1 + j % 2, "turn": turn, "own": own, "enemy": enemy, "action": int(rng.integers(0, 64)),
+                          "has_row": bool(j % 4), "solved": bool(j % 4 == 0), "sims": 10, "loops": 1,
+                          "n": float(rng.integers(1, 9)), "q": float(rng.random() * 2 - 1), "root_n": rn, "root_w": None})
+        games.append((plies, {"winner": int(rng.integers(1, 4)), "status": 1, "plies": len(plies), "game_id": 500 + i,
+                              "enable_resign": int(i % 3 > 0), "resigned_black": int(i % 2), "resigned_white": int(i % 5 == 0)}))
+
+    def run(kind, tau1):
+        cfg = Config()
+        cfg.play_data.update(dict(nb_game_in_file=3, nb_game_in_ggf_file=4, drop_draw_game_rate=0.5, save_policy_of_tau_1=tau1))
+        rc = cfg.resource
+        root = tmp_path / f"{kind}{int(tau1)}"
+        rc.data_dir, rc.play_data_dir, rc.self_play_ggf_data_dir = str(root), str(root / "play"), str(root / "ggf")
+        os.makedirs(rc.play_data_dir)
+        os.makedirs(rc.self_play_ggf_data_dir)
+        w = BatchedSelfPlayWorker(cfg, b"", games_in_flight=11, seed=4, device="cpu")
+        if kind == "py":
+            recs = [([dict(p, saved_policy=saved_policy(p["root_n"], p["turn"], cfg.play.change_tau_turn, tau1)) for p in pl], s)
+                    for pl, s in games]
+            w.emit(recs, first_local_idx=1)
+        else:
+            w.emit_raw(_raw_of_games(games), first_local_idx=1, threads=3)
+        play = [open(os.path.join(rc.play_data_dir, f)).read() for f in sorted(os.listdir(rc.play_data_dir))]
+        ggf = [open(os.path.join(rc.self_play_ggf_data_dir, f)).read() for f in sorted(os.listdir(rc.self_play_ggf_data_dir))]
+        return play, ggf, (w.resign_test_game_count, w.false_positive_count_of_resign), len(w.buffer) if kind == "py" else None
+
+    for tau1 in (True, False):
+        p_py, g_py, book_py, _ = run("py", tau1)
+        p_raw, g_raw, book_raw, _ = run("raw", tau1)
+        assert len(p_py) >= 3 and p_py == p_raw and g_py == g_raw and book_py == book_raw
+
+
+_GATHER_RAW_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import numpy as np
+import torch.distributed as dist
+from test_worker_host import _fake_records, _raw_of_games
+from reversi_alpha_zero_amd.worker.self_play import gather_raw
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+fix = lambda recs: [([dict(p, action=max(p["action"], 0)) for p in pl], s) for pl, s in recs]
+got = gather_raw(_raw_of_games(fix(_fake_records(rank, 4))), rank, world)
+if rank == 0:
+    exp = _raw_of_games(fix(_fake_records(0, 4) + _fake_records(1, 4)))
+    assert set(got) == set(exp) and all(np.array_equal(got[k], exp[k]) for k in exp), "gathered arrays differ"
+    print("GATHER_RAW_OK", len(got["n_plies"]))
+else:
+    assert got is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_raw_two_ranks_gloo(tmp_path):
+    """The collective of the worker's raw path at world_size 2 on CPU (gloo): rank-ordered concatenation."""
+    script = tmp_path / "gather_raw2.py"
+    script.write_text(_GATHER_RAW_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GATHER_RAW_OK 8" in r.stdout
