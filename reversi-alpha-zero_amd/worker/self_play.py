@@ -273,7 +273,7 @@ class BatchedSelfPlayWorker:
                     f.write("[" + ", ".join(self.buffer_json) + "]")
                 self.buffer_json = []
                 paths.append(path)
-            self.remove_play_data()
+                self.remove_play_data()   # (the reference lists the directory after every game; only a write changes it)
             if pd.enable_ggf_data:
                 self.save_ggf_data(plies_for_ggf(raw["headers"][g], raw["n_plies"][g]),
                                    write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
