@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/par_vs_realtime.py — how far is raz-sched-v1 (the reference's asyncio loop in exact virtual
+"""tests/golden/par_vs_realtime.py — how far is raz-sched-v1 (the reference's asyncio loop in exact virtual
 time) from what the reference does on the REAL event loop at parallel_search_num > 1?
 The real interleaving depends on wall-clock timers and differs run to run, so only distributions can
 be compared: for G self-play games per setting this prints, for the unmodified reference on the real
@@ -8,13 +8,14 @@ loop and on ref_harness.VirtualTimeLoop (== the oracle == the engine, bit for bi
     top share   mean over plies of max(N) / sum(N) at the root (how concentrated the search is)
     entropy     mean over plies of the entropy of N / sum(N) (nats)
     plies       mean game length
-Build container only (needs /root/reference):  python tools/par_vs_realtime.py [--games 8] [--sims 30]"""
+Test infrastructure (it drives the oracle harness), build container only (needs /root/reference):
+    python tests/golden/par_vs_realtime.py [--games 8] [--sims 30]"""
 import argparse
 import math
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
