@@ -182,3 +182,26 @@ def test_live_reference_parallel_search_matches_oracle(blob):
         for a, b in zip(plies, ref["plies"]):
             assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"]
         assert summ["n_expand"] == ref["nn_positions"] and summ["winner"] == ref["winner"]
+
+
+@pytest.mark.needs_reference
+def test_virtual_time_schedule_is_representative_of_the_real_event_loop():
+    """raz-sched-v1 is the reference's event loop with computation taking no time; on the REAL loop the
+    interleaving depends on wall-clock timers and differs run to run, so only distributions are comparable
+    (tests/golden/par_vs_realtime.py): NN leaves per simulation and root concentration agree within 20 %."""
+    import importlib.util
+    import os
+    import ref_harness as rh
+    import ref_selfplay as rs
+    spec = importlib.util.spec_from_file_location("par_vs_realtime", os.path.join(os.path.dirname(__file__), "golden", "par_vs_realtime.py"))
+    pvr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pvr)
+    blob = golden_net_blob(load_mcts_golden()["net"])
+    over = {"play": {"parallel_search_num": 4, "use_solver_turn": 0, "use_solver_turn_in_simulation": 0,
+                     "reset_mtcs_info_per_game": 1, "thinking_loop": 1}}
+    st = {}
+    for loop, vt in (("real", False), ("virtual", True)):
+        games = [rs.run_reference_game(rh.load_config("mini.yml", over), blob, 91, gid, 24, virtual_time=vt) for gid in range(3)]
+        st[loop] = pvr.stats(games, 24)
+    for k in ("leaves/sim", "top share", "entropy"):
+        assert abs(st["real"][k] - st["virtual"][k]) <= 0.2 * abs(st["virtual"][k]), (k, st)
