@@ -227,3 +227,45 @@ def test_worker_series_of_three_rounds_equals_oracle(blob, tmp_path):
         if rnd:   # the slots skipped above still have to advance their oracle trees
             for i in range(1, n, 2):
                 O.selfplay_game(ocfg, blob, 9, 100 + rnd * n + i, 10, tree=trees[i])
+
+
+def test_self_play_start_entry_point_writes_the_series_files(blob, tmp_path, monkeypatch):
+    """worker.self_play.start(config) - the reference's entry point (worker/self_play.py:28) - with mini.yml's play
+    settings as shipped: 3 rounds of 8 slots (one series of 3 games per slot on a carried tree), through the
+    production path (record arrays -> native JSON text).  The files' rows == the oracle's games in file order, the
+    game-index file is advanced, and they load the way the reference's trainer reads them."""
+    import json
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker import self_play
+    from reversi_alpha_zero_amd.lib.data_helper import get_game_data_filenames, read_game_data_from_file
+    from oracle_util import rows_of_game
+    g0 = next(g for g in load_mcts_golden("mcts_series_games.json")["games"] if g["variant"] == "mini_yml_as_shipped_3_games")
+    cfg = Config()
+    cfg.play.update(g0["resolved_play"])
+    cfg.play.schedule_of_simulation_num_per_move = [(0, 8)]
+    cfg.play_data.update(dict(g0["resolved_play_data"], nb_game_in_file=4, nb_game_in_ggf_file=6))
+    rc = cfg.resource
+    rc.data_dir = str(tmp_path)
+    rc.play_data_dir = str(tmp_path / "play_data")
+    rc.self_play_ggf_data_dir = str(tmp_path / "ggf")
+    rc.model_dir = str(tmp_path / "model")
+    rc.next_generation_model_dir = str(tmp_path / "model" / "next")
+    rc.log_dir = str(tmp_path / "logs")
+    rc.project_dir = str(tmp_path)
+    rc.force_simulation_num_file = str(tmp_path / ".force-sim")
+    rc.self_play_game_idx_file = str(tmp_path / ".self-play-game-idx")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    n = 8
+    w = self_play.start(cfg, net_blob=blob, games_in_flight=n, total_games=3 * n, seed=13)
+    assert open(rc.self_play_game_idx_file).read() == str(3 * n)
+    got = [row for f in get_game_data_filenames(rc) for row in read_game_data_from_file(f)]
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=cfg.play.parallel_search_num)
+    trees = [O.Tree() for _ in range(n)]
+    exp = []
+    for rnd in range(3):
+        for i in range(n):
+            plies, summ = O.selfplay_game(ocfg, blob, 13, rnd * n + i, 8, tree=trees[i])
+            exp += rows_of_game(plies, summ["winner"])
+    assert json.dumps(got) == json.dumps(exp)
+    assert len(get_game_data_filenames(rc)) == 6 and len(list((tmp_path / "ggf").iterdir())) >= 4
