@@ -42,6 +42,8 @@ VARIANTS = [
     # thinking_loop 2, solver from turn 50) except parallel_search_num=1 (the reproducible mode)
     ("config0_mini_yml_100sims", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
                                               "use_solver_turn_in_simulation": 50}, {}, 100, 0, [0]),
+    # the sims/move of BASELINE.json's metric and configs[2..3] (800), ch5.yml play settings, one in flight
+    ("ch5_800sims", "ch5.yml", {"thinking_loop": 1}, {}, 800, 38, [0]),
     ("agz_solver_52_50", "alpha_go_zero.yml", {"use_solver_turn": 52, "use_solver_turn_in_simulation": 50,
                                                "resign_threshold": None}, {}, 25, 19, [1]),
 ]
@@ -62,6 +64,8 @@ PAR_VARIANTS = [
     # BASELINE.json configs[0] with nothing overridden but the tree reset: config/mini.yml, 1 game, 100 sims/move
     ("config0_mini_yml_100sims_as_shipped", "mini.yml", {"reset_mtcs_info_per_game": 1, "use_solver_turn": 50,
                                                          "use_solver_turn_in_simulation": 50, "parallel_search_num": 4}, {}, 100, 0, [0]),
+    # ... and the same with ch5.yml's own (default) parallel_search_num 8
+    ("ch5_800sims_par8", "ch5.yml", {"thinking_loop": 1, "parallel_search_num": 8}, {}, 800, 38, [0]),
     ("agz_par3_solver_52_50", "alpha_go_zero.yml", {"use_solver_turn": 52, "use_solver_turn_in_simulation": 50,
                                                     "resign_threshold": None, "parallel_search_num": 3}, {}, 25, 37, [1]),
 ]

@@ -104,16 +104,25 @@ def test_tree_carried_across_games_bit_exact_vs_reference(blob):
     check_games_bit_exact(ser, blob, series=True)
 
 
+_played = {}   # (golden file, variant, game id) -> the oracle's game: played once, checked by several tests
+
+
+def _oracle_game(golden, g, blob, tree=None):
+    key = (golden["_generator"], golden.get("event_loop"), g["variant"], g["game_id"])
+    if key not in _played:
+        _played[key] = O.selfplay_game(orc_cfg_of(g), blob, g["seed"], g["game_id"], g["sims_per_move"], tree=tree)
+    return _played[key]
+
+
 def check_games_bit_exact(golden, blob, series=False):
     trees = {}
     for g in golden["games"]:
-        cfg = orc_cfg_of(g)
         tree = None
         if series:   # the games of a variant were played in order by one worker: one MCTSInfo
             assert g["series_index"] == (0 if g["variant"] not in trees else trees[g["variant"]][1] + 1)
             tree = trees[g["variant"]][0] if g["variant"] in trees else O.Tree()
             trees[g["variant"]] = (tree, g["series_index"])
-        plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"], tree=tree)
+        plies, summ = _oracle_game(golden, g, blob, tree)
         tag = f'{g["variant"]}/{g["game_id"]}'
         assert [p["action"] for p in plies] == [p["action"] for p in g["plies"]], tag
         assert summ["winner"] == g["winner"] and summ["turn"] == g["turn"], tag
@@ -141,8 +150,7 @@ def test_play_rows_identical_to_reference_files(golden, blob):
 
 def check_play_rows(golden, blob):
     for g in golden["games"]:
-        cfg = orc_cfg_of(g)
-        plies, summ = O.selfplay_game(cfg, blob, g["seed"], g["game_id"], g["sims_per_move"])
+        plies, summ = _oracle_game(golden, g, blob)
         rows = rows_of_game(plies, summ["winner"])
         dropped = summ["winner"] == 3 and not (g["resolved_play_data"]["drop_draw_game_rate"] <= summ["drop_draw_u"])
         if g["play_rows_sha256"] is None:
