@@ -17,6 +17,13 @@ if not os.path.exists(LIB_PATH):
         "Run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root "
         "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
 
+try:
+    # PyTorch (the HBM allocator and stream provider of every device entry point) ships its own copy of the HIP
+    # runtime.  Load it FIRST: libraz.so then binds to that same libamdhip64; loaded in the other order the process
+    # holds two runtimes that do not see each other's allocations ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+except Exception:  # host-only use (scalar bitboard entry points, row emission) works without it
+    pass
 lib = ctypes.CDLL(LIB_PATH)
 
 u64p = POINTER(c_uint64)
