@@ -143,6 +143,9 @@ def play_cfg_from_config(config, parallel_search_num=1):
         share_mtcs_info=int(bool(p.share_mtcs_info_in_self_play)), save_policy_of_tau_1=int(bool(pd.save_policy_of_tau_1)))
 
 
+# the reference's NN seam as a C callback (orc.h orc_nn_fn)
+NN_FN = ctypes.CFUNCTYPE(None, c_void_p, c_uint64, c_uint64, POINTER(c_float), POINTER(c_float))
+
 _ext_done = False
 
 
@@ -179,6 +182,8 @@ def load_ext():
         lib.orc_tree_new.restype = c_void_p
         lib.orc_tree_free.argtypes = [c_void_p]
         lib.orc_selfplay_game_on.argtypes = [c_void_p] + lib.orc_selfplay_game.argtypes
+        lib.orc_selfplay_game_ex.argtypes = [c_void_p, POINTER(OrcPlayCfg), c_char_p, c_size_t, NN_FN, c_void_p, c_uint32,
+                                             c_uint32, c_int, POINTER(OrcPlyRecord), c_int, c_int, POINTER(OrcGameSummary)]
         _ext_done = True
     return lib
 
@@ -218,13 +223,26 @@ class Tree:
             self.h = None
 
 
-def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128, tree=None):
-    """Run one oracle self-play game.  Returns (list of ply dicts, summary dict)."""
+def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128, tree=None, nn=None, stop_after_plies=0):
+    """Run one oracle self-play game.  Returns (list of ply dicts, summary dict).
+    nn (optional): callable (own, enemy) -> (policy64 float32 array, value float): the injected NN seam
+    (ReversiPlayer(api=...)); blob may then be None.  stop_after_plies > 0: only the game's first plies."""
+    import numpy as np
     lib = load_ext()
     plies = (OrcPlyRecord * max_plies)()
     summ = OrcGameSummary()
-    n = lib.orc_selfplay_game_on(tree.h if tree is not None else None, ctypes.byref(cfg), blob, len(blob), seed, game_id,
-                                 sims_per_move, plies, max_plies, ctypes.byref(summ))
+    if nn is not None:
+        def _cb(ctx, own, enemy, pol, val):
+            p, v = nn(int(own), int(enemy))
+            p = np.ascontiguousarray(p, dtype=np.float32)
+            ctypes.memmove(pol, p.ctypes.data, 256)
+            val[0] = float(v)
+        cb = NN_FN(_cb)
+    else:
+        cb = ctypes.cast(None, NN_FN)
+    n = lib.orc_selfplay_game_ex(tree.h if tree is not None else None, ctypes.byref(cfg), blob, len(blob) if blob else 0,
+                                 cb, None, seed, game_id, sims_per_move, plies, max_plies, stop_after_plies,
+                                 ctypes.byref(summ))
     if n < 0:
         raise RuntimeError("orc_selfplay_game failed (unsupported config or too many plies)")
     out = []

@@ -88,6 +88,8 @@ typedef struct {
     const orc_play_cfg* cfg;
     const void* blob;
     size_t blob_bytes;
+    orc_nn_fn nn;       /* nullable: the NN seam (ReversiPlayer(api=...), agent/player.py:41,346) injected by the test */
+    void* nn_ctx;
     uint32_t seed, game_id;
     uint32_t ev_expand, ev_choice, ev_dirichlet;
     otable tables[2];   /* tables[1] unused (aliased) when share_mtcs_info */
@@ -216,10 +218,9 @@ static void expand_begin(ogame* g, int pl, osim* s) {
     int rot = (int)(d[1] * 4);
     if (is_flip) { black = orc_flip_vertical(black); white = orc_flip_vertical(white); }
     for (int i = 0; i < rot; ++i) { black = orc_rotate90(black); white = orc_rotate90(white); }
-    if (env->next_player == 1)
-        orc_net_forward(g->blob, g->blob_bytes, black, white, s->pol, &s->val);
-    else
-        orc_net_forward(g->blob, g->blob_bytes, white, black, s->pol, &s->val);
+    const u64 o_ = env->next_player == 1 ? black : white, e_ = env->next_player == 1 ? white : black;
+    if (g->nn) g->nn(g->nn_ctx, o_, e_, s->pol, &s->val);   /* injected api.predict (same seam as the reference's) */
+    else orc_net_forward(g->blob, g->blob_bytes, o_, e_, s->pol, &s->val);
     for (int i = 0; i < rot; ++i) rot90_left(s->pol);
     if (is_flip) flipud(s->pol);
 }
@@ -523,12 +524,14 @@ void orc_tree_free(orc_tree* t) {
  * tree (nullable): the worker's MCTSInfo; used - and left holding this game's statistics too - when
  * share_mtcs_info.  The game's two new ReversiPlayers start with expanded = set(var_p.keys())
  * (agent/player.py:47) and an empty now_expanding. */
-int orc_selfplay_game_on(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,
-                         uint32_t game_id, int sims_per_move, orc_ply_record* plies, int max_plies,
-                         orc_game_summary* sum) {
+int orc_selfplay_game_ex(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, orc_nn_fn nn,
+                         void* nn_ctx, uint32_t seed, uint32_t game_id, int sims_per_move, orc_ply_record* plies,
+                         int max_plies, int stop_after_plies, orc_game_summary* sum) {
     ogame g;
     memset(&g, 0, sizeof g);
     g.cfg = cfg; g.blob = blob; g.blob_bytes = blob_bytes; g.seed = seed; g.game_id = game_id;
+    g.nn = nn; g.nn_ctx = nn_ctx;
+    if (!nn && !blob) return -1;
     if (cfg->parallel_search_num < 1 || cfg->parallel_search_num > ORC_MAX_PAR) return -1;
     const int carried = tree && cfg->share_mtcs_info;
     g.solver[0] = orc_solver_new();
@@ -552,6 +555,7 @@ int orc_selfplay_game_on(orc_tree* tree, const orc_play_cfg* cfg, const void* bl
     orc_env_reset(&env);
     int np = 0;
     while (!env.done) {
+        if (stop_after_plies > 0 && np >= stop_after_plies) break; /* partial replay (spot checks): the prefix is the game's */
         if (np >= max_plies) { np = -1; break; }
         int pl = env.next_player == 1 ? 0 : 1;
         u64 own = pl == 0 ? env.black : env.white, enemy = pl == 0 ? env.white : env.black;
@@ -580,6 +584,12 @@ int orc_selfplay_game_on(orc_tree* tree, const orc_play_cfg* cfg, const void* bl
     else table_free(&g.tables[0]);
     if (!cfg->share_mtcs_info) table_free(&g.tables[1]);
     return np;
+}
+
+int orc_selfplay_game_on(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,
+                         uint32_t game_id, int sims_per_move, orc_ply_record* plies, int max_plies,
+                         orc_game_summary* sum) {
+    return orc_selfplay_game_ex(tree, cfg, blob, blob_bytes, NULL, NULL, seed, game_id, sims_per_move, plies, max_plies, 0, sum);
 }
 
 int orc_selfplay_game(const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,
