@@ -1,30 +1,35 @@
 #!/usr/bin/env python
 """bench.py — MCTS self-play throughput of the batched engine on MI355X.  ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--games B] [--sims S] [--net mini|ch5]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`python bench.py --gpus N` on its own re-executes itself through torch.distributed.run with N ranks.)
 
-Workload (BASELINE.json configs[1], SURVEY.md §8(d) "Config 2"): B = 4096 concurrent games per GPU
-from the initial position, mini.yml net (F=16, R=1, V=16; random-init, Keras initialisers, seed 0),
-S = 200 simulations per move, play settings of config/mini.yml (c_puct 5, change_tau_turn 10,
-Dirichlet root noise eps .25 / alpha .5, shared black/white tree, resign threshold -0.9 from turn
-10) with the declared overrides thinking_loop = 1 and end-game solver off (use_solver_turn = 0).
+HEADLINE workload = BASELINE.json configs[2] / SURVEY.md §8(d) "Config 3", the configuration the metric's
+"800 sims/move" is quoted on: 8192 concurrent games per GPU, the 256x10 residual net (config.py:187-193
+defaults: ch5.yml has no model section; random-init, Keras initialisers, seed 0), S = 800 simulations per
+move, play settings of config/ch5.yml:9-16 over config.py:128-166 (c_puct 5, change_tau_turn 4, shared
+black/white tree, Dirichlet noise eps .25 / alpha .5, resign threshold -0.9 from turn 50), with the declared
+overrides thinking_loop = 1 (ch5.yml:13 says 10), end-game solver off, parallel_search_num = 1 (the
+reference's reproducible mode).  Rank r plays global game ids [r*8192, (r+1)*8192) (weak scaling).
 
-A "step" is one pass of the hot path over the batch: the tree kernel (backup + per-move controller
-+ PUCT descent for every live game) followed by ONE net evaluation of all gathered leaves.
-Without --steps the timed region runs the whole batch of games to completion and K is the number
-of steps that took; with --steps K exactly K steps are timed (from the opening position after W
-warm-up steps on a throw-away start).  metric = MCTS simulations/sec (start_search_my_move
-invocations / wall time, NN included, inputs resident in HBM), whole job over all GPUs.
+A "step" is one pass of the hot path over the batch: the tree kernel (backup of the previous leaf, per-move
+controller, PUCT descent to the next leaf, for every live game) followed by ONE net evaluation of all gathered
+leaves.  A whole batch of games is ~50 000 steps at this size, so the timed region is K steps of the batch in
+its STEADY STATE under continuous batching: slot i holds a game at a ply drawn uniformly from 0..58 (positions
+reached by on-device random playouts, raz_step_batch), i.e. the mix of opening, middle-game and end-game
+positions (terminal leaves, deep boards) a long run holds at any instant; W warm-up steps are run on that
+state first.  metric = MCTS simulations/sec = start_search_my_move invocations / wall time, NN included,
+inputs resident in HBM, whole job over all GPUs.  games/hour is extrapolated from it (labelled).
 
-At N = 1 the same JSON line also carries "mini_yml_parallel_search_num_4" (the same workload at mini.yml's own
-parallel_search_num = 4, whole games) and "config2_8192x800_ch5": --config2-steps steps of BASELINE.json
-configs[2] (8192 games, 256x10 net, 800 sims/move - the shape the metric's "800 sims/move" names),
-whose dominant kernel is the MFMA convolution, with its own roofline object.  --config2-steps 0 skips both.
+The same line carries, at N = 1: the parity spot check (8 sampled games of the 8192-game batch against the CPU
+oracle fed with the device net's outputs), BASELINE configs[1] (4096 games x mini net x 200 sims/move, WHOLE
+games, with its own spot check), the bitboard-sweep HBM leg, and the CPU baselines.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 import types
@@ -32,178 +37,388 @@ import types
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (≈6.3 TB/s achievable)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/F16 MFMA dense peak
 TREE_BYTES_PER_SELECTION = 142   # per selection 126 B read + 16 B backup RMW
 TREE_BYTES_PER_SIM = 556         # expansion 280 B + leaf I/O 276 B
+MEAN_SEARCHED_PLIES = 58.6       # searched plies per self-play game (turn 0 is bypassed, agent/player.py:143-148);
+                                 # replaced by the value measured in the whole-game leg when that leg runs
 
 NETS = {"mini": (16, 1, 16), "ch5": (256, 10, 256)}
 
 
-def bench_config(args):
+def mini_config(sims, par=1, share=True):
     """Play settings: config/mini.yml:10-26 over the defaults of config.py:128-166, with the two
     declared overrides (thinking_loop=1, solver off)."""
     play = types.SimpleNamespace(
-        simulation_num_per_move=args.sims, share_mtcs_info_in_self_play=bool(args.share),
+        simulation_num_per_move=sims, share_mtcs_info_in_self_play=bool(share),
         thinking_loop=1, required_visit_to_decide_action=40, start_rethinking_turn=10, c_puct=5,
-        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3, parallel_search_num=args.par,
+        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3, parallel_search_num=par,
         resign_threshold=-0.9, allowed_resign_turn=10, disable_resignation_rate=0.1,
         use_solver_turn=0, use_solver_turn_in_simulation=0)
     return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
 
 
-def ch5_config(sims):
+def ch5_config(sims, par=1):
     """Play settings of config/ch5.yml:9-16 over config.py:128-166 (c_puct 5, change_tau_turn 4, shared
     tree, resign from turn 50), with the declared overrides of SURVEY.md §8(d) "Config 3":
     thinking_loop = 1 (ch5.yml:13 says 10), solver off, parallel_search_num = 1."""
     play = types.SimpleNamespace(
         simulation_num_per_move=sims, share_mtcs_info_in_self_play=True,
         thinking_loop=1, required_visit_to_decide_action=400, start_rethinking_turn=8, c_puct=5,
-        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=4, virtual_loss=3, parallel_search_num=1,
+        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=4, virtual_loss=3, parallel_search_num=par,
         resign_threshold=-0.9, allowed_resign_turn=50, disable_resignation_rate=0.1,
         use_solver_turn=0, use_solver_turn_in_simulation=0)
     return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
 
 
-def mini_par_leg(dev, args, par):
-    """The configs[1] workload at config/mini.yml's own parallel_search_num (4): that many simulations in
-    flight per game on the deterministic raz-sched-v1 schedule (bit-exact vs the reference run on a
-    virtual-time event loop, tests/golden/mcts_par_games.json).  Whole games, same settings otherwise."""
-    import copy
+# ------------------------------------------------------------------------------------------------------------
+# parity spot checks (outside every timed region): the oracle is the CHECKER here, nothing measured runs on it
+# ------------------------------------------------------------------------------------------------------------
+def device_nn(dnet):
+    """The reference's NN seam (ReversiPlayer(api=...), agent/player.py:41,346) served by the device net, one position
+    per call: the oracle's search is then checked GIVEN the net's outputs (the net itself is checked against fp32
+    torch in tests/)."""
+    import numpy as np
     import torch
-    from reversi_alpha_zero_amd.agent.model import ReversiNet
-    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
-    a = copy.copy(args)
-    a.par = par
-    cfg = bench_config(a)
-    F, R, V = NETS[args.net]
-    net = DeviceNet(ReversiNet(F, R, V).keras_init_(0).to_blob(), dev)
-    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims)
-    eng.start(0, args.sims)
-    eng.step(20)
-    eng.stats()
-    eng.start(0, args.sims)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        eng.step(args.chunk)
-        steps += args.chunk
-        st = eng.stats()
-        if st["max_pool_used"] + eng.nodes_per_step * args.chunk + 64 > eng.cfg.nodes_per_game:
-            eng.gc(eng.cfg.nodes_per_game // 4)
-        if st["finished_games"] >= args.games or steps > 80 * args.sims * 4:
-            break
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = {"workload": f"{args.games} concurrent self-play games/GPU, {args.net} net, {args.sims} sims/move, mini.yml play settings, "
-                       f"thinking_loop=1, solver off, parallel_search_num={par} (mini.yml:19), whole games",
-           "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
-           "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
-           "finished_games": st["finished_games"]}
-    del eng, net
-    torch.cuda.empty_cache()
-    return out
+
+    def nn(own, enemy):
+        o = torch.tensor([own - (1 << 64) if own >= 1 << 63 else own], dtype=torch.int64, device=dnet.device)
+        e = torch.tensor([enemy - (1 << 64) if enemy >= 1 << 63 else enemy], dtype=torch.int64, device=dnet.device)
+        p, v = dnet.predict_bitboards(o, e)
+        return p[0].cpu().numpy().astype(np.float32), float(v[0].item())
+    return nn
 
 
-def config2_leg(dev, steps, games=8192, sims=800):
-    """BASELINE.json configs[2] (the shape the metric's "800 sims/move" is quoted on): 8192 concurrent
-    games on one GPU, 256x10 net (ch5.yml has no model section => config.py:187-193), 800 sims/move.
-    A whole batch of games is ~80 minutes at this size, so exactly `steps` steps are timed from the
-    opening (every game has one leaf in every step there, so the rate is if anything pessimistic:
-    later in the game terminal leaves cost no net evaluation).  Node pools are pruned by k_gc in
-    real runs (16*S nodes per game = 147 GB for the batch)."""
-    import torch
-    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
-    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
-    F, R, V = NETS["ch5"]
-    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
-    cfg = ch5_config(sims)
-    net = DeviceNet(blob, dev)
-    # one slice: the net forward (~95 ms for 8192 positions) dwarfs the tree kernel, so there is nothing to
-    # overlap, and the per-launch duration of the convolution is then its stand-alone duration
-    parts = 1
-    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, nodes_per_game=16 * sims, parts=parts)
-    eng.start(0, sims)
-    eng.step(2)
-    eng.stats()
-    eng.start(0, sims)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tree_ms, net_ms = eng.step_timed(steps)   # HIP events around every launch, on the launching stream
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = eng.stats()
-    macs = macs_per_position(F, R, V)
-    leaves_per_launch = st["nn_leaves"] / (steps * parts)
-    net_avg_ms = net_ms / (steps * parts)
-    ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
-    out = {"workload": f"{games} concurrent self-play games/GPU, 256x10 net (F{F} R{R} V{V}), {sims} sims/move, ch5.yml play "
-                       f"settings, thinking_loop=1, solver off, first {steps} steps of the batch",
-           "value": st["total_sims"] / dt, "unit": "sims/s", "leaves_per_s": st["nn_leaves"] / dt,
-           "steps": steps, "ms_per_step": 1e3 * dt / steps,
-           "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
-           "roofline": {"bound": "mfma", "kernel": "k_conv3x3_wide+k_conv0_wide+k_heads_wide (one net forward per slice)",
-                        "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch, "avg_kernel_ms": net_avg_ms,
-                        "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                        "traffic": None},
-           "k_tree_avg_ms": tree_ms / (steps * parts),
-           "sustained_net_TFLOPs": 2.0 * macs * st["nn_leaves"] / dt / 1e12,
-           "bound_sims_per_s_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs)}
-    del eng, net
-    torch.cuda.empty_cache()
-    return out
+def spotcheck_partial_search(eng, cfg, dnet, seed, first_id, slots):
+    """Games of the big batch in the middle of their first searched move: the engine's root statistics (N as u32, W as
+    f64 bit patterns) of slot g after n completed simulations must equal the oracle's after an n-simulation search of
+    the same game id (simulations are sequential at parallel_search_num 1, so the first n of 800 are an n-simulation
+    search).  The oracle evaluates leaves through the device net (batch of 1): the same function as the batch's."""
+    import numpy as np
+    import oracle as O
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
+    nn = device_nn(dnet)
+    raw = eng.read_raw()
+    checked = []
+    for g in slots:
+        assert int(raw["n_plies"][g]) == 1 and int(raw["headers"][g, 0]["action"]) == 19, "turn-0 bypass (player.py:143-148)"
+        black, white = int(raw["final_black"][g]), int(raw["final_white"][g])
+        found, w, n, _ = eng.read_node(g, white, black, 1, 0)   # white to move: the player's own discs are "black" (player.py:95)
+        done = int(n.sum())
+        if not found or done == 0:
+            raise AssertionError(f"spot check: slot {g} has no root statistics yet")
+        plies, _ = O.selfplay_game(ocfg, None, seed, first_id + g, done, nn=nn, stop_after_plies=2)
+        on, ow = np.array(plies[1]["root_n"]), np.array(plies[1]["root_w"])
+        if not (np.array_equal(on, n.astype(np.float64)) and np.array_equal(ow.view(np.uint64), w.view(np.uint64))):
+            raise AssertionError(f"parity spot check FAILED: game id {first_id + g}, {done} simulations: root N/W differ from the oracle")
+        checked.append({"game_id": first_id + g, "sims": done})
+    return checked
 
 
-def cpu_baseline(cfg, blob, sims, budget_games):
-    """The oracle (C port of agent/player.py + env + bitboard + the same net), one game per thread on
-    the host cores (ctypes releases the GIL), same settings.  Reported, not optimised."""
+def spotcheck_whole_games(eng, cfg, blob, seed, first_id, slots, sims):
+    """Finished games of the batch against complete oracle games (C net): every action and every root visit count."""
     import concurrent.futures as cf
     import oracle as O
     ocfg = O.play_cfg_from_config(cfg, parallel_search_num=cfg.play.parallel_search_num)
-    cores = min(os.cpu_count() or 1, budget_games)
+    raw = eng.read_raw()
+    with cf.ThreadPoolExecutor(max_workers=min(len(slots), os.cpu_count() or 1)) as ex:
+        games = list(ex.map(lambda g: O.selfplay_game(ocfg, blob, seed, first_id + g, sims), slots))
+    for g, (plies, summ) in zip(slots, games):
+        n = int(raw["n_plies"][g])
+        acts = [int(a) for a in raw["headers"][g, :n]["action"]]
+        if acts != [p["action"] for p in plies] or (int(raw["status"][g]) & 0x0f) != summ["winner"]:
+            raise AssertionError(f"parity spot check FAILED: game id {first_id + g}: moves differ from the oracle")
+        for i, p in enumerate(plies):
+            if [float(x) for x in raw["root_n"][g, i]] != p["root_n"]:
+                raise AssertionError(f"parity spot check FAILED: game id {first_id + g}, ply {i}: root N differs")
+    return [{"game_id": first_id + g, "plies": int(raw["n_plies"][g])} for g in slots]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# headline: Config 3
+# ------------------------------------------------------------------------------------------------------------
+def stagger(eng, n, sims, seed, dev):
+    """Continuous-batching steady state: slot i continues a game from a position at a ply drawn uniformly from
+    0..58, reached by random playouts on the device (the sweep kernels; SURVEY §8(d) "value distributions")."""
+    from bench_sweep import harvest_positions
+    black, white, player, _ = harvest_positions(n, seed, dev)
+    b, w, p = black.cpu().numpy(), white.cpu().numpy(), player.cpu().numpy()
+    for g in range(n):
+        eng.set_position(g, int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g]), sims, enable_resign=True, one_move=False)
+    import numpy as np
+    occ = np.unpackbits((b.view(np.uint64) | w.view(np.uint64)).view(np.uint8)).reshape(n, 64).sum(1)
+    return {"mean_discs_on_board": float(occ.mean()), "min": int(occ.min()), "max": int(occ.max())}
+
+
+def conv_traffic():
+    """HBM bytes per net forward from the committed PMC passes (separate rocprofv3 --pmc runs of this command:
+    tools/run_profiles.sh -> tools/pmc_summary.py); None when no pass is committed for this build."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc", "config3_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    return t.get("net_forward_hbm_bytes_per_launch"), "profiles/r2_pmc/config3_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE over the launches of one net forward)"
+
+
+def headline_leg(args, dev, rank, world, cdev):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    F, R, V = NETS[args.net]
+    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
+    cfg = ch5_config(args.sims) if args.net == "ch5" else mini_config(args.sims)
+    net = DeviceNet(blob, dev, kernel=args.net_kernel)
+    parts = args.parts or (1 if args.net == "ch5" else 3)   # a 256x10 forward dwarfs the tree kernel: nothing to overlap
+    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims,
+                         nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=parts)
+    first_id = rank * args.games
+    out = {}
+
+    # (1) untimed: the batch from the opening, 24 steps, then 8 sampled slots against the oracle
+    spot = None
+    if rank == 0 and not args.no_spotcheck:
+        eng.start(first_id, args.sims)
+        eng.step(24)
+        eng.stats()
+        slots = [int(x) for x in np.linspace(0, args.games - 1, 8).astype(int)]
+        t0 = time.perf_counter()
+        checked = spotcheck_partial_search(eng, cfg, net, 0, first_id, slots)
+        spot = {"result": "ok", "what": f"{len(checked)} game ids sampled from the {args.games}-game batch after 24 steps from the opening: "
+                                        "root N (u32) and W (f64 bits) == the CPU oracle searching the same ids with the device net's outputs",
+                "games": checked, "seconds": time.perf_counter() - t0}
+
+    # (2) the steady state of continuous batching, W warm-up steps, K timed steps
+    eng.start(first_id, args.sims)
+    if not args.opening:
+        out["stagger"] = stagger(eng, args.games, args.sims, 12345 + rank, dev)
+    eng.step(max(args.warmup, 1))
+    st0 = eng.stats()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
-        res = list(ex.map(lambda gid: O.selfplay_game(ocfg, blob, 0, gid, sims)[1], range(cores)))
+    tree_ms, net_ms = eng.step_timed(args.steps)   # HIP events around every launch, on the launching stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    st = eng.stats()
+    d = {k: float(st[k] - st0[k]) for k in ("total_sims", "nn_leaves", "selections")}
+    tot = torch.tensor([d["total_sims"], d["nn_leaves"], d["selections"], elapsed, float(st["finished_games"])],
+                       dtype=torch.float64, device=cdev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        elapsed = float(mx[3].item())
+    total_sims, leaves, selections = (float(tot[i].item()) for i in range(3))
+
+    # (3) the single collective of the path: records -> rank 0, from HBM, cut to the games' plies
+    t1 = time.perf_counter()
+    gather = {"collective": "none (1 GPU)", "bytes": 0}
+    if world > 1:
+        from reversi_alpha_zero_amd.worker.self_play import gather_packed
+        raw, moved = gather_packed(lambda plies: eng.pack_records(0, args.games, plies), rank, world)
+        torch.cuda.synchronize()
+        gather = {"collective": f"{dist.get_backend()} gather of packed records from HBM ({world} ranks)", "bytes": moved,
+                  "games": (len(raw["n_plies"]) if raw is not None else None)}
+    gather["seconds"] = time.perf_counter() - t1
+
+    if rank != 0:
+        return None
+    macs = macs_per_position(F, R, V)
+    launches = args.steps * parts
+    leaves_per_launch = leaves / world / launches
+    net_avg_ms, tree_avg_ms = net_ms / launches, tree_ms / launches
+    ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
+    traffic, traffic_src = conv_traffic() if args.net == "ch5" else (None, None)
+    net_kernel = {"ch5": "one net forward = k_conv0_wide + 20 x k_conv3x3 (implicit GEMM, >99% of it) + k_heads_wide",
+                  "mini": "k_net_mfma"}[args.net]
+    value = total_sims / elapsed
+    out.update({
+        "metric": "MCTS simulations/sec (self-play, NN included)", "value": value, "unit": "sims/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 tree statistics + f32 net" + (f" ({net.kernel_name})" if getattr(net, "kernel_name", None) else ""),
+        "data": "synthetic (random-init net of the named architecture; positions from on-device random playouts, uniformly random ply)",
+        "config": {"workload": f"BASELINE configs[2]: {args.games} concurrent self-play games/GPU, {args.net} net (F{F} R{R} V{V}), "
+                               f"{args.sims} sims/move, ch5.yml play settings, thinking_loop=1, solver off, parallel_search_num=1; "
+                               + ("first steps from the opening" if args.opening else
+                                  "steady state of continuous batching (slots at uniformly random plies 0..58)"),
+                   "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
+                   "kernel_launches_per_step": parts * (2 if args.net == "mini" else 23), "slices": parts},
+        "sims_per_sec_per_gpu": value / world, "leaves_per_sec": leaves / elapsed,
+        "games_per_hour": value / (args.sims * MEAN_SEARCHED_PLIES) * 3600.0,
+        "games_per_hour_note": f"extrapolated: sims/s / ({args.sims} sims/move x {MEAN_SEARCHED_PLIES} searched plies/game); a whole batch is ~50 000 steps",
+        "total_sims": total_sims, "nn_leaves": leaves, "leaf_slot_occupancy": leaves / world / (args.steps * args.games),
+        "mean_selections_per_sim": selections / max(total_sims, 1.0),
+        "roofline": {"bound": "mfma", "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
+                     "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "peak_note": "f32 MFMA dense peak (the arithmetic the path is specified in)"},
+        "kernels": {"k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms,
+                               "algorithmic_bytes_per_launch": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / launches}},
+        "bound_sims_per_s_per_gpu_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs),
+        "record_gather": gather, "parity_spotcheck": spot if spot else "skipped",
+    })
+    k = out["kernels"]["k_tree"]
+    k["achieved"] = k["algorithmic_bytes_per_launch"] / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None
+    k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"
+    k["frac"] = k["achieved"] / HBM_PEAK_GBS if k["achieved"] else None
+    del eng, net
+    torch.cuda.empty_cache()
+    return out, blob, cfg
+
+
+# ------------------------------------------------------------------------------------------------------------
+# extra legs at N = 1
+# ------------------------------------------------------------------------------------------------------------
+def config1_leg(dev, args, par=1):
+    """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch)."""
+    import numpy as np
+    import torch
+    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    games, sims, chunk = 4096, 200, 200
+    cfg = mini_config(sims, par)
+    F, R, V = NETS["mini"]
+    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
+    net = DeviceNet(blob, dev)
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims)
+    eng.start(0, sims)
+    eng.step(50)
+    eng.stats()
+    eng.start(0, sims)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps, tree_ms, net_ms, timed = 0, 0.0, 0.0, 0
+    while True:
+        if (steps // chunk) % 8 == 0:
+            a, b = eng.step_timed(chunk)
+            tree_ms, net_ms, timed = tree_ms + a, net_ms + b, timed + chunk
+        else:
+            eng.step(chunk)
+        steps += chunk
+        st = eng.stats()
+        if st["max_pool_used"] + eng.nodes_per_step * chunk + 64 > eng.cfg.nodes_per_game:
+            eng.gc(eng.cfg.nodes_per_game // 4)
+        if st["finished_games"] >= games:
+            break
+        if steps > 80 * sims * 4 + 4000:
+            raise RuntimeError("engine did not finish")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lps = 3
+    macs = macs_per_position(F, R, V)
+    leaves_per_launch = st["nn_leaves"] / (steps * lps)
+    net_avg = net_ms / (timed * lps)
+    ach = 2.0 * macs * leaves_per_launch / (net_avg * 1e-3) / 1e12
+    out = {"workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
+                       f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)",
+           "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
+           "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims,
+           "leaf_slot_occupancy": st["nn_leaves"] / (steps * games * max(par, 1)),
+           "roofline": {"bound": "mfma", "kernel": "k_net_mfma", "avg_kernel_ms": net_avg, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                        "note": "3 slices on 3 streams overlap, so the per-launch duration is stretched by co-residency"},
+           "k_tree_avg_ms": tree_ms / (timed * lps)}
+    if par == 1 and not args.no_spotcheck:
+        slots = [int(x) for x in np.linspace(0, games - 1, 8).astype(int)]
+        t1 = time.perf_counter()
+        checked = spotcheck_whole_games(eng, cfg, blob, 0, 0, slots, sims)
+        out["parity_spotcheck"] = {"result": "ok", "what": "8 game ids sampled from the finished batch: every action and root N == complete oracle games",
+                                   "games": checked, "seconds": time.perf_counter() - t1}
+    del eng, net
+    torch.cuda.empty_cache()
+    return out, blob, cfg
+
+
+def sweep_leg(dev, boards=1 << 24, steps=10):
+    """The bitboard-sweep HBM leg of the north star: k_step / k_legal_moves GB/s (tools/bench_sweep.py)."""
+    import bench_sweep
+    a = types.SimpleNamespace(boards=boards, steps=steps, warmup=3, no_cpu_baseline=True, cpu_budget=0.0)
+    o = bench_sweep.run_sweep(a, 0, 1, dev)
+    return {"workload": o["config"]["workload"], "k_step": o["roofline"], "k_legal_moves": o["k_legal_moves"],
+            "boards_per_s": o["value"]}
+
+
+def cpu_baseline_port(cfg, blob, sims, threads, stop_after_plies=0, what=""):
+    """The oracle (C port of agent/player.py + env + bitboard + the same net), one game per host thread (ctypes
+    releases the GIL), same settings.  Reported, not optimised."""
+    import concurrent.futures as cf
+    import oracle as O
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=cfg.play.parallel_search_num)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        res = list(ex.map(lambda gid: O.selfplay_game(ocfg, blob, 0, gid, sims, stop_after_plies=stop_after_plies)[1], range(threads)))
     dt = time.perf_counter() - t0
     total = sum(r["n_sims"] for r in res)
-    return {"value": total / dt, "unit": "sims/s", "cores": cores, "kind": "port",
-            "games_per_hour": cores / dt * 3600.0,
-            "sample": f"{cores} complete self-play games, one per host thread, {sims} sims/move, same net and "
-                      f"play settings (oracle/orc_mcts.c: C port of the reference player; {total} sims in {dt:.1f} s)"}
+    return {"value": total / dt, "unit": "sims/s", "cores": threads, "kind": "port",
+            "sample": f"{what}; oracle/orc_mcts.c + orc_net.c (C port of the reference player and net), one game per host thread; "
+                      f"{total} sims in {dt:.1f} s"}
+
+
+def committed_reference_baseline():
+    """The reference's own pure-Python self-play (SelfPlayWorker.start_game, unmodified source) timed in the BUILD
+    container by tools/ref_python_baseline.py (the GPU box has no /root/reference): a committed measurement."""
+    path = os.path.join(ROOT, "profiles", "r2_cpu_baseline_reference_python.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) started without a launcher: become N ranks."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("RAZ_BENCH_SHARED_GPU") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (RAZ_BENCH_SHARED_GPU=1 runs the ranks on shared "
+                         f"GPUs over gloo: a test rig, labelled as such)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="0 = run the batch of games to completion")
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
-    ap.add_argument("--sims", type=int, default=200)
-    ap.add_argument("--net", default="mini", choices=sorted(NETS))
-    ap.add_argument("--share", type=int, default=1, help="share_mtcs_info_in_self_play (mini.yml: True)")
-    ap.add_argument("--chunk", type=int, default=200, help="steps enqueued between completion polls")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--games", type=int, default=8192, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--net", default="ch5", choices=sorted(NETS))
+    ap.add_argument("--net-kernel", default=None, help="DeviceNet kernel override (tests / comparisons)")
+    ap.add_argument("--parts", type=int, default=0, help="slices/streams the batch is stepped in (0 = 1 for the 256x10 net, 3 for mini)")
+    ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = 16 x sims: pools are pruned by k_gc in long runs)")
+    ap.add_argument("--opening", action="store_true", help="time the first steps from the opening instead of the steady state")
+    ap.add_argument("--no-spotcheck", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-games", type=int, default=64)
-    ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = sized for whole games)")
-    ap.add_argument("--parts", type=int, default=0, help="slices/streams the batch is stepped in (0 = engine default 3)")
-    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs of 16 steps instead of launching kernel by kernel")
-    ap.add_argument("--inner-max", type=int, default=0, help="max simulations completed per game per tree launch (0 = default 2)")
-    ap.add_argument("--no-overlap", action="store_true", help="step the batch on one stream (no half-batch overlap)")
-    ap.add_argument("--phase-profile", action="store_true", help="in-kernel s_memtime phase breakdown (perturbs timing)")
-    ap.add_argument("--par", type=int, default=1,
-                    help="play.parallel_search_num: simulations in flight per game (1 = the reference's reproducible mode, the headline; "
-                         "mini.yml ships 4, the other configs 8: raz-sched-v1)")
-    ap.add_argument("--config2-steps", type=int, default=12,
-                    help="also time this many steps of BASELINE configs[2] (8192 games, 256x10 net, 800 sims/move) on rank 0 at N=1; 0 = skip")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (configs[1], par-4 and sweep legs skipped)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args)
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is device-only; there is no CPU fallback)")
     # RAZ_BENCH_SHARED_GPU=1 (test rig only): several ranks share the visible GPUs and rendezvous over
@@ -226,181 +441,38 @@ def main():
             g.build()
         dist.barrier()
     g.build()
-    from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
-    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
 
-    F, R, V = NETS[args.net]
-    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
-    cfg = bench_config(args)
-    net = DeviceNet(blob, dev)
-    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, phase_profile=args.phase_profile,
-                         nodes_per_game=args.nodes_per_game or None,
-                         single_stream=args.no_overlap, parts=args.parts, inner_max=args.inner_max,
-                         use_graph=args.graph)
-    first_id = rank * args.games
-
-    # warm-up on a throw-away start (clocks, caches, code objects), then restart the same games
-    eng.start(first_id, args.sims)
-    eng.step(max(args.warmup, 1))
-    eng.stats()
-    eng.start(first_id, args.sims)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    steps, tree_ms, net_ms, timed_steps = 0, 0.0, 0.0, 0
-    if args.steps > 0:
-        left = args.steps
-        while left > 0:
-            n = min(args.chunk, left)
-            if (steps // args.chunk) % 8 == 0:   # sample kernel durations with HIP events 1 chunk in 8
-                a, b = eng.step_timed(n)
-                tree_ms, net_ms, timed_steps = tree_ms + a, net_ms + b, timed_steps + n
-            else:
-                eng.step(n)
-            steps, left = steps + n, left - n
-        st = eng.stats()
-    else:
-        while True:
-            if (steps // args.chunk) % 8 == 0:
-                a, b = eng.step_timed(args.chunk)
-                tree_ms, net_ms, timed_steps = tree_ms + a, net_ms + b, timed_steps + args.chunk
-            else:
-                eng.step(args.chunk)
-            steps += args.chunk
-            st = eng.stats()
-            if st["max_pool_used"] + eng.nodes_per_step * args.chunk + 64 > eng.cfg.nodes_per_game:   # prune before a pool can overflow
-                eng.gc(eng.cfg.nodes_per_game // 4)
-            if st["finished_games"] >= args.games:
-                break
-            if steps > 80 * args.sims * 4 + 4000:
-                raise SystemExit("engine did not finish")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    tot = torch.tensor([float(st["total_sims"]), float(st["finished_games"]), float(st["nn_leaves"]),
-                        float(st["selections"]), elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        elapsed = float(mx[4].item())
-    total_sims, finished, leaves, selections = (float(tot[i].item()) for i in range(4))
-
-    # the single collective of the path: finished-game records -> rank 0 (timed separately)
-    t1 = time.perf_counter()
-    raw = eng.read_raw()
-    gather_bytes = 0
-    if world > 1:
-        for k in ("headers", "root_n", "n_plies", "status", "resigned", "game_id", "final_black", "final_white"):
-            t = torch.from_numpy(raw[k].view("u1").reshape(-1)).to(cdev)
-            lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-            dist.gather(t, lst, dst=0)
-            gather_bytes += t.numel() * world
-        torch.cuda.synchronize()
-    gather_s = time.perf_counter() - t1
-
-    used_graph = eng.uses_graph()
-    # standalone kernel durations (whole batch, one stream, nothing overlapping) on the opening phase,
-    # for reference beside the in-run (overlapped) numbers
-    standalone = None
-    if rank == 0 and not args.no_overlap and args.games >= 256:
-        eng.start(first_id, args.sims)
-        eng.set_parts(1)
-        eng.step(300)
-        a, b = eng.step_timed(300)
-        st1 = eng.stats()
-        standalone = {"tree_ms": a / 300, "net_ms": b / 300, "steps_sampled": "300..600 of a fresh start",
-                      "sims_per_step": st1["total_sims"] / 600.0, "leaves_per_step": st1["nn_leaves"] / 600.0,
-                      "selections_per_step": st1["selections"] / 600.0}
-        eng.set_parts(args.parts or 3)
-
-
+    res = headline_leg(args, dev, rank, world, cdev)
     if rank == 0:
-        macs = macs_per_position(F, R, V)
-        lps = 1 if (args.no_overlap or args.games < 256) else (args.parts or 3)   # launches of each kernel per step
-        per_launch_tree_bytes = (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / max(steps * lps, 1)
-        tree_avg_ms = tree_ms / max(timed_steps * lps, 1)
-        net_avg_ms = net_ms / max(timed_steps * lps, 1)
-        leaves_per_launch = leaves / world / max(steps * lps, 1)
-        net_kernel = "k_net_mfma" if F in (16, 32, 64) else ("k_conv3x3_wide+heads" if F >= 128 and F % 64 == 0 else "k_net_wave")
-        kern = {
-            "k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms, "algorithmic_bytes_per_launch": per_launch_tree_bytes,
-                       "achieved": per_launch_tree_bytes / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s"},
-            net_kernel: {"bound": "mfma", "avg_ms": net_avg_ms, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
-                           "achieved": 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12 if net_avg_ms else None,
-                           "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"},
-        }
-        for k in kern.values():
-            k["frac"] = (k["achieved"] / k["peak"]) if k["achieved"] else None
-        dom = "k_tree" if tree_avg_ms >= net_avg_ms else net_kernel
-        # HBM bytes per launch from the committed PMC passes of this same command (separate rocprofv3 --pmc runs,
-        # tools/run_profiles.sh -> tools/pmc_summary.py); only for the default workload they were collected on
-        traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc", "final2_traffic.json")
-        default_workload = (args.games, args.sims, args.net, args.share, lps, args.par) == (4096, 200, "mini", 1, 3, 1)
-        if default_workload and os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            for k in kern:
-                t = tj["kernels"].get(k)
-                if t:
-                    kern[k]["traffic"] = t["hbm_bytes_per_launch"]
-            traffic = kern[dom].get("traffic")
-            traffic_src = "profiles/r1_pmc/final2_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; per slice launch)"
-        roof = dict(kern[dom], kernel=dom, traffic=traffic, traffic_source=traffic_src)
-        roof.pop("avg_ms")
-        roof["avg_kernel_ms"] = kern[dom]["avg_ms"]
-        out = {
-            "metric": "MCTS simulations/sec (self-play, NN included)", "value": total_sims / elapsed, "unit": "sims/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 tree statistics + f32 net",
-            "data": "synthetic (random-init net of the named architecture, games from the initial position)",
-            "config": {"workload": f"{args.games} concurrent self-play games/GPU, {args.net} net (F{F} R{R} V{V}), "
-                                   f"{args.sims} sims/move, mini.yml play settings, thinking_loop=1, solver off, parallel_search_num={args.par}"
-                                   + ("" if args.steps == 0 else f", first {args.steps} steps only"),
-                       "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
-                       "share_mtcs_info_in_self_play": bool(args.share), "whole_games": args.steps == 0,
-                       "parallel_search_num": args.par,
-                       "kernel_launches_per_step": lps * 2,
-                       "overlap": f"{lps} slices on {lps} HIP streams" if lps > 1 else "single stream",
-                       "launch": "hipGraph replay (16 steps per graph)" if used_graph else "kernel by kernel"},
-            "sims_per_sec_per_gpu": total_sims / elapsed / world,
-            "games_per_hour": finished / elapsed * 3600.0 if args.steps == 0 else None,
-            "finished_games": finished, "total_sims": total_sims, "nn_leaves": leaves,
-            "mean_selections_per_sim": selections / max(total_sims, 1.0),
-            "roofline": roof, "kernels": kern,
-            "record_gather": {"seconds": gather_s, "bytes": gather_bytes, "collective": ("gather (gloo test rig, ranks share GPUs)" if shared_gpu else "gather (RCCL)") if world > 1 else "none (1 GPU): D2H read"},
-        }
-        if standalone:
-            sb = TREE_BYTES_PER_SELECTION * standalone["selections_per_step"] + TREE_BYTES_PER_SIM * standalone["sims_per_step"]
-            sf = 2.0 * macs * standalone["leaves_per_step"]
-            out["standalone_kernels"] = {
-                "note": "one launch over the whole batch on one stream, nothing overlapping (opening phase)",
-                "k_tree": {"avg_ms": standalone["tree_ms"], "achieved_GBps": sb / (standalone["tree_ms"] * 1e-3) / 1e9,
-                           "frac_of_hbm_peak": sb / (standalone["tree_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                net_kernel: {"avg_ms": standalone["net_ms"], "achieved_TFLOPs": sf / (standalone["net_ms"] * 1e-3) / 1e12,
-                             "frac_of_f32_mfma_peak": sf / (standalone["net_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
-            out["sustained_in_timed_region"] = {
-                "net_TFLOPs": 2.0 * macs * leaves / world / elapsed / 1e12,
-                "tree_algorithmic_GBps": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / elapsed / 1e9}
-        if args.phase_profile:
-            pp = eng.phase_profile()
-            launches = max(pp["active_launches"], 1)
-            out["phase_profile_ticks_per_active_game_launch"] = {k: v / launches for k, v in pp.items()}
-        if world == 1 and args.config2_steps > 0 and (args.games, args.sims, args.net, args.par) == (4096, 200, "mini", 1):
-            del eng, net   # the workspaces do not fit in HBM together
-            torch.cuda.empty_cache()
-            for key, leg in (("mini_yml_parallel_search_num_4", lambda: mini_par_leg(dev, args, 4)),
-                             ("config2_8192x800_ch5", lambda: config2_leg(dev, args.config2_steps))):
+        out, blob, cfg = res
+        if shared_gpu:
+            out["config"]["test_rig"] = "RAZ_BENCH_SHARED_GPU=1: ranks share GPUs, gloo collectives - not a scaling measurement"
+        if world == 1 and not args.no_extra_legs:
+            legs = (("config1_4096x200_mini", lambda: config1_leg(dev, args, 1)[0]),
+                    ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4)[0]),
+                    ("bitboard_sweep", lambda: sweep_leg(dev)))
+            for key, leg in legs:
                 try:
                     out[key] = leg()
+                except AssertionError:
+                    raise
                 except Exception as ex:   # never lose the main line over an extra leg
                     out[key] = {"error": repr(ex)}
+            spp = out.get("config1_4096x200_mini", {}).get("searched_plies_per_game")
+            if spp:
+                out["games_per_hour"] = out["value"] / (args.sims * spp) * 3600.0
+                out["games_per_hour_note"] = (f"extrapolated: sims/s / ({args.sims} sims/move x {spp:.2f} searched plies/game, the figure "
+                                              "measured on the whole-game configs[1] leg of this run); a whole batch is ~50 000 steps")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, blob, args.sims, args.cpu_games)
+            threads = min(os.cpu_count() or 1, 128)
+            per_thread = 6 if args.net == "ch5" else 400
+            out["cpu_baseline"] = cpu_baseline_port(
+                cfg, blob, per_thread, threads, stop_after_plies=2,
+                what=f"same workload (net, play settings), bounded sample: the first {per_thread} simulations of the first searched move of "
+                     f"{threads} games")
+            ref = committed_reference_baseline()
+            if ref:
+                out["cpu_baseline_reference_python"] = ref
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

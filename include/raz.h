@@ -247,6 +247,26 @@ int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* root_n, doub
                             uint32_t* n_plies, uint8_t* status, uint8_t* resigned,
                             uint32_t* game_id, uint8_t* enable_resign, uint64_t* final_black,
                             uint64_t* final_white, raz_stream_t stream);
+/* The unit of the record gather ("gather of finished-game records to rank 0"): the records of slots
+ * [first_slot, first_slot + n_slots), cut to `plies` plies per game (raz_engine_records_extent gives the largest
+ * n_plies; unused plies are zero), packed device-to-device into dense caller arrays that a collective can move as
+ * they are: d_headers n_slots*plies*48 bytes, d_root_n n_slots*plies*64 u32, d_summary n_slots raz_game_summary.
+ * Asynchronous on `stream`. */
+typedef struct {
+    uint64_t final_black, final_white;  /* the board when the game ended */
+    uint32_t game_id, n_plies;
+    uint8_t status;                     /* winner | flags, as raz_env_step */
+    uint8_t resigned_black, resigned_white, enable_resign;
+    uint32_t reserved;
+} raz_game_summary;                     /* 32 bytes */
+int raz_engine_records_extent(raz_engine* e, uint32_t first_slot, uint32_t n_slots, uint32_t* max_plies,
+                              raz_stream_t stream);   /* synchronises `stream` */
+int raz_engine_pack_records(raz_engine* e, uint32_t first_slot, uint32_t n_slots, uint32_t plies, void* d_headers,
+                            uint32_t* d_root_n, raz_game_summary* d_summary, raz_stream_t stream);
+/* config.play.resign_threshold is mutated while the worker runs (worker/self_play.py:250-260: +-0.01 per 100
+ * no-resign test games); moves decided from the next raz_engine_step on use the new value.  Trees, records and
+ * random streams are untouched. */
+int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold, double threshold);
 /* The play_*.json text of ONE finished game, natively: the rows SelfPlayWorker.save_play_data appends for it
  * (worker/self_play.py:180-194: black.moves + white.moves; agent/player.py:166-179: 8 symmetric rows
  * [[own, enemy], [64 floats]] per searched ply, :357-364: z appended; saved policy per :132,366-385), as the

@@ -108,7 +108,7 @@ def injected(stream):
          rp.ReversiPlayer.__init__) = saved
 
 
-def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False, carry=None):
+def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False, carry=None, api=None):
     """One game through the reference's SelfPlayWorker.start_game.  Returns a dict with per-ply
     captures (root N/W, action, n, q, emitted rows) and the play_*.json content the reference wrote.
     carry (dict, optional): holds the worker's MCTSInfo from call to call, the way SelfPlayWorker.start
@@ -130,7 +130,7 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
     config.play.schedule_of_simulation_num_per_move = [(0, sims_per_move)]
     config.play_data.nb_game_in_file = 1
     stream = GameStream(seed, game_id)
-    api = OracleNetAPI(blob)
+    api = api if api is not None else OracleNetAPI(blob)
     plies = []
     orig_awe = rp.ReversiPlayer.action_with_evaluation
 

@@ -107,6 +107,9 @@ SIGNATURES.update({
     "raz_engine_stats_sync": (c_int, [c_void_p, POINTER(RazEngineStats), c_void_p]),
     "raz_engine_read_records": (c_int, [c_void_p] * 11 + [c_void_p]),
     "raz_engine_device_ptr": (c_void_p, [c_void_p, c_int]),
+    "raz_engine_records_extent": (c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint32), c_void_p]),
+    "raz_engine_pack_records": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "raz_engine_set_resign_threshold": (c_int, [c_void_p, c_int, ctypes.c_double]),
 })
 
 for _name, (_res, _args) in SIGNATURES.items():

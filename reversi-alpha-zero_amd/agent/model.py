@@ -140,10 +140,93 @@ def macs_per_position(F, R, V):
     return 64 * (F * 18 + R * 2 * F * F * 9 + 2 * F + F) + 128 * 64 + 64 * V + V
 
 
+# ---- weight interchange with the reference's Keras files --------------------------------------------------------
+# The reference stores model_*_weight.h5 (Keras 2.1 save_weights, HDF5) + a model config JSON (agent/model.py:82-101).
+# h5py is not available to this package, so the interchange format is a Keras-NAMED .npz: one array per Keras weight,
+# key "<layer name>/<weight name>" exactly as `w.name` gives it on the reference side (e.g. "conv2d_3/kernel:0",
+# "batch_normalization_3/moving_variance:0", "policy_out/bias:0"), arrays in Keras layouts (Conv2D kernel (kh, kw, in,
+# out), Dense kernel (in, out)).  tools/keras_npz_bridge.py - run where keras + h5py exist - converts h5 <-> npz in
+# three lines each way.  Layers are identified by kind, creation number (the numeric suffix Keras appends; any offset)
+# and shape, never by absolute names.
+def _suffix(name):
+    import re
+    m = re.search(r"_(\d+)$", name)
+    return int(m.group(1)) if m else 0
+
+
+def keras_named_arrays(net):
+    """ReversiNet -> {keras weight name: array} in Keras layouts, layers named as a fresh Keras session names them
+    for agent/model.py:28-58 (conv2d_1.., batch_normalization_1.., dense_1, policy_out, value_out)."""
+    out = {}
+    convbns = [net.stem] + [c for blk in net.res for c in blk] + [net.policy_conv, net.value_conv]
+    for i, cb in enumerate(convbns, start=1):
+        out[f"conv2d_{i}/kernel:0"] = cb.conv.weight.detach().permute(2, 3, 1, 0).contiguous().numpy()
+        out[f"conv2d_{i}/bias:0"] = cb.conv.bias.detach().numpy()
+        out[f"batch_normalization_{i}/gamma:0"] = cb.bn.weight.detach().numpy()
+        out[f"batch_normalization_{i}/beta:0"] = cb.bn.bias.detach().numpy()
+        out[f"batch_normalization_{i}/moving_mean:0"] = cb.bn.running_mean.detach().numpy()
+        out[f"batch_normalization_{i}/moving_variance:0"] = cb.bn.running_var.detach().numpy()
+    for name, lin in (("policy_out", net.policy_fc), ("dense_1", net.value_fc1), ("value_out", net.value_fc2)):
+        out[f"{name}/kernel:0"] = lin.weight.detach().t().contiguous().numpy()
+        out[f"{name}/bias:0"] = lin.bias.detach().numpy()
+    return out
+
+
+def net_from_keras_named_arrays(arrays):
+    """{keras weight name: array} -> ReversiNet.  Raises ValueError naming what is missing or mis-shaped."""
+    layers = {}
+    for key, a in arrays.items():
+        lname, _, wname = key.partition("/")
+        layers.setdefault(lname, {})[wname.split(":")[0].split("/")[-1]] = np.asarray(a)
+    convs = sorted((n for n in layers if "kernel" in layers[n] and layers[n]["kernel"].ndim == 4), key=_suffix)
+    bns = sorted((n for n in layers if "moving_variance" in layers[n]), key=_suffix)
+    denses = [n for n in layers if "kernel" in layers[n] and layers[n]["kernel"].ndim == 2]
+    if len(convs) < 3 or len(convs) != len(bns) or (len(convs) - 3) % 2 or len(denses) != 3:
+        raise ValueError(f"not a reversi_zero model: {len(convs)} conv, {len(bns)} batch-norm, {len(denses)} dense layers")
+    F, ks = layers[convs[0]]["kernel"].shape[3], layers[convs[0]]["kernel"].shape[0]
+    R = (len(convs) - 3) // 2
+    heads = convs[-2:]
+    pol_conv = next((n for n in heads if layers[n]["kernel"].shape[3] == 2), None)
+    val_conv = next((n for n in heads if layers[n]["kernel"].shape[3] == 1), None)
+    if pol_conv is None or val_conv is None:
+        raise ValueError("policy (2 filters) / value (1 filter) head convolutions not found")
+    bn_of = dict(zip(convs, bns))   # Keras creates each BatchNormalization right after its Conv2D: same order
+    pol_fc = next((n for n in denses if layers[n]["kernel"].shape == (128, 64)), None)
+    v2 = next((n for n in denses if layers[n]["kernel"].shape[1] == 1), None)
+    v1 = next((n for n in denses if n not in (pol_fc, v2)), None)
+    if pol_fc is None or v1 is None or v2 is None or layers[v1]["kernel"].shape[0] != 64:
+        raise ValueError("dense layers 128->64 (policy), 64->V, V->1 (value) not found")
+    V = layers[v1]["kernel"].shape[1]
+    net = ReversiNet(F, R, V, ks)
+    convbns = [net.stem] + [c for blk in net.res for c in blk]
+    with torch.no_grad():
+        for cb, cname in list(zip(convbns, convs[:-2])) + [(net.policy_conv, pol_conv), (net.value_conv, val_conv)]:
+            L, B = layers[cname], layers[bn_of[cname]]
+            k = torch.from_numpy(np.ascontiguousarray(L["kernel"], dtype=np.float32)).permute(3, 2, 0, 1)
+            if tuple(k.shape) != tuple(cb.conv.weight.shape):
+                raise ValueError(f"{cname}: kernel shape {tuple(L['kernel'].shape)} does not fit {tuple(cb.conv.weight.shape)}")
+            cb.conv.weight.copy_(k)
+            cb.conv.bias.copy_(torch.from_numpy(np.asarray(L["bias"], dtype=np.float32)))
+            cb.bn.weight.copy_(torch.from_numpy(np.asarray(B["gamma"], dtype=np.float32)))
+            cb.bn.bias.copy_(torch.from_numpy(np.asarray(B["beta"], dtype=np.float32)))
+            cb.bn.running_mean.copy_(torch.from_numpy(np.asarray(B["moving_mean"], dtype=np.float32)))
+            cb.bn.running_var.copy_(torch.from_numpy(np.asarray(B["moving_variance"], dtype=np.float32)))
+        for lin, name in ((net.policy_fc, pol_fc), (net.value_fc1, v1), (net.value_fc2, v2)):
+            lin.weight.copy_(torch.from_numpy(np.ascontiguousarray(layers[name]["kernel"], dtype=np.float32)).t())
+            lin.bias.copy_(torch.from_numpy(np.asarray(layers[name]["bias"], dtype=np.float32)))
+    return net.eval()
+
+
+HDF5_MAGIC = b"\x89HDF\r\n\x1a\n"
+NPZ_MAGIC = b"PK"
+
+
 class ReversiModel:
-    """Same role and method names as the reference's ReversiModel (agent/model.py:22-101).
-    `self.model` is the torch module.  load/save use a JSON config + torch state-dict file (the
-    reference's Keras h5 files need h5py, absent here: interchange is a listed follow-up)."""
+    """Same role and method names as the reference's ReversiModel (agent/model.py:22-101).  `self.model` is the torch
+    module.  Weight files, told apart by their first bytes whatever the (reference-fixed) file name says:
+      * a Keras-named .npz (see above): the interchange format with the reference's opt / eval workers;
+      * a torch state-dict (what save() wrote before the bridge existed);
+      * a Keras HDF5 file -> ValueError telling the operator to run tools/keras_npz_bridge.py (no h5py here)."""
 
     def __init__(self, config):
         self.config = config
@@ -164,21 +247,47 @@ class ReversiModel:
             return m.hexdigest()
 
     def load(self, config_path, weight_path):
-        if os.path.exists(config_path) and os.path.exists(weight_path):
+        if not (os.path.exists(config_path) and os.path.exists(weight_path)):
+            return False
+        with open(weight_path, "rb") as f:
+            magic = f.read(8)
+        if magic == HDF5_MAGIC:
+            raise ValueError(f"{weight_path} is a Keras HDF5 weight file; this package reads the Keras-named .npz bridge "
+                             f"format instead (h5py is not available here): convert it where keras is installed with "
+                             f"`python tools/keras_npz_bridge.py h5-to-npz {config_path} {weight_path} {weight_path}`")
+        if magic[:2] == NPZ_MAGIC and not _is_torch_zip(weight_path):
+            with np.load(weight_path) as z:
+                self.model = net_from_keras_named_arrays({k: z[k] for k in z.files})
+        else:
             with open(config_path, "rt") as f:
                 c = json.load(f)
-            self.model = ReversiNet(c["cnn_filter_num"], c["res_layer_num"], c["value_fc_size"],
-                                    c.get("cnn_filter_size", 3))
+            if "cnn_filter_num" not in c:
+                raise ValueError(f"{config_path} is a Keras model config but {weight_path} is not a Keras-named .npz")
+            self.model = ReversiNet(c["cnn_filter_num"], c["res_layer_num"], c["value_fc_size"], c.get("cnn_filter_size", 3))
             self.model.load_state_dict(torch.load(weight_path, map_location="cpu"))
             self.model.eval()
-            self.digest = self.fetch_digest(weight_path)
-            return True
-        return False
+        self.digest = self.fetch_digest(weight_path)
+        return True
 
     def save(self, config_path, weight_path):
+        """Config JSON (the architecture numbers; the reference's Keras get_config() dump is rebuilt by the bridge
+        script from them) + the Keras-named .npz under the reference's file name."""
         m = self.model
         with open(config_path, "wt") as f:
             json.dump({"cnn_filter_num": m.filters, "res_layer_num": m.res_layers,
-                       "value_fc_size": m.value_fc, "cnn_filter_size": m.filter_size}, f)
-        torch.save(m.state_dict(), weight_path)
+                       "value_fc_size": m.value_fc, "cnn_filter_size": m.filter_size,
+                       "format": "keras-named npz (reversi_alpha_zero_amd.agent.model)"}, f)
+        tmp = weight_path + ".tmp.npz"
+        np.savez(tmp, **keras_named_arrays(m))
+        os.replace(tmp, weight_path)   # readers poll the digest (api.py:117-125): never expose a half-written file
         self.digest = self.fetch_digest(weight_path)
+
+
+def _is_torch_zip(path):
+    """torch.save also writes a zip archive: it holds a `*/data.pkl` member, an .npz holds only `*.npy` members."""
+    import zipfile
+    try:
+        with zipfile.ZipFile(path) as z:
+            return any(n.endswith("data.pkl") for n in z.namelist())
+    except zipfile.BadZipFile:
+        return False

@@ -1630,7 +1630,7 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.M = cfg.solver_memo_slots;
     d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
     d.gc_remap = (uint32_t*)take(B * C * 4);
-    d.counters = (unsigned long long*)take(8 * 8);
+    d.counters = (unsigned long long*)take(16 * 8);
     d.node_out = take(RAZ_NODE_BYTES + 64);
     d.prof = (unsigned long long*)take(B * 8 * 8);
     if (E) *E = d;
@@ -1846,7 +1846,7 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_start: clear solver memo");
-    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_start: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 128, s), "raz_engine_start: clear counters");
     if (d.par) {
         RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_start: clear simulation slots");
         RAZ_HIP_TRY(hipMemsetAsync(d.nn_active, 0, (size_t)d.B * d.K, s), "raz_engine_start: clear leaf flags");
@@ -1872,7 +1872,7 @@ extern "C" int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const
     RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)d.B * 4, hipMemcpyHostToDevice, s), "raz_engine_next_game: copy sims");
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_next_game: sync");  // host array may be transient
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_next_game: clear solver memo");
-    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 64, s), "raz_engine_next_game: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 128, s), "raz_engine_next_game: clear counters");
     if (d.par) {
         RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_next_game: clear simulation slots");
         RAZ_HIP_TRY(hipMemsetAsync(d.nn_active, 0, (size_t)d.B * d.K, s), "raz_engine_next_game: clear leaf flags");
@@ -2187,6 +2187,87 @@ extern "C" int raz_engine_read_records(raz_engine* e, void* headers, uint32_t* r
         if (final_black) final_black[g] = G.root_black;
         if (final_white) final_white[g] = G.root_white;
     }
+    return RAZ_OK;
+}
+
+namespace {
+// The largest n_plies over the slots [g0, g0 + n): one block.
+__global__ __launch_bounds__(256) void k_records_extent(raz_engine_dev E, uint32_t g0, uint32_t n, uint32_t* out) {
+    __shared__ uint32_t sh[256];
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t p = E.game[g0 + i].n_plies;
+        m = p > m ? p : m;
+    }
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] > sh[threadIdx.x + s] ? sh[threadIdx.x] : sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+// Records of slot g0 + blockIdx.x, cut to `plies` plies, into dense caller arrays (the unit of the record gather).
+__global__ __launch_bounds__(256) void k_pack_records(raz_engine_dev E, uint32_t g0, uint32_t plies, raz_ply_header* hdr,
+                                                      uint32_t* root_n, raz_game_summary* summ) {
+    const uint32_t j = blockIdx.x, g = g0 + j;
+    const raz_game& G = E.game[g];
+    const uint32_t np = G.n_plies < plies ? G.n_plies : plies;
+    const uint32_t* hs = (const uint32_t*)(E.rec + (size_t)g * E.max_plies);
+    uint32_t* hd = (uint32_t*)(hdr + (size_t)j * plies);
+    for (uint32_t i = threadIdx.x; i < plies * 12; i += 256) hd[i] = i < np * 12 ? hs[i] : 0u;
+    const uint32_t* ns = E.rec_n + (size_t)g * E.max_plies * 64;
+    uint32_t* nd = root_n + (size_t)j * plies * 64;
+    for (uint32_t i = threadIdx.x; i < plies * 64; i += 256) nd[i] = i < np * 64 ? ns[i] : 0u;
+    if (threadIdx.x == 0) {
+        raz_game_summary S;
+        S.final_black = G.root_black;
+        S.final_white = G.root_white;
+        S.game_id = G.game_id;
+        S.n_plies = G.n_plies;
+        S.status = (uint8_t)G.status;
+        S.resigned_black = (uint8_t)G.resigned[0];
+        S.resigned_white = (uint8_t)G.resigned[1];
+        S.enable_resign = (uint8_t)G.enable_resign;
+        S.reserved = 0;
+        summ[j] = S;
+    }
+}
+}  // namespace
+
+extern "C" int raz_engine_records_extent(raz_engine* e, uint32_t first_slot, uint32_t n_slots, uint32_t* max_plies,
+                                         raz_stream_t stream) {
+    if (!e || !max_plies) return raz_fail(RAZ_EINVAL, "raz_engine_records_extent: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_records_extent: call raz_engine_start first");
+    if ((size_t)first_slot + n_slots > e->dev.B) return raz_fail(RAZ_EINVAL, "raz_engine_records_extent: slot range");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* d = (uint32_t*)(e->dev.counters + 15);
+    hipLaunchKernelGGL(k_records_extent, dim3(1), dim3(256), 0, s, e->dev, first_slot, n_slots, d);
+    int rc = raz_check_launch("raz_engine_records_extent");
+    if (rc != RAZ_OK) return rc;
+    RAZ_HIP_TRY(hipMemcpyAsync(max_plies, d, 4, hipMemcpyDeviceToHost, s), "raz_engine_records_extent: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_records_extent: sync");
+    return RAZ_OK;
+}
+
+extern "C" int raz_engine_pack_records(raz_engine* e, uint32_t first_slot, uint32_t n_slots, uint32_t plies,
+                                       void* d_headers, uint32_t* d_root_n, raz_game_summary* d_summary,
+                                       raz_stream_t stream) {
+    if (!e || !d_headers || !d_root_n || !d_summary) return raz_fail(RAZ_EINVAL, "raz_engine_pack_records: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_pack_records: call raz_engine_start first");
+    if ((size_t)first_slot + n_slots > e->dev.B || plies == 0 || plies > e->dev.max_plies)
+        return raz_fail(RAZ_EINVAL, "raz_engine_pack_records: slot range / plies");
+    if (n_slots == 0) return RAZ_OK;
+    hipLaunchKernelGGL(k_pack_records, dim3(n_slots), dim3(256), 0, (hipStream_t)stream, e->dev, first_slot, plies,
+                       (raz_ply_header*)d_headers, d_root_n, d_summary);
+    return raz_check_launch("raz_engine_pack_records");
+}
+
+extern "C" int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold, double threshold) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_resign_threshold: NULL engine");
+    e->dev.cfg.has_resign_threshold = has_threshold ? 1 : 0;
+    e->dev.cfg.resign_threshold = threshold;
+    drop_graph(e);   // a captured graph holds the old parameter block
     return RAZ_OK;
 }
 

@@ -134,7 +134,10 @@ class SelfPlayEngine:
         self.workspace_bytes = nbytes
         self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         base = (self._ws.data_ptr() + 255) // 256 * 256
-        sp, sb = net.scratch(n_games * self.slots)
+        # the engine's own net scratch: DeviceNet.scratch() may re-allocate its buffer for a later, larger predict call
+        need = lib.raz_net_scratch_bytes(net.filters, net.value_fc, n_games * self.slots)
+        self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device) if need else None
+        sp, sb = (self._scratch.data_ptr(), need) if need else (None, 0)
         self._h = ctypes.c_void_p()
         check(lib.raz_engine_create(ctypes.byref(self.cfg), ctypes.byref(net.c), base, nbytes, sp, sb,
                                     ctypes.byref(self._h)), "raz_engine_create")
@@ -242,6 +245,31 @@ class SelfPlayEngine:
                   "raz_engine_read_node")
         return bool(found.value), w, n, p
 
+    def set_resign_threshold(self, threshold):
+        """config.play.resign_threshold changed (worker/self_play.py:250-260); None = no resignation rule."""
+        check(lib.raz_engine_set_resign_threshold(self._h, int(threshold is not None),
+                                                  float(threshold if threshold is not None else 0.0)),
+              "raz_engine_set_resign_threshold")
+
+    def pack_records(self, first_slot=0, n_slots=None, plies=None):
+        """The records of slots [first_slot, first_slot + n_slots) cut to `plies` plies (None: the largest n_plies
+        among them), as dense DEVICE tensors (uint8 views) a collective can move as they are (include/raz.h
+        raz_engine_pack_records): {"headers": [n, plies, 48] u8, "root_n": [n, plies, 64] i32, "summary": [n, 32] u8}."""
+        import torch
+        n = self.n_games - first_slot if n_slots is None else n_slots
+        with torch.cuda.device(self.device):
+            if plies is None:
+                mp = ctypes.c_uint32(0)
+                check(lib.raz_engine_records_extent(self._h, first_slot, n, ctypes.byref(mp), _stream()),
+                      "raz_engine_records_extent")
+                plies = max(1, mp.value)
+            hdr = torch.empty((n, plies, 48), dtype=torch.uint8, device=self.device)
+            rn = torch.empty((n, plies, 64), dtype=torch.int32, device=self.device)
+            sm = torch.empty((n, 32), dtype=torch.uint8, device=self.device)
+            check(lib.raz_engine_pack_records(self._h, first_slot, n, plies, hdr.data_ptr(), rn.data_ptr(),
+                                              sm.data_ptr(), _stream()), "raz_engine_pack_records")
+        return {"headers": hdr, "root_n": rn, "summary": sm}
+
     def gc(self, threshold=0):
         """Prune unreachable nodes in every game whose pool holds >= threshold nodes."""
         import torch
@@ -312,6 +340,24 @@ class SelfPlayEngine:
                                 "resigned_black": int(raw["resigned"][g, 0]), "resigned_white": int(raw["resigned"][g, 1]),
                                 "black": int(raw["final_black"][g]), "white": int(raw["final_white"][g])}))
         return out
+
+
+GAME_SUMMARY = np.dtype([("final_black", "<u8"), ("final_white", "<u8"), ("game_id", "<u4"), ("n_plies", "<u4"),
+                         ("status", "u1"), ("resigned_black", "u1"), ("resigned_white", "u1"), ("enable_resign", "u1"),
+                         ("reserved", "<u4")])
+assert GAME_SUMMARY.itemsize == 32
+
+
+def raw_from_packed(headers_u8, root_n_i32, summary_u8):
+    """Host numpy views of packed record arrays (SelfPlayEngine.pack_records, possibly concatenated over ranks)
+    in the dict shape SelfPlayEngine.read_raw returns (minus root_w)."""
+    hdr = np.ascontiguousarray(headers_u8).view(PLY_HEADER).reshape(headers_u8.shape[0], headers_u8.shape[1])
+    sm = np.ascontiguousarray(summary_u8).view(GAME_SUMMARY).reshape(-1)
+    return dict(headers=hdr, root_n=np.ascontiguousarray(root_n_i32).view(np.uint32), root_w=None,
+                n_plies=sm["n_plies"].copy(), status=sm["status"].copy(),
+                resigned=np.stack([sm["resigned_black"], sm["resigned_white"]], axis=1),
+                game_id=sm["game_id"].copy(), enable_resign=sm["enable_resign"].copy(),
+                final_black=sm["final_black"].copy(), final_white=sm["final_white"].copy())
 
 
 def saved_policy(root_n, turn, change_tau_turn, save_policy_of_tau_1):

@@ -154,6 +154,36 @@ def gather_raw(raw, rank, world, device=None):
     return out if rank == 0 else None
 
 
+def gather_packed(packed, rank, world):
+    """The single collective of the path, device side: every rank's packed record tensors
+    (SelfPlayEngine.pack_records: dense, cut to the games' plies) gathered on rank 0 straight from HBM - RCCL over
+    xGMI under the nccl backend; under gloo (CPU test rig) the tensors are staged through host memory - and
+    concatenated in rank order = global game id order.  One all_reduce(MAX) of the ply extent first, so that every
+    rank packs to the same shape.  Returns (raw dict in read_raw's shape, bytes moved) on rank 0, (None, bytes) elsewhere.
+    `packed` is a callable plies -> dict so the pack happens once, at the common extent."""
+    import torch
+    import torch.distributed as dist
+    from ..engine import raw_from_packed
+    backend = dist.get_backend()
+    first = packed(None)
+    dev = first["headers"].device if backend == "nccl" else torch.device("cpu")
+    ext = torch.tensor([first["headers"].shape[1]], dtype=torch.int64, device=dev)
+    dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+    plies = int(ext.item())
+    pk = first if plies == first["headers"].shape[1] else packed(plies)
+    out, moved = {}, 0
+    for k in ("headers", "root_n", "summary"):
+        t = pk[k].contiguous().to(dev)
+        lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, lst, dst=0)
+        moved += t.numel() * t.element_size() * (world - 1)
+        if rank == 0:
+            out[k] = torch.cat(lst, dim=0).cpu().numpy()
+    if rank != 0:
+        return None, moved
+    return raw_from_packed(out["headers"], out["root_n"], out["summary"]), moved
+
+
 class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
@@ -176,6 +206,11 @@ class BatchedSelfPlayWorker:
         # reset_mtcs_info_per_game consecutive games (mini.yml: 3).  Here a "worker" is a game slot: the games a
         # slot plays in consecutive play_batch calls form such a series on the slot's device tree.
         self._series_pos = 0
+        # The reference steps the threshold after every 100 no-resign test games of ONE process playing one game at a
+        # time (self_play.py:250-260).  A batch finishes thousands of games that were all played under the SAME
+        # threshold: stepping once per 100 of them would multiply the control gain by the batch size, so the emitters
+        # defer the check and apply it once per emitted batch (>= 100 test games accumulated, as in the reference).
+        self._defer_threshold_update = False
 
     # -- engine life cycle -------------------------------------------------------------------
     def _series_length(self):
@@ -190,7 +225,9 @@ class BatchedSelfPlayWorker:
 
     def _get_engine(self, max_sims):
         from ..engine import DeviceNet, SelfPlayEngine
-        key = (max_sims, self.config.play.resign_threshold, self.config.play.thinking_loop)
+        # (resign_threshold is a run-time parameter of the engine - raz_engine_set_resign_threshold - not part of
+        #  its identity: the reference keeps mtcs_info across threshold updates, worker/self_play.py:250-260)
+        key = (max_sims, self.config.play.thinking_loop)
         if self._net is None:
             self._net = DeviceNet(self.net_blob, self.device)
         if self._engine is None or self._engine_key != key:
@@ -204,6 +241,7 @@ class BatchedSelfPlayWorker:
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes)
             self._engine_key = key
+        self._engine.set_resign_threshold(self.config.play.resign_threshold)
         return self._engine
 
     def play_batch(self, first_game_idx, n_games=None):
@@ -224,9 +262,10 @@ class BatchedSelfPlayWorker:
         self.last_stats = stats
         return recs
 
-    def play_batch_raw(self, first_game_idx, n_games=None):
+    def play_batch_raw(self, first_game_idx, n_games=None, device_records=False):
         """play_batch without the per-ply Python objects: the engine's record arrays (SelfPlayEngine.read_raw),
-        cut to the n games played."""
+        cut to the n games played.  device_records: leave the records in HBM and return (engine, n) - the caller
+        packs / gathers them there (run())."""
         n = self.games_in_flight if n_games is None else n_games
         base = first_game_idx + self.rank * self.games_in_flight
         sims = np.array([decide_simulation_num_per_move(self.config, base + i) for i in range(self.games_in_flight)],
@@ -239,6 +278,8 @@ class BatchedSelfPlayWorker:
             eng.next_game(base, sims, n_active=n)
         self.last_stats = eng.run(allow_gc=(r == 1))
         self._series_pos = (self._series_pos + 1) % r
+        if device_records:
+            return eng, n
         raw = eng.read_raw()
         return {k: raw[k][:n] for k in RAW_KEYS}
 
@@ -256,6 +297,7 @@ class BatchedSelfPlayWorker:
         with cf.ThreadPoolExecutor(max_workers=threads or min(32, os.cpu_count() or 1)) as ex:
             frags = list(ex.map(frag, range(n)))
         paths = []
+        self._defer_threshold_update = True
         for g in range(n):
             local_idx = first_local_idx + g
             gid = int(raw["game_id"][g])
@@ -277,6 +319,8 @@ class BatchedSelfPlayWorker:
             if pd.enable_ggf_data:
                 self.save_ggf_data(plies_for_ggf(raw["headers"][g], raw["n_plies"][g]),
                                    write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
+        self._defer_threshold_update = False
+        self.check_and_update_resignation_threshold()
         return paths
 
     # -- bookkeeping identical to the reference worker ---------------------------------------------
@@ -293,7 +337,8 @@ class BatchedSelfPlayWorker:
             self.resign_test_game_count += 1
             if fp:
                 self.false_positive_count_of_resign += 1
-            self.check_and_update_resignation_threshold()
+            if not self._defer_threshold_update:
+                self.check_and_update_resignation_threshold()
 
     def check_and_update_resignation_threshold(self):
         pc = self.config.play
@@ -351,6 +396,7 @@ class BatchedSelfPlayWorker:
         """Write one batch of finished games the way the reference loop would, game by game."""
         pd = self.config.play_data
         paths = []
+        self._defer_threshold_update = True
         for k, (plies, summary) in enumerate(records):
             local_idx = first_local_idx + k
             self.finish_game(summary)
@@ -360,29 +406,54 @@ class BatchedSelfPlayWorker:
             self.remove_play_data()
             if pd.enable_ggf_data:
                 self.save_ggf_data(plies, write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
+        self._defer_threshold_update = False
+        self.check_and_update_resignation_threshold()
         return paths
 
-    def run(self, total_games=None):
-        """_start (self_play.py:95-137): play batches until total_games (None = forever)."""
+    def run(self, total_games=None, reload_model=None):
+        """_start (self_play.py:95-137): play batches until total_games (None = forever).
+        Per batch: every rank plays its id range; the finished games' records are packed in HBM and gathered on
+        rank 0 (the path's single collective), which writes the files, does the resignation bookkeeping and
+        broadcasts what every rank needs for the next batch: the game index and the resign threshold (so that all
+        ranks keep playing under the same rule and results stay independent of the sharding).
+        reload_model (optional): callable returning a new net blob or None, polled between batches (api.py:117-125)."""
         import torch.distributed as dist
+        from ..engine import raw_from_packed
         rc = self.config.resource
         if self.rank == 0:
             rc.create_directories()
         game_idx = read_as_int(rc.self_play_game_idx_file) or 0
         local_idx = 1
         while total_games is None or local_idx <= total_games:
-            raw = self.play_batch_raw(game_idx)
-            allraw = gather_raw(raw, self.rank, self.world) if self.world > 1 else raw
+            eng, n = self.play_batch_raw(game_idx, device_records=True)
+            if self.world > 1:
+                allraw, _ = gather_packed(lambda plies: eng.pack_records(0, n, plies), self.rank, self.world)
+            else:
+                pk = eng.pack_records(0, n)
+                allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
             if self.rank == 0:
                 self.emit_raw(allraw, local_idx)
                 game_idx += len(allraw["n_plies"])
                 with open(rc.self_play_game_idx_file, "wt") as f:
                     f.write(str(game_idx))
             if self.world > 1:
-                t = [game_idx]
+                t = [game_idx, self.config.play.resign_threshold]
                 dist.broadcast_object_list(t, src=0)
-                game_idx = t[0]
+                game_idx, self.config.play.resign_threshold = t
             local_idx += self.games_in_flight * self.world
+            if reload_model is not None:
+                blob = reload_model()
+                if blob is not None:   # every rank polls the same files: the digest decides
+                    self.set_net_blob(blob)
+
+    def set_net_blob(self, blob):
+        """A new generation of weights between two batches (agent/api.py:117-125 try_reload_model): the engine is
+        rebuilt on the new net at the next batch (a tree searched with the old priors is not carried over)."""
+        self.net_blob = blob
+        self._net = None
+        self._engine = None
+        self._engine_key = None
+        self._series_pos = 0
 
 
 # ---- the single collective: finished-game records -> rank 0 ------------------------------------------
@@ -468,6 +539,39 @@ def gather_records(records, rank, world, device=None):
     return out
 
 
+def load_model(config):
+    """MultiProcessReversiModelAPIServer.load_model (agent/api.py:102-115): the newest next-generation model or the best
+    model, in the order play.use_newest_next_generation_model asks for, unless opts.new; a fresh net is built - and saved
+    as the best model, so that the reference's opt / eval workers find one - when nothing could be loaded."""
+    from ..agent.model import ReversiModel
+    from ..lib.model_helpler import (load_best_model_weight, reload_newest_next_generation_model_if_changed,
+                                     save_as_best_model)
+    model = ReversiModel(config)
+    loaded = False
+    if not getattr(getattr(config, "opts", None), "new", False):
+        if config.play.use_newest_next_generation_model:
+            loaded = reload_newest_next_generation_model_if_changed(model) or load_best_model_weight(model)
+        else:
+            loaded = load_best_model_weight(model) or reload_newest_next_generation_model_if_changed(model)
+    if not loaded:
+        model.build()
+        save_as_best_model(model)
+    return model
+
+
+def try_reload_model(config, model):
+    """try_reload_model (agent/api.py:117-125), polled between batches instead of every 60 s: True when the weight
+    file's digest changed and the new weights were loaded."""
+    from ..lib.model_helpler import reload_best_model_weight_if_changed, reload_newest_next_generation_model_if_changed
+    try:
+        if config.play.use_newest_next_generation_model:
+            return bool(reload_newest_next_generation_model_if_changed(model))
+        return bool(reload_best_model_weight_if_changed(model))
+    except Exception as e:   # the reference logs and keeps serving the old weights
+        logger.error(e)
+        return False
+
+
 def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0):
     """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU."""
     import torch
@@ -480,13 +584,20 @@ def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0)
     torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    reload_model = None
     if net_blob is None:
-        from ..agent.model import ReversiModel
-        m = ReversiModel(config)
-        if not m.load(config.resource.model_best_config_path, config.resource.model_best_weight_path):
-            m.build()
-        net_blob = m.model.to_blob()
+        if rank == 0:
+            config.resource.create_directories()
+            model = load_model(config)       # may write the fresh best model: one rank only
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            model = load_model(config)
+        net_blob = model.model.to_blob()
+
+        def reload_model():
+            return model.model.to_blob() if try_reload_model(config, model) else None
     w = BatchedSelfPlayWorker(config, net_blob, games_in_flight or 4096, seed=seed,
                               device=f"cuda:{local}", rank=rank, world=world)
-    w.run(total_games)
+    w.run(total_games, reload_model=reload_model)
     return w

@@ -81,11 +81,25 @@ SERIES_VARIANTS = [
 ]
 
 
+# dirichlet_alpha other than the shipped 0.5 (lib/bitboard.py:162-171 np.random.dirichlet([alpha]*k)): the general
+# Gamma(alpha <= 1) sampler of raz-rng-v1 instead of the Box-Muller pairs -> mcts_alpha_games.json
+ALPHA_VARIANTS = [
+    ("agz_alpha03", "alpha_go_zero.yml", {"dirichlet_alpha": 0.3}, {}, 30, 51, [0, 3]),
+    ("ch5_alpha1_shared", "ch5.yml", {"thinking_loop": 1, "dirichlet_alpha": 1.0, "noise_eps": 0.4}, {}, 30, 52, [1]),
+    ("mini_alpha003_eps05", "mini.yml", {"reset_mtcs_info_per_game": 1, "dirichlet_alpha": 0.03, "noise_eps": 0.5}, {}, 20, 53, [2]),
+]
+
+
 def sparse(v):
     return {str(i): x for i, x in enumerate(v) if x != 0}
 
 
 def main():
+    import sys
+    if "--alpha-only" in sys.argv:
+        generate(ALPHA_VARIANTS, "mcts_alpha_games.json", virtual_time=False)
+        return
+    generate(ALPHA_VARIANTS, "mcts_alpha_games.json", virtual_time=False)
     generate(VARIANTS, "mcts_games.json", virtual_time=False)
     generate(PAR_VARIANTS, "mcts_par_games.json", virtual_time=True)
     generate(SERIES_VARIANTS, "mcts_series_games.json", virtual_time=True, series=True)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import oracle as O
-from oracle_util import load_mcts_golden, golden_net_blob, config_of, dense
+from oracle_util import load_mcts_golden, golden_net_blob, config_of, dense  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -110,6 +110,60 @@ def test_net_kernel_bitwise_vs_oracle_and_torch(shape, n):
     assert np.abs(gp.cpu().numpy() - pol).max() <= 1e-5 and np.abs(gv.cpu().numpy()[:, 0] - val).max() <= 1e-5
 
 
+def test_net_metric_shape_vs_oracle_and_torch():
+    """The shape the metric is quoted on (config.py:187-193 defaults: F=256, R=10, V=256; agent/model.py:28-72), 64
+    positions harvested from play: k_conv3x3_wide forward == the C oracle bit for bit on sampled positions, and every
+    position within 1e-5 of the fp32 torch graph on CPU and through PyTorch-ROCm (20 stacked 256-channel convolutions
+    is where f32 ordering differences accumulate)."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    net = ReversiNet(256, 10, 256).keras_init_(5).randomize_bn_(6)
+    blob = net.to_blob()
+    own, enemy = _harvested_positions(64, 3)
+    pol, val = DeviceNet(blob, DEV).predict_bitboards(torch.from_numpy(own.view(np.int64)).to(DEV),
+                                                      torch.from_numpy(enemy.view(np.int64)).to(DEV))
+    pol, val = pol.cpu().numpy(), val.cpu().numpy()
+    lib = O.load_ext()
+    for i in (0, 31, 63):   # 0.76 GMAC each on one host core
+        p = np.zeros(64, np.float32)
+        v = np.zeros(1, np.float32)
+        assert lib.orc_net_forward(blob, len(blob), int(own[i]), int(enemy[i]), p.ctypes.data, v.ctypes.data) == 0
+        assert np.array_equal(p.view(np.uint32), pol[i].view(np.uint32)) and v.view(np.uint32)[0] == val[i:i + 1].view(np.uint32)[0], i
+    bits = lambda a: ((a[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.float32)
+    x = torch.from_numpy(np.stack([bits(own), bits(enemy)], axis=1).reshape(-1, 2, 8, 8))
+    with torch.no_grad():
+        tp, tv = net(x)
+        gp, gv = net.to(DEV)(x.to(DEV))
+    ep, ev = np.abs(tp.numpy() - pol).max(), np.abs(tv.numpy()[:, 0] - val).max()
+    gep, gev = np.abs(gp.cpu().numpy() - pol).max(), np.abs(gv.cpu().numpy()[:, 0] - val).max()
+    print(f"F256 R10 V256, 64 positions: max |dp| {ep:.2e} |dv| {ev:.2e} vs torch CPU; {gep:.2e} {gev:.2e} vs torch ROCm")
+    assert ep <= 1e-5 and ev <= 1e-5 and gep <= 1e-5 and gev <= 1e-5
+
+
+def _harvested_positions(n, seed):
+    """Positions the way SURVEY 8(d) asks for them: random playouts from the start, stopped at a random ply
+    (oracle env = test infrastructure); returned from the mover's view."""
+    rng = np.random.default_rng(seed)
+    own, enemy = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    orc = O.load()
+    for i in range(n):
+        env = O.OrcEnv()
+        orc.orc_env_reset(env)
+        for _ in range(int(rng.integers(0, 58))):
+            if env.done:
+                break
+            o, e = (env.black, env.white) if env.next_player == 1 else (env.white, env.black)
+            legal = orc.orc_find_correct_moves(o, e)
+            moves = [s for s in range(64) if legal >> s & 1]
+            prev = (env.black, env.white, env.next_player)
+            orc.orc_env_step(env, int(moves[rng.integers(0, len(moves))]))
+            if env.done:   # keep the last live position
+                orc.orc_env_update(env, prev[0], prev[1], prev[2])
+                break
+        own[i], enemy[i] = (env.black, env.white) if env.next_player == 1 else (env.white, env.black)
+    return own, enemy
+
+
 def _compare_game(tag, eng_plies, eng_sum, ref_plies, ref_winner, check_w=True):
     assert [p["action"] for p in eng_plies] == [p["action"] for p in ref_plies], tag
     assert eng_sum["winner"] == ref_winner, tag
@@ -143,6 +197,46 @@ def test_engine_reproduces_reference_golden_games(golden, blob):
         _compare_game(f'{g["variant"]}/{g["game_id"]}', plies, summ, ref, g["winner"])
         assert (bool(summ["resigned_black"]), bool(summ["resigned_white"])) == (g["resigned_black"], g["resigned_white"])
         assert (summ["black"], summ["white"]) == (int(g["black"], 16), int(g["white"], 16))
+
+
+def test_engine_reproduces_reference_games_at_other_dirichlet_alphas(blob):
+    """B6 with alphas other than 0.5 (the lane-parallel rejection sampler of raz_engine.hip select_action, not the
+    Box-Muller pairs): the reference's games at dirichlet_alpha 0.3, 1.0 and 0.03 replayed bit-exactly on the device."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    alpha = load_mcts_golden("mcts_alpha_games.json")
+    dnet = DeviceNet(blob, DEV)
+    seen = set()
+    for g in alpha["games"]:
+        cfg = config_of(g)
+        seen.add(cfg.play.dirichlet_alpha)
+        eng = SelfPlayEngine(cfg, dnet, n_games=1, seed=g["seed"], sims_hint=g["sims_per_move"], record_root_w=True)
+        eng.start(first_game_id=g["game_id"], sims_per_move=g["sims_per_move"])
+        eng.run(chunk=256)
+        (plies, summ), = eng.records(save_policy_of_tau_1=g["resolved_play_data"]["save_policy_of_tau_1"])
+        ref = [dict(p, own=int(p["own"], 16), enemy=int(p["enemy"], 16), root_n=dense(p["root_n"]),
+                    root_w=dense(p["root_w"]), saved_policy=dense(p["saved_policy"]) if p["has_row"] else None)
+               for p in g["plies"]]
+        _compare_game(f'{g["variant"]}/{g["game_id"]}', plies, summ, ref, g["winner"])
+        assert (summ["black"], summ["white"]) == (int(g["black"], 16), int(g["white"], 16))
+    assert seen == {0.3, 1.0, 0.03}
+
+
+@pytest.mark.parametrize("alpha,eps", [(0.3, 0.25), (1.0, 0.25), (0.03, 0.5), (0.75, 0.1)])
+def test_engine_batch_vs_oracle_at_other_dirichlet_alphas(golden, blob, alpha, eps):
+    """40 concurrent games per alpha (shared tree, ch5-like settings) == the oracle's games, bit for bit."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    g0 = next(g for g in golden["games"] if g["variant"] == "mini_shared")
+    cfg = config_of(g0)
+    cfg.play.dirichlet_alpha, cfg.play.noise_eps = alpha, eps
+    n, sims = 40, 22
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, DEV), n_games=n, seed=61, sims_hint=sims, record_root_w=True)
+    eng.start(first_game_id=3000, sims_per_move=sims)
+    eng.run(chunk=128)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg)
+    for i in range(0, n, 2):
+        plies, summ = O.selfplay_game(ocfg, blob, 61, 3000 + i, sims)
+        _compare_game(f"alpha{alpha}/{3000 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
 @pytest.mark.parametrize("variant", ["agz", "mini_shared"])

@@ -83,6 +83,16 @@ def test_games_bit_exact_vs_reference(golden, blob):
     check_games_bit_exact(golden, blob)
 
 
+def test_dirichlet_alpha_games_bit_exact_vs_reference(blob):
+    """dirichlet_alpha 0.3, 1.0 and 0.03 (lib/bitboard.py:162-171 with alphas other than the shipped 0.5: the general
+    Gamma(alpha <= 1) sampler of raz-rng-v1, not the Box-Muller pairs): games of the unmodified reference == oracle."""
+    alpha = load_mcts_golden("mcts_alpha_games.json")
+    assert alpha["net"] == load_mcts_golden()["net"]
+    assert {g["resolved_play"]["dirichlet_alpha"] for g in alpha["games"]} == {0.3, 1.0, 0.03}
+    check_games_bit_exact(alpha, blob)
+    check_play_rows(alpha, blob)
+
+
 def test_parallel_search_games_bit_exact_vs_reference_on_virtual_time_loop(blob):
     """parallel_search_num = 2..16 (raz-sched-v1): the oracle's round schedule against the unmodified
     reference player run on the exact-virtual-time event loop - same bit-exact bar as above."""

@@ -348,3 +348,165 @@ def test_gather_raw_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_RAW_OK 8" in r.stdout
+
+
+_GATHER_PACKED_SCRIPT = '''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from reversi_alpha_zero_amd.engine import PLY_HEADER, GAME_SUMMARY
+from reversi_alpha_zero_amd.worker.self_play import gather_packed
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+def packed_of(rank, plies):   # what SelfPlayEngine.pack_records yields: dense, cut to `plies`, here as CPU tensors
+    n, own = 3, 20 + 9 * rank   # rank 0 holds games of <= 20 plies, rank 1 of <= 29: the extents differ
+    rng = np.random.default_rng(100 + rank)
+    npl = rng.integers(5, own + 1, n)
+    npl[0] = own
+    plies = own if plies is None else plies
+    hdr = np.zeros((n, plies), dtype=PLY_HEADER); rn = np.zeros((n, plies, 64), dtype=np.uint32); sm = np.zeros(n, dtype=GAME_SUMMARY)
+    for g in range(n):
+        for i in range(int(npl[g])):
+            hdr[g, i]["own"] = rng.integers(0, 2**63); hdr[g, i]["action"] = rng.integers(0, 64); hdr[g, i]["n"] = float(i)
+            rn[g, i] = rng.integers(0, 800, 64)
+        sm[g]["game_id"] = 10 * rank + g; sm[g]["n_plies"] = npl[g]; sm[g]["status"] = 1 + g % 3
+        sm[g]["final_black"] = rng.integers(0, 2**63); sm[g]["resigned_white"] = g & 1; sm[g]["enable_resign"] = 1
+    return {{"headers": torch.from_numpy(hdr.view(np.uint8).reshape(n, plies, 48)), "root_n": torch.from_numpy(rn.view(np.int32)),
+             "summary": torch.from_numpy(sm.view(np.uint8).reshape(n, 32))}}
+raw, moved = gather_packed(lambda plies: packed_of(rank, plies), rank, world)
+if rank == 0:
+    assert raw["headers"].shape == (6, 29) and raw["root_n"].shape == (6, 29, 64) and raw["root_n"].dtype == np.uint32
+    assert list(raw["game_id"]) == [0, 1, 2, 10, 11, 12] and list(raw["n_plies"][[0, 3]]) == [20, 29]
+    for r in range(2):
+        exp = packed_of(r, 29)
+        eh = exp["headers"].numpy().view(PLY_HEADER).reshape(3, 29)
+        assert np.array_equal(raw["headers"][3 * r:3 * r + 3], eh) and np.array_equal(raw["root_n"][3 * r:3 * r + 3].view(np.int32), exp["root_n"].numpy())
+        es = exp["summary"].numpy().view(GAME_SUMMARY).reshape(-1)
+        assert list(raw["status"][3 * r:3 * r + 3]) == list(es["status"]) and list(raw["resigned"][3 * r:3 * r + 3, 1]) == list(es["resigned_white"])
+        assert list(raw["final_black"][3 * r:3 * r + 3]) == list(es["final_black"])
+    print("GATHER_PACKED_OK", len(raw["n_plies"]), moved)
+else:
+    assert raw is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_packed_two_ranks_gloo(tmp_path):
+    """The worker's record gather on packed (dense, ply-trimmed) arrays at world_size 2 on CPU (gloo): the ranks'
+    extents differ, one all_reduce(MAX) aligns them, rank-ordered concatenation, summaries decoded."""
+    script = tmp_path / "gather_packed2.py"
+    script.write_text(_GATHER_PACKED_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GATHER_PACKED_OK 6" in r.stdout
+
+
+def _model_config(tmp_path):
+    from reversi_alpha_zero_amd.config import Config
+    cfg = Config()
+    rc = cfg.resource
+    rc.model_dir = str(tmp_path / "model")
+    rc.model_best_config_path = os.path.join(rc.model_dir, "model_best_config.json")
+    rc.model_best_weight_path = os.path.join(rc.model_dir, "model_best_weight.h5")
+    rc.next_generation_model_dir = os.path.join(rc.model_dir, "next_generation")
+    os.makedirs(rc.next_generation_model_dir)
+    cfg.model.update(dict(cnn_filter_num=16, res_layer_num=1, value_fc_size=16))
+    return cfg
+
+
+def test_keras_named_npz_bridge_round_trip(tmp_path):
+    """SURVEY 8(f)3 weight interchange without h5py: torch module -> Keras-named arrays (Keras layouts) -> .npz under the
+    reference's file name -> module -> blob, bit-exact; layer names with an arbitrary creation-number offset (a second
+    model built in one Keras session) still load; a torch state-dict file still loads; an HDF5 file is refused with the
+    conversion command."""
+    import re
+    import torch
+    from reversi_alpha_zero_amd.agent.model import (ReversiNet, ReversiModel, keras_named_arrays, net_from_keras_named_arrays)
+    net = ReversiNet(32, 2, 48).keras_init_(1).randomize_bn_(2)
+    arrs = keras_named_arrays(net)
+    assert arrs["conv2d_1/kernel:0"].shape == (3, 3, 2, 32) and arrs["conv2d_6/kernel:0"].shape == (1, 1, 32, 2)
+    assert arrs["policy_out/kernel:0"].shape == (128, 64) and arrs["dense_1/kernel:0"].shape == (64, 48) and arrs["value_out/kernel:0"].shape == (48, 1)
+    shifted = {}
+    for k, v in arrs.items():
+        lname, _, w = k.partition("/")
+        m = re.search(r"_(\d+)$", lname)
+        if m and lname.startswith(("conv2d", "batch_normalization", "dense")):
+            lname = f"{lname[:m.start()]}_{int(m.group(1)) + 37}"
+        shifted[f"{lname}/{w}"] = v
+    assert net_from_keras_named_arrays(shifted).to_blob() == net.to_blob()
+    cfg = _model_config(tmp_path)
+    cpath, wpath = str(tmp_path / "c.json"), str(tmp_path / "model_weight.h5")
+    m = ReversiModel(cfg)
+    m.model = net
+    m.save(cpath, wpath)
+    with np.load(wpath) as z:
+        assert set(z.files) == set(arrs)
+    m2 = ReversiModel(cfg)
+    assert m2.load(cpath, wpath) and m2.model.to_blob() == net.to_blob() and m2.digest == m.digest
+    torch.save(net.state_dict(), str(tmp_path / "legacy.h5"))
+    m3 = ReversiModel(cfg)
+    assert m3.load(cpath, str(tmp_path / "legacy.h5")) and m3.model.to_blob() == net.to_blob()
+    (tmp_path / "keras.h5").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(ValueError, match="keras_npz_bridge"):
+        ReversiModel(cfg).load(cpath, str(tmp_path / "keras.h5"))
+    with pytest.raises(ValueError):
+        net_from_keras_named_arrays({k: v for k, v in arrs.items() if not k.startswith("dense_1")})
+
+
+def test_load_model_and_reload_semantics(tmp_path):
+    """agent/api.py:102-125 as the worker's start() applies it: nothing on disk -> fresh net saved as the best model;
+    newest next-generation model preferred when play.use_newest_next_generation_model (else the best model); opts.new
+    skips loading; try_reload_model picks up a changed file by digest and reports no change otherwise."""
+    from reversi_alpha_zero_amd.agent.model import ReversiModel
+    from reversi_alpha_zero_amd.worker.self_play import load_model, try_reload_model
+    cfg = _model_config(tmp_path)
+    rc = cfg.resource
+    m = load_model(cfg)
+    assert os.path.exists(rc.model_best_weight_path) and m.digest == ReversiModel.fetch_digest(rc.model_best_weight_path)
+    best_blob = m.model.to_blob()
+    assert try_reload_model(cfg, m) is False
+
+    def add_next_gen(name, seed):
+        d = os.path.join(rc.next_generation_model_dir, rc.next_generation_model_dirname_tmpl % name)
+        os.makedirs(d)
+        ng = ReversiModel(cfg)
+        ng.build(seed=seed)
+        ng.save(os.path.join(d, rc.next_generation_model_config_filename), os.path.join(d, rc.next_generation_model_weight_filename))
+        return ng.model.to_blob()
+    b1 = add_next_gen("20260101-000000.000000", 11)
+    assert cfg.play.use_newest_next_generation_model is True
+    assert try_reload_model(cfg, m) is True and m.model.to_blob() == b1 != best_blob
+    assert try_reload_model(cfg, m) is False
+    b2 = add_next_gen("20260102-000000.000000", 12)
+    assert load_model(cfg).model.to_blob() == b2           # newest directory wins
+    cfg.play.use_newest_next_generation_model = False
+    assert load_model(cfg).model.to_blob() == best_blob
+    m_best = load_model(cfg)
+    assert try_reload_model(cfg, m_best) is False
+    cfg.opts = types.SimpleNamespace(new=True)
+    fresh = load_model(cfg)                                  # opts.new: build + overwrite the best model
+    assert fresh.digest == ReversiModel.fetch_digest(rc.model_best_weight_path)
+    other = ReversiModel(cfg)
+    other.build(seed=5)
+    other.save(rc.model_best_config_path, rc.model_best_weight_path)   # the eval worker promotes a new best model ...
+    assert try_reload_model(cfg, m_best) is True and m_best.model.to_blob() == other.model.to_blob()   # ... a running worker picks it up
+
+
+def test_threshold_update_once_per_emitted_batch(tmp_path):
+    """worker/self_play.py:250-260 under batching: 1000 games finished under one threshold step it ONCE (by the rate over
+    the batch's no-resign test games), not once per 100 test games."""
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+    cfg = Config()
+    w = BatchedSelfPlayWorker(cfg, b"", games_in_flight=8)
+    w._defer_threshold_update = True
+    t0 = cfg.play.resign_threshold
+    for i in range(1000):   # 500 test games, 40 % false positives (>= false_positive_threshold 0.05)
+        w.finish_game({"winner": 1, "resigned_black": int(i % 5 < 2), "resigned_white": 0, "enable_resign": i % 2})
+    assert cfg.play.resign_threshold == t0 and w.resign_test_game_count == 500
+    w._defer_threshold_update = False
+    w.check_and_update_resignation_threshold()
+    assert abs(cfg.play.resign_threshold - (t0 - cfg.play.resign_threshold_delta)) < 1e-12 and w.resign_test_game_count == 0
