@@ -108,13 +108,18 @@ def spotcheck_partial_search(eng, cfg, dnet, seed, first_id, slots):
         assert int(raw["n_plies"][g]) == 1 and int(raw["headers"][g, 0]["action"]) == 19, "turn-0 bypass (player.py:143-148)"
         black, white = int(raw["final_black"][g]), int(raw["final_white"][g])
         found, w, n, _ = eng.read_node(g, white, black, 1, 0)   # white to move: the player's own discs are "black" (player.py:95)
-        done = int(n.sum())
-        if not found or done == 0:
+        if not found or int(n.sum()) == 0:
             raise AssertionError(f"spot check: slot {g} has no root statistics yet")
+        # the first simulation of a move on a fresh tree expands the root and backs nothing up (player.py:283-327: "a leaf
+        # expansion updates no N/W at the leaf"), every later one adds 1 to one root edge
+        done = int(n.sum()) + 1
         plies, _ = O.selfplay_game(ocfg, None, seed, first_id + g, done, nn=nn, stop_after_plies=2)
         on, ow = np.array(plies[1]["root_n"]), np.array(plies[1]["root_w"])
         if not (np.array_equal(on, n.astype(np.float64)) and np.array_equal(ow.view(np.uint64), w.view(np.uint64))):
-            raise AssertionError(f"parity spot check FAILED: game id {first_id + g}, {done} simulations: root N/W differ from the oracle")
+            bad = [int(i) for i in np.nonzero((on != n) | (ow.view(np.uint64) != w.view(np.uint64)))[0]]
+            raise AssertionError(f"parity spot check FAILED: game id {first_id + g}, {done} simulations: root N/W differ from the oracle "
+                                 f"at actions {bad}: engine N {[int(n[i]) for i in bad]} W {[float(w[i]) for i in bad]}, "
+                                 f"oracle N {[on[i] for i in bad]} W {[ow[i] for i in bad]}")
         checked.append({"game_id": first_id + g, "sims": done})
     return checked
 
@@ -401,7 +406,7 @@ def main():
     ap.add_argument("--games", type=int, default=8192, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--net", default="ch5", choices=sorted(NETS))
-    ap.add_argument("--net-kernel", default=None, help="DeviceNet kernel override (tests / comparisons)")
+    ap.add_argument("--net-kernel", default="auto", help="DeviceNet kernel: auto = f16x3 (raznet-forward-v2) where supported, f32 = exact-f32 kernels")
     ap.add_argument("--parts", type=int, default=0, help="slices/streams the batch is stepped in (0 = 1 for the 256x10 net, 3 for mini)")
     ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = 16 x sims: pools are pruned by k_gc in long runs)")
     ap.add_argument("--opening", action="store_true", help="time the first steps from the opening instead of the steady state")

@@ -30,6 +30,12 @@ size_t raz_net_wide_scratch_bytes(int F, size_t n);
 int raz_net_forward_wide(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, void* scratch,
                          size_t scratch_bytes, hipStream_t s);
+void raz_net_build_f16x3(const float* src, float* dst, int F, int R, int V);
+size_t raz_net_f16x3_scratch_bytes(int F, size_t n);
+unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V);
+int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
+                          const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
+                          hipStream_t s);
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
                          unsigned long long* prof, int variant);
@@ -280,6 +286,7 @@ extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, v
             lsrc += (size_t)F * F * 9 + F;
         }
     }
+    if (f16x3_supported(F)) raz_net_build_f16x3((const float*)((const char*)blob + 32), dst.data(), F, R, V);  // region 4 (+ a cleared range flag)
     RAZ_HIP_TRY(hipMemcpyAsync(d_weights, dst.data(), need, hipMemcpyHostToDevice, (hipStream_t)stream),
                 "raz_net_load: hipMemcpyAsync");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_load: sync");  // dst is a local
@@ -288,6 +295,22 @@ extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, v
     net->value_fc = V;
     net->d_weights = d_weights;
     net->weight_bytes = need;
+    return RAZ_OK;
+}
+
+// raznet-forward-v2 carries activations as pairs of halfs: an activation beyond the f16 range (>= 60000; none in any
+// net we have seen: BatchNorm keeps them O(1)) would become inf.  The kernels raise a sticky flag in the weight image
+// instead of failing silently; *overflowed = 1 means the outputs since the net was loaded cannot be trusted and the net
+// must be run with the exact-f32 kernels (raz_net.reserved = 0).  Synchronises `stream`.
+extern "C" int raz_net_range_check(const raz_net* net, int* overflowed, raz_stream_t stream) {
+    if (!net || !net->d_weights || !overflowed) return raz_fail(RAZ_EINVAL, "raz_net_range_check: NULL argument");
+    *overflowed = 0;
+    if (!f16x3_supported(net->filters)) return RAZ_OK;
+    unsigned v = 0;
+    RAZ_HIP_TRY(hipMemcpyAsync(&v, raz_net_f16x3_flag((const float*)net->d_weights, net->filters, net->res_layers, net->value_fc), 4,
+                               hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_net_range_check: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_range_check: sync");
+    *overflowed = v != 0;
     return RAZ_OK;
 }
 
@@ -307,6 +330,12 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
         return raz_net_forward_mfma((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
                                     value, n, (hipStream_t)stream, prof, net->reserved == 2 || net->reserved == 3 ? net->reserved : 0);
     }
+    // reserved 4: raznet-forward-v2 - the trunk on the f16 matrix cores with split operands (raz_net_f16x3.hip), within 1e-5
+    // of the fp32 graph but not bit-identical to the exact-f32 kernels (0 / 5: raznet-forward-v1)
+    if (f16x3_supported(F) && net->reserved == 4)
+        return raz_net_forward_f16x3((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy, value, n,
+                                     scratch, scratch_bytes, (hipStream_t)stream);
+    if (net->reserved == 4) return raz_fail(RAZ_EINVAL, "raz_net_forward: the f16x3 kernel needs filters % 128 == 0");
     if (wide_supported(F) && net->reserved != 1)
         return raz_net_forward_wide((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
                                     value, n, scratch, scratch_bytes, (hipStream_t)stream);

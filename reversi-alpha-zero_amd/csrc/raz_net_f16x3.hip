@@ -1,0 +1,359 @@
+// raz_net_f16x3.hip — forward pass of WIDE policy/value nets (F % 128 == 0, e.g. the 256x10 net of config.py:187-193)
+// with the 3x3 convolutions of the trunk on the f16 matrix cores at f32-class accuracy: "raznet-forward-v2".
+//
+// f32 MFMA runs at the f32 vector rate (157 TF); f16 MFMA at 16x that.  Every f32 operand x is carried as a pair of halfs
+// (hi, lo) = (f16(x), f16(x - hi)) - 22 significant bits; subnormal halfs are kept by the matrix core (probed:
+// tools/probe_f16.hip) - and a product x*w is evaluated as  hi_x*hi_w + hi_x*lo_w + lo_x*hi_w  (the dropped lo*lo term is
+// 2^-22 relative), three v_mfma_f32_32x32x16_f16 accumulating in f32 into ONE accumulator.  Weights are pre-scaled per
+// layer by a power of two S (max |w| * S in [2^14, 2^15): the lo halves of all but negligible weights stay normal numbers;
+// the accumulator is multiplied by the exact 1/S before the bias).  Net effect: 3/16 of the f32-MFMA time per MAC, results
+// within 1e-5 of the fp32 graph (tests: vs fp32 torch and vs the exact-f32 kernel raznet-forward-v1 on the benchmarked
+// shape), NOT bit-identical to the CPU oracle's fmaf chains - the matrix core's internal 16-term summation is not a
+// documented IEEE sequence - so games played on this path are checked against the oracle fed with THIS net's outputs
+// through the reference's own NN seam (ReversiPlayer(api=...), agent/player.py:41).  The first layer (2 planes) and the
+// heads stay exact-f32 VALU chains as in v1.
+//
+// Activations live in HBM already split, in the order the kernel's LDS image wants them:
+//     [position][16-channel chunk][plane: k-group(8 ch) x {hi, lo} = 4][square 64][8 halfs]      (F*256 bytes per position)
+// so that one (position, chunk) is four lane-linear 1 KiB pieces moved by global_load_lds (no registers, no ds_write).
+//
+// GEMM view per layer: D[oc, sq] += W[oc, k] * X[k, sq], k = (chunk, tap, channel in chunk).
+//   workgroup = 4 waves = 128 output channels x 4 positions; wave = 128 oc x 64 squares of ONE position
+//             = 4 x 2 MFMA tiles (128 accumulator registers), 2 workgroups per CU (<= 256 VGPRs, 42 KB LDS each)
+//   K loop    = 16 chunks x 3 tap groups: stage the chunk's activations (16 KB, once per chunk) and the tap group's
+//               weights (24 KB: 3 taps x 16 channels x 128 oc x {hi, lo}) by LDS-DMA, barrier, then 3 taps x 8 tiles x 3 MFMAs
+//   taps      = per-lane LDS addresses precomputed once (18 VGPRs): square + tap shift, or - off the board - a slot of a
+//               zero row in the same bank class, so there are no predicates and no halo in the image
+//   LDS reads = ds_read_b128, conflict-free by construction: lanes 0-31 read consecutive 16-byte slots (squares or channels),
+//               lanes 32-63 the other k-group's plane; 0.5 reads per MFMA
+//   epilogue  = * 1/S, + bias, (+ skip), relu, split into (hi, lo), 8-byte stores that tile 512-byte runs
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include "raz_bitboard.h"
+#include "raz_detmath.h"
+#include "raz_internal.h"
+#include "raz_net_layout.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int OCT = 128;                         // output channels per workgroup
+constexpr int W_STAGE = 3 * 2 * 2 * OCT * 16;    // 24,576 B: [tap 3][k-group 2][hi/lo][oc 128][16 B]
+constexpr int ACT_POS = 4 * 64 * 16;             // 4,096 B: [plane 4][square 64][16 B]
+constexpr int LDS_W = 0;
+constexpr int LDS_ACT = W_STAGE;
+constexpr int LDS_ZERO = LDS_ACT + 4 * ACT_POS;  // two zero rows of 256 B, 1,024 B apart (the hi and the lo read of a lane)
+constexpr int LDS_BYTES = LDS_ZERO + 1024 + 256;
+
+#define GLDS16(gptr, lptr)                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                     \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// in / out / skip: split activations (header).  Wl: this layer's region-4 weights.  grid = (ceil(n / 4) * F / 128), block 256.
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
+                                                          const float* __restrict__ inv_scale_ptr, const unsigned char* in, unsigned char* out,
+                                                          const unsigned char* skip, const uint8_t* __restrict__ active, int n, int F,
+                                                          unsigned* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int noct = F / OCT, nchunks = F / 16;
+    // blocks b and b + 8 run on the same XCD (round-robin dispatch): give them the two oc tiles of the SAME positions, so the
+    // second one finds the activations in that XCD's L2
+    const int b = blockIdx.x;
+    const int ot = (b >> 3) % noct;
+    const int pg = (b / (8 * noct)) * 8 + (b & 7);
+    const int p0 = pg * 4, pos = p0 + wv;
+    if (p0 >= n) return;
+    const bool live = pos < n && (!active || active[pos]);
+    const size_t pos_bytes = (size_t)F * 256;
+    const unsigned char* in_pos = in + (size_t)(pos < n ? pos : n - 1) * pos_bytes;
+    if (tid < 80) ((f32x4*)(lds + LDS_ZERO))[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // per-lane LDS byte addresses of the B operand (activations) for the 9 taps x 2 square tiles
+    const int kg = lane >> 5;
+    uint32_t baddr[2][9];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int sq = nt * 32 + (lane & 31), y = sq >> 3, x = sq & 7;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+            const int s2 = sq + (t / 3 - 1) * 8 + (t % 3 - 1);
+            baddr[nt][t] = ok ? (uint32_t)(LDS_ACT + wv * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(LDS_ZERO + (s2 & 15) * 16);
+        }
+    }
+    const uint32_t aaddr = (uint32_t)(LDS_W + kg * 4096 + (lane & 31) * 16);   // + tap*8192 + hl*2048 + mtile*512
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE;
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int tg = 0; tg < 3; ++tg) {
+            __syncthreads();   // the previous stage's reads are done
+            if (tg == 0) {     // this chunk's activations: wave w moves its position's four planes
+                const unsigned char* src = in_pos + (size_t)c * ACT_POS + lane * 16;
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) GLDS16(src + pl * 1024, lds + LDS_ACT + wv * ACT_POS + pl * 1024);
+            }
+            {   // this tap group's weights: 24 pieces of 1 KiB, 6 per wave
+                const unsigned char* src = wsrc + ((size_t)c * 3 + tg) * W_STAGE + lane * 16;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) GLDS16(src + (wv * 6 + i) * 1024, lds + LDS_W + (wv * 6 + i) * 1024);
+            }
+            __syncthreads();   // (the compiler drains vmcnt before the barrier: the DMA has landed)
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int t = tg * 3 + tt;
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    bh[nt] = *(const h8*)(lds + baddr[nt][t]);
+                    bl[nt] = *(const h8*)(lds + baddr[nt][t] + 1024);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const h8 ah = *(const h8*)(lds + aaddr + tt * 8192 + m * 512);
+                    const h8 al = *(const h8*)(lds + aaddr + tt * 8192 + m * 512 + 2048);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[m][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const float inv_scale = *inv_scale_ptr;
+    // epilogue.  D layout: column = lane & 31 = square, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = channel in the 32-tile
+    unsigned char* out_pos = out + (size_t)pos * pos_bytes;
+    const unsigned char* skip_pos = skip ? skip + (size_t)pos * pos_bytes : nullptr;
+    bool over = false;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oc8 = ot * OCT + m * 32 + q * 8;   // this lane pair's 8-channel group; this lane holds 4 of them
+            const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
+            const size_t unit = (size_t)(oc8 >> 4) * ACT_POS + (size_t)((oc8 >> 3) & 1) * 2048;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const size_t o = unit + (size_t)(nt * 32 + (lane & 31)) * 16 + kg * 8;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[m][nt][q * 4 + j] * inv_scale + bv[j];
+                if (skip_pos) {
+                    const h4 sh = *(const h4*)(skip_pos + o), sl = *(const h4*)(skip_pos + o + 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] + ((float)sh[j] + (float)sl[j]);
+                }
+                h4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = v[j] > 0.0f ? v[j] : 0.0f;
+                    over |= !(r < 60000.0f);
+                    hi[j] = (_Float16)r;
+                    lo[j] = (_Float16)(r - (float)hi[j]);
+                }
+                *(h4*)(out_pos + o) = hi;
+                *(h4*)(out_pos + o + 1024) = lo;
+            }
+        }
+    if (over) atomicOr(flag, 1u);   // an activation beyond the f16 range: the caller must fall back to the f32 kernel
+}
+
+// Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.
+__global__ __launch_bounds__(64) void k_conv0_split(const float* __restrict__ W0, const raz_bb* __restrict__ own,
+                                                    const raz_bb* __restrict__ enemy, const uint8_t* __restrict__ active,
+                                                    unsigned char* out, int n, int F) {
+    const int pos = blockIdx.x, lane = threadIdx.x;
+    if (pos >= n || (active && !active[pos])) return;
+    const raz_bb bo = own[pos], be = enemy[pos];
+    const int y = lane >> 3, x = lane & 7;
+    float x0[9], x1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool ok = (yy >= 0) && (yy < 8) && (xx >= 0) && (xx < 8);
+        const int s = (yy * 8 + xx) & 63;
+        x0[t] = ok ? (float)((bo >> s) & 1) : 0.0f;
+        x1[t] = ok ? (float)((be >> s) & 1) : 0.0f;
+    }
+    const float* bias = W0 + (size_t)F * 18;
+    unsigned char* op = out + (size_t)pos * F * 256;
+    for (int ocb = 0; ocb < F / 16; ++ocb) {
+        float acc[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = bias[ocb * 16 + o];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* wt = W0 + ((size_t)ocb * 9 + t) * 32;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(x0[t], wt[o], acc[o]);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(x1[t], wt[16 + o], acc[o]);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            h8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float r = acc[g * 8 + j] > 0.0f ? acc[g * 8 + j] : 0.0f;
+                hi[j] = (_Float16)r;
+                lo[j] = (_Float16)(r - (float)hi[j]);
+            }
+            *(h8*)(op + (size_t)ocb * ACT_POS + (g * 2 + 0) * 1024 + lane * 16) = hi;
+            *(h8*)(op + (size_t)ocb * ACT_POS + (g * 2 + 1) * 1024 + lane * 16) = lo;
+        }
+    }
+}
+
+// Heads as in k_heads_wide (exact f32 chains), reading the trunk output in the split layout: x = hi + lo (exact in f32).
+__global__ __launch_bounds__(64) void k_heads_split(const float* __restrict__ H, const unsigned char* trunk,
+                                                    const uint8_t* __restrict__ active, float* __restrict__ policy,
+                                                    float* __restrict__ value, int n, int F, int V) {
+    extern __shared__ __attribute__((aligned(16))) float head[];  // ph[128] vh[64] h1[V]
+    const int pos = blockIdx.x, lane = threadIdx.x;
+    if (pos >= n || (active && !active[pos])) return;
+    const float* pol_w = H;
+    const float* pol_b = pol_w + 2 * F;
+    const float* pfc_w = pol_b + 2;
+    const float* pfc_b = pfc_w + 128 * 64;
+    const float* val_w = pfc_b + 64;
+    const float* val_b = val_w + F;
+    const float* v1_w = val_b + 1;
+    const float* v1_b = v1_w + 64 * V;
+    const float* v2_w = v1_b + V;
+    const float* v2_b = v2_w + V;
+    float* ph = head;
+    float* vh = head + 128;
+    float* h1 = head + 192;
+    const unsigned char* a = trunk + (size_t)pos * F * 256 + lane * 16;
+    float p0 = pol_b[0], p1 = pol_b[1], v0 = val_b[0];
+    for (int c = 0; c < F / 16; ++c) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const h8 hi = *(const h8*)(a + (size_t)c * ACT_POS + (g * 2 + 0) * 1024);
+            const h8 lo = *(const h8*)(a + (size_t)c * ACT_POS + (g * 2 + 1) * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ic = c * 16 + g * 8 + j;
+                const float xv = (float)hi[j] + (float)lo[j];
+                p0 = fmaf(xv, pol_w[ic], p0);
+                p1 = fmaf(xv, pol_w[F + ic], p1);
+                v0 = fmaf(xv, val_w[ic], v0);
+            }
+        }
+    }
+    ph[lane] = p0 > 0.0f ? p0 : 0.0f;
+    ph[64 + lane] = p1 > 0.0f ? p1 : 0.0f;
+    vh[lane] = v0 > 0.0f ? v0 : 0.0f;
+    __syncthreads();
+    float logit = pfc_b[lane];
+#pragma unroll 16
+    for (int j = 0; j < 128; ++j) logit = fmaf(ph[j], pfc_w[j * 64 + lane], logit);
+    float m = logit;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
+    const float e = raz_det_expf(logit - m);
+    float sum = e;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) sum = sum + __shfl_xor(sum, s);
+    policy[(size_t)pos * 64 + lane] = e / sum;
+    for (int o0 = 0; o0 < V; o0 += 64) {
+        const int o = o0 + lane;
+        if (o < V) {
+            float acc = v1_b[o];
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) acc = fmaf(vh[j], v1_w[j * V + o], acc);
+            h1[o] = acc > 0.0f ? acc : 0.0f;
+        }
+    }
+    __syncthreads();
+    float acc = v2_b[0];
+    for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
+    if (lane == 0) value[pos] = raz_det_tanhf(acc);
+}
+
+}  // namespace
+
+// Host side of raz_net_load for region 4: `src` = the blob's float parameters, `dst` = the device image being built.
+void raz_net_build_f16x3(const float* src, float* dst, int F, int R, int V) {
+    const float* lsrc = src + ((size_t)F * 18 + F);   // layer 1
+    float* scales = dst + f16x3_scale_off(F, R, V);
+    const int nchunks = F / 16, noct = F / 128;
+    for (int l = 1; l < 2 * R + 1; ++l) {
+        float mx = 0.f;
+        for (size_t i = 0; i < (size_t)F * F * 9; ++i) mx = fmaxf(mx, fabsf(lsrc[i]));
+        int e = 0;
+        if (mx > 0.f) frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)  =>  mx * 2^(15 - e) in [2^14, 2^15)
+        const float S = ldexpf(1.0f, 15 - e);
+        scales[l - 1] = ldexpf(1.0f, e - 15);
+        _Float16* w = (_Float16*)(dst + f16x3_layer_off(F, R, V, l));
+        for (int ot = 0; ot < noct; ++ot)
+            for (int c = 0; c < nchunks; ++c)
+                for (int t = 0; t < 9; ++t)
+                    for (int kg = 0; kg < 2; ++kg)
+                        for (int o = 0; o < 128; ++o)
+                            for (int j = 0; j < 8; ++j) {
+                                const int oc = ot * 128 + o, ic = c * 16 + kg * 8 + j;
+                                const float v = lsrc[((size_t)oc * F + ic) * 9 + t] * S;
+                                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                                const size_t stage = ((size_t)ot * nchunks + c) * 3 + t / 3;
+                                const size_t base = stage * (W_STAGE / 2) + ((size_t)(t % 3) * 2 + kg) * 2 * 128 * 8;
+                                w[base + (size_t)o * 8 + j] = hi;
+                                w[base + 128 * 8 + (size_t)o * 8 + j] = lo;
+                            }
+        lsrc += (size_t)F * F * 9 + F;
+    }
+}
+
+size_t raz_net_f16x3_scratch_bytes(int F, size_t n) { return (size_t)2 * n * F * 256; }
+
+// The sticky range flag lives in the device weight image, after the per-layer scales (raz_net_layout.h leaves 64 floats there).
+unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V) { return (unsigned*)(W + f16x3_scale_off(F, R, V) + (size_t)2 * R + 8); }
+
+int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
+                          const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
+                          hipStream_t s) {
+    if (!scratch || scratch_bytes < raz_net_f16x3_scratch_bytes(F, n))
+        return raz_fail(RAZ_ENOMEM, "raz_net_forward: scratch too small (raz_net_scratch_bytes)");
+    unsigned char* bufA = (unsigned char*)scratch;
+    unsigned char* bufT = bufA + (size_t)n * F * 256;
+    unsigned* flag = raz_net_f16x3_flag(W, F, R, V);
+    const float* scales = W + f16x3_scale_off(F, R, V);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(64), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
+                       (const raz_bb*)enemy, active, bufA, (int)n, F);
+    const unsigned groups = (unsigned)((n + 3) / 4);
+    const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
+    for (int r = 0; r < R; ++r) {
+        const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
+        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(256), LDS_BYTES, s,
+                           (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
+                           scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, active, (int)n, F, flag);
+        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(256), LDS_BYTES, s,
+                           (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
+                           scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, active, (int)n, F, flag);
+    }
+    hipLaunchKernelGGL(k_heads_split, dim3((unsigned)n), dim3(64), (192 + (size_t)V) * sizeof(float), s,
+                       W + heads_off(F, R), (const unsigned char*)bufA, active, policy, value, (int)n, F, V);
+    return raz_check_launch("raz_net_forward (f16x3)");
+}

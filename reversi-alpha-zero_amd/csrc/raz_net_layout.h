@@ -34,6 +34,17 @@ RAZ_HD_LAYOUT size_t wide_layer_floats(int F) { return (size_t)F * F * 9; }
 RAZ_HD_LAYOUT size_t wide_tile_off(int F, int R, int V, int l, int c, int nt) {  // l >= 1
     return wide_off(F, R, V) + (size_t)(l - 1) * wide_layer_floats(F) + ((size_t)c * (F / 64) + nt) * (72 * 128);
 }
+// Region 4 ("f16x3" layout, used by k_conv3x3_f16x3, F % 128 == 0): every weight w of a conv layer l >= 1 as the pair of
+//   halfs (hi, lo) = (f16(w * S_l), f16(w * S_l - hi)) with S_l a power of two chosen per layer so that max |w| * S_l is in
+//   [2^14, 2^15); 4 bytes per weight like region 3.  Per layer: [oc tile of 128][16-channel chunk][tap group of 3][tap in
+//   group][k group of 8 channels: 2][hi, lo][oc in tile: 128][8 halfs] - i.e. one (oc tile, chunk, tap group) stage of the
+//   kernel is 24,576 contiguous bytes in exactly its LDS image order (lane-linear 16-byte units for global_load_lds).  Then
+//   2R floats: 1 / S_l per layer.
+RAZ_HD_LAYOUT bool f16x3_supported(int F) { return F >= 128 && F % 128 == 0; }
+RAZ_HD_LAYOUT size_t f16x3_off(int F, int R, int V) { return (wide_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F) + 63) / 64 * 64; }
+RAZ_HD_LAYOUT size_t f16x3_layer_off(int F, int R, int V, int l) { return f16x3_off(F, R, V) + (size_t)(l - 1) * wide_layer_floats(F); }  // l >= 1
+RAZ_HD_LAYOUT size_t f16x3_scale_off(int F, int R, int V) { return f16x3_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F); }
 RAZ_HD_LAYOUT size_t total_floats(int F, int R, int V) {
+    if (f16x3_supported(F)) return f16x3_scale_off(F, R, V) + (size_t)2 * R + 64;
     return wide_supported(F) ? wide_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F) : mfma_layer_off(F, R, V, 2 * R + 1);
 }

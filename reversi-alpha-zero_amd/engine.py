@@ -28,8 +28,11 @@ class DeviceNet:
     """The policy/value net resident in HBM (agent/api.py ReversiModelAPI role, device side)."""
 
     def __init__(self, blob: bytes, device="cuda:0", force_valu_kernel=False, kernel=None):
-        """kernel (tests): None = chosen by shape and batch size; "valu" = k_net_wave; "mfma_wave" = one single-wave
-        workgroup per position; "mfma_wg" = eight-wave workgroups sharing the dense weights in LDS (F == 16)."""
+        """kernel: None / "f32" = the exact-f32 kernels chosen by shape (raznet-forward-v1, bit-identical to the CPU oracle);
+        "f16x3" = raznet-forward-v2 for filters % 128 == 0: the 3x3 trunk on the f16 matrix cores with split operands, within
+        1e-5 of the fp32 graph (include/raz.h raz_net_range_check); "auto" = "f16x3" where supported, else "f32".
+        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position; "mfma_wg" = eight-wave
+        workgroups sharing the dense weights in LDS (F == 16)."""
         import torch
         import struct
         magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -41,7 +44,10 @@ class DeviceNet:
         self._weights = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.c = N.RazNet()
         kernel = "valu" if force_valu_kernel else kernel
-        self.c.reserved = {None: 0, "valu": 1, "mfma_wave": 2, "mfma_wg": 3}[kernel]
+        if kernel == "auto":
+            kernel = "f16x3" if (F >= 128 and F % 128 == 0) else "f32"
+        self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk"}.get(kernel, kernel)
+        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "mfma_wg": 3, "f16x3": 4}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")
@@ -53,6 +59,14 @@ class DeviceNet:
         if need and (self._scratch is None or self._scratch.numel() < need):
             self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         return (self._scratch.data_ptr(), self._scratch.numel()) if need else (None, 0)
+
+    def range_ok(self):
+        """False when a split-f16 activation left the f16 range since the net was loaded (raz_net_range_check)."""
+        import torch
+        v = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            check(lib.raz_net_range_check(ctypes.byref(self.c), ctypes.byref(v), _stream()), "raz_net_range_check")
+        return v.value == 0
 
     def predict_bitboards(self, own, enemy, active=None):
         """own/enemy: int64 device tensors (side to move's view).  -> (policy (n,64), value (n,)).

@@ -140,6 +140,88 @@ def test_net_metric_shape_vs_oracle_and_torch():
     assert ep <= 1e-5 and ev <= 1e-5 and gep <= 1e-5 and gev <= 1e-5
 
 
+@pytest.mark.parametrize("shape,n", [((256, 10, 256), 67), ((128, 2, 64), 9)])
+def test_net_f16x3_within_tolerance_of_torch_and_exact_kernel(shape, n):
+    """raznet-forward-v2 (csrc/raz_net_f16x3.hip: the 3x3 trunk on the f16 matrix cores, every operand split into two halfs,
+    3 MFMAs per product, f32 accumulation) on the metric's shape, ragged batch with an active mask: within 1e-5 of the fp32
+    torch graph (the north star's tolerance) AND of the exact-f32 kernel (raznet-forward-v1, itself bit-equal to the oracle);
+    skipped positions stay untouched; no activation left the f16 range; results do not depend on the batch a position is in."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    net = ReversiNet(*shape).keras_init_(5).randomize_bn_(6)
+    blob = net.to_blob()
+    own, enemy = _harvested_positions(n, 11)
+    o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
+    act = torch.from_numpy((np.arange(n) % 7 != 3).astype(np.uint8)).to(DEV)
+    v2 = DeviceNet(blob, DEV, kernel="f16x3")
+    p2, q2 = v2.predict_bitboards(o, e, active=act)
+    p1, q1 = DeviceNet(blob, DEV, kernel="f32").predict_bitboards(o, e, active=act)
+    assert v2.range_ok()
+    on = act.bool()
+    assert bool((p2[~on] == 0).all()) and bool((q2[~on] == 0).all())
+    d12p, d12v = float((p2 - p1)[on].abs().max()), float((q2 - q1)[on].abs().max())
+    bits = lambda a: ((a[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.float32)
+    x = torch.from_numpy(np.stack([bits(own), bits(enemy)], axis=1).reshape(-1, 2, 8, 8))
+    with torch.no_grad():
+        tp, tv = net(x)
+    dtp = float((p2.cpu() - tp)[on.cpu()].abs().max())
+    dtv = float((q2.cpu() - tv[:, 0])[on.cpu()].abs().max())
+    print(f"f16x3 {shape}: max |dp| {dtp:.2e} |dv| {dtv:.2e} vs fp32 torch; {d12p:.2e} {d12v:.2e} vs the exact-f32 kernel")
+    assert dtp <= 1e-5 and dtv <= 1e-5 and d12p <= 1e-5 and d12v <= 1e-5
+    # batch invariance: a position alone == the same position inside the batch, bit for bit
+    for i in (0, n - 1):
+        pa, qa = v2.predict_bitboards(o[i:i + 1], e[i:i + 1])
+        if bool(on[i]):
+            assert torch.equal(pa[0].view(torch.int32), p2[i].view(torch.int32)) and torch.equal(qa.view(torch.int32), q2[i:i + 1].view(torch.int32))
+
+
+def test_net_f16x3_range_flag():
+    """A net whose activations leave the f16 range must say so (raz_net_range_check), not return garbage silently."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    net = ReversiNet(128, 1, 64).keras_init_(5)
+    with torch.no_grad():
+        net.stem.conv.weight.mul_(3.0e4)
+    own, enemy = _harvested_positions(8, 2)
+    o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
+    v2 = DeviceNet(net.to_blob(), DEV, kernel="f16x3")
+    assert v2.range_ok()
+    v2.predict_bitboards(o, e)
+    assert not v2.range_ok()
+
+
+def test_engine_on_f16x3_net_equals_oracle_given_the_nets_outputs():
+    """Games on raznet-forward-v2: the engine (wide net, split-f16 trunk, cross-game leaf batches) == the CPU oracle's
+    games when the oracle evaluates leaves through the SAME device net via the reference's NN seam
+    (ReversiPlayer(api=...), agent/player.py:41,346) - every action, root N and W, bit for bit."""
+    import types
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    blob = ReversiNet(128, 1, 64).keras_init_(7).randomize_bn_(8).to_blob()
+    play = types.SimpleNamespace(
+        simulation_num_per_move=14, share_mtcs_info_in_self_play=True, thinking_loop=1, required_visit_to_decide_action=400,
+        start_rethinking_turn=8, c_puct=5, noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=4, virtual_loss=3,
+        parallel_search_num=1, resign_threshold=-0.9, allowed_resign_turn=50, disable_resignation_rate=0.1,
+        use_solver_turn=0, use_solver_turn_in_simulation=0)
+    cfg = types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+    dnet = DeviceNet(blob, DEV, kernel="f16x3")
+    n = 12
+    eng = SelfPlayEngine(cfg, dnet, n_games=n, seed=3, sims_hint=14, record_root_w=True)
+    eng.start(first_game_id=40, sims_per_move=14)
+    eng.run(chunk=64)
+    recs = eng.records()
+
+    def nn(own, enemy):
+        to = lambda v: torch.tensor([v - (1 << 64) if v >= 1 << 63 else v], dtype=torch.int64, device=DEV)
+        p, v = dnet.predict_bitboards(to(own), to(enemy))
+        return p[0].cpu().numpy(), float(v[0].item())
+    ocfg = O.play_cfg_from_config(cfg)
+    for i in (0, 5, 11):
+        plies, summ = O.selfplay_game(ocfg, None, 3, 40 + i, 14, nn=nn)
+        _compare_game(f"f16x3/{40 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+    assert dnet.range_ok()
+
+
 def _harvested_positions(n, seed):
     """Positions the way SURVEY 8(d) asks for them: random playouts from the start, stopped at a random ply
     (oracle env = test infrastructure); returned from the mover's view."""
