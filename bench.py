@@ -162,12 +162,12 @@ def stagger(eng, n, sims, seed, dev):
 def conv_traffic():
     """HBM bytes per net forward from the committed PMC passes (separate rocprofv3 --pmc runs of this command:
     tools/run_profiles.sh -> tools/pmc_summary.py); None when no pass is committed for this build."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc", "config3_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc", "headline_config3_traffic.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         t = json.load(f)
-    return t.get("net_forward_hbm_bytes_per_launch"), "profiles/r2_pmc/config3_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE over the launches of one net forward)"
+    return t.get("net_forward_hbm_bytes_per_launch"), "profiles/r2_pmc/headline_config3_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE over the launches of one net forward)"
 
 
 def headline_leg(args, dev, rank, world, cdev):
@@ -244,8 +244,12 @@ def headline_leg(args, dev, rank, world, cdev):
     net_avg_ms, tree_avg_ms = net_ms / launches, tree_ms / launches
     ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
     traffic, traffic_src = conv_traffic() if args.net == "ch5" else (None, None)
-    net_kernel = {"ch5": "one net forward = k_conv0_wide + 20 x k_conv3x3 (implicit GEMM, >99% of it) + k_heads_wide",
+    v2 = "f16x3" in (net.kernel_name or "")
+    net_kernel = {"ch5": ("one net forward = k_conv0_split + 20 x k_conv3x3_f16x3 (implicit GEMM on the f16 matrix cores, split operands: "
+                          "3 MFMA flops per algorithmic flop; >99% of the forward) + k_heads_split") if v2 else
+                         "one net forward = k_conv0_wide + 20 x k_conv3x3_wide (implicit GEMM on the f32 matrix cores, >99% of it) + k_heads_wide",
                   "mini": "k_net_mfma"}[args.net]
+    peak = F16_PEAK_TFLOPS if v2 else FP32_PEAK_TFLOPS
     value = total_sims / elapsed
     out.update({
         "metric": "MCTS simulations/sec (self-play, NN included)", "value": value, "unit": "sims/s",
@@ -265,9 +269,12 @@ def headline_leg(args, dev, rank, world, cdev):
         "total_sims": total_sims, "nn_leaves": leaves, "leaf_slot_occupancy": leaves / world / (args.steps * args.games),
         "mean_selections_per_sim": selections / max(total_sims, 1.0),
         "roofline": {"bound": "mfma", "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
-                     "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "peak_note": "f32 MFMA dense peak (the arithmetic the path is specified in)"},
+                     "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                     "peak_note": ("f16 MFMA dense peak - the pipe the trunk runs on; every algorithmic (f32-accurate) flop costs 3 f16 MFMA "
+                                   "flops, so this fraction cannot exceed 1/3" if v2 else "f32 MFMA dense peak"),
+                     "executed_mfma_tflops": ach * (3.0 if v2 else 1.0), "executed_mfma_frac_of_pipe_peak": ach * (3.0 if v2 else 1.0) / peak,
+                     "achieved_over_f32_mfma_peak": ach / FP32_PEAK_TFLOPS},
         "kernels": {"k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms,
                                "algorithmic_bytes_per_launch": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / launches}},
         "bound_sims_per_s_per_gpu_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs),
@@ -470,7 +477,7 @@ def main():
                                               "measured on the whole-game configs[1] leg of this run); a whole batch is ~50 000 steps")
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 128)
-            per_thread = 6 if args.net == "ch5" else 400
+            per_thread = 2 if args.net == "ch5" else 400
             out["cpu_baseline"] = cpu_baseline_port(
                 cfg, blob, per_thread, threads, stop_after_plies=2,
                 what=f"same workload (net, play settings), bounded sample: the first {per_thread} simulations of the first searched move of "

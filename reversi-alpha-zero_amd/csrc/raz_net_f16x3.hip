@@ -177,9 +177,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const unsigned char* _
 // Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.
 __global__ __launch_bounds__(64) void k_conv0_split(const float* __restrict__ W0, const raz_bb* __restrict__ own,
                                                     const raz_bb* __restrict__ enemy, const uint8_t* __restrict__ active,
-                                                    unsigned char* out, int n, int F) {
+                                                    unsigned char* out, int n, int F, unsigned* __restrict__ flag) {
     const int pos = blockIdx.x, lane = threadIdx.x;
     if (pos >= n || (active && !active[pos])) return;
+    bool over = false;
     const raz_bb bo = own[pos], be = enemy[pos];
     const int y = lane >> 3, x = lane & 7;
     float x0[9], x1[9];
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(64) void k_conv0_split(const float* __restrict__ W0
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float r = acc[g * 8 + j] > 0.0f ? acc[g * 8 + j] : 0.0f;
+                over |= !(r < 60000.0f);
                 hi[j] = (_Float16)r;
                 lo[j] = (_Float16)(r - (float)hi[j]);
             }
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(64) void k_conv0_split(const float* __restrict__ W0
             *(h8*)(op + (size_t)ocb * ACT_POS + (g * 2 + 1) * 1024 + lane * 16) = lo;
         }
     }
+    if (over) atomicOr(flag, 1u);
 }
 
 // Heads as in k_heads_wide (exact f32 chains), reading the trunk output in the split layout: x = hi + lo (exact in f32).
@@ -341,7 +344,7 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
         attr_set = true;
     }
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(64), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
-                       (const raz_bb*)enemy, active, bufA, (int)n, F);
+                       (const raz_bb*)enemy, active, bufA, (int)n, F, flag);
     const unsigned groups = (unsigned)((n + 3) / 4);
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
     for (int r = 0; r < R; ++r) {

@@ -181,7 +181,7 @@ def test_net_f16x3_range_flag():
     from reversi_alpha_zero_amd.engine import DeviceNet
     net = ReversiNet(128, 1, 64).keras_init_(5)
     with torch.no_grad():
-        net.stem.conv.weight.mul_(3.0e4)
+        net.stem.conv.weight.mul_(1.0e6)
     own, enemy = _harvested_positions(8, 2)
     o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
     v2 = DeviceNet(net.to_blob(), DEV, kernel="f16x3")

@@ -11,7 +11,8 @@ import os
 import sys
 
 SHORT = {"k_tree_par": "k_tree_par", "k_tree": "k_tree", "k_net_mfma": "k_net_mfma", "k_conv3x3_wide": "k_conv3x3_wide", "k_heads_wide": "k_heads_wide",
-         "k_conv0_wide": "k_conv0_wide", "k_stats": "k_stats", "k_start": "k_start", "k_gc": "k_gc"}
+         "k_conv0_wide": "k_conv0_wide", "k_conv3x3_f16x3": "k_conv3x3_f16x3", "k_conv0_split": "k_conv0_split", "k_heads_split": "k_heads_split",
+         "k_stats": "k_stats", "k_start": "k_start", "k_gc": "k_gc"}
 
 
 def short(name):
@@ -50,8 +51,24 @@ def main(src, out):
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profiles.sh), KiB -> bytes, "
                              "average per dispatch; FETCH_SIZE under-reports wide coalesced reads on gfx950 (guide)",
                    "kernels": traffic}, f, indent=1, sort_keys=True)
+    # one net forward of the wide nets = conv0 + 2R conv launches + heads: HBM bytes per forward for bench.py's roofline.traffic
+    for conv, c0, hd in (("k_conv3x3_f16x3", "k_conv0_split", "k_heads_split"), ("k_conv3x3_wide", "k_conv0_wide", "k_heads_wide")):
+        if conv in traffic and c0 in traffic and hd in traffic and res[c0]["dispatches"]:
+            per_fwd = res[conv]["dispatches"] / res[c0]["dispatches"]
+            fwd = traffic[c0]["hbm_bytes_per_launch"] + per_fwd * traffic[conv]["hbm_bytes_per_launch"] + traffic[hd]["hbm_bytes_per_launch"]
+            with open(out + "_config3_traffic.json", "w") as f:
+                json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the headline bench command (tools/run_profiles.sh); "
+                                     "FETCH_SIZE is reported at 1/2 of the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md): "
+                                     "fetch bytes doubled here as the guide prescribes",
+                           "conv_kernel": conv, "conv_launches_per_forward": per_fwd,
+                           "conv_fetch_bytes_per_launch_raw": traffic[conv]["fetch_bytes"], "conv_write_bytes_per_launch": traffic[conv]["write_bytes"],
+                           "net_forward_hbm_bytes_per_launch": traffic[c0]["hbm_bytes_per_launch"] + traffic[c0]["fetch_bytes"]
+                           + per_fwd * (traffic[conv]["hbm_bytes_per_launch"] + traffic[conv]["fetch_bytes"])
+                           + traffic[hd]["hbm_bytes_per_launch"] + traffic[hd]["fetch_bytes"],
+                           "net_forward_hbm_bytes_per_launch_uncorrected": fwd}, f, indent=1)
+            break
     print(json.dumps({k: {c: (round(v, 1) if isinstance(v, float) else v) for c, v in res[k].items()}
-                      for k in ("k_tree", "k_tree_par", "k_net_mfma") if k in res}, indent=1))
+                      for k in ("k_tree", "k_tree_par", "k_net_mfma", "k_conv3x3_f16x3", "k_conv3x3_wide") if k in res}, indent=1))
 
 
 if __name__ == "__main__":

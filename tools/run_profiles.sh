@@ -3,6 +3,7 @@
 # /opt/skills/guides/MI355X_MICROARCH.md (one counter set per pass, --kernel-trace only) for the
 # self-play bench, written under gpurun_out/<name>/.  Summarise afterwards with tools/pmc_summary.py.
 #   usage: tools/run_profiles.sh [steps] [name] [passes: "stats 1 2 3 4"] [extra bench.py args...]
+# (the headline leg only: BASELINE configs[2]; add "--net mini --games 4096 --sims 200" for the configs[1] kernels)
 set -u
 STEPS=${1:-600}
 NAME=${2:-prof_final}
@@ -13,17 +14,17 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$NAME
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --config2-steps 0 $EXTRA"
+BENCH="python $ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-extra-legs --no-spotcheck $EXTRA"
 SETS=("" \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32" \
   "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES" \
   "FETCH_SIZE" "WRITE_SIZE")
 for P in $PASSES; do
   if [ "$P" = "stats" ]; then
-    timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
     echo "stats rc=$?"
   else
-    timeout 240 rocprofv3 --pmc ${SETS[$P]} --kernel-trace --output-format csv -d "$OUT/pmc$P" -- $BENCH < /dev/null > "$OUT/pmc$P.log" 2>&1
+    timeout 400 rocprofv3 --pmc ${SETS[$P]} --kernel-trace --output-format csv -d "$OUT/pmc$P" -- $BENCH < /dev/null > "$OUT/pmc$P.log" 2>&1
     echo "pmc$P rc=$?"
   fi
 done
