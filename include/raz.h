@@ -271,6 +271,27 @@ int raz_engine_records_extent(raz_engine* e, uint32_t first_slot, uint32_t n_slo
                               raz_stream_t stream);   /* synchronises `stream` */
 int raz_engine_pack_records(raz_engine* e, uint32_t first_slot, uint32_t n_slots, uint32_t plies, void* d_headers,
                             uint32_t* d_root_n, raz_game_summary* d_summary, raz_stream_t stream);
+/* Continuous batching.  The reference worker starts its next game the moment one ends (worker/self_play.py:95-137); a
+ * lock-step batch idles every finished slot until its slowest game is over.  raz_engine_harvest, called between
+ * raz_engine_step calls: every slot whose game has finished is emptied into the caller's OUTBOX (device arrays indexed by
+ * game id - out_first_id, so the outbox is in id order whatever order the games finish in: headers out_games*max_plies*48
+ * bytes, root_n out_games*max_plies*64 u32, summaries, done flags set to 1) and restarted - empty tree, fresh records - on
+ * the next unplayed ids next_game_id, next_game_id + 1, ... (handed to the freed slots in slot order; at most n_new_ids of
+ * them, the remaining freed slots idle).  sims_per_move[k] / resign_threshold[k] (nullable; NaN = no resignation rule;
+ * NULL = the engine's run-time value) are the parameters of id next_game_id + k: a game keeps the threshold it was started
+ * under, so its result depends on its id and parameters only - not on the batch size, the slot, or when other games end.
+ * A finished game whose id has no outbox row stays in its slot (counted in `skipped`).  Not for series of games on a
+ * carried tree (raz_engine_next_game).  Synchronises `stream`. */
+typedef struct {
+    uint32_t harvested;   /* games moved to the outbox by this call */
+    uint32_t restarted;   /* of their slots, how many started a new game (ids next_game_id .. next_game_id + restarted - 1) */
+    uint32_t skipped;     /* finished games left in place: id outside the outbox */
+    uint32_t playing;     /* slots with a game in progress after the call */
+} raz_harvest_result;
+int raz_engine_harvest(raz_engine* e, uint32_t next_game_id, uint32_t n_new_ids, const uint32_t* sims_per_move,
+                       const double* resign_threshold, uint32_t out_first_id, uint32_t out_games, void* d_headers,
+                       uint32_t* d_root_n, raz_game_summary* d_summary, uint8_t* d_done, raz_harvest_result* result,
+                       raz_stream_t stream);
 /* config.play.resign_threshold is mutated while the worker runs (worker/self_play.py:250-260: +-0.01 per 100
  * no-resign test games); moves decided from the next raz_engine_step on use the new value.  Trees, records and
  * random streams are untouched. */

@@ -74,6 +74,10 @@ class RazEngineConfig(ctypes.Structure):
                 ("solver_memo_slots", c_uint32), ("parallel_search_num", c_uint32)]
 
 
+class RazHarvestResult(ctypes.Structure):
+    _fields_ = [("harvested", c_uint32), ("restarted", c_uint32), ("skipped", c_uint32), ("playing", c_uint32)]
+
+
 class RazEngineStats(ctypes.Structure):
     _fields_ = [("finished_games", c_uint64), ("total_sims", c_uint64), ("nn_leaves", c_uint64),
                 ("error_flags", c_uint64), ("selections", c_uint64), ("max_pool_used", c_uint64), ("idle_or_done", c_uint64)]
@@ -110,6 +114,8 @@ SIGNATURES.update({
     "raz_engine_device_ptr": (c_void_p, [c_void_p, c_int]),
     "raz_engine_records_extent": (c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint32), c_void_p]),
     "raz_engine_pack_records": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "raz_engine_harvest": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, POINTER(RazHarvestResult), c_void_p]),
     "raz_engine_set_resign_threshold": (c_int, [c_void_p, c_int, ctypes.c_double]),
 })
 

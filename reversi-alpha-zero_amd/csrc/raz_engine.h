@@ -104,7 +104,11 @@ struct raz_game {
     // into / out of the register-resident control block is one masked select / one masked store.
     uint32_t sim_state, sim_seq, sim_parked;        // per slot: RAZ_SIM_*, order number (queue put order / sleep order), node slept on
     uint32_t par_seq_next, par_stage;               // per game: next order number; 0 = round boundary, 1 = filling (C), 2 = refilling (C')
-    uint32_t pad[14];
+    // continuous batching (raz_engine_harvest): a game started by a harvest carries the resign threshold it was started
+    // under, so that its result does not depend on when other games finish (worker/self_play.py:250-260 mutates the value)
+    unsigned long long resign_thr;                  // f64 bits, valid when resign_mode == 1
+    uint32_t resign_mode;                           // 0 = the engine's run-time value (raz_engine_set_resign_threshold), 1 = resign_thr, 2 = no rule
+    uint32_t pad[11];
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");

@@ -830,9 +830,12 @@ __device__ void decide_move(const raz_engine_dev& E, Regs& R, uint32_t g, int la
     // resignation (:123-130)
     int final_action = action;
     bool has_row = true;
-    if (c.has_resign_threshold) {
+    const uint32_t rmode = G32(R, GW(resign_mode));   // per-game rule of a game started by raz_engine_harvest, else the engine's
+    const bool has_thr = rmode ? rmode == 1u : c.has_resign_threshold != 0;
+    if (has_thr) {
+        const double thr = rmode == 1u ? __longlong_as_double((long long)G64(R, GW(resign_thr))) : c.resign_threshold;
         const double mx = wave_max_f64(q - (Ni == 0 ? 10.0 : 0.0));
-        if (mx <= c.resign_threshold) {
+        if (mx <= thr) {
             R.cw = writelane_r(R.cw, 1u, GW(resigned) + (int)pl, lane);
             if (G32(R, GW(enable_resign)) && turn >= c.allowed_resign_turn) {
                 final_action = -1;
@@ -1391,6 +1394,11 @@ __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
             const unsigned long long x = sh[threadIdx.x][i];
             a = (threadIdx.x == 2) ? (a | x) : (threadIdx.x == 5 ? (x > a ? x : a) : a + x);
         }
+        // + the games raz_engine_harvest took out of their slots since raz_engine_start: [8] finished, [9] sims, [10] leaves, [11] selections
+        if (threadIdx.x == 0) a += E.counters[8];
+        if (threadIdx.x == 1) a += E.counters[9];
+        if (threadIdx.x == 3) a += E.counters[10];
+        if (threadIdx.x == 4) a += E.counters[11];
         E.counters[threadIdx.x] = a;
     }
 }
@@ -1668,6 +1676,7 @@ struct raz_engine {
     void* net_scratch;
     size_t net_scratch_bytes;
     uint32_t* d_sims;  // staging for sims_per_move
+    double* d_thr;     // staging for per-game resign thresholds (raz_engine_harvest)
     bool started;
     // The batch is stepped as `parts` independent slices on as many streams (the caller's and
     // parts-1 internal ones): while one slice's leaves are in the net kernel (matrix pipe) another
@@ -1754,7 +1763,7 @@ extern "C" void raz_engine_destroy(raz_engine* e);
 
 extern "C" size_t raz_engine_workspace_bytes(const raz_engine_config* cfg) {
     if (validate(cfg) != RAZ_OK) return 0;
-    return carve(*cfg, nullptr, nullptr) + align_up((size_t)cfg->n_games * 4, 256);
+    return carve(*cfg, nullptr, nullptr) + align_up((size_t)cfg->n_games * 4, 256) + align_up((size_t)cfg->n_games * 8, 256);
 }
 
 extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* net, void* d_workspace,
@@ -1774,6 +1783,7 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     if (!e) return raz_fail(RAZ_ENOMEM, "raz_engine_create: host allocation failed");
     const size_t used = carve(*cfg, (unsigned char*)d_workspace, &e->dev);
     e->d_sims = (uint32_t*)((unsigned char*)d_workspace + used);
+    e->d_thr = (double*)((unsigned char*)d_workspace + used + align_up((size_t)cfg->n_games * 4, 256));
     e->net = *net;
     e->net_scratch = d_net_scratch;
     e->net_scratch_bytes = net_scratch_bytes;
@@ -2261,6 +2271,160 @@ extern "C" int raz_engine_pack_records(raz_engine* e, uint32_t first_slot, uint3
     hipLaunchKernelGGL(k_pack_records, dim3(n_slots), dim3(256), 0, (hipStream_t)stream, e->dev, first_slot, plies,
                        (raz_ply_header*)d_headers, d_root_n, d_summary);
     return raz_check_launch("raz_engine_pack_records");
+}
+
+namespace {
+// ---- continuous batching -------------------------------------------------------------------------------------------
+// The reference worker starts its next game the moment one ends (worker/self_play.py:95-137).  Here a finished game's
+// slot is emptied into the caller's outbox (row = game id - out_first_id: the outbox is in id order whatever order the
+// games finish in) and restarted on the next unplayed id; ids are handed to the freed slots in slot order, results do not
+// depend on the assignment (every random draw is keyed by the game id, the tree starts empty).
+// plan[2g] = 0 nothing / 1 harvest, slot idles / 2 harvest and restart; plan[2g+1] = index of the new id.
+__global__ __launch_bounds__(1024) void k_harvest_plan(raz_engine_dev E, uint32_t n_new, uint32_t out_first, uint32_t out_games,
+                                                       uint32_t* plan, uint32_t* result) {
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t base, skipped, live;
+    if (threadIdx.x == 0) { base = 0; skipped = 0; live = 0; }
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < E.B; g0 += 1024) {
+        const uint32_t g = g0 + threadIdx.x;
+        bool fin = false;
+        if (g < E.B) {
+            const raz_game& G = E.game[g];
+            fin = G.phase == RAZ_PHASE_DONE && G.status != 0;
+            if (fin && G.game_id - out_first >= out_games) { fin = false; atomicAdd(&skipped, 1u); }   // no row for it: left in place
+            if (!fin && G.phase != RAZ_PHASE_IDLE && G.phase != RAZ_PHASE_DONE) atomicAdd(&live, 1u);
+        }
+        sh[threadIdx.x] = fin ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
+            const uint32_t v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t rank = base + sh[threadIdx.x] - (fin ? 1u : 0u);
+        if (g < E.B) {
+            plan[2 * g] = fin ? (rank < n_new ? 2u : 1u) : 0u;
+            plan[2 * g + 1] = rank;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) base += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        result[0] = base;                          // harvested
+        result[1] = base < n_new ? base : n_new;   // restarted
+        result[2] = skipped;
+        result[3] = live + result[1];              // slots playing after this call
+    }
+}
+
+__global__ __launch_bounds__(256) void k_harvest_apply(raz_engine_dev E, const uint32_t* plan, uint32_t next_id, const uint32_t* sims,
+                                                       const double* thr, uint32_t out_first, raz_ply_header* out_hdr,
+                                                       uint32_t* out_n, raz_game_summary* out_sum, uint8_t* out_done) {
+    const uint32_t g = blockIdx.x, what = plan[2 * g];
+    if (what == 0) return;
+    raz_game& G = E.game[g];
+    const uint32_t row = G.game_id - out_first, np = G.n_plies < E.max_plies ? G.n_plies : E.max_plies, MP = E.max_plies;
+    {   // the game's records -> its outbox row (unused plies zero)
+        const uint32_t* hs = (const uint32_t*)(E.rec + (size_t)g * MP);
+        uint32_t* hd = (uint32_t*)(out_hdr + (size_t)row * MP);
+        for (uint32_t i = threadIdx.x; i < MP * 12; i += 256) hd[i] = i < np * 12 ? hs[i] : 0u;
+        const uint32_t* ns = E.rec_n + (size_t)g * MP * 64;
+        uint32_t* nd = out_n + (size_t)row * MP * 64;
+        for (uint32_t i = threadIdx.x; i < MP * 64; i += 256) nd[i] = i < np * 64 ? ns[i] : 0u;
+    }
+    if (what == 2) {   // the slot's tree starts empty again
+        raz_slot* tab = E.table + (size_t)g * E.H;
+        for (uint32_t i = threadIdx.x; i < E.H; i += 256) tab[i].idx_tag = 0;
+        if (E.M) {
+            raz_slot* memo = E.memo + (size_t)g * E.M;
+            for (uint32_t i = threadIdx.x; i < E.M; i += 256) memo[i].idx_tag = 0;
+        }
+        if (E.par) {
+            uint32_t* sm = E.sim + (size_t)g * E.K * 64;
+            for (uint32_t i = threadIdx.x; i < E.K * 64; i += 256) sm[i] = 0;
+        }
+        for (uint32_t i = threadIdx.x; i < E.K; i += 256) E.nn_active[(size_t)g * E.K + i] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    raz_game_summary S;
+    S.final_black = G.root_black; S.final_white = G.root_white; S.game_id = G.game_id; S.n_plies = G.n_plies;
+    S.status = (uint8_t)G.status; S.resigned_black = (uint8_t)G.resigned[0]; S.resigned_white = (uint8_t)G.resigned[1];
+    S.enable_resign = (uint8_t)G.enable_resign; S.reserved = 0;
+    out_sum[row] = S;
+    out_done[row] = 1;
+    atomicAdd(&E.counters[8], 1ULL);
+    atomicAdd(&E.counters[9], G.sims);
+    atomicAdd(&E.counters[10], G.leaves);
+    atomicAdd(&E.counters[11], G.selections);
+    const uint32_t err = G.error;
+    raz_game N;
+    memset(&N, 0, sizeof N);
+    N.error = err;   // (sticky: an overflowed pool must still be reported by raz_engine_stats_sync)
+    N.root_black = RAZ_INIT_BLACK;
+    N.root_white = RAZ_INIT_WHITE;
+    N.player = RAZ_PLAYER_BLACK;
+    N.leaf_kind = RAZ_LEAF_NONE;
+    N.root_node = RAZ_NO_NODE;
+    N.leaf_node = RAZ_NO_NODE;
+    N.leaf_mirror = RAZ_NO_NODE;
+    if (what == 2) {
+        const uint32_t k = plan[2 * g + 1], id = next_id + k;
+        N.phase = RAZ_PHASE_NEW_MOVE;
+        N.game_id = id;
+        double d0, d1;
+        raz_rng_pair(E.cfg.seed, id, RAZ_RNG_GAME, 0, 0, 0, d0, d1);
+        N.enable_resign = E.cfg.disable_resignation_rate <= d0 ? 1 : 0;  // worker/self_play.py:144
+        N.sims_per_move = sims[k];
+        if (thr) {
+            const double t = thr[k];
+            N.resign_mode = t == t ? 1u : 2u;   // NaN = resign_threshold is None
+            N.resign_thr = (unsigned long long)__double_as_longlong(t);
+        }
+    } else {
+        N.phase = RAZ_PHASE_IDLE;
+        N.game_id = G.game_id;
+    }
+    G = N;
+}
+}  // namespace
+
+extern "C" int raz_engine_harvest(raz_engine* e, uint32_t next_game_id, uint32_t n_new_ids, const uint32_t* sims_per_move,
+                                  const double* resign_threshold, uint32_t out_first_id, uint32_t out_games, void* d_headers,
+                                  uint32_t* d_root_n, raz_game_summary* d_summary, uint8_t* d_done, raz_harvest_result* result,
+                                  raz_stream_t stream) {
+    if (!e || !d_headers || !d_root_n || !d_summary || !d_done || !result || (n_new_ids && !sims_per_move))
+        return raz_fail(RAZ_EINVAL, "raz_engine_harvest: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_harvest: call raz_engine_start first");
+    const raz_engine_dev& d = e->dev;
+    if (n_new_ids > d.B) n_new_ids = d.B;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_new_ids) {
+        RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)n_new_ids * 4, hipMemcpyHostToDevice, s), "raz_engine_harvest: copy sims");
+        if (resign_threshold)
+            RAZ_HIP_TRY(hipMemcpyAsync(e->d_thr, resign_threshold, (size_t)n_new_ids * 8, hipMemcpyHostToDevice, s), "raz_engine_harvest: copy thresholds");
+    }
+    uint32_t* plan = d.gc_remap;                       // scratch of k_gc, idle between steps: 2 words per slot
+    uint32_t* dres = (uint32_t*)(d.counters + 12);     // 4 words
+    hipLaunchKernelGGL(k_harvest_plan, dim3(1), dim3(1024), 0, s, d, n_new_ids, out_first_id, out_games, plan, dres);
+    int rc = raz_check_launch("raz_engine_harvest: plan");
+    if (rc != RAZ_OK) return rc;
+    hipLaunchKernelGGL(k_harvest_apply, dim3(d.B), dim3(256), 0, s, d, (const uint32_t*)plan, next_game_id, (const uint32_t*)e->d_sims,
+                       resign_threshold ? (const double*)e->d_thr : (const double*)nullptr, out_first_id, (raz_ply_header*)d_headers,
+                       d_root_n, d_summary, d_done);
+    rc = raz_check_launch("raz_engine_harvest: apply");
+    if (rc != RAZ_OK) return rc;
+    uint32_t h[4];
+    RAZ_HIP_TRY(hipMemcpyAsync(h, dres, 16, hipMemcpyDeviceToHost, s), "raz_engine_harvest: copy result");
+    RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_harvest: sync");   // (also keeps the host arrays alive long enough)
+    result->harvested = h[0];
+    result->restarted = h[1];
+    result->skipped = h[2];
+    result->playing = h[3];
+    return RAZ_OK;
 }
 
 extern "C" int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold, double threshold) {

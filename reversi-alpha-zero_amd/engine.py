@@ -284,6 +284,75 @@ class SelfPlayEngine:
                                               sm.data_ptr(), _stream()), "raz_engine_pack_records")
         return {"headers": hdr, "root_n": rn, "summary": sm}
 
+    # ---- continuous batching (include/raz.h raz_engine_harvest) -------------------------------------------------
+    def new_outbox(self, first_game_id, n_games):
+        """Device arrays that receive finished games in id order (row = game id - first_game_id)."""
+        import torch
+        mp = self.max_plies
+        return {"first": first_game_id, "n": n_games,
+                "headers": torch.zeros((n_games, mp, 48), dtype=torch.uint8, device=self.device),
+                "root_n": torch.zeros((n_games, mp, 64), dtype=torch.int32, device=self.device),
+                "summary": torch.zeros((n_games, 32), dtype=torch.uint8, device=self.device),
+                "done": torch.zeros(n_games, dtype=torch.uint8, device=self.device)}
+
+    def harvest(self, outbox, next_game_id, sims_per_move, resign_threshold=None):
+        """Move every finished game into `outbox` and restart the freed slots on ids next_game_id, next_game_id + 1, ...
+        (len(sims_per_move) of them at most).  resign_threshold: None = the engine's run-time value; else one value per
+        new id (None entries / NaN = no resignation rule).  Returns (harvested, restarted, skipped, playing)."""
+        import torch
+        sims = np.ascontiguousarray(sims_per_move, dtype=np.uint32)
+        thr = None
+        if resign_threshold is not None:
+            thr = np.array([np.nan if t is None else float(t) for t in resign_threshold], dtype=np.float64)
+            assert thr.size == sims.size
+        res = N.RazHarvestResult()
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_harvest(self._h, next_game_id, sims.size, sims.ctypes.data if sims.size else None,
+                                         thr.ctypes.data if thr is not None and thr.size else None, outbox["first"], outbox["n"],
+                                         outbox["headers"].data_ptr(), outbox["root_n"].data_ptr(), outbox["summary"].data_ptr(),
+                                         outbox["done"].data_ptr(), ctypes.byref(res), _stream()), "raz_engine_harvest")
+        return res.harvested, res.restarted, res.skipped, res.playing
+
+    def play_continuous(self, first_game_id, total_games, sims_of, chunk=64, resign_threshold_of=None, max_steps=100_000_000):
+        """Play global game ids first_game_id .. first_game_id + total_games - 1 with continuous batching: the batch's
+        slots are refilled with the next unplayed id as games finish (worker/self_play.py:95-137: a reference worker
+        starts its next game the moment one ends), finished games land in an id-ordered device outbox.
+        sims_of(id) -> simulations per move of that game (the reference's per-game-index schedule, self_play.py:145).
+        resign_threshold_of(id) (optional) -> the threshold that game is played under.
+        Returns (outbox, stats): outbox = device tensors in id order (pack/gather them as they are, or
+        raw_from_packed(...) on the host); stats adds steps, leaf_slot_occupancy and gc_runs."""
+        B = self.n_games
+        n0 = min(B, total_games)
+        sims0 = np.array([sims_of(first_game_id + i) if i < n0 else 1 for i in range(B)], dtype=np.uint32)
+        if resign_threshold_of is not None:
+            self.set_resign_threshold(resign_threshold_of(first_game_id))
+        self.start(first_game_id, sims0, n_active=n0)
+        if resign_threshold_of is not None and len({resign_threshold_of(first_game_id + i) for i in range(n0)}) > 1:
+            raise ValueError("the first batch of ids must share one resign threshold (raz_engine_start takes the engine's run-time value)")
+        outbox = self.new_outbox(first_game_id, total_games)
+        nxt, done, steps, cap = first_game_id + n0, 0, 0, int(self.cfg.nodes_per_game)
+        end = first_game_id + total_games
+        self.gc_runs = 0
+        while done < total_games:
+            self.step(chunk)
+            steps += chunk
+            st = self.stats()
+            if st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
+                self.gc(threshold=cap // 4)
+                self.gc_runs += 1
+            k = min(B, end - nxt)
+            ids = range(nxt, nxt + k)
+            h, r, skipped, playing = self.harvest(outbox, nxt, [sims_of(i) for i in ids],
+                                                  [resign_threshold_of(i) for i in ids] if resign_threshold_of else None)
+            assert skipped == 0
+            nxt += r
+            done += h
+            if steps >= max_steps:
+                raise RuntimeError("engine did not finish within max_steps")
+        st = self.stats()
+        st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs)
+        return outbox, st
+
     def gc(self, threshold=0):
         """Prune unreachable nodes in every game whose pool holds >= threshold nodes."""
         import torch
