@@ -1,20 +1,30 @@
-"""The `eval` worker on the device engine — drop-in for reversi_zero/worker/evaluate.py:17-124.
+"""The `eval` worker as ONE batched match on the device — replaces reversi_zero/worker/evaluate.py:17-124.
 
-Best model vs next-generation model: `game_num` games, colours drawn at random, each side a
-`ReversiPlayer` (agent/player.py of this package: one engine slot per player, searching with
-`config.eval.play_config`); the challenger replaces the best model when its winning rate over the
-decided games reaches `replace_rate`, with the reference's early stopping.  Same class, method
-names and file handling as the reference, so `manager.py`'s `eval` command only needs the import
-changed.  Random draws (colour assignment) come from a seeded `random.Random`, the players'
-move sampling from their raz-rng-v1 streams: an evaluation is reproducible.
+The reference pits the best model against a challenger one game at a time (evaluate.py:44-96): two fresh
+`ReversiPlayer`s per game (separate trees, `config.eval.play_config`), colours drawn at random, and stops early once the
+result is decided.  Here all `eval.game_num` games of a challenge are in flight at once:
+
+  * two engines, one per model (an engine evaluates leaves with ONE net): slot g of the best model's engine holds the best
+    model's tree of game g, slot g of the challenger's engine the challenger's tree;
+  * a round = every unfinished game makes one ply: the mover's engine is armed on the position
+    (`raz_engine_set_position`, the engine-side form of `ReversiPlayer.action`), both engines are stepped until every armed
+    slot has decided - the searches of all games whose mover is the same model share that model's leaf batches - and the
+    actions are applied to the games' `ReversiEnv`s;
+  * the reference's early-stopping rule (evaluate.py:55-60) is then applied to the outcomes in game order, which yields
+    the decision the sequential loop would have reached (the rule only looks at a prefix of the games).
+
+Each (model, game) pair owns one raz-rng-v1 stream, so a match is reproducible and game g is the game two `ReversiPlayer`
+objects on those streams would play (`play_game_sequential`, kept as the cross-check the tests use).
+Model-file handling (`load_best_model`, `load_next_generation_model`, `remove_model`) follows evaluate.py:98-124.
 """
+import copy
 import os
 from logging import getLogger
 from random import Random
 from time import sleep
+from types import SimpleNamespace
 
 from ..agent.model import ReversiModel
-from ..agent.player import ReversiPlayer
 from ..env.reversi_env import Player, ReversiEnv, Winner
 from ..lib.data_helper import get_next_generation_model_dirs
 from ..lib.model_helpler import load_best_model_weight, save_as_best_model
@@ -23,8 +33,61 @@ logger = getLogger(__name__)
 
 
 def start(config, max_models=None, seed=0):
-    """evaluate.py:17-19.  max_models: stop after that many challengers (None = run forever, as the reference)."""
+    """evaluate.py:17-19.  max_models: stop after that many challengers (None = keep polling, as the reference)."""
     return EvaluateWorker(config, seed=seed).start(max_models=max_models)
+
+
+def decide(outcomes, game_num, replace_rate):
+    """evaluate.py:46-64 on a list of per-game outcomes (1 challenger won, 0 lost, None draw) in game order:
+    returns (challenger_is_better, games_the_sequential_loop_would_have_played, winning_rate)."""
+    wins = losses = played = 0
+    for o in outcomes[:game_num]:
+        played += 1
+        wins += o == 1
+        losses += o == 0
+        if losses >= game_num * (1 - replace_rate) or wins >= game_num * replace_rate:
+            break
+    rate = wins / (wins + losses) if wins + losses else 0
+    return rate >= replace_rate, played, rate
+
+
+class _Side:
+    """One model's half of the match: an engine whose slot g is that model's player in game g."""
+
+    def __init__(self, config, model, n_games, seed, first_game_id, device):
+        from ..engine import DeviceNet, SelfPlayEngine
+        pc = copy.copy(config.eval.play_config)
+        pc.allowed_resign_turn = config.play.allowed_resign_turn   # agent/player.py:127 reads config.play
+        # (every ReversiPlayer of evaluate.py:69-70 has a tree of its own: here one engine slot per player, used by that
+        #  player only, with the mirror-key updates of player.py:279-280 as the play config's tree mode implies)
+        self.sims = int(pc.simulation_num_per_move)
+        net = getattr(model, "model", model)
+        self.engine = SelfPlayEngine(SimpleNamespace(play=pc, play_data=config.play_data), DeviceNet(net.to_blob(), device),
+                                     n_games, seed=seed, sims_hint=self.sims, max_plies=64, parts=1, single_stream=True)
+        self.engine.start(first_game_id, self.sims, n_active=0)   # every slot idle until it is asked for a move
+        self.armed = []
+
+    def ask(self, slot, own, enemy):
+        # the player's own discs are "black" inside its tree, whatever its colour in the game (agent/player.py:95)
+        self.engine.set_position(slot, own, enemy, 1, self.sims, enable_resign=True, one_move=True)
+        self.armed.append(slot)
+
+    def busy(self):
+        eng = self.engine
+        st = eng.stats()   # raises on engine error flags
+        cap = int(eng.cfg.nodes_per_game)
+        if st["max_pool_used"] + eng.nodes_per_step * 64 + 64 > cap:
+            eng.gc(threshold=cap // 4)
+        return st["idle_or_done"] < eng.n_games
+
+    def answers(self):
+        """{slot: action or None (resigned)} of the slots armed in this round."""
+        pk = self.engine.pack_records(0, self.engine.n_games, plies=1)
+        from ..engine import PLY_HEADER
+        hdr = pk["headers"].cpu().numpy().view(PLY_HEADER).reshape(-1)
+        out = {g: (int(hdr[g]["action"]) if int(hdr[g]["action"]) >= 0 else None) for g in self.armed}
+        self.armed = []
+        return out
 
 
 class EvaluateWorker:
@@ -36,14 +99,14 @@ class EvaluateWorker:
         self.random = Random(seed)
         self.games_played = 0
 
+    # -- the challenge loop (evaluate.py:31-42) ---------------------------------------------------------------------
     def start(self, max_models=None):
         self.best_model = self.load_best_model()
         done = 0
         while max_models is None or done < max_models:
             ng_model, model_dir = self.load_next_generation_model()
             logger.debug(f"start evaluate model {model_dir}")
-            ng_is_great = self.evaluate_model(ng_model)
-            if ng_is_great:
+            if self.evaluate_model(ng_model):
                 logger.debug(f"New Model become best model: {model_dir}")
                 save_as_best_model(ng_model)
                 self.best_model = ng_model
@@ -52,57 +115,72 @@ class EvaluateWorker:
         return done
 
     def evaluate_model(self, ng_model):
-        """evaluate.py:44-64."""
         ec = self.config.eval
-        results = []
-        winning_rate = 0
-        for game_idx in range(ec.game_num):
-            # ng_win := if ng_model win -> 1, lose -> 0, draw -> None
-            ng_win, black_is_best, black_white = self.play_game(self.best_model, ng_model)
-            if ng_win is not None:
-                results.append(ng_win)
-                winning_rate = sum(results) / len(results)
-            logger.debug(f"game {game_idx}: ng_win={ng_win} black_is_best_model={black_is_best} score={black_white} "
-                         f"winning rate {winning_rate * 100:.1f}%")
-            if results.count(0) >= ec.game_num * (1 - ec.replace_rate):
-                logger.debug(f"lose count reach {results.count(0)} so give up challenge")
-                break
-            if results.count(1) >= ec.game_num * ec.replace_rate:
-                logger.debug(f"win count reach {results.count(1)} so change best model")
-                break
-        winning_rate = sum(results) / len(results) if results else 0
-        logger.debug(f"winning rate {winning_rate * 100:.1f}%")
-        return winning_rate >= ec.replace_rate
+        results = self.play_games(self.best_model, ng_model, ec.game_num)
+        better, played, rate = decide([r[0] for r in results], ec.game_num, ec.replace_rate)
+        self.last_results = results[:played]
+        logger.debug(f"{played} of {ec.game_num} games decide: winning rate {rate * 100:.1f}% -> "
+                     f"{'change best model' if better else 'keep best model'}")
+        return better
+
+    # -- the batched match ------------------------------------------------------------------------------------------
+    def play_games(self, best_model, ng_model, n):
+        """n games, all in flight at once.  Returns per game (ng_win: 1 / 0 / None for a draw, best_is_black, (blacks, whites))
+        - what the reference's play_game returns (evaluate.py:66-96) - in game order."""
+        first = self.games_played
+        self.games_played += n
+        best_is_black = [self.random.random() < 0.5 for _ in range(n)]
+        sides = {True: _Side(self.config, best_model, n, 2 * self.seed, first, self.device),        # the best model
+                 False: _Side(self.config, ng_model, n, 2 * self.seed + 1, first, self.device)}     # the challenger
+        envs = [ReversiEnv().reset() for _ in range(n)]
+        live = list(range(n))
+        while live:
+            for g in live:
+                env = envs[g]
+                own, enemy = env.get_own_and_enemy()
+                mover_is_best = (env.next_player == Player.black) == best_is_black[g]
+                sides[mover_is_best].ask(g, own, enemy)
+            while True:
+                for s in sides.values():
+                    if s.armed:
+                        s.engine.step(64)
+                if not any(s.armed and s.busy() for s in sides.values()):
+                    break
+            for s in sides.values():
+                for g, action in s.answers().items():
+                    envs[g].step(action)
+            live = [g for g in live if not envs[g].done]
+        out = []
+        for g, env in enumerate(envs):
+            ng_win = None
+            if env.winner in (Winner.black, Winner.white):
+                ng_win = int((env.winner == Winner.black) != best_is_black[g])
+            out.append((ng_win, best_is_black[g], env.observation.number_of_black_and_white))
+        return out
 
     def play_game(self, best_model, ng_model):
-        """evaluate.py:66-96."""
-        env = ReversiEnv().reset()
-        gid = self.games_played
-        self.games_played += 1
-        pc = self.config.eval.play_config
-        best_player = ReversiPlayer(self.config, best_model, play_config=pc,
-                                    mtcs_info=ReversiPlayer.create_mtcs_info(self.seed, 2 * gid, self.device))
-        ng_player = ReversiPlayer(self.config, ng_model, play_config=pc,
-                                  mtcs_info=ReversiPlayer.create_mtcs_info(self.seed, 2 * gid + 1, self.device))
-        best_is_black = self.random.random() < 0.5
-        if best_is_black:
-            black, white = best_player, ng_player
-        else:
-            black, white = ng_player, best_player
-        observation = env.observation
-        while not env.done:
-            if env.next_player == Player.black:
-                action = black.action(observation.black, observation.white)
-            else:
-                action = white.action(observation.white, observation.black)
-            observation, info = env.step(action)
-        ng_win = None
-        if env.winner == Winner.black:
-            ng_win = 0 if best_is_black else 1
-        elif env.winner == Winner.white:
-            ng_win = 1 if best_is_black else 0
-        return ng_win, best_is_black, observation.number_of_black_and_white
+        """evaluate.py:66-96: one game (a match of one)."""
+        return self.play_games(best_model, ng_model, 1)[0]
 
+    def play_game_sequential(self, best_model, ng_model, game_index, best_is_black):
+        """Game `game_index` of a match the way evaluate.py:66-96 plays it - two ReversiPlayer objects and one ReversiEnv,
+        one move at a time - on the same random streams as the batched match: the cross-check of play_games."""
+        from ..agent.player import ReversiPlayer
+        pc = self.config.eval.play_config
+        players = {True: ReversiPlayer(self.config, best_model, play_config=pc,
+                                       mtcs_info=ReversiPlayer.create_mtcs_info(2 * self.seed, game_index, self.device)),
+                   False: ReversiPlayer(self.config, ng_model, play_config=pc,
+                                        mtcs_info=ReversiPlayer.create_mtcs_info(2 * self.seed + 1, game_index, self.device))}
+        env = ReversiEnv().reset()
+        while not env.done:
+            own, enemy = env.get_own_and_enemy()
+            env.step(players[(env.next_player == Player.black) == best_is_black].action(own, enemy))
+        ng_win = None
+        if env.winner in (Winner.black, Winner.white):
+            ng_win = int((env.winner == Winner.black) != best_is_black)
+        return ng_win, best_is_black, env.observation.number_of_black_and_white
+
+    # -- model files (evaluate.py:98-124) -----------------------------------------------------------------------------
     def load_best_model(self):
         model = ReversiModel(self.config)
         if not load_best_model_weight(model):
@@ -111,21 +189,19 @@ class EvaluateWorker:
 
     def load_next_generation_model(self, poll_seconds=60):
         rc = self.config.resource
-        while True:
-            dirs = get_next_generation_model_dirs(rc)
-            if dirs:
-                break
+        dirs = get_next_generation_model_dirs(rc)
+        while not dirs:
             logger.info("There is no next generation model to evaluate")
             sleep(poll_seconds)
+            dirs = get_next_generation_model_dirs(rc)
         model_dir = dirs[-1] if self.config.eval.evaluate_latest_first else dirs[0]
-        config_path = os.path.join(model_dir, rc.next_generation_model_config_filename)
-        weight_path = os.path.join(model_dir, rc.next_generation_model_weight_filename)
         model = ReversiModel(self.config)
-        model.load(config_path, weight_path)
+        model.load(os.path.join(model_dir, rc.next_generation_model_config_filename),
+                   os.path.join(model_dir, rc.next_generation_model_weight_filename))
         return model, model_dir
 
     def remove_model(self, model_dir):
         rc = self.config.resource
-        os.remove(os.path.join(model_dir, rc.next_generation_model_config_filename))
-        os.remove(os.path.join(model_dir, rc.next_generation_model_weight_filename))
+        for name in (rc.next_generation_model_config_filename, rc.next_generation_model_weight_filename):
+            os.remove(os.path.join(model_dir, name))
         os.rmdir(model_dir)

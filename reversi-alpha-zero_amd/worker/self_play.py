@@ -187,10 +187,15 @@ def gather_packed(packed, rank, world):
 class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
-    def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1):
+    def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None):
+        """games_in_flight: game slots resident on the device.  block_games (per rank; default = games_in_flight): the
+        number of consecutive game ids a rank plays between two gathers.  With block_games > games_in_flight the slots are
+        refilled as games finish (continuous batching, SelfPlayEngine.play_continuous); the files do not depend on either
+        number as long as world * block_games - the ids per gather, after which the resign threshold may move - is the same."""
         self.config = config
         self.net_blob = net_blob
         self.games_in_flight = games_in_flight
+        self.block_games = block_games or games_in_flight
         self.seed = seed
         self.device = device
         self.rank, self.world = rank, world
@@ -282,6 +287,29 @@ class BatchedSelfPlayWorker:
             return eng, n
         raw = eng.read_raw()
         return {k: raw[k][:n] for k in RAW_KEYS}
+
+    def play_block_continuous(self, first_game_idx):
+        """This rank's block of game ids [first + rank * block_games, + block_games) with continuous batching: the slots are
+        refilled with the next id as games finish.  Returns the id-ordered device outbox as a `plies -> packed tensors`
+        callable for gather_packed (cut to the block's longest game, or to the extent the ranks agreed on)."""
+        blk = self.block_games
+        base = first_game_idx + self.rank * blk
+        cache = {}
+
+        def sims_of(gid):
+            if gid not in cache:
+                cache[gid] = decide_simulation_num_per_move(self.config, gid)
+            return cache[gid]
+        eng = self._get_engine(max(sims_of(base + i) for i in range(blk)))
+        outbox, self.last_stats = eng.play_continuous(base, blk, sims_of)
+
+        def packed(plies):
+            if plies is None:   # n_plies is the u32 at byte 20 of a raz_game_summary
+                import torch
+                plies = max(1, int(outbox["summary"][:, 20:24].contiguous().view(torch.int32).max().item()))
+            return {"headers": outbox["headers"][:, :plies].contiguous(), "root_n": outbox["root_n"][:, :plies].contiguous(),
+                    "summary": outbox["summary"]}
+        return packed
 
     def emit_raw(self, raw, first_local_idx=1, threads=None):
         """emit() on raw record arrays: the same files, with the rows' JSON text produced natively
@@ -425,11 +453,16 @@ class BatchedSelfPlayWorker:
         game_idx = read_as_int(rc.self_play_game_idx_file) or 0
         local_idx = 1
         while total_games is None or local_idx <= total_games:
-            eng, n = self.play_batch_raw(game_idx, device_records=True)
-            if self.world > 1:
-                allraw, _ = gather_packed(lambda plies: eng.pack_records(0, n, plies), self.rank, self.world)
+            continuous = self.block_games > self.games_in_flight and self._series_length() == 1
+            if continuous:
+                packed = self.play_block_continuous(game_idx)
             else:
-                pk = eng.pack_records(0, n)
+                eng, n = self.play_batch_raw(game_idx, device_records=True)
+                packed = lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)
+            if self.world > 1:
+                allraw, _ = gather_packed(packed, self.rank, self.world)
+            else:
+                pk = packed(None)
                 allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
             if self.rank == 0:
                 self.emit_raw(allraw, local_idx)
@@ -440,7 +473,7 @@ class BatchedSelfPlayWorker:
                 t = [game_idx, self.config.play.resign_threshold]
                 dist.broadcast_object_list(t, src=0)
                 game_idx, self.config.play.resign_threshold = t
-            local_idx += self.games_in_flight * self.world
+            local_idx += (self.block_games if continuous else self.games_in_flight) * self.world
             if reload_model is not None:
                 blob = reload_model()
                 if blob is not None:   # every rank polls the same files: the digest decides
@@ -572,7 +605,7 @@ def try_reload_model(config, model):
         return False
 
 
-def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0):
+def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None):
     """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU."""
     import torch
     import torch.distributed as dist
@@ -597,7 +630,8 @@ def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0)
 
         def reload_model():
             return model.model.to_blob() if try_reload_model(config, model) else None
-    w = BatchedSelfPlayWorker(config, net_blob, games_in_flight or 4096, seed=seed,
-                              device=f"cuda:{local}", rank=rank, world=world)
+    B = games_in_flight or 4096
+    w = BatchedSelfPlayWorker(config, net_blob, B, seed=seed, device=f"cuda:{local}", rank=rank, world=world,
+                              block_games=block_games or 4 * B)   # continuous batching: 4 games per slot between two gathers
     w.run(total_games, reload_model=reload_model)
     return w

@@ -107,3 +107,30 @@ def test_continuous_batching_with_simulation_slots_solver_and_pruning(blob):
     outbox, st = eng.play_continuous(300, 20, lambda gid: 14, chunk=24)
     assert st["gc_runs"] >= 1
     _check_vs_oracle(_raw(outbox), cfg, blob, 23, 300, range(300, 320, 2), lambda gid: 14, par=4)
+
+
+def test_worker_files_do_not_depend_on_slots_or_refill(gold, blob, tmp_path):
+    """The `self` worker: 36 game ids as one block on 6 slots (continuous batching: each slot plays ~6 games) and as one
+    lock-step batch of 36 slots -> byte-identical play_*.json files (games are emitted in id order either way)."""
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+    g0 = next(g for g in gold["games"] if g["variant"] == "agz_resign")
+    outs = []
+    for tag, slots, block in (("refill", 6, 36), ("lockstep", 36, 36)):
+        cfg = Config()
+        cfg.play.update(g0["resolved_play"])
+        cfg.play.schedule_of_simulation_num_per_move = [(0, 9), (20, 14)]
+        cfg.play_data.update(dict(g0["resolved_play_data"], nb_game_in_file=7, enable_ggf_data=False))
+        rc = cfg.resource
+        out = tmp_path / tag
+        rc.data_dir = str(out); rc.play_data_dir = str(out / "play_data"); rc.self_play_ggf_data_dir = str(out / "ggf")
+        rc.model_dir = str(out / "model"); rc.next_generation_model_dir = str(out / "model" / "next"); rc.log_dir = str(out / "logs")
+        rc.project_dir = str(out); rc.force_simulation_num_file = str(out / ".force-sim"); rc.self_play_game_idx_file = str(out / ".idx")
+        w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=slots, seed=8, device=DEV, block_games=block)
+        w.run(total_games=36)
+        files = sorted((out / "play_data").iterdir())
+        outs.append([f.read_text() for f in files])
+        assert (out / ".idx").read_text() == "36"
+        if tag == "refill":
+            assert w.last_stats["steps"] > 0 and w.last_stats["finished_games"] == 36
+    assert len(outs[0]) == 5 and outs[0] == outs[1]

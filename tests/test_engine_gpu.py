@@ -591,14 +591,16 @@ def test_reversi_player_callback_and_stop_thinking(golden, blob):
     assert len(p.moves) == 8 and p.ask_thought_about(own, enemy).action == ae.action
 
 
-def test_evaluate_worker_end_to_end(tmp_path):
-    """The `eval` worker (worker/evaluate.py of the reference) on ReversiPlayer drop-ins: a best model and
-    one next-generation model on disk, 3 short games, the reference's file handling (challenger directory
-    removed; best model replaced iff the winning rate reaches replace_rate), deterministic for a seed."""
+def test_evaluate_worker_batched_match(tmp_path):
+    """The `eval` worker as one batched match (worker/evaluate.py of this package; reference: worker/evaluate.py:44-96):
+    6 games of best model vs challenger all in flight on two engines == the same 6 games played one at a time by two
+    ReversiPlayer objects and a ReversiEnv the way the reference's play_game does (same random streams); reproducible;
+    the reference's file handling (challenger directory removed, best model replaced iff the winning rate reaches
+    replace_rate) and its early-stopping decision rule."""
     import os
     from reversi_alpha_zero_amd.config import Config
     from reversi_alpha_zero_amd.agent.model import ReversiModel
-    from reversi_alpha_zero_amd.worker.evaluate import EvaluateWorker
+    from reversi_alpha_zero_amd.worker.evaluate import EvaluateWorker, decide
     from reversi_alpha_zero_amd.lib.model_helpler import save_as_best_model
 
     def make_cfg(root):
@@ -610,7 +612,7 @@ def test_evaluate_worker_end_to_end(tmp_path):
         rc.model_best_weight_path = str(root / "model" / "model_best_weight.h5")
         rc.next_generation_model_dir = str(root / "model" / "next_generation")
         os.makedirs(rc.next_generation_model_dir)
-        cfg.eval.game_num = 3
+        cfg.eval.game_num = 6
         cfg.eval.play_config.simulation_num_per_move = 8
         best = ReversiModel(cfg)
         best.build(seed=1)
@@ -630,16 +632,25 @@ def test_evaluate_worker_end_to_end(tmp_path):
         w = EvaluateWorker(cfg, seed=11, device=DEV)
         w.best_model = w.load_best_model()
         ng_model, model_dir = w.load_next_generation_model()
-        results = [w.play_game(w.best_model, ng_model) for _ in range(2)]
+        results = w.play_games(w.best_model, ng_model, 6)
+        assert len(results) == 6 and {r[1] for r in results} == {True, False}    # both colour assignments occur
         for ng_win, best_is_black, (nb, nw) in results:
             assert ng_win in (0, 1, None) and 0 < nb + nw <= 64
         outcomes.append(results)
+        if rep == 0:   # the batched games are the games the reference's sequential play_game would play on these streams
+            for g in (0, 3, 5):
+                assert w.play_game_sequential(w.best_model, ng_model, g, results[g][1]) == results[g], g
         assert w.start(max_models=1) == 1
         assert not os.path.exists(model_dir)                      # challenger consumed
         kept = ReversiModel(cfg)
         assert kept.load(cfg.resource.model_best_config_path, cfg.resource.model_best_weight_path)
-        assert kept.model.to_blob() in (best.model.to_blob(), ng.model.to_blob())
+        better, played, rate = decide([r[0] for r in w.last_results] + [None] * 6, 6, cfg.eval.replace_rate)
+        assert kept.model.to_blob() == (ng.model.to_blob() if better else best.model.to_blob())
     assert outcomes[0] == outcomes[1]                             # reproducible for a seed
+    # evaluate.py:55-60: stop as soon as the losses reach game_num * (1 - replace_rate) or the wins game_num * replace_rate
+    assert decide([0, 0, 1, 0, 1, 1], 6, 0.55) == (False, 4, 0.25)
+    assert decide([1, None, 1, 1, 1, 0], 6, 0.55) == (True, 5, 1.0)
+    assert decide([None] * 6, 6, 0.55) == (False, 6, 0)
 
 
 def test_training_tensors_on_device():
