@@ -18,10 +18,11 @@
 // so that one (position, chunk) is four lane-linear 1 KiB pieces moved by global_load_lds (no registers, no ds_write).
 //
 // GEMM view per layer: D[oc, sq] += W[oc, k] * X[k, sq], k = (chunk, tap, channel in chunk).
-//   workgroup = 4 waves = 128 output channels x 4 positions; wave = 128 oc x 64 squares of ONE position
-//             = 4 x 2 MFMA tiles (128 accumulator registers), 2 workgroups per CU (<= 256 VGPRs, 42 KB LDS each)
-//   K loop    = 16 chunks x 3 tap groups: stage the chunk's activations (16 KB, once per chunk) and the tap group's
-//               weights (24 KB: 3 taps x 16 channels x 128 oc x {hi, lo}) by LDS-DMA, barrier, then 3 taps x 8 tiles x 3 MFMAs
+//   workgroup = 8 waves = 128 output channels x 8 positions (one workgroup per CU, 2 waves per SIMD, <= 256 VGPRs);
+//               wave = 128 oc x 64 squares of ONE position = 4 x 2 MFMA tiles (128 accumulator registers)
+//   K loop    = 16 chunks x 3 tap groups = 48 stages; a stage's weights (24 KB: 3 taps x 16 channels x 128 oc x {hi, lo})
+//               and, once per chunk, the 8 positions' activations (32 KB) arrive by LDS-DMA in a double buffer while the
+//               previous stage's 3 taps x 8 tiles x 3 MFMAs per wave run: one barrier per stage, no register staging
 //   taps      = per-lane LDS addresses precomputed once (18 VGPRs): square + tap shift, or - off the board - a slot of a
 //               zero row in the same bank class, so there are no predicates and no halo in the image
 //   LDS reads = ds_read_b128, conflict-free by construction: lanes 0-31 read consecutive 16-byte slots (squares or channels),
@@ -44,39 +45,47 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int OCT = 128;                         // output channels per workgroup
+constexpr int NWAVE = 8;                         // waves per workgroup = positions per workgroup
 constexpr int W_STAGE = 3 * 2 * 2 * OCT * 16;    // 24,576 B: [tap 3][k-group 2][hi/lo][oc 128][16 B]
 constexpr int ACT_POS = 4 * 64 * 16;             // 4,096 B: [plane 4][square 64][16 B]
-constexpr int LDS_W = 0;
-constexpr int LDS_ACT = W_STAGE;
-constexpr int LDS_ZERO = LDS_ACT + 4 * ACT_POS;  // two zero rows of 256 B, 1,024 B apart (the hi and the lo read of a lane)
-constexpr int LDS_BYTES = LDS_ZERO + 1024 + 256;
+constexpr int ACT_IMG = NWAVE * ACT_POS + 1280;  // one chunk's image: 8 positions + two zero rows of 256 B, 1,024 B apart
+constexpr int LDS_W = 0;                         // two weight stages (double buffer)
+constexpr int LDS_ACT = 2 * W_STAGE;             // two activation images (double buffer)
+constexpr int LDS_BYTES = LDS_ACT + 2 * ACT_IMG; // 117,248 B: one workgroup of 8 waves per CU
+constexpr int Z_OFF = NWAVE * ACT_POS;           // the zero rows inside an image (at Z_OFF and Z_OFF + 1024)
 
 #define GLDS16(gptr, lptr)                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                     \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// in / out / skip: split activations (header).  Wl: this layer's region-4 weights.  grid = (ceil(n / 4) * F / 128), block 256.
-__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
+// in / out / skip: split activations (header).  Wl: this layer's region-4 weights.  grid = ceil(n / 8) * F / 128, block 512.
+// Pipeline: stage s+1 (the next tap group's weights, and with the first tap group of a chunk that chunk's activations) is
+// in flight as LDS-DMA into the other buffer while stage s is computed; ONE barrier per stage (it also drains this wave's
+// share of the DMA issued a whole stage earlier).
+__global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
                                                           const float* __restrict__ inv_scale_ptr, const unsigned char* in, unsigned char* out,
                                                           const unsigned char* skip, const uint8_t* __restrict__ active, int n, int F,
                                                           unsigned* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int noct = F / OCT, nchunks = F / 16;
-    // blocks b and b + 8 run on the same XCD (round-robin dispatch): give them the two oc tiles of the SAME positions, so the
-    // second one finds the activations in that XCD's L2
+    // blocks b and b + 8 run on the same XCD (round-robin dispatch): give them the oc tiles of the SAME positions, so the
+    // later one finds the activations in that XCD's L2
     const int b = blockIdx.x;
     const int ot = (b >> 3) % noct;
     const int pg = (b / (8 * noct)) * 8 + (b & 7);
-    const int p0 = pg * 4, pos = p0 + wv;
+    const int p0 = pg * NWAVE, pos = p0 + wv;
     if (p0 >= n) return;
     const bool live = pos < n && (!active || active[pos]);
     const size_t pos_bytes = (size_t)F * 256;
     const unsigned char* in_pos = in + (size_t)(pos < n ? pos : n - 1) * pos_bytes;
-    if (tid < 80) ((f32x4*)(lds + LDS_ZERO))[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // per-lane LDS byte addresses of the B operand (activations) for the 9 taps x 2 square tiles
+    if (tid < 160) {   // the zero rows of both images
+        const int im = tid / 80, k = tid % 80;
+        ((f32x4*)(lds + LDS_ACT + im * ACT_IMG + Z_OFF))[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // per-lane LDS byte offsets (inside an activation image) of the B operand for the 9 taps x 2 square tiles
     const int kg = lane >> 5;
-    uint32_t baddr[2][9];
+    uint32_t boff[2][9];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int sq = nt * 32 + (lane & 31), y = sq >> 3, x = sq & 7;
@@ -85,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const unsigned char* _
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
             const int s2 = sq + (t / 3 - 1) * 8 + (t % 3 - 1);
-            baddr[nt][t] = ok ? (uint32_t)(LDS_ACT + wv * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(LDS_ZERO + (s2 & 15) * 16);
+            boff[nt][t] = ok ? (uint32_t)(wv * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(Z_OFF + (s2 & 15) * 16);
         }
     }
-    const uint32_t aaddr = (uint32_t)(LDS_W + kg * 4096 + (lane & 31) * 16);   // + tap*8192 + hl*2048 + mtile*512
+    const uint32_t aoff = (uint32_t)(kg * 4096 + (lane & 31) * 16);   // + tap*8192 + hl*2048 + mtile*512 inside a weight stage
     f32x16 acc[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -96,35 +105,46 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const unsigned char* _
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
-    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE;
+    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE + lane * 16;
+    const unsigned char* asrc = in_pos + lane * 16;
+    // stage `st` = (chunk st / 3, tap group st % 3): 24 weight pieces of 1 KiB (3 per wave) + with tap group 0 this wave's
+    // position's four activation planes of that chunk
+    auto issue = [&](int c, int tg) {
+        const int st = c * 3 + tg;
+        const unsigned char* src = wsrc + (size_t)st * W_STAGE;
+        unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) GLDS16(src + (wv * 3 + i) * 1024, dst + (wv * 3 + i) * 1024);
+        if (tg == 0) {
+            const unsigned char* a = asrc + (size_t)c * ACT_POS;
+            unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + wv * ACT_POS;
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) GLDS16(a + pl * 1024, ad + pl * 1024);
+        }
+    };
+    issue(0, 0);
     for (int c = 0; c < nchunks; ++c) {
+        const uint32_t abase = (uint32_t)(LDS_ACT + (c & 1) * ACT_IMG);
 #pragma unroll
         for (int tg = 0; tg < 3; ++tg) {
-            __syncthreads();   // the previous stage's reads are done
-            if (tg == 0) {     // this chunk's activations: wave w moves its position's four planes
-                const unsigned char* src = in_pos + (size_t)c * ACT_POS + lane * 16;
-#pragma unroll
-                for (int pl = 0; pl < 4; ++pl) GLDS16(src + pl * 1024, lds + LDS_ACT + wv * ACT_POS + pl * 1024);
-            }
-            {   // this tap group's weights: 24 pieces of 1 KiB, 6 per wave
-                const unsigned char* src = wsrc + ((size_t)c * 3 + tg) * W_STAGE + lane * 16;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) GLDS16(src + (wv * 6 + i) * 1024, lds + LDS_W + (wv * 6 + i) * 1024);
-            }
-            __syncthreads();   // (the compiler drains vmcnt before the barrier: the DMA has landed)
+            const int st = c * 3 + tg;
+            __syncthreads();   // stage st has landed (every wave drained its DMA before arriving); stage st-1's reads are done
+            if (tg < 2) issue(c, tg + 1);
+            else if (c + 1 < nchunks) issue(c + 1, 0);
+            const uint32_t wbase = (uint32_t)(LDS_W + (st & 1) * W_STAGE) + aoff;
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt) {
                 const int t = tg * 3 + tt;
                 h8 bh[2], bl[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    bh[nt] = *(const h8*)(lds + baddr[nt][t]);
-                    bl[nt] = *(const h8*)(lds + baddr[nt][t] + 1024);
+                    bh[nt] = *(const h8*)(lds + abase + boff[nt][t]);
+                    bl[nt] = *(const h8*)(lds + abase + boff[nt][t] + 1024);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const h8 ah = *(const h8*)(lds + aaddr + tt * 8192 + m * 512);
-                    const h8 al = *(const h8*)(lds + aaddr + tt * 8192 + m * 512 + 2048);
+                    const h8 ah = *(const h8*)(lds + wbase + tt * 8192 + m * 512);
+                    const h8 al = *(const h8*)(lds + wbase + tt * 8192 + m * 512 + 2048);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], acc[m][nt], 0, 0, 0);
@@ -345,14 +365,14 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     }
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(64), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag);
-    const unsigned groups = (unsigned)((n + 3) / 4);
+    const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
     for (int r = 0; r < R; ++r) {
         const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(256), LDS_BYTES, s,
+        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
                            scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, active, (int)n, F, flag);
-        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(256), LDS_BYTES, s,
+        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
                            scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, active, (int)n, F, flag);
     }
