@@ -187,7 +187,8 @@ def gather_packed(packed, rank, world):
 class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
-    def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None):
+    def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None,
+                 net_kernel="auto"):
         """games_in_flight: game slots resident on the device.  block_games (per rank; default = games_in_flight): the
         number of consecutive game ids a rank plays between two gathers.  With block_games > games_in_flight the slots are
         refilled as games finish (continuous batching, SelfPlayEngine.play_continuous); the files do not depend on either
@@ -196,6 +197,9 @@ class BatchedSelfPlayWorker:
         self.net_blob = net_blob
         self.games_in_flight = games_in_flight
         self.block_games = block_games or games_in_flight
+        # "auto": wide nets (filters % 128 == 0) run their trunk on the f16 matrix cores (raznet-forward-v2, within 1e-5 of
+        # the fp32 graph, 3.7x the exact-f32 kernels); "f32": the exact kernels everywhere (engine.DeviceNet)
+        self.net_kernel = net_kernel
         self.seed = seed
         self.device = device
         self.rank, self.world = rank, world
@@ -234,7 +238,7 @@ class BatchedSelfPlayWorker:
         #  its identity: the reference keeps mtcs_info across threshold updates, worker/self_play.py:250-260)
         key = (max_sims, self.config.play.thinking_loop)
         if self._net is None:
-            self._net = DeviceNet(self.net_blob, self.device)
+            self._net = DeviceNet(self.net_blob, self.device, kernel=self.net_kernel)
         if self._engine is None or self._engine_key != key:
             self._engine = None
             self._series_pos = 0   # a new engine starts from empty trees
@@ -459,6 +463,9 @@ class BatchedSelfPlayWorker:
             else:
                 eng, n = self.play_batch_raw(game_idx, device_records=True)
                 packed = lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)
+            if not self._net.range_ok():
+                raise RuntimeError("an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2): "
+                                   "this block's games are not trustworthy - run the worker with net_kernel='f32'")
             if self.world > 1:
                 allraw, _ = gather_packed(packed, self.rank, self.world)
             else:

@@ -308,7 +308,9 @@ def test_emit_raw_writes_the_same_files_as_emit(tmp_path):
         else:
             w.emit_raw(_raw_of_games(games), first_local_idx=1, threads=3)
         play = [open(os.path.join(rc.play_data_dir, f)).read() for f in sorted(os.listdir(rc.play_data_dir))]
-        ggf = [open(os.path.join(rc.self_play_ggf_data_dir, f)).read() for f in sorted(os.listdir(rc.self_play_ggf_data_dir))]
+        import re   # (the GGF header carries the wall-clock time: DT[...])
+        ggf = [re.sub(r"DT\[[^\]]*\]", "DT[]", open(os.path.join(rc.self_play_ggf_data_dir, f)).read())
+               for f in sorted(os.listdir(rc.self_play_ggf_data_dir))]
         return play, ggf, (w.resign_test_game_count, w.false_positive_count_of_resign), len(w.buffer) if kind == "py" else None
 
     for tau1 in (True, False):
