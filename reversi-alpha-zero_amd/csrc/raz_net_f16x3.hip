@@ -194,11 +194,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
     if (over) atomicOr(flag, 1u);   // an activation beyond the f16 range: the caller must fall back to the f32 kernel
 }
 
-// Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.
-__global__ __launch_bounds__(64) void k_conv0_split(const float* __restrict__ W0, const raz_bb* __restrict__ own,
-                                                    const raz_bb* __restrict__ enemy, const uint8_t* __restrict__ active,
-                                                    unsigned char* out, int n, int F, unsigned* __restrict__ flag) {
-    const int pos = blockIdx.x, lane = threadIdx.x;
+// Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.  The work per
+// position is tiny and latency-bound (scalar weight loads), so a position's 16-channel chunks are spread over the 4 waves
+// of a workgroup (lane = square, wave w takes chunks w, w + 4, ...).
+__global__ __launch_bounds__(256) void k_conv0_split(const float* __restrict__ W0, const raz_bb* __restrict__ own,
+                                                     const raz_bb* __restrict__ enemy, const uint8_t* __restrict__ active,
+                                                     unsigned char* out, int n, int F, unsigned* __restrict__ flag) {
+    const int pos = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (pos >= n || (active && !active[pos])) return;
     bool over = false;
     const raz_bb bo = own[pos], be = enemy[pos];
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(64) void k_conv0_split(const float* __restrict__ W0
     }
     const float* bias = W0 + (size_t)F * 18;
     unsigned char* op = out + (size_t)pos * F * 256;
-    for (int ocb = 0; ocb < F / 16; ++ocb) {
+    for (int ocb = wv; ocb < F / 16; ocb += 4) {
         float acc[16];
 #pragma unroll
         for (int o = 0; o < 16; ++o) acc[o] = bias[ocb * 16 + o];
@@ -363,7 +365,7 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
         if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(64), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
+    hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);

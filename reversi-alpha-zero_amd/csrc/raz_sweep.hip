@@ -27,22 +27,44 @@ inline unsigned grid_for(size_t work_items) {
     return (unsigned)g;
 }
 
+// A wave works on blocks of 256 adjacent boards (128 pairs): lane l takes pairs l and 64 + l of the block, so that every
+// load / store instruction of the wave covers ONE contiguous 1 KiB run, and the next block's loads are issued before the
+// current block is computed (the integer work of a block then overlaps the memory time of the next instead of adding to it).
 __global__ __launch_bounds__(kBlock) void k_legal_moves(const ulonglong2* __restrict__ own2,
                                                         const ulonglong2* __restrict__ enemy2,
                                                         ulonglong2* __restrict__ legal2,
                                                         const raz_bb* __restrict__ own,
                                                         const raz_bb* __restrict__ enemy,
                                                         raz_bb* __restrict__ legal, size_t n) {
-    const size_t pairs = n >> 1;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += stride) {
-        ulonglong2 o = own2[i], e = enemy2[i], r;
-        r.x = bb_legal_moves(o.x, e.x);
-        r.y = bb_legal_moves(o.y, e.y);
-        legal2[i] = r;
+    const size_t pairs = n >> 1, nblocks = pairs >> 7;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+    size_t blk = wave;
+    ulonglong2 o0, o1, e0, e1;
+    if (blk < nblocks) {
+        const size_t i = (blk << 7) + lane;
+        o0 = own2[i]; o1 = own2[i + 64]; e0 = enemy2[i]; e1 = enemy2[i + 64];
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
-        legal[n - 1] = bb_legal_moves(own[n - 1], enemy[n - 1]);
+    while (blk < nblocks) {
+        const size_t i = (blk << 7) + lane, nb = blk + nwaves;
+        ulonglong2 no0, no1, ne0, ne1;
+        if (nb < nblocks) {
+            const size_t k = (nb << 7) + lane;
+            no0 = own2[k]; no1 = own2[k + 64]; ne0 = enemy2[k]; ne1 = enemy2[k + 64];
+        }
+        ulonglong2 r0, r1;
+        r0.x = bb_legal_moves(o0.x, e0.x);
+        r0.y = bb_legal_moves(o0.y, e0.y);
+        r1.x = bb_legal_moves(o1.x, e1.x);
+        r1.y = bb_legal_moves(o1.y, e1.y);
+        legal2[i] = r0;
+        legal2[i + 64] = r1;
+        o0 = no0; o1 = no1; e0 = ne0; e1 = ne1;
+        blk = nb;
+    }
+    // ragged tail: the boards after the last full block
+    for (size_t t = (nblocks << 8) + (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock)
+        legal[t] = bb_legal_moves(own[t], enemy[t]);
 }
 
 __global__ __launch_bounds__(kBlock) void k_calc_flip(const uint8_t* __restrict__ pos,
@@ -82,51 +104,66 @@ __device__ __forceinline__ void step_one(raz_bb& b, raz_bb& w, uint8_t& pl, uint
     lg = r.legal;
 }
 
-// Four adjacent boards per thread: the u64 streams move as 2 x 16 B per lane and the u8 streams as
-// 4 B per lane, and the four independent flip/mobility computations give the VALU instruction-level
-// parallelism (the kernel sits near the crossover between the HBM and the integer-VALU bound).
+// Blocks of 256 adjacent boards per wave as in k_legal_moves (lane l: pairs l and 64 + l), next block prefetched: four
+// independent flip / mobility computations per lane give the VALU instruction-level parallelism, every memory instruction
+// of a wave covers one contiguous run (1 KiB for the u64 streams, 128 B for the u8 streams).
+struct StepRegs {
+    ulonglong2 b0, b1, w0, w1;
+    uchar2 p0, p1, s0, s1, a0, a1;
+};
+__device__ __forceinline__ StepRegs step_load(const ulonglong2* black2, const ulonglong2* white2, const uchar2* player2,
+                                              const uchar2* status2, const uchar2* action2, size_t i) {
+    StepRegs r;
+    r.b0 = black2[i]; r.b1 = black2[i + 64]; r.w0 = white2[i]; r.w1 = white2[i + 64];
+    r.p0 = player2[i]; r.p1 = player2[i + 64]; r.s0 = status2[i]; r.s1 = status2[i + 64];
+    r.a0 = action2[i]; r.a1 = action2[i + 64];
+    return r;
+}
 __global__ __launch_bounds__(kBlock) void k_step(raz_bb* __restrict__ black,
                                                  raz_bb* __restrict__ white,
                                                  uint8_t* __restrict__ player,
                                                  uint8_t* __restrict__ status,
                                                  raz_bb* __restrict__ legal,
                                                  const uint8_t* __restrict__ action, size_t n) {
-    const size_t quads = n >> 2;
-    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t pairs = n >> 1, nblocks = pairs >> 7;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * kBlock) >> 6;
     ulonglong2* black2 = (ulonglong2*)black;
     ulonglong2* white2 = (ulonglong2*)white;
     ulonglong2* legal2 = (ulonglong2*)legal;
-    uchar4* player4 = (uchar4*)player;
-    uchar4* status4 = (uchar4*)status;
-    const uchar4* action4 = (const uchar4*)action;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < quads; i += stride) {
-        ulonglong2 b0 = black2[2 * i], b1 = black2[2 * i + 1], w0 = white2[2 * i], w1 = white2[2 * i + 1], l0, l1;
-        uchar4 p = player4[i], s = status4[i], a = action4[i];
-        step_one(b0.x, w0.x, p.x, s.x, l0.x, a.x);
-        step_one(b0.y, w0.y, p.y, s.y, l0.y, a.y);
-        step_one(b1.x, w1.x, p.z, s.z, l1.x, a.z);
-        step_one(b1.y, w1.y, p.w, s.w, l1.y, a.w);
-        black2[2 * i] = b0;
-        black2[2 * i + 1] = b1;
-        white2[2 * i] = w0;
-        white2[2 * i + 1] = w1;
-        legal2[2 * i] = l0;
-        legal2[2 * i + 1] = l1;
-        player4[i] = p;
-        status4[i] = s;
+    uchar2* player2 = (uchar2*)player;
+    uchar2* status2 = (uchar2*)status;
+    const uchar2* action2 = (const uchar2*)action;
+    size_t blk = wave;
+    StepRegs c;
+    if (blk < nblocks) c = step_load(black2, white2, player2, status2, action2, (blk << 7) + lane);
+    while (blk < nblocks) {
+        const size_t i = (blk << 7) + lane, nb = blk + nwaves;
+        StepRegs nx;
+        if (nb < nblocks) nx = step_load(black2, white2, player2, status2, action2, (nb << 7) + lane);
+        ulonglong2 l0, l1;
+        step_one(c.b0.x, c.w0.x, c.p0.x, c.s0.x, l0.x, c.a0.x);
+        step_one(c.b0.y, c.w0.y, c.p0.y, c.s0.y, l0.y, c.a0.y);
+        step_one(c.b1.x, c.w1.x, c.p1.x, c.s1.x, l1.x, c.a1.x);
+        step_one(c.b1.y, c.w1.y, c.p1.y, c.s1.y, l1.y, c.a1.y);
+        black2[i] = c.b0; black2[i + 64] = c.b1;
+        white2[i] = c.w0; white2[i + 64] = c.w1;
+        legal2[i] = l0; legal2[i + 64] = l1;
+        player2[i] = c.p0; player2[i + 64] = c.p1;
+        status2[i] = c.s0; status2[i + 64] = c.s1;
+        c = nx;
+        blk = nb;
     }
-    // ragged tail (n % 4 boards)
-    const size_t tail0 = quads << 2;
-    if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
-        const size_t i = tail0 + threadIdx.x;
-        raz_bb b = black[i], w = white[i], l;
-        uint8_t p = player[i], s = status[i];
-        step_one(b, w, p, s, l, action[i]);
-        black[i] = b;
-        white[i] = w;
-        legal[i] = l;
-        player[i] = p;
-        status[i] = s;
+    // ragged tail: the boards after the last full block
+    for (size_t t = (nblocks << 8) + (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
+        raz_bb b = black[t], w = white[t], l;
+        uint8_t p = player[t], st = status[t];
+        step_one(b, w, p, st, l, action[t]);
+        black[t] = b;
+        white[t] = w;
+        legal[t] = l;
+        player[t] = p;
+        status[t] = st;
     }
 }
 

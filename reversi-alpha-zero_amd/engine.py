@@ -126,6 +126,11 @@ class SelfPlayEngine:
         self.net = net
         self.device = net.device
         self.n_games = n_games
+        if inner_max == 0 and net.filters >= 128 and int(getattr(config.play, "parallel_search_num", 1) or 1) <= 1:
+            # a wide net's forward dwarfs the tree kernel: let a game whose simulations end on finished positions (no net
+            # evaluation needed) keep simulating inside the launch until it has a leaf for the batch, instead of idling a
+            # batch row (results do not depend on this budget)
+            inner_max = 8
         if nodes_per_game is None:
             s = sims_hint or config.play.simulation_num_per_move
             loops = max(1, config.play.thinking_loop)
