@@ -16,10 +16,11 @@ reference's reproducible mode).  Rank r plays global game ids [r*8192, (r+1)*819
 A "step" is one pass of the hot path over the batch: the tree kernel (backup of the previous leaf, per-move
 controller, PUCT descent to the next leaf, for every live game) followed by ONE net evaluation of all gathered
 leaves.  A whole batch of games is ~50 000 steps at this size, so the timed region is K steps of the batch in
-its STEADY STATE under continuous batching: slot i holds a game at a ply drawn uniformly from 0..58 (positions
-reached by on-device random playouts, raz_step_batch), i.e. the mix of opening, middle-game and end-game
-positions (terminal leaves, deep boards) a long run holds at any instant; W warm-up steps are run on that
-state first.  metric = MCTS simulations/sec = start_search_my_move invocations / wall time, NN included,
+its STEADY STATE under continuous batching: slot i holds a game at a ply drawn from the time share each ply has
+in a long run (calibrated in the same run, untimed; positions reached by on-device random playouts,
+raz_step_batch), i.e. the mix of opening, middle-game and end-game positions (terminal leaves, deep boards) a
+long run holds at any instant; --tree-warm + W warm-up steps are run on that state first, so the timed steps
+search trees that already hold a few dozen simulations.  metric = MCTS simulations/sec = start_search_my_move invocations / wall time, NN included,
 inputs resident in HBM, whole job over all GPUs.  games/hour is extrapolated from it (labelled).
 
 The same line carries, at N = 1: the parity spot check (8 sampled games of the 8192-game batch against the CPU
@@ -146,17 +147,45 @@ def spotcheck_whole_games(eng, cfg, blob, seed, first_id, slots, sims):
 # ------------------------------------------------------------------------------------------------------------
 # headline: Config 3
 # ------------------------------------------------------------------------------------------------------------
-def stagger(eng, n, sims, seed, dev):
-    """Continuous-batching steady state: slot i continues a game from a position at a ply drawn uniformly from
-    0..58, reached by random playouts on the device (the sweep kernels; SURVEY §8(d) "value distributions")."""
+def stagger(eng, n, sims, seed, dev, ply_weights=None):
+    """Continuous-batching steady state: slot i continues a game from a position at ply p_i in 0..58 reached by random
+    playouts on the device (the sweep kernels; SURVEY §8(d) "value distributions").  p_i is drawn uniformly, or with
+    `ply_weights` (the time share of each ply in a long run, see calibrate_ply_weights).  Returns the plies."""
+    import numpy as np
     from bench_sweep import harvest_positions
-    black, white, player, _ = harvest_positions(n, seed, dev)
+    black, white, player, _ = harvest_positions(n, seed, dev, ply_weights)
     b, w, p = black.cpu().numpy(), white.cpu().numpy(), player.cpu().numpy()
     for g in range(n):
         eng.set_position(g, int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g]), sims, enable_resign=True, one_move=False)
-    import numpy as np
     occ = np.unpackbits((b.view(np.uint64) | w.view(np.uint64)).view(np.uint8)).reshape(n, 64).sum(1)
-    return {"mean_discs_on_board": float(occ.mean()), "min": int(occ.min()), "max": int(occ.max())}
+    return occ.astype(np.int64) - 4
+
+
+def slot_sims(eng):
+    import numpy as np
+    from reversi_alpha_zero_amd.engine import GAME_SUMMARY
+    pk = eng.pack_records(0, eng.n_games, plies=1)
+    return pk["summary"].cpu().numpy().view(GAME_SUMMARY).reshape(-1)["sims"].astype(np.int64)
+
+
+def calibrate_ply_weights(eng, n, sims, seed, dev, first_id, steps=12):
+    """In a long run with continuous batching a slot spends at ply p a time proportional to the steps a move takes there,
+    S / r(p) with r(p) = simulations completed per step at ply p (1 while every simulation needs the net; more near the end
+    of a game, where simulations end on finished positions and several complete per step).  r(p) is measured here on a
+    uniformly staggered batch (untimed); the timed batch is then drawn with weights 1 / r(p)."""
+    import numpy as np
+    eng.start(first_id, sims)
+    ply = stagger(eng, n, sims, seed, dev)
+    eng.step(24)
+    s0 = slot_sims(eng)
+    eng.step(steps)
+    r_slot = (slot_sims(eng) - s0) / float(steps)
+    r = np.ones(59)
+    for p in range(59):
+        m = ply == p
+        if m.any():
+            r[p] = max(float(r_slot[m].mean()), 0.5)
+    return (1.0 / r), r
 
 
 def conv_traffic():
@@ -200,10 +229,16 @@ def headline_leg(args, dev, rank, world, cdev):
                 "games": checked, "seconds": time.perf_counter() - t0}
 
     # (2) the steady state of continuous batching, W warm-up steps, K timed steps
+    if not args.opening:
+        weights, r = calibrate_ply_weights(eng, args.games, args.sims, 777 + rank, dev, first_id)
     eng.start(first_id, args.sims)
     if not args.opening:
-        out["stagger"] = stagger(eng, args.games, args.sims, 12345 + rank, dev)
-    eng.step(max(args.warmup, 1))
+        ply = stagger(eng, args.games, args.sims, 12345 + rank, dev, weights)
+        out["steady_state"] = {"ply_distribution": "time share of ply p in a long run ~ 1 / r(p), r = simulations completed per step at ply p, "
+                                                   "calibrated on a uniformly staggered batch in this run (untimed)",
+                               "sims_per_step_by_ply_sampled": {str(p): round(float(r[p]), 3) for p in (1, 10, 20, 30, 40, 45, 50, 54, 56, 58)},
+                               "mean_ply_of_the_timed_batch": float(ply.mean())}
+    eng.step(max(args.warmup, 1) + (0 if args.opening else args.tree_warm))
     st0 = eng.stats()
     torch.cuda.synchronize()
     if world > 1:
@@ -260,7 +295,7 @@ def headline_leg(args, dev, rank, world, cdev):
         "config": {"workload": f"BASELINE configs[2]: {args.games} concurrent self-play games/GPU, {args.net} net (F{F} R{R} V{V}), "
                                f"{args.sims} sims/move, ch5.yml play settings, thinking_loop=1, solver off, parallel_search_num=1; "
                                + ("first steps from the opening" if args.opening else
-                                  "steady state of continuous batching (slots at uniformly random plies 0..58)"),
+                                  "steady state of continuous batching (slots at plies 0..58 drawn from the time share of each ply in a long run)"),
                    "games_per_gpu": args.games, "sims_per_move": args.sims, "net": args.net,
                    "kernel_launches_per_step": parts * (2 if args.net == "mini" else 23), "slices": parts},
         "sims_per_sec_per_gpu": value / world, "leaves_per_sec": leaves / elapsed,
@@ -416,6 +451,7 @@ def main():
     ap.add_argument("--net-kernel", default="auto", help="DeviceNet kernel: auto = f16x3 (raznet-forward-v2) where supported, f32 = exact-f32 kernels")
     ap.add_argument("--parts", type=int, default=0, help="slices/streams the batch is stepped in (0 = 1 for the 256x10 net, 3 for mini)")
     ap.add_argument("--nodes-per-game", type=int, default=0, help="node pool per game (0 = 16 x sims: pools are pruned by k_gc in long runs)")
+    ap.add_argument("--tree-warm", type=int, default=40, help="untimed steps on the staggered batch before the W warm-up steps")
     ap.add_argument("--opening", action="store_true", help="time the first steps from the opening instead of the steady state")
     ap.add_argument("--no-spotcheck", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

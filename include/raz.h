@@ -265,7 +265,7 @@ typedef struct {
     uint32_t game_id, n_plies;
     uint8_t status;                     /* winner | flags, as raz_env_step */
     uint8_t resigned_black, resigned_white, enable_resign;
-    uint32_t reserved;
+    uint32_t sims_lo;                   /* simulations run for this game so far (low 32 bits) */
 } raz_game_summary;                     /* 32 bytes */
 int raz_engine_records_extent(raz_engine* e, uint32_t first_slot, uint32_t n_slots, uint32_t* max_plies,
                               raz_stream_t stream);   /* synchronises `stream` */

@@ -2239,7 +2239,7 @@ __global__ __launch_bounds__(256) void k_pack_records(raz_engine_dev E, uint32_t
         S.resigned_black = (uint8_t)G.resigned[0];
         S.resigned_white = (uint8_t)G.resigned[1];
         S.enable_resign = (uint8_t)G.enable_resign;
-        S.reserved = 0;
+        S.sims_lo = (uint32_t)G.sims;
         summ[j] = S;
     }
 }
@@ -2353,7 +2353,7 @@ __global__ __launch_bounds__(256) void k_harvest_apply(raz_engine_dev E, const u
     raz_game_summary S;
     S.final_black = G.root_black; S.final_white = G.root_white; S.game_id = G.game_id; S.n_plies = G.n_plies;
     S.status = (uint8_t)G.status; S.resigned_black = (uint8_t)G.resigned[0]; S.resigned_white = (uint8_t)G.resigned[1];
-    S.enable_resign = (uint8_t)G.enable_resign; S.reserved = 0;
+    S.enable_resign = (uint8_t)G.enable_resign; S.sims_lo = (uint32_t)G.sims;
     out_sum[row] = S;
     out_done[row] = 1;
     atomicAdd(&E.counters[8], 1ULL);

@@ -432,7 +432,7 @@ class SelfPlayEngine:
 
 GAME_SUMMARY = np.dtype([("final_black", "<u8"), ("final_white", "<u8"), ("game_id", "<u4"), ("n_plies", "<u4"),
                          ("status", "u1"), ("resigned_black", "u1"), ("resigned_white", "u1"), ("enable_resign", "u1"),
-                         ("reserved", "<u4")])
+                         ("sims", "<u4")])
 assert GAME_SUMMARY.itemsize == 32
 
 
@@ -444,7 +444,7 @@ def raw_from_packed(headers_u8, root_n_i32, summary_u8):
     return dict(headers=hdr, root_n=np.ascontiguousarray(root_n_i32).view(np.uint32), root_w=None,
                 n_plies=sm["n_plies"].copy(), status=sm["status"].copy(),
                 resigned=np.stack([sm["resigned_black"], sm["resigned_white"]], axis=1),
-                game_id=sm["game_id"].copy(), enable_resign=sm["enable_resign"].copy(),
+                game_id=sm["game_id"].copy(), enable_resign=sm["enable_resign"].copy(), sims=sm["sims"].copy(),
                 final_black=sm["final_black"].copy(), final_white=sm["final_white"].copy())
 
 

@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s measure
 STEP_BYTES_PER_BOARD = 45  # include/raz.h raz_step_batch: 19 B read + 26 B written
 
 
-def harvest_positions(n, seed, dev):
-    """Random playouts on device; game g is frozen at a uniformly random ply in [0, 58]."""
+def harvest_positions(n, seed, dev, ply_weights=None):
+    """Random playouts on device; game g is frozen at a ply drawn from [0, 58]: uniformly, or with the given 59 weights."""
     import torch
     from reversi_alpha_zero_amd.lib import bitboard as bb
     black = torch.full((n,), 0x0000000810000000, dtype=torch.int64, device=dev)
@@ -37,7 +37,11 @@ def harvest_positions(n, seed, dev):
     status = torch.zeros(n, dtype=torch.uint8, device=dev)
     legal = bb.legal_moves_batch(black, white)
     g = torch.Generator(device=dev).manual_seed(seed)
-    target = torch.randint(0, 59, (n,), generator=g, device=dev, dtype=torch.int32)
+    if ply_weights is None:
+        target = torch.randint(0, 59, (n,), generator=g, device=dev, dtype=torch.int32)
+    else:
+        w = torch.as_tensor(ply_weights, dtype=torch.float32, device=dev)
+        target = torch.multinomial(w / w.sum(), n, replacement=True, generator=g).to(torch.int32)
     snap = [black.clone(), white.clone(), player.clone(), legal.clone()]
     for ply in range(59):
         take = (target == ply) & (status == 0)
