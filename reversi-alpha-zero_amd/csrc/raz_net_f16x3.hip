@@ -200,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
 __global__ __launch_bounds__(256) void k_conv0_split(const float* __restrict__ W0, const raz_bb* __restrict__ own,
                                                      const raz_bb* __restrict__ enemy, const uint8_t* __restrict__ active,
                                                      unsigned char* out, int n, int F, unsigned* __restrict__ flag) {
-    const int pos = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pos = blockIdx.x, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the weight reads below stay scalar loads
     if (pos >= n || (active && !active[pos])) return;
     bool over = false;
     const raz_bb bo = own[pos], be = enemy[pos];

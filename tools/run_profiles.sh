@@ -28,4 +28,8 @@ for P in $PASSES; do
     echo "pmc$P rc=$?"
   fi
 done
+# gpurun copies back at most 64 MiB: summarise here and drop the per-dispatch traces
+cd "$ROOT" && python tools/pmc_summary.py "$OUT" "$OUT/summary" > "$OUT/summary_pmc.txt" 2>&1
+find "$OUT" -name "*_kernel_trace.csv" -delete
+find "$OUT" -name "*_counter_collection.csv" -delete
 find "$OUT" -name "*.csv" | head -40
