@@ -388,6 +388,54 @@ def config1_leg(dev, args, par=1):
     return out, blob, cfg
 
 
+def continuous_leg(dev, args, rounds=3):
+    """configs[1] with continuous batching (raz_engine_harvest: a finished slot restarts on the next game id at once,
+    worker/self_play.py:95-137): 4096 slots, rounds x 4096 game ids, whole games.  games/hour and sims/s here are measured
+    on complete games in a (mostly) steady state, not extrapolated; leaf_slot_occupancy = nn leaves / (steps x slots)."""
+    import numpy as np
+    import torch
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine, raw_from_packed
+    games, sims = 4096, 200
+    cfg = mini_config(sims, 1)
+    blob = ReversiNet(*NETS["mini"]).keras_init_(0).to_blob()
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, dev), n_games=games, seed=0, sims_hint=sims)
+    eng.start(0, sims)
+    eng.step(50)
+    eng.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outbox, st = eng.play_continuous(0, rounds * games, lambda gid: sims, chunk=200)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"BASELINE configs[1] with continuous batching: {games} slots, {rounds * games} game ids (whole games), mini net, {sims} sims/move, "
+                       "mini.yml play settings, thinking_loop=1, solver off, parallel_search_num=1",
+           "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
+           "finished_games": st["finished_games"], "steps": st["steps"], "ms_per_step": 1e3 * dt / st["steps"],
+           "leaf_slot_occupancy": st["leaf_slot_occupancy"], "gc_runs": st["gc_runs"],
+           "note": "includes the ramp-down of the last games (slots idle once no unplayed id is left) and one host synchronisation per 200 steps"}
+    if not args.no_spotcheck:
+        import oracle as O
+        import concurrent.futures as cf
+        ids = [int(x) for x in np.linspace(0, rounds * games - 1, 8).astype(int)]
+        rows = torch.tensor(ids, device=dev)
+        raw = raw_from_packed(*(outbox[k][rows].cpu().numpy() for k in ("headers", "root_n", "summary")))
+        ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
+        with cf.ThreadPoolExecutor(max_workers=8) as ex:
+            ref = list(ex.map(lambda gid: O.selfplay_game(ocfg, blob, 0, gid, sims), ids))
+        for r, (gid, (plies, summ)) in enumerate(zip(ids, ref)):
+            n = int(raw["n_plies"][r])
+            ok = int(raw["game_id"][r]) == gid and [int(a) for a in raw["headers"][r, :n]["action"]] == [p["action"] for p in plies] \
+                and all([float(x) for x in raw["root_n"][r, i]] == p["root_n"] for i, p in enumerate(plies))
+            if not ok:
+                raise AssertionError(f"parity spot check FAILED: continuous batching, game id {gid} differs from the oracle")
+        out["parity_spotcheck"] = {"result": "ok", "what": "8 game ids sampled from the id-ordered outbox (refilled slots included): every action and root N == complete oracle games",
+                                   "game_ids": ids}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def sweep_leg(dev, boards=1 << 24, steps=10):
     """The bitboard-sweep HBM leg of the north star: k_step / k_legal_moves GB/s (tools/bench_sweep.py)."""
     import bench_sweep
@@ -498,6 +546,7 @@ def main():
         if world == 1 and not args.no_extra_legs:
             legs = (("config1_4096x200_mini", lambda: config1_leg(dev, args, 1)[0]),
                     ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4)[0]),
+                    ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             for key, leg in legs:
                 try:

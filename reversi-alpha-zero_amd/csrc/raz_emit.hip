@@ -30,6 +30,12 @@ namespace {
 // spacing is below 1e-15 relative).  Hence: first of 15 / 16 / 17 digits that round-trips, trailing zeros
 // stripped; subnormals, whose spacing is coarse, search from one digit up.
 int fmt_repr(double x, char* out) {
+    if (!(fabs(x) <= 1.7976931348623157e308)) {   // float.__repr__ of non-finite values (json.dump writes NaN / Infinity)
+        const char* t = x != x ? "NaN" : (x > 0 ? "Infinity" : "-Infinity");
+        const int n = (int)strlen(t);
+        memcpy(out, t, (size_t)n);
+        return n;
+    }
     if (x == 0.0) {
         const bool neg = signbit(x);
         memcpy(out, neg ? "-0.0" : "0.0", neg ? 4 : 3);
@@ -113,13 +119,15 @@ extern "C" long long raz_emit_game_rows_json(const void* headers, const uint32_t
                                              int* n_rows) {
     if (!headers || !root_n || !out || n_plies < 0) return raz_fail(RAZ_EINVAL, "raz_emit_game_rows_json: bad argument");
     const raz_ply_header* H = (const raz_ply_header*)headers;
-    static int perm[8][64];
-    static bool perm_ready = false;
-    if (!perm_ready) {  // (idempotent: racing threads write the same values)
-        for (int f = 0; f < 2; ++f)
-            for (int r = 0; r < 4; ++r) policy_permutation(f, r, perm[f * 4 + r]);
-        perm_ready = true;
-    }
+    struct Perms {   // built once; a function-local static's initialisation is thread-safe (C++11) - callers are host threads
+        int p[8][64];
+        Perms() {
+            for (int f = 0; f < 2; ++f)
+                for (int r = 0; r < 4; ++r) policy_permutation(f, r, p[f * 4 + r]);
+        }
+    };
+    static const Perms perms;
+    const int (*perm)[64] = perms.p;
     const int black_win = winner == RAZ_WIN_BLACK ? 1 : (winner == RAZ_WIN_WHITE ? -1 : 0);
     size_t pos = 0;
     int rows = 0;
@@ -135,6 +143,7 @@ extern "C" long long raz_emit_game_rows_json(const void* headers, const uint32_t
             if (save_policy_of_tau_1 || (int)h.turn < change_tau_turn) {
                 double sum = 0.0;  // np.sum of integers below 2^53: exact in any order
                 for (int i = 0; i < 64; ++i) sum += (double)n[i];
+                // (sum == 0 cannot come from a searched ply; numpy would give nan = "NaN" in the reference's json.dump)
                 for (int i = 0; i < 64; ++i) len[i] = fmt_repr((double)n[i] / sum, txt[i]);
             } else {
                 int am = 0;
