@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <mutex>
 #include <vector>
 #include "raz_bitboard.h"
 #include "raz_detmath.h"
@@ -1670,6 +1671,28 @@ int validate(const raz_engine_config* cfg) {
 
 constexpr int kMaxParts = 8;
 
+// The internal streams of all engines of a process, per device, created once and never destroyed.  HIP maps streams onto a
+// few hardware queues round-robin in creation order: an engine that creates fresh streams after other engines have come
+// and gone can land two of its slices on ONE queue, which serialises them (measured: the same workload 3.3x slower after
+// an engine with a different stream history had been destroyed).  A fixed pool keeps every engine on the mapping of the
+// first one.  Engines of one host thread run one at a time (include/raz.h), so sharing the streams orders nothing extra.
+static hipError_t raz_pool_stream(int h, hipStream_t* out) {
+    static std::mutex mu;
+    static hipStream_t pool[64][kMaxParts] = {};
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (dev < 0 || dev >= 64 || h < 0 || h >= kMaxParts) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i <= h; ++i)   // always in index order, so that stream i of a device is the i-th created
+        if (!pool[dev][i]) {
+            err = hipStreamCreateWithFlags(&pool[dev][i], hipStreamNonBlocking);
+            if (err != hipSuccess) return err;
+        }
+    *out = pool[dev][h];
+    return hipSuccess;
+}
+
 struct raz_engine {
     raz_engine_dev dev;
     raz_net net;
@@ -1806,7 +1829,7 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     if (parts > 1) {
         hipError_t err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
         for (int h = 1; h < parts && err == hipSuccess; ++h) {
-            err = hipStreamCreateWithFlags(&e->aux[h], hipStreamNonBlocking);
+            err = raz_pool_stream(h, &e->aux[h]);
             if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
         }
         if (err != hipSuccess) {
@@ -1826,7 +1849,7 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
     hipError_t err = hipSuccess;
     if (parts > 1 && !e->ev_fork) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
     for (int h = 1; h < parts && err == hipSuccess; ++h) {
-        if (!e->aux[h]) err = hipStreamCreateWithFlags(&e->aux[h], hipStreamNonBlocking);
+        if (!e->aux[h]) err = raz_pool_stream(h, &e->aux[h]);
         if (err == hipSuccess && !e->ev_join[h]) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
     }
     if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_set_parts");
@@ -1838,7 +1861,7 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
 extern "C" void raz_engine_destroy(raz_engine* e) {
     if (!e) return;
     for (int h = 0; h < kMaxParts; ++h) {
-        if (e->aux[h]) hipStreamDestroy(e->aux[h]);
+        // (aux streams belong to the process-wide pool)
         if (e->ev_join[h]) hipEventDestroy(e->ev_join[h]);
     }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -1952,7 +1975,7 @@ extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t str
     hipStream_t run = s;
     if (s == nullptr) {
         if (!e->aux[0]) {
-            hipError_t err = hipStreamCreateWithFlags(&e->aux[0], hipStreamNonBlocking);
+            hipError_t err = raz_pool_stream(0, &e->aux[0]);
             if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming);
             if (err == hipSuccess && !e->ev_fork) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
             if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step: internal stream");
