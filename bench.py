@@ -404,15 +404,16 @@ def continuous_leg(dev, args, rounds=3):
     eng.step(50)
     eng.stats()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
     outbox, st = eng.play_continuous(0, rounds * games, lambda gid: sims, chunk=200)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # the stepping loop (steps + per-chunk stats + harvests, host clock, every chunk ends synchronised) - like the lock-step
+    # leg, the start of the batch and the allocation of the id-ordered outbox are outside the timed region
+    dt = sum(st["seconds"].values())
     out = {"workload": f"BASELINE configs[1] with continuous batching: {games} slots, {rounds * games} game ids (whole games), mini net, {sims} sims/move, "
                        "mini.yml play settings, thinking_loop=1, solver off, parallel_search_num=1",
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "finished_games": st["finished_games"], "steps": st["steps"], "ms_per_step": 1e3 * dt / st["steps"],
-           "leaf_slot_occupancy": st["leaf_slot_occupancy"], "gc_runs": st["gc_runs"],
+           "leaf_slot_occupancy": st["leaf_slot_occupancy"], "gc_runs": st["gc_runs"], "seconds": st["seconds"],
            "note": "includes the ramp-down of the last games (slots idle once no unplayed id is left) and one host synchronisation per 200 steps"}
     if not args.no_spotcheck:
         import oracle as O
@@ -549,6 +550,9 @@ def main():
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             for key, leg in legs:
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
                 try:
                     out[key] = leg()
                 except AssertionError:

@@ -338,13 +338,17 @@ class SelfPlayEngine:
         nxt, done, steps, cap = first_game_id + n0, 0, 0, int(self.cfg.nodes_per_game)
         end = first_game_id + total_games
         self.gc_runs = 0
+        import time
+        host = {"steps_and_stats": 0.0, "harvest": 0.0}
         while done < total_games:
+            t0 = time.perf_counter()
             self.step(chunk)
             steps += chunk
             st = self.stats()
             if st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
                 self.gc(threshold=cap // 4)
                 self.gc_runs += 1
+            t1 = time.perf_counter()
             k = min(B, end - nxt)
             ids = range(nxt, nxt + k)
             h, r, skipped, playing = self.harvest(outbox, nxt, [sims_of(i) for i in ids],
@@ -352,10 +356,13 @@ class SelfPlayEngine:
             assert skipped == 0
             nxt += r
             done += h
+            host["steps_and_stats"] += t1 - t0
+            host["harvest"] += time.perf_counter() - t1
             if steps >= max_steps:
                 raise RuntimeError("engine did not finish within max_steps")
         st = self.stats()
-        st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs)
+        st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs,
+                  seconds=host)
         return outbox, st
 
     def gc(self, threshold=0):
