@@ -229,6 +229,7 @@ def headline_leg(args, dev, rank, world, cdev):
                 "games": checked, "seconds": time.perf_counter() - t0}
 
     # (2) the steady state of continuous batching, W warm-up steps, K timed steps
+    weights = None
     if not args.opening:
         weights, r = calibrate_ply_weights(eng, args.games, args.sims, 777 + rank, dev, first_id)
     eng.start(first_id, args.sims)
@@ -319,9 +320,42 @@ def headline_leg(args, dev, rank, world, cdev):
     k["achieved"] = k["algorithmic_bytes_per_launch"] / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None
     k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"
     k["frac"] = k["achieved"] / HBM_PEAK_GBS if k["achieved"] else None
+    out["_ply_weights"] = weights
     del eng, net
     torch.cuda.empty_cache()
     return out, blob, cfg
+
+
+def exact_f32_leg(args, dev, blob, cfg, weights, steps=8):
+    """The headline workload on the exact-f32 kernels (raznet-forward-v1: every output one k-ordered fmaf chain on the f32
+    matrix cores, bit-identical to the CPU oracle), same steady-state batch recipe, fewer steps (a step is ~96 ms)."""
+    import torch
+    from reversi_alpha_zero_amd.agent.model import macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    F, R, V = NETS[args.net]
+    net = DeviceNet(blob, dev, kernel="f32")
+    eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims, nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=1)
+    eng.start(0, args.sims)
+    if weights is not None:
+        stagger(eng, args.games, args.sims, 12345, dev, weights)
+    eng.step(12)
+    st0 = eng.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tree_ms, net_ms = eng.step_timed(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    sims, leaves = st["total_sims"] - st0["total_sims"], st["nn_leaves"] - st0["nn_leaves"]
+    ach = 2.0 * macs_per_position(F, R, V) * (leaves / steps) / (net_ms / steps * 1e-3) / 1e12
+    out = {"workload": "the headline workload on the exact-f32 kernels (raz_net.reserved = 0: k_conv3x3_wide on v_mfma_f32_32x32x2_f32), "
+                       f"same steady-state batch recipe, {steps} steps",
+           "value": sims / dt, "unit": "sims/s", "leaves_per_sec": leaves / dt, "ms_per_step": 1e3 * dt / steps,
+           "roofline": {"bound": "mfma", "avg_kernel_ms": net_ms / steps, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / FP32_PEAK_TFLOPS}}
+    del eng, net
+    torch.cuda.empty_cache()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -542,10 +576,13 @@ def main():
     res = headline_leg(args, dev, rank, world, cdev)
     if rank == 0:
         out, blob, cfg = res
+        ply_weights = out.pop("_ply_weights", None)
         if shared_gpu:
             out["config"]["test_rig"] = "RAZ_BENCH_SHARED_GPU=1: ranks share GPUs, gloo collectives - not a scaling measurement"
         if world == 1 and not args.no_extra_legs:
-            legs = (("config1_4096x200_mini", lambda: config1_leg(dev, args, 1)[0]),
+            legs = ((("headline_on_exact_f32_kernels", lambda: exact_f32_leg(args, dev, blob, cfg, ply_weights)),)
+                    if "f16x3" in out["dtype"] else ()) + (
+                    ("config1_4096x200_mini", lambda: config1_leg(dev, args, 1)[0]),
                     ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4)[0]),
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
