@@ -243,15 +243,36 @@ class BatchedSelfPlayWorker:
             self._engine = None
             self._series_pos = 0   # a new engine starts from empty trees
             r = self._series_length()
+            p = self.config.play
+            whole = (max_sims * max(1, p.thinking_loop) * 62 + 128) * 2   # a whole game's tree (two nodes per simulation at most)
             nodes = None
             if r > 1:   # the tree of a series is never pruned (its early positions are searched again): room for r games
-                p = self.config.play
-                nodes = r * (max_sims * max(1, p.thinking_loop) * 62 + 128) * 2
+                nodes = r * whole
+            else:
+                # 8192 games x 800 sims/move would need 1.1 TB for whole-game trees: size the pools for the HBM that is
+                # there (k_gc prunes the positions the real game has left behind; pools of ~16 x sims nodes suffice)
+                cap = self._pool_nodes_that_fit()
+                if cap is not None and cap < whole:
+                    if cap < 12 * max_sims:
+                        raise RuntimeError(f"{self.games_in_flight} games in flight at {max_sims} sims/move leave {cap} tree nodes per "
+                                           f"game in this GPU's free memory (< 12 x sims): lower games_in_flight")
+                    nodes = cap
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes)
             self._engine_key = key
         self._engine.set_resign_threshold(self.config.play.resign_threshold)
         return self._engine
+
+    def _pool_nodes_that_fit(self, fraction=0.7):
+        """Tree nodes per game that fit in `fraction` of the device's free memory (node 1408 B + 2 table slots of 32 B + a
+        prune-map word; include/raz.h raz_engine_workspace_bytes is the exact figure).  None when torch cannot tell."""
+        try:
+            import torch
+            free, _ = torch.cuda.mem_get_info(torch.device(self.device))
+        except Exception:
+            return None
+        per_node = 1408 + 2 * 32 * 2 + 4   # (table_slots is the next power of two >= 2 x nodes: up to 4 slots per node)
+        return int(free * fraction) // (self.games_in_flight * per_node)
 
     def play_batch(self, first_game_idx, n_games=None):
         """Play global game ids first_game_idx + rank*B .. on this rank.  Returns [(plies, summary)]."""
