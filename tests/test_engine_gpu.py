@@ -190,8 +190,9 @@ def test_net_f16x3_range_flag():
     assert not v2.range_ok()
 
 
-def test_engine_on_f16x3_net_equals_oracle_given_the_nets_outputs():
-    """Games on raznet-forward-v2: the engine (wide net, split-f16 trunk, cross-game leaf batches) == the CPU oracle's
+@pytest.mark.parametrize("par", [1, 4])
+def test_engine_on_f16x3_net_equals_oracle_given_the_nets_outputs(par):
+    """Games on raznet-forward-v2 (par = parallel_search_num: k_tree / the slot kernel k_tree_par): the engine (wide net, split-f16 trunk, cross-game leaf batches) == the CPU oracle's
     games when the oracle evaluates leaves through the SAME device net via the reference's NN seam
     (ReversiPlayer(api=...), agent/player.py:41,346) - every action, root N and W, bit for bit."""
     import types
@@ -201,7 +202,7 @@ def test_engine_on_f16x3_net_equals_oracle_given_the_nets_outputs():
     play = types.SimpleNamespace(
         simulation_num_per_move=14, share_mtcs_info_in_self_play=True, thinking_loop=1, required_visit_to_decide_action=400,
         start_rethinking_turn=8, c_puct=5, noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=4, virtual_loss=3,
-        parallel_search_num=1, resign_threshold=-0.9, allowed_resign_turn=50, disable_resignation_rate=0.1,
+        parallel_search_num=par, resign_threshold=-0.9, allowed_resign_turn=50, disable_resignation_rate=0.1,
         use_solver_turn=0, use_solver_turn_in_simulation=0)
     cfg = types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
     dnet = DeviceNet(blob, DEV, kernel="f16x3")
@@ -215,10 +216,10 @@ def test_engine_on_f16x3_net_equals_oracle_given_the_nets_outputs():
         to = lambda v: torch.tensor([v - (1 << 64) if v >= 1 << 63 else v], dtype=torch.int64, device=DEV)
         p, v = dnet.predict_bitboards(to(own), to(enemy))
         return p[0].cpu().numpy(), float(v[0].item())
-    ocfg = O.play_cfg_from_config(cfg)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=par)
     for i in (0, 5, 11):
         plies, summ = O.selfplay_game(ocfg, None, 3, 40 + i, 14, nn=nn)
-        _compare_game(f"f16x3/{40 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        _compare_game(f"f16x3/par{par}/{40 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
     assert dnet.range_ok()
 
 
