@@ -307,6 +307,9 @@ def headline_leg(args, dev, rank, world, cdev):
         "roofline": {"bound": "mfma", "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
                      "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                     # activations are 4 B per element in both kernel families: per conv layer one read + one write of
+                     # n x F x 64 elements, a skip read every other layer, + the stem's write and the heads' read
+                     "algorithmic_hbm_bytes_per_launch": (leaves_per_launch * F * 256.0 * (2 * 2 * R + R + 2)) if args.net == "ch5" else None,
                      "peak_note": ("f16 MFMA dense peak - the pipe the trunk runs on; every algorithmic (f32-accurate) flop costs 3 f16 MFMA "
                                    "flops, so this fraction cannot exceed 1/3" if v2 else "f32 MFMA dense peak"),
                      "executed_mfma_tflops": ach * (3.0 if v2 else 1.0), "executed_mfma_frac_of_pipe_peak": ach * (3.0 if v2 else 1.0) / peak,
