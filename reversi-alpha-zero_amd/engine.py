@@ -318,12 +318,14 @@ class SelfPlayEngine:
                                          outbox["done"].data_ptr(), ctypes.byref(res), _stream()), "raz_engine_harvest")
         return res.harvested, res.restarted, res.skipped, res.playing
 
-    def play_continuous(self, first_game_id, total_games, sims_of, chunk=64, resign_threshold_of=None, max_steps=100_000_000):
+    def play_continuous(self, first_game_id, total_games, sims_of, chunk=64, resign_threshold_of=None, max_steps=100_000_000,
+                        on_chunk=None):
         """Play global game ids first_game_id .. first_game_id + total_games - 1 with continuous batching: the batch's
         slots are refilled with the next unplayed id as games finish (worker/self_play.py:95-137: a reference worker
         starts its next game the moment one ends), finished games land in an id-ordered device outbox.
         sims_of(id) -> simulations per move of that game (the reference's per-game-index schedule, self_play.py:145).
         resign_threshold_of(id) (optional) -> the threshold that game is played under.
+        on_chunk(steps, games_done, stats) (optional) is called after every chunk's harvest (progress reporting).
         Returns (outbox, stats): outbox = device tensors in id order (pack/gather them as they are, or
         raw_from_packed(...) on the host); stats adds steps, leaf_slot_occupancy and gc_runs."""
         B = self.n_games
@@ -358,6 +360,8 @@ class SelfPlayEngine:
             done += h
             host["steps_and_stats"] += t1 - t0
             host["harvest"] += time.perf_counter() - t1
+            if on_chunk is not None:
+                on_chunk(steps, done, st)
             if steps >= max_steps:
                 raise RuntimeError("engine did not finish within max_steps")
         st = self.stats()

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--games", type=int, default=1024)
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--check-plies", type=int, default=3)
+    ap.add_argument("--progress", default=None, help="file to append a progress line to every ~2000 steps")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -40,7 +41,15 @@ def main():
     eng = SelfPlayEngine(cfg, net, n_games=a.slots, seed=0, sims_hint=a.sims, nodes_per_game=16 * a.sims, parts=1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outbox, st = eng.play_continuous(0, a.games, lambda gid: a.sims, chunk=256)
+    last = [0]
+
+    def progress(steps, done, stc):
+        if a.progress and steps - last[0] >= 2048:
+            last[0] = steps
+            with open(a.progress, "at") as f:
+                f.write(json.dumps({"seconds": time.perf_counter() - t0, "steps": steps, "games_done": done, "total_sims": stc["total_sims"],
+                                    "nn_leaves": stc["nn_leaves"], "max_pool_used": stc["max_pool_used"]}) + "\n")
+    outbox, st = eng.play_continuous(0, a.games, lambda gid: a.sims, chunk=256, on_chunk=progress)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     raw = raw_from_packed(*(outbox[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
