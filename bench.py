@@ -319,17 +319,20 @@ def headline_leg(args, dev, rank, world, cdev):
         "bound_sims_per_s_per_gpu_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs),
         "record_gather": gather, "parity_spotcheck": spot if spot else "skipped",
     })
-    wg = os.path.join(ROOT, "profiles", "r2", "whole_games_config3_1024slots.json")
-    if args.net == "ch5" and os.path.exists(wg):   # committed measurement on COMPLETE games (tools/whole_games_config3.py)
+    wg = os.path.join(ROOT, "profiles", "r2", "whole_games_config3_8192slots.json")
+    if args.net == "ch5" and os.path.exists(wg):   # committed measurement of the WHOLE batch (tools/whole_games_config3.py, 19 min)
         with open(wg) as f:
             w = json.load(f)
         lpg = w["nn_leaves"] / float(w["workload"].split(" ")[0])
-        out["whole_game_calibration"] = {
-            "source": "profiles/r2/whole_games_config3_1024slots.json: 1024 complete games of this search on 1024 slots (tools/whole_games_config3.py)",
+        out["whole_batch_measured"] = {
+            "source": "profiles/r2/whole_games_config3_8192slots.json: this workload played to the end - 8192 complete games, one batch, "
+                      "1153 s on one MI355X (tools/whole_games_config3.py --slots 8192 --games 8192; first plies == oracle)",
+            "sims_per_s": w["sims_per_s_at_this_batch"], "games_per_hour": w["games_per_hour_at_this_batch"],
+            "net_evaluations_per_s": w["leaves_per_s_at_this_batch"], "ms_per_step": w["ms_per_step"], "steps": w["steps"],
             "sims_per_net_evaluation": w["sims_per_net_evaluation"], "searched_plies_per_game": w["searched_plies_per_game"],
-            "net_evaluations_per_game": lpg, "measured_games_per_hour_at_1024_slots": w["games_per_hour_at_this_batch"],
-            "sims_per_s_at_whole_game_sims_per_evaluation": leaves / elapsed * w["sims_per_net_evaluation"],
-            "games_per_hour_from_leaves": leaves / elapsed / lpg * 3600.0}
+            "leaf_slot_occupancy_incl_ramp_down": w["leaf_slot_occupancy"],
+            "this_runs_sims_per_s_at_the_whole_batch_sims_per_evaluation": leaves / elapsed * w["sims_per_net_evaluation"],
+            "this_runs_games_per_hour_from_net_evaluations": leaves / elapsed / lpg * 3600.0}
     k = out["kernels"]["k_tree"]
     k["achieved"] = k["algorithmic_bytes_per_launch"] / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None
     k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"

@@ -46,8 +46,7 @@ def npz_to_h5(npz_path, config_path, weight_path):
     convs = sorted((n for n in layers if "kernel" in layers[n] and layers[n]["kernel"].ndim == 4), key=suffix)
     bns = sorted((n for n in layers if "moving_variance" in layers[n]), key=suffix)
     denses = [n for n in layers if "kernel" in layers[n] and layers[n]["kernel"].ndim == 2]
-    v1 = next(n for n in denses if layers[n]["kernel"].shape[0] == 64 and layers[n]["kernel"].shape[1] != 1 or
-              (layers[n]["kernel"].shape[0] == 64 and n not in ("policy_out", "value_out")))
+    v1 = next(n for n in denses if layers[n]["kernel"].shape[0] == 64 and layers[n]["kernel"].shape[1] != 1)   # 64 -> value_fc_size
     mc = SimpleNamespace(cnn_filter_num=int(layers[convs[0]]["kernel"].shape[3]), cnn_filter_size=int(layers[convs[0]]["kernel"].shape[0]),
                          res_layer_num=(len(convs) - 3) // 2, l2_reg=1e-4, value_fc_size=int(layers[v1]["kernel"].shape[1]))
     rm = ReversiModel(SimpleNamespace(model=mc))
