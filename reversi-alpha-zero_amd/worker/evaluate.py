@@ -62,7 +62,9 @@ class _Side:
         #  player only, with the mirror-key updates of player.py:279-280 as the play config's tree mode implies)
         self.sims = int(pc.simulation_num_per_move)
         net = getattr(model, "model", model)
-        self.engine = SelfPlayEngine(SimpleNamespace(play=pc, play_data=config.play_data), DeviceNet(net.to_blob(), device),
+        # "auto": wide nets on the split-f16 trunk (raznet-forward-v2), narrow nets on the exact-f32 kernels (engine.DeviceNet)
+        self.engine = SelfPlayEngine(SimpleNamespace(play=pc, play_data=config.play_data),
+                                     DeviceNet(net.to_blob(), device, kernel=getattr(config, "net_kernel", "auto")),
                                      n_games, seed=seed, sims_hint=self.sims, max_plies=64, parts=1, single_stream=True)
         self.engine.start(first_game_id, self.sims, n_active=0)   # every slot idle until it is asked for a move
         self.armed = []
