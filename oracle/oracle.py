@@ -1,6 +1,6 @@
 """ctypes wrapper of oracle/liboracle.so — the CPU oracle.  TEST INFRASTRUCTURE ONLY (see orc.h):
-imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
-product package."""
+imported by tests/, __graft_entry__.smoke(), bench.py (cpu_baseline leg + the parity spot checks outside its timed
+regions) and tools/whole_games_config3.py's end-of-run check, never by the product package."""
 import ctypes
 import os
 import subprocess
