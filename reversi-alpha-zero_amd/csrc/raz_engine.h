@@ -114,6 +114,18 @@ struct raz_game {
 static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");
 #endif
 
+// Cross-game evaluation cache (raz_leaf_cache.hip): pointers into the caller-provided cache buffer.  Passed BY VALUE to kernels.
+struct raz_leaf_cache_dev {
+    unsigned long long* tags;      // [E] 0 = empty, else hash64(own, enemy) | 1
+    unsigned long long* keys;      // [E][2] the full key
+    uint32_t *stamp, *owner, *ready;   // [E] step that claimed the entry / exchange row computing it / answer present
+    float* pv;                     // [E][72] policy 64, value, pad
+    unsigned long long* counters;  // [0] hits, [1] in-batch duplicates, [2] rows evaluated, [3] claims that found no room
+    uint32_t* n_compact;           // [slice] rows in the slice's compact list
+    uint32_t *list, *role;         // [rows] compact list (per slice, at the slice's first row) / what each row is doing this step
+    uint32_t mask, entries;
+};
+
 // Pointers into the caller-provided workspace + the play parameters.  Passed BY VALUE to kernels.
 struct raz_engine_dev {
     raz_engine_config cfg;

@@ -1671,6 +1671,16 @@ int validate(const raz_engine_config* cfg) {
 
 constexpr int kMaxParts = 8;
 
+// raz_leaf_cache.hip / raz_net.hip
+size_t raz_leaf_cache_layout(uint32_t log2_entries, size_t rows, unsigned char* base, raz_leaf_cache_dev* out);
+int raz_leaf_cache_clear(const raz_leaf_cache_dev& c, size_t rows, hipStream_t s);
+int raz_leaf_cache_before(const raz_leaf_cache_dev& c, const raz_engine_dev& d, uint32_t p0, uint32_t pn, uint32_t part, uint32_t step,
+                          hipStream_t s);
+int raz_leaf_cache_after(const raz_leaf_cache_dev& c, const raz_engine_dev& d, uint32_t p0, uint32_t pn, uint32_t step, hipStream_t s);
+int raz_net_forward_compact(const raz_net* net, const uint64_t* own, const uint64_t* enemy, const uint8_t* active, float* policy,
+                            float* value, size_t n, void* scratch, size_t scratch_bytes, hipStream_t stream, const uint32_t* list,
+                            const uint32_t* n_ptr);
+
 // The internal streams of all engines of a process, per device, created once and never destroyed.  HIP maps streams onto a
 // few hardware queues round-robin in creation order: an engine that creates fresh streams after other engines have come
 // and gone can land two of its slices on ONE queue, which serialises them (measured: the same workload 3.3x slower after
@@ -1700,6 +1710,8 @@ struct raz_engine {
     size_t net_scratch_bytes;
     uint32_t* d_sims;  // staging for sims_per_move
     double* d_thr;     // staging for per-game resign thresholds (raz_engine_harvest)
+    raz_leaf_cache_dev cache;   // cross-game evaluation cache (raz_engine_set_leaf_cache); cache.tags == nullptr: none
+    uint32_t cache_step;        // stamp of the next half step
     bool started;
     // The batch is stepped as `parts` independent slices on as many streams (the caller's and
     // parts-1 internal ones): while one slice's leaves are in the net kernel (matrix pipe) another
@@ -1758,9 +1770,22 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
     const size_t p0 = (size_t)hf.g0 * d.K, pn = (size_t)hf.count * d.K;
     const size_t soff = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, p0);
     const size_t sbytes = raz_net_scratch_bytes(e->net.filters, e->net.value_fc, pn);
-    rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + p0, (const uint64_t*)d.nn_enemy + p0,
-                         d.nn_active + p0, d.nn_policy + p0 * 64, d.nn_value + p0, pn,
-                         e->net_scratch ? (unsigned char*)e->net_scratch + soff : nullptr, sbytes, (raz_stream_t)s);
+    if (e->cache.tags) {
+        // positions the table already holds (or that another row of this batch is evaluating) leave the batch; the rest is
+        // evaluated over a compact list and its answers are added to the table
+        const uint32_t step = e->cache_step++;
+        rc = raz_leaf_cache_before(e->cache, d, (uint32_t)p0, (uint32_t)pn, (uint32_t)h, step, s);
+        if (rc != RAZ_OK) return rc;
+        rc = raz_net_forward_compact(&e->net, (const uint64_t*)d.nn_own + p0, (const uint64_t*)d.nn_enemy + p0, d.nn_active + p0,
+                                     d.nn_policy + p0 * 64, d.nn_value + p0, pn,
+                                     e->net_scratch ? (unsigned char*)e->net_scratch + soff : nullptr, sbytes, s,
+                                     e->cache.list + p0, e->cache.n_compact + h);
+        if (rc != RAZ_OK) return rc;
+        rc = raz_leaf_cache_after(e->cache, d, (uint32_t)p0, (uint32_t)pn, step, s);
+    } else
+        rc = raz_net_forward(&e->net, (const uint64_t*)d.nn_own + p0, (const uint64_t*)d.nn_enemy + p0,
+                             d.nn_active + p0, d.nn_policy + p0 * 64, d.nn_value + p0, pn,
+                             e->net_scratch ? (unsigned char*)e->net_scratch + soff : nullptr, sbytes, (raz_stream_t)s);
     if (ev) hipEventRecord(ev[2], s);
     return rc;
 }
@@ -1811,6 +1836,8 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     e->net_scratch = d_net_scratch;
     e->net_scratch_bytes = net_scratch_bytes;
     e->started = false;
+    memset(&e->cache, 0, sizeof e->cache);
+    e->cache_step = 1;
     // reserved bit 1: single stream; bits 8..11: number of slices (default 3); bits 12..15: kInnerMax override
     int parts = (int)((cfg->reserved >> 8) & 0xf);
     if (parts == 0) parts = 3;
@@ -2447,6 +2474,41 @@ extern "C" int raz_engine_harvest(raz_engine* e, uint32_t next_game_id, uint32_t
     result->restarted = h[1];
     result->skipped = h[2];
     result->playing = h[3];
+    return RAZ_OK;
+}
+
+extern "C" size_t raz_leaf_cache_bytes(uint32_t log2_entries, size_t rows) {
+    if (log2_entries < 10 || log2_entries > 28) return 0;
+    return raz_leaf_cache_layout(log2_entries, rows, nullptr, nullptr);
+}
+
+extern "C" int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32_t log2_entries, raz_stream_t stream) {
+    if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_leaf_cache: NULL engine");
+    drop_graph(e);   // a captured graph holds the old launch sequence
+    if (!d_cache) {
+        memset(&e->cache, 0, sizeof e->cache);
+        return RAZ_OK;
+    }
+    const size_t rows = (size_t)e->dev.B * e->dev.K;
+    const size_t need = raz_leaf_cache_bytes(log2_entries, rows);
+    if (need == 0) return raz_fail(RAZ_EINVAL, "raz_engine_set_leaf_cache: log2_entries must be 10..28");
+    if (bytes < need || ((uintptr_t)d_cache & 255)) return raz_fail(RAZ_ENOMEM, "raz_engine_set_leaf_cache: buffer too small (raz_leaf_cache_bytes) or not 256-byte aligned");
+    raz_leaf_cache_dev c;
+    raz_leaf_cache_layout(log2_entries, rows, (unsigned char*)d_cache, &c);
+    const int rc = raz_leaf_cache_clear(c, rows, (hipStream_t)stream);
+    if (rc != RAZ_OK) return rc;
+    e->cache = c;
+    return RAZ_OK;
+}
+
+extern "C" int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_stream_t stream) {
+    if (!e || !out4) return raz_fail(RAZ_EINVAL, "raz_engine_leaf_cache_stats: NULL argument");
+    if (!e->cache.tags) {
+        memset(out4, 0, 32);
+        return RAZ_OK;
+    }
+    RAZ_HIP_TRY(hipMemcpyAsync(out4, e->cache.counters, 32, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_leaf_cache_stats: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_leaf_cache_stats: sync");
     return RAZ_OK;
 }
 

@@ -1,0 +1,192 @@
+// raz_leaf_cache.hip — cross-game evaluation cache between the tree kernel and the net.
+//
+// The reference evaluates every leaf position through the net (agent/player.py:283-327 -> agent/api.py:30-45), one small
+// batch per worker.  With thousands of games on one device the same positions are asked for again and again: every game
+// passes through the same few openings (black's first move is forced, agent/player.py:143-148), and in a lock-step batch
+// all games search the same roots at the same time.  The net is a pure function of the (D4-transformed) position and the
+// kernels are batch-invariant (tested), so serving a repeated position from a table is BIT-IDENTICAL to evaluating it again:
+// games do not change, only the number of rows the net sees.
+//
+// Table (caller-owned HBM, raz_engine_set_leaf_cache): E = 2^k entries, open addressing, 8 probes:
+//   tags[E]   u64   0 = empty, else hash64(own, enemy) | 1          claimed with one atomicCAS
+//   keys[E]   2 u64 the full key (own, enemy): a tag match is always verified against it
+//   stamp[E]  u32   the step that claimed the entry                  owner[E] u32: the exchange row that computes it
+//   ready[E]  u32   1 once the entry holds the net's answer          pv[E] 72 f32: policy 64, value, pad
+// Per step and slice, three small kernels around the net forward:
+//   k_leaf_claim   per active row: probe; a matching tag -> FOLLOW(entry), an empty slot won by CAS -> OWN(entry) (writes the
+//                  key), no room -> PLAIN
+//   k_leaf_resolve FOLLOW: key verified; entry ready -> HIT: answer copied to the row, row leaves the batch; entry claimed in
+//                  THIS step by a row of this slice -> the row leaves the batch and copies the owner's answer afterwards;
+//                  anything else -> PLAIN.  OWN and PLAIN rows are appended to the slice's compact list.
+//   (net forward over the compact list: raz_net_forward_compact)
+//   k_leaf_fill    OWN: answer -> table, ready = 1; followers: copy the owner row's answer
+// An entry claimed by a step that never finished (a restart between the two halves) carries an old stamp and is never
+// followed or filled: it is dead weight, not a wrong answer.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "raz_engine.h"
+#include "raz_internal.h"
+
+namespace {
+
+constexpr uint32_t kProbes = 8;
+enum : uint32_t { ROLE_NONE = 0, ROLE_PLAIN = 1, ROLE_OWN = 2, ROLE_FOLLOW = 3, ROLE_WAIT = 4 };   // role = entry << 3 | kind
+
+__device__ __forceinline__ unsigned long long leaf_tag(unsigned long long a, unsigned long long b) {
+    unsigned long long x = a * 0x9E3779B97F4A7C15ULL ^ (b + 0xD6E8FEB86659FD93ULL) * 0xC2B2AE3D27D4EB4FULL;
+    x ^= x >> 32; x *= 0xFF51AFD7ED558CCDULL; x ^= x >> 29; x *= 0xC4CEB9FE1A85EC53ULL; x ^= x >> 32;
+    return x | 1ULL;
+}
+
+// rows [p0, p0 + pn) of the leaf exchange; one thread per row
+__global__ __launch_bounds__(256) void k_leaf_claim(raz_leaf_cache_dev C, const unsigned long long* __restrict__ own,
+                                                    const unsigned long long* __restrict__ enemy, const uint8_t* __restrict__ active,
+                                                    uint32_t p0, uint32_t pn, uint32_t part, uint32_t step) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) C.n_compact[part] = 0;
+    if (j >= pn) return;
+    const uint32_t r = p0 + j;
+    if (!active[r]) {
+        C.role[r] = ROLE_NONE;
+        return;
+    }
+    const unsigned long long o = own[r], e = enemy[r], tag = leaf_tag(o, e);
+    const uint32_t h = (uint32_t)(tag >> 24) & C.mask;
+    uint32_t role = ROLE_PLAIN;
+    for (uint32_t k = 0; k < kProbes; ++k) {
+        const uint32_t i = (h + k) & C.mask;
+        unsigned long long t = __hip_atomic_load(&C.tags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {
+            t = atomicCAS(&C.tags[i], 0ULL, tag);
+            if (t == 0) {   // ours: publish the key (read by k_leaf_resolve, a later kernel)
+                C.keys[2 * (size_t)i] = o;
+                C.keys[2 * (size_t)i + 1] = e;
+                C.stamp[i] = step;
+                C.owner[i] = r;
+                role = (i << 3) | ROLE_OWN;
+                break;
+            }
+        }
+        if (t == tag) {
+            role = (i << 3) | ROLE_FOLLOW;
+            break;
+        }
+    }
+    if (role == ROLE_PLAIN) atomicAdd(&C.counters[3], 1ULL);   // no room within the probe window
+    C.role[r] = role;
+}
+
+// one wave per row (the answer of a hit is 65 floats)
+__global__ __launch_bounds__(256) void k_leaf_resolve(raz_leaf_cache_dev C, const unsigned long long* __restrict__ own,
+                                                      const unsigned long long* __restrict__ enemy, uint8_t* __restrict__ active,
+                                                      float* __restrict__ policy, float* __restrict__ value, uint32_t p0, uint32_t pn,
+                                                      uint32_t part, uint32_t step) {
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= pn) return;
+    const uint32_t r = p0 + j;
+    uint32_t role = C.role[r];
+    const uint32_t kind = role & 7u, i = role >> 3;
+    if (kind == ROLE_NONE) return;
+    if (kind == ROLE_FOLLOW) {
+        const bool same = C.keys[2 * (size_t)i] == own[r] && C.keys[2 * (size_t)i + 1] == enemy[r];
+        const uint32_t ow = C.owner[i];
+        if (same && C.ready[i]) {   // HIT
+            policy[(size_t)r * 64 + lane] = C.pv[(size_t)i * 72 + lane];
+            if (lane == 0) {
+                value[r] = C.pv[(size_t)i * 72 + 64];
+                active[r] = 0;
+                C.role[r] = ROLE_NONE;
+                atomicAdd(&C.counters[0], 1ULL);
+            }
+            return;
+        }
+        if (same && C.stamp[i] == step && ow >= p0 && ow < p0 + pn && ow != r) {   // the owner is in this very batch
+            if (lane == 0) {
+                active[r] = 0;
+                C.role[r] = (i << 3) | ROLE_WAIT;
+                atomicAdd(&C.counters[1], 1ULL);
+            }
+            return;
+        }
+        role = ROLE_PLAIN;   // tag collision, an entry of another slice or of an unfinished step: just evaluate it
+        if (lane == 0) C.role[r] = ROLE_PLAIN;
+    }
+    if (lane == 0) {
+        const uint32_t ci = atomicAdd(&C.n_compact[part], 1u);
+        C.list[p0 + ci] = j;   // row index relative to the slice (the forward's pointers are offset by p0)
+        atomicAdd(&C.counters[2], 1ULL);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_leaf_fill(raz_leaf_cache_dev C, float* __restrict__ policy, float* __restrict__ value,
+                                                   uint32_t p0, uint32_t pn, uint32_t step) {
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= pn) return;
+    const uint32_t r = p0 + j, role = C.role[r], kind = role & 7u, i = role >> 3;
+    if (kind == ROLE_OWN) {
+        if (C.stamp[i] != step || C.owner[i] != r) return;
+        C.pv[(size_t)i * 72 + lane] = policy[(size_t)r * 64 + lane];
+        if (lane == 0) {
+            C.pv[(size_t)i * 72 + 64] = value[r];
+            __threadfence();
+            C.ready[i] = 1;
+        }
+    } else if (kind == ROLE_WAIT) {
+        const uint32_t ow = C.owner[i];
+        policy[(size_t)r * 64 + lane] = policy[(size_t)ow * 64 + lane];
+        if (lane == 0) value[r] = value[ow];
+    }
+}
+
+}  // namespace
+
+size_t raz_leaf_cache_layout(uint32_t log2_entries, size_t rows, unsigned char* base, raz_leaf_cache_dev* out) {
+    const size_t E = (size_t)1 << log2_entries;
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> unsigned char* {
+        unsigned char* p = base ? base + off : nullptr;
+        off = (off + bytes + 255) / 256 * 256;
+        return p;
+    };
+    raz_leaf_cache_dev c;
+    memset(&c, 0, sizeof c);
+    c.tags = (unsigned long long*)take(E * 8);
+    c.keys = (unsigned long long*)take(E * 16);
+    c.stamp = (uint32_t*)take(E * 4);
+    c.owner = (uint32_t*)take(E * 4);
+    c.ready = (uint32_t*)take(E * 4);
+    c.pv = (float*)take(E * 72 * 4);
+    c.counters = (unsigned long long*)take(8 * 8);
+    c.n_compact = (uint32_t*)take(16 * 4);
+    c.list = (uint32_t*)take(rows * 4);
+    c.role = (uint32_t*)take(rows * 4);
+    c.mask = (uint32_t)(E - 1);
+    c.entries = (uint32_t)E;
+    if (out) *out = c;
+    return off;
+}
+
+int raz_leaf_cache_clear(const raz_leaf_cache_dev& c, size_t rows, hipStream_t s) {
+    const size_t E = (size_t)c.entries;
+    RAZ_HIP_TRY(hipMemsetAsync(c.tags, 0, E * 8, s), "leaf cache: clear tags");
+    RAZ_HIP_TRY(hipMemsetAsync(c.ready, 0, E * 4, s), "leaf cache: clear ready flags");
+    RAZ_HIP_TRY(hipMemsetAsync(c.stamp, 0, E * 4, s), "leaf cache: clear stamps");
+    RAZ_HIP_TRY(hipMemsetAsync(c.counters, 0, 64, s), "leaf cache: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(c.n_compact, 0, 64, s), "leaf cache: clear counts");
+    RAZ_HIP_TRY(hipMemsetAsync(c.role, 0, rows * 4, s), "leaf cache: clear roles");
+    return RAZ_OK;
+}
+
+// before the net forward of rows [p0, p0 + pn): serve what the table holds, compact the rest
+int raz_leaf_cache_before(const raz_leaf_cache_dev& c, const raz_engine_dev& d, uint32_t p0, uint32_t pn, uint32_t part, uint32_t step,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_leaf_claim, dim3((pn + 255) / 256), dim3(256), 0, s, c, d.nn_own, d.nn_enemy, d.nn_active, p0, pn, part, step);
+    hipLaunchKernelGGL(k_leaf_resolve, dim3((pn + 3) / 4), dim3(256), 0, s, c, d.nn_own, d.nn_enemy, d.nn_active, d.nn_policy, d.nn_value,
+                       p0, pn, part, step);
+    return raz_check_launch("raz_engine_step: leaf cache lookup");
+}
+
+int raz_leaf_cache_after(const raz_leaf_cache_dev& c, const raz_engine_dev& d, uint32_t p0, uint32_t pn, uint32_t step, hipStream_t s) {
+    hipLaunchKernelGGL(k_leaf_fill, dim3((pn + 3) / 4), dim3(256), 0, s, c, d.nn_policy, d.nn_value, p0, pn, step);
+    return raz_check_launch("raz_engine_step: leaf cache fill");
+}

@@ -35,7 +35,7 @@ size_t raz_net_f16x3_scratch_bytes(int F, size_t n);
 unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V);
 int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                           const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
-                          hipStream_t s);
+                          hipStream_t s, const uint32_t* list, const uint32_t* n_ptr);
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
                          unsigned long long* prof, int variant);
@@ -314,6 +314,17 @@ extern "C" int raz_net_range_check(const raz_net* net, int* overflowed, raz_stre
     return RAZ_OK;
 }
 
+// Engine-internal: raz_net_forward over a compacted batch (raz_leaf_cache.hip).  Only the f16x3 path has the indexed form;
+// other nets run the ordinary forward over the rows whose `active` flag the cache left set.
+int raz_net_forward_compact(const raz_net* net, const uint64_t* own, const uint64_t* enemy, const uint8_t* active, float* policy,
+                            float* value, size_t n, void* scratch, size_t scratch_bytes, hipStream_t stream, const uint32_t* list,
+                            const uint32_t* n_ptr) {
+    if (n && net && f16x3_supported(net->filters) && net->reserved == 4)
+        return raz_net_forward_f16x3((const float*)net->d_weights, net->filters, net->res_layers, net->value_fc, own, enemy, active,
+                                     policy, value, n, scratch, scratch_bytes, stream, list, n_ptr);
+    return raz_net_forward(net, own, enemy, active, policy, value, n, scratch, scratch_bytes, (raz_stream_t)stream);
+}
+
 extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* enemy,
                                const uint8_t* active, float* policy, float* value, size_t n,
                                void* scratch, size_t scratch_bytes, raz_stream_t stream) {
@@ -334,7 +345,7 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     // of the fp32 graph but not bit-identical to the exact-f32 kernels (0 / 5: raznet-forward-v1)
     if (f16x3_supported(F) && net->reserved == 4)
         return raz_net_forward_f16x3((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy, value, n,
-                                     scratch, scratch_bytes, (hipStream_t)stream);
+                                     scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr);
     if (net->reserved == 4) return raz_fail(RAZ_EINVAL, "raz_net_forward: the f16x3 kernel needs filters % 128 == 0");
     if (wide_supported(F) && net->reserved != 1)
         return raz_net_forward_wide((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,

@@ -65,9 +65,10 @@ constexpr int Z_OFF = NWAVE * ACT_POS;           // the zero rows inside an imag
 __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
                                                           const float* __restrict__ inv_scale_ptr, const unsigned char* in, unsigned char* out,
                                                           const unsigned char* skip, const uint8_t* __restrict__ active, int n, int F,
-                                                          unsigned* __restrict__ flag) {
+                                                          unsigned* __restrict__ flag, const uint32_t* __restrict__ n_ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;   // rows 0..n-1 of a compacted batch (raz_leaf_cache.hip): the count lives on the device
     const int noct = F / OCT, nchunks = F / 16;
     // blocks b and b + 8 run on the same XCD (round-robin dispatch): give them the oc tiles of the SAME positions, so the
     // later one finds the activations in that XCD's L2
@@ -199,12 +200,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
 // of a workgroup (lane = square, wave w takes chunks w, w + 4, ...).
 __global__ __launch_bounds__(256) void k_conv0_split(const float* __restrict__ W0, const raz_bb* __restrict__ own,
                                                      const raz_bb* __restrict__ enemy, const uint8_t* __restrict__ active,
-                                                     unsigned char* out, int n, int F, unsigned* __restrict__ flag) {
+                                                     unsigned char* out, int n, int F, unsigned* __restrict__ flag,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr) {
     const int pos = blockIdx.x, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the weight reads below stay scalar loads
-    if (pos >= n || (active && !active[pos])) return;
+    if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
+    if (pos >= n || (!list && active && !active[pos])) return;
     bool over = false;
-    const raz_bb bo = own[pos], be = enemy[pos];
+    const size_t src = list ? list[pos] : (size_t)pos;   // compacted batch: row `pos` holds the leaf of exchange row list[pos]
+    const raz_bb bo = own[src], be = enemy[src];
     const int y = lane >> 3, x = lane & 7;
     float x0[9], x1[9];
 #pragma unroll
@@ -249,10 +253,13 @@ __global__ __launch_bounds__(256) void k_conv0_split(const float* __restrict__ W
 // Heads as in k_heads_wide (exact f32 chains), reading the trunk output in the split layout: x = hi + lo (exact in f32).
 __global__ __launch_bounds__(64) void k_heads_split(const float* __restrict__ H, const unsigned char* trunk,
                                                     const uint8_t* __restrict__ active, float* __restrict__ policy,
-                                                    float* __restrict__ value, int n, int F, int V) {
+                                                    float* __restrict__ value, int n, int F, int V,
+                                                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr) {
     extern __shared__ __attribute__((aligned(16))) float head[];  // ph[128] vh[64] h1[V]
     const int pos = blockIdx.x, lane = threadIdx.x;
-    if (pos >= n || (active && !active[pos])) return;
+    if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
+    if (pos >= n || (!list && active && !active[pos])) return;
+    const size_t dst = list ? list[pos] : (size_t)pos;   // results go back to the leaf-exchange row
     const float* pol_w = H;
     const float* pol_b = pol_w + 2 * F;
     const float* pfc_w = pol_b + 2;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(64) void k_heads_split(const float* __restrict__ H,
     float sum = e;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) sum = sum + __shfl_xor(sum, s);
-    policy[(size_t)pos * 64 + lane] = e / sum;
+    policy[dst * 64 + lane] = e / sum;
     for (int o0 = 0; o0 < V; o0 += 64) {
         const int o = o0 + lane;
         if (o < V) {
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(64) void k_heads_split(const float* __restrict__ H,
     __syncthreads();
     float acc = v2_b[0];
     for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
-    if (lane == 0) value[pos] = raz_det_tanhf(acc);
+    if (lane == 0) value[dst] = raz_det_tanhf(acc);
 }
 
 }  // namespace
@@ -351,9 +358,11 @@ size_t raz_net_f16x3_scratch_bytes(int F, size_t n) { return (size_t)2 * n * F *
 // The sticky range flag lives in the device weight image, after the per-layer scales (raz_net_layout.h leaves 64 floats there).
 unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V) { return (unsigned*)(W + f16x3_scale_off(F, R, V) + (size_t)2 * R + 8); }
 
+// list / n_ptr (both or neither; engine-internal, raz_leaf_cache.hip): evaluate only the exchange rows list[0 .. *n_ptr), packed
+// densely in the activation buffers - *n_ptr lives on the device, so every launch keeps its full grid and surplus blocks exit.
 int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                           const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
-                          hipStream_t s) {
+                          hipStream_t s, const uint32_t* list, const uint32_t* n_ptr) {
     if (!scratch || scratch_bytes < raz_net_f16x3_scratch_bytes(F, n))
         return raz_fail(RAZ_ENOMEM, "raz_net_forward: scratch too small (raz_net_scratch_bytes)");
     unsigned char* bufA = (unsigned char*)scratch;
@@ -367,19 +376,19 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
         attr_set = true;
     }
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
-                       (const raz_bb*)enemy, active, bufA, (int)n, F, flag);
+                       (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
     for (int r = 0; r < R; ++r) {
         const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
         hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
-                           scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, active, (int)n, F, flag);
+                           scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, list ? nullptr : active, (int)n, F, flag, n_ptr);
         hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
-                           scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, active, (int)n, F, flag);
+                           scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr);
     }
     hipLaunchKernelGGL(k_heads_split, dim3((unsigned)n), dim3(64), (192 + (size_t)V) * sizeof(float), s,
-                       W + heads_off(F, R), (const unsigned char*)bufA, active, policy, value, (int)n, F, V);
+                       W + heads_off(F, R), (const unsigned char*)bufA, active, policy, value, (int)n, F, V, list, n_ptr);
     return raz_check_launch("raz_net_forward (f16x3)");
 }

@@ -121,7 +121,9 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 use_graph=False, force_slot_kernel=False):
+                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None):
+        """leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h
+        raz_engine_set_leaf_cache): repeated positions are served from it, bit-identically.  None: no cache."""
         import torch
         self.net = net
         self.device = net.device
@@ -162,6 +164,29 @@ class SelfPlayEngine:
                                     ctypes.byref(self._h)), "raz_engine_create")
         self.record_root_w = record_root_w
         self.max_plies = max_plies
+        self._cache = None
+        if leaf_cache_log2:
+            self.attach_leaf_cache(leaf_cache_log2)
+
+    def attach_leaf_cache(self, log2_entries):
+        """(Re-)attach a cleared evaluation cache; call again after the net's weights changed."""
+        import torch
+        need = lib.raz_leaf_cache_bytes(log2_entries, self.n_games * self.slots)
+        if need == 0:
+            raise ValueError("leaf_cache_log2 must be 10..28")
+        if self._cache is None or self._cache.numel() < need + 256:
+            self._cache = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = (self._cache.data_ptr() + 255) // 256 * 256
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_set_leaf_cache(self._h, base, need, log2_entries, _stream()), "raz_engine_set_leaf_cache")
+
+    def leaf_cache_stats(self):
+        """{hits, in_batch_duplicates, evaluated, no_room} since the cache was attached (zeros without a cache)."""
+        import torch
+        out = (ctypes.c_uint64 * 4)()
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_leaf_cache_stats(self._h, out, _stream()), "raz_engine_leaf_cache_stats")
+        return {"hits": out[0], "in_batch_duplicates": out[1], "evaluated": out[2], "no_room": out[3]}
 
     def __del__(self):
         h = getattr(self, "_h", None)
