@@ -210,8 +210,12 @@ def headline_leg(args, dev, rank, world, cdev):
     cfg = ch5_config(args.sims) if args.net == "ch5" else mini_config(args.sims)
     net = DeviceNet(blob, dev, kernel=args.net_kernel)
     parts = args.parts or (1 if args.net == "ch5" else 3)   # a 256x10 forward dwarfs the tree kernel: nothing to overlap
+    # the cross-game evaluation cache as the worker attaches it for wide nets (2^26 entries, positions of <= 24 discs): the
+    # synthetic steady-state batch comes from independent random playouts, so it finds next to nothing to share - the line
+    # reports what the cache did; real self-play from the opening shares a lot (tools/whole_games_config3.py)
+    cache_log2 = None if (args.no_leaf_cache or args.net != "ch5") else 26
     eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims,
-                         nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=parts)
+                         nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=parts, leaf_cache_log2=cache_log2, leaf_cache_max_discs=24)
     first_id = rank * args.games
     out = {}
 
@@ -241,6 +245,7 @@ def headline_leg(args, dev, rank, world, cdev):
                                "mean_ply_of_the_timed_batch": float(ply.mean())}
     eng.step(max(args.warmup, 1) + (0 if args.opening else args.tree_warm))
     st0 = eng.stats()
+    c0 = eng.leaf_cache_stats()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -251,7 +256,9 @@ def headline_leg(args, dev, rank, world, cdev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
+    c1 = eng.leaf_cache_stats()
     d = {k: float(st[k] - st0[k]) for k in ("total_sims", "nn_leaves", "selections")}
+    served = float((c1["hits"] - c0["hits"]) + (c1["in_batch_duplicates"] - c0["in_batch_duplicates"]))
     tot = torch.tensor([d["total_sims"], d["nn_leaves"], d["selections"], elapsed, float(st["finished_games"])],
                        dtype=torch.float64, device=cdev)
     if world > 1:
@@ -276,7 +283,7 @@ def headline_leg(args, dev, rank, world, cdev):
         return None
     macs = macs_per_position(F, R, V)
     launches = args.steps * parts
-    leaves_per_launch = leaves / world / launches
+    leaves_per_launch = (leaves / world - served) / launches   # rows the net evaluated on this rank (the cache serves the rest)
     net_avg_ms, tree_avg_ms = net_ms / launches, tree_ms / launches
     ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
     traffic, traffic_src = conv_traffic() if args.net == "ch5" else (None, None)
@@ -317,6 +324,9 @@ def headline_leg(args, dev, rank, world, cdev):
         "kernels": {"k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms,
                                "algorithmic_bytes_per_launch": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / launches}},
         "bound_sims_per_s_per_gpu_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs),
+        "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table_in_the_timed_region": served,
+                        "note": "independent random-playout positions share nothing; see whole_batch_measured / tools/whole_games_config3.py for self-play from the opening"}
+                       if cache_log2 else None),
         "record_gather": gather, "parity_spotcheck": spot if spot else "skipped",
     })
     wg = os.path.join(ROOT, "profiles", "r2", "whole_games_config3_8192slots.json")
@@ -554,6 +564,7 @@ def main():
     ap.add_argument("--tree-warm", type=int, default=40, help="untimed steps on the staggered batch before the W warm-up steps")
     ap.add_argument("--opening", action="store_true", help="time the first steps from the opening instead of the steady state")
     ap.add_argument("--no-spotcheck", action="store_true")
+    ap.add_argument("--no-leaf-cache", action="store_true", help="headline engine without the cross-game evaluation cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only (configs[1], par-4 and sweep legs skipped)")
     args = ap.parse_args()

@@ -298,12 +298,14 @@ int raz_engine_harvest(raz_engine* e, uint32_t next_game_id, uint32_t n_new_ids,
  * batch-invariant function of the position, so a repeated position is served from a table - bit-identical to evaluating
  * it again: games do not change, only the number of rows the net sees.  d_cache: caller-owned device buffer of
  * raz_leaf_cache_bytes(log2_entries, n_games * max(parallel_search_num, 1)) bytes, 256-byte aligned, cleared by this call;
- * NULL detaches.  Attach a FRESH (or re-attached = cleared) cache whenever the net's weights change.  With the split-f16
+ * NULL detaches.  max_discs: only positions with at most that many discs on the board are looked up and stored (0 = all;
+ * positions deep in a game hardly ever repeat, the openings do).  Attach a FRESH (or re-attached = cleared) cache whenever the net's weights change.  With the split-f16
  * trunk (raz_net.reserved = 4) the rows still to evaluate are compacted, so the convolutions shrink with the hit rate;
  * other nets skip the served rows through their `active` mask.  stats: out4 = {hits, duplicates inside a batch, rows
  * evaluated, claims that found no room in the table} since the cache was attached (synchronises `stream`). */
 size_t raz_leaf_cache_bytes(uint32_t log2_entries, size_t rows);
-int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32_t log2_entries, raz_stream_t stream);
+int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32_t log2_entries, uint32_t max_discs,
+                              raz_stream_t stream);
 int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_stream_t stream);
 /* config.play.resign_threshold is mutated while the worker runs (worker/self_play.py:250-260: +-0.01 per 100
  * no-resign test games); moves decided from the next raz_engine_step on use the new value.  Trees, records and

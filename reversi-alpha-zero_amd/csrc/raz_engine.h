@@ -124,6 +124,7 @@ struct raz_leaf_cache_dev {
     uint32_t* n_compact;           // [slice] rows in the slice's compact list
     uint32_t *list, *role;         // [rows] compact list (per slice, at the slice's first row) / what each row is doing this step
     uint32_t mask, entries;
+    uint32_t max_discs;            // only positions with at most this many discs are cached (later positions hardly ever repeat)
 };
 
 // Pointers into the caller-provided workspace + the play parameters.  Passed BY VALUE to kernels.

@@ -2482,7 +2482,8 @@ extern "C" size_t raz_leaf_cache_bytes(uint32_t log2_entries, size_t rows) {
     return raz_leaf_cache_layout(log2_entries, rows, nullptr, nullptr);
 }
 
-extern "C" int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32_t log2_entries, raz_stream_t stream) {
+extern "C" int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32_t log2_entries, uint32_t max_discs,
+                                         raz_stream_t stream) {
     if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_leaf_cache: NULL engine");
     drop_graph(e);   // a captured graph holds the old launch sequence
     if (!d_cache) {
@@ -2495,6 +2496,7 @@ extern "C" int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t by
     if (bytes < need || ((uintptr_t)d_cache & 255)) return raz_fail(RAZ_ENOMEM, "raz_engine_set_leaf_cache: buffer too small (raz_leaf_cache_bytes) or not 256-byte aligned");
     raz_leaf_cache_dev c;
     raz_leaf_cache_layout(log2_entries, rows, (unsigned char*)d_cache, &c);
+    c.max_discs = max_discs ? max_discs : 64u;
     const int rc = raz_leaf_cache_clear(c, rows, (hipStream_t)stream);
     if (rc != RAZ_OK) return rc;
     e->cache = c;

@@ -7,7 +7,8 @@
 // kernels are batch-invariant (tested), so serving a repeated position from a table is BIT-IDENTICAL to evaluating it again:
 // games do not change, only the number of rows the net sees.
 //
-// Table (caller-owned HBM, raz_engine_set_leaf_cache): E = 2^k entries, open addressing, 8 probes:
+// Table (caller-owned HBM, raz_engine_set_leaf_cache): E = 2^k entries, open addressing, 8 probes; only positions with at
+// most `max_discs` discs are looked up and stored (positions deep in a game hardly ever repeat, the openings do):
 //   tags[E]   u64   0 = empty, else hash64(own, enemy) | 1          claimed with one atomicCAS
 //   keys[E]   2 u64 the full key (own, enemy): a tag match is always verified against it
 //   stamp[E]  u32   the step that claimed the entry                  owner[E] u32: the exchange row that computes it
@@ -51,6 +52,10 @@ __global__ __launch_bounds__(256) void k_leaf_claim(raz_leaf_cache_dev C, const 
         return;
     }
     const unsigned long long o = own[r], e = enemy[r], tag = leaf_tag(o, e);
+    if ((uint32_t)__popcll(o | e) > C.max_discs) {   // deep positions hardly ever repeat: keep the table for the openings
+        C.role[r] = ROLE_PLAIN;
+        return;
+    }
     const uint32_t h = (uint32_t)(tag >> 24) & C.mask;
     uint32_t role = ROLE_PLAIN;
     for (uint32_t k = 0; k < kProbes; ++k) {

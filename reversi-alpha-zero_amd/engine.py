@@ -121,9 +121,10 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None):
+                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0):
         """leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h
-        raz_engine_set_leaf_cache): repeated positions are served from it, bit-identically.  None: no cache."""
+        raz_engine_set_leaf_cache): repeated positions are served from it, bit-identically.  None: no cache.
+        leaf_cache_max_discs: cache only positions with at most that many discs (0 = all)."""
         import torch
         self.net = net
         self.device = net.device
@@ -166,9 +167,9 @@ class SelfPlayEngine:
         self.max_plies = max_plies
         self._cache = None
         if leaf_cache_log2:
-            self.attach_leaf_cache(leaf_cache_log2)
+            self.attach_leaf_cache(leaf_cache_log2, leaf_cache_max_discs)
 
-    def attach_leaf_cache(self, log2_entries):
+    def attach_leaf_cache(self, log2_entries, max_discs=0):
         """(Re-)attach a cleared evaluation cache; call again after the net's weights changed."""
         import torch
         need = lib.raz_leaf_cache_bytes(log2_entries, self.n_games * self.slots)
@@ -178,7 +179,7 @@ class SelfPlayEngine:
             self._cache = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = (self._cache.data_ptr() + 255) // 256 * 256
         with torch.cuda.device(self.device):
-            check(lib.raz_engine_set_leaf_cache(self._h, base, need, log2_entries, _stream()), "raz_engine_set_leaf_cache")
+            check(lib.raz_engine_set_leaf_cache(self._h, base, need, log2_entries, max_discs, _stream()), "raz_engine_set_leaf_cache")
 
     def leaf_cache_stats(self):
         """{hits, in_batch_duplicates, evaluated, no_room} since the cache was attached (zeros without a cache)."""

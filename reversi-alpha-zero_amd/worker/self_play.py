@@ -188,7 +188,7 @@ class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
     def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None,
-                 net_kernel="auto"):
+                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24):
         """games_in_flight: game slots resident on the device.  block_games (per rank; default = games_in_flight): the
         number of consecutive game ids a rank plays between two gathers.  With block_games > games_in_flight the slots are
         refilled as games finish (continuous batching, SelfPlayEngine.play_continuous); the files do not depend on either
@@ -200,6 +200,10 @@ class BatchedSelfPlayWorker:
         # "auto": wide nets (filters % 128 == 0) run their trunk on the f16 matrix cores (raznet-forward-v2, within 1e-5 of
         # the fp32 graph, 3.7x the exact-f32 kernels); "f32": the exact kernels everywhere (engine.DeviceNet)
         self.net_kernel = net_kernel
+        # cross-game evaluation cache (include/raz.h raz_engine_set_leaf_cache): "auto" = 2^26 entries (21 GB) for wide nets,
+        # whose forward is what a step costs; none for narrow nets (two extra launches per step cost more than they save)
+        self.leaf_cache_log2 = leaf_cache_log2
+        self.leaf_cache_max_discs = leaf_cache_max_discs
         self.seed = seed
         self.device = device
         self.rank, self.world = rank, world
@@ -257,8 +261,12 @@ class BatchedSelfPlayWorker:
                         raise RuntimeError(f"{self.games_in_flight} games in flight at {max_sims} sims/move leave {cap} tree nodes per "
                                            f"game in this GPU's free memory (< 12 x sims): lower games_in_flight")
                     nodes = cap
+            cache = self.leaf_cache_log2
+            if cache == "auto":
+                cache = 26 if self._net.filters >= 128 else None
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
-                                          sims_hint=max_sims, nodes_per_game=nodes)
+                                          sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=cache,
+                                          leaf_cache_max_discs=self.leaf_cache_max_discs)
             self._engine_key = key
         self._engine.set_resign_threshold(self.config.play.resign_threshold)
         return self._engine

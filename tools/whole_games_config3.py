@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--check-plies", type=int, default=3)
     ap.add_argument("--leaf-cache-log2", type=int, default=0, help="cross-game evaluation cache of 2**k entries (0 = none)")
+    ap.add_argument("--leaf-cache-max-discs", type=int, default=24)
     ap.add_argument("--progress", default=None, help="file to append a progress line to every ~2000 steps")
     a = ap.parse_args()
     import numpy as np
@@ -40,7 +41,7 @@ def main():
     blob = ReversiNet(256, 10, 256).keras_init_(0).to_blob()
     net = DeviceNet(blob, dev, kernel="f16x3")
     eng = SelfPlayEngine(cfg, net, n_games=a.slots, seed=0, sims_hint=a.sims, nodes_per_game=16 * a.sims, parts=1,
-                         leaf_cache_log2=a.leaf_cache_log2 or None)
+                         leaf_cache_log2=a.leaf_cache_log2 or None, leaf_cache_max_discs=a.leaf_cache_max_discs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = [0]
@@ -65,7 +66,7 @@ def main():
            "games_per_hour_at_this_batch": a.games / dt * 3600.0, "leaf_slot_occupancy": st["leaf_slot_occupancy"],
            "winners_black_white_draw": [int((raw["status"] & 0x0f == w).sum()) for w in (1, 2, 3)],
            "resigned_games": int(((raw["status"] & 0x20) != 0).sum()), "range_ok": net.range_ok(),
-           "leaf_cache": dict(eng.leaf_cache_stats(), log2_entries=a.leaf_cache_log2) if a.leaf_cache_log2 else None}
+           "leaf_cache": dict(eng.leaf_cache_stats(), log2_entries=a.leaf_cache_log2, max_discs=a.leaf_cache_max_discs) if a.leaf_cache_log2 else None}
     if a.check_plies:
         nn = bench.device_nn(net)
         ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
