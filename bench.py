@@ -211,8 +211,9 @@ def headline_leg(args, dev, rank, world, cdev):
     net = DeviceNet(blob, dev, kernel=args.net_kernel)
     parts = args.parts or (1 if args.net == "ch5" else 3)   # a 256x10 forward dwarfs the tree kernel: nothing to overlap
     # the cross-game evaluation cache as the worker attaches it for wide nets (2^26 entries, positions of <= 24 discs): the
-    # synthetic steady-state batch comes from independent random playouts, so it finds next to nothing to share - the line
-    # reports what the cache did; real self-play from the opening shares a lot (tools/whole_games_config3.py)
+    # synthetic steady-state batch comes from independent random playouts, so only its slots in the first plies find
+    # positions to share - the line reports what the cache did; self-play from the opening shares more
+    # (tools/whole_games_config3.py)
     cache_log2 = None if (args.no_leaf_cache or args.net != "ch5") else 26
     eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims,
                          nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=parts, leaf_cache_log2=cache_log2, leaf_cache_max_discs=24)
@@ -325,7 +326,8 @@ def headline_leg(args, dev, rank, world, cdev):
                                "algorithmic_bytes_per_launch": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / launches}},
         "bound_sims_per_s_per_gpu_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs),
         "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table_in_the_timed_region": served,
-                        "note": "independent random-playout positions share nothing; see whole_batch_measured / tools/whole_games_config3.py for self-play from the opening"}
+                        "note": "the steady-state batch comes from independent random playouts: only its slots in the first plies share positions; "
+                                "self-play from the opening shares more (profiles/r2/whole_games_config3_1024slots_leaf_cache.json)"}
                        if cache_log2 else None),
         "record_gather": gather, "parity_spotcheck": spot if spot else "skipped",
     })
