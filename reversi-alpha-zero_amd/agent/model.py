@@ -7,8 +7,9 @@ Keras defaults restated: Conv2D use_bias=True; 3x3 convs padd
 convs "valid"; BatchNormalization(axis=1) eps=1e-3, inference uses moving statistics;
 Flatten on channels_first => index c*64 + y*8 + x; Dense kernels stored (in, out); policy head
 softmax, value head tanh.  Initialisation = Keras defaults (glorot_uniform kernels, zero biases,
-BN gamma=1 beta=0 mean=0 var=1) from a seeded torch.Generator: trained h5 weights cannot be read
-in this environment (no h5py), so benches use random-init weights of the right architecture.
+BN gamma=1 beta=0 mean=0 var=1) from a seeded torch.Generator; benches use random-init weights of the
+right architecture (no trained weight file travels with the repository).  Keras weight files are read
+and written through lib/keras_h5.py (no h5py needed).
 """
 import hashlib
 import json
@@ -142,12 +143,13 @@ def macs_per_position(F, R, V):
 
 # ---- weight interchange with the reference's Keras files --------------------------------------------------------
 # The reference stores model_*_weight.h5 (Keras 2.1 save_weights, HDF5) + a model config JSON (agent/model.py:82-101).
-# h5py is not available to this package, so the interchange format is a Keras-NAMED .npz: one array per Keras weight,
-# key "<layer name>/<weight name>" exactly as `w.name` gives it on the reference side (e.g. "conv2d_3/kernel:0",
-# "batch_normalization_3/moving_variance:0", "policy_out/bias:0"), arrays in Keras layouts (Conv2D kernel (kh, kw, in,
-# out), Dense kernel (in, out)).  tools/keras_npz_bridge.py - run where keras + h5py exist - converts h5 <-> npz in
-# three lines each way.  Layers are identified by kind, creation number (the numeric suffix Keras appends; any offset)
-# and shape, never by absolute names.
+# lib/keras_h5.py reads and writes those files without h5py.  In memory the interchange form is a dict of Keras-NAMED
+# arrays: one array per Keras weight, key "<layer name>/<weight name>" exactly as `w.name` gives it on the reference
+# side (e.g. "conv2d_3/kernel:0", "batch_normalization_3/moving_variance:0", "policy_out/bias:0"), arrays in Keras
+# layouts (Conv2D kernel (kh, kw, in, out), Dense kernel (in, out)).  The same dict saved with np.savez is the ".npz
+# bridge" of earlier versions (still read; tools/keras_npz_bridge.py converts on a machine with keras).  Layers are
+# identified by kind, creation number (the numeric suffix Keras appends; any offset) and shape, never by absolute
+# names or by their order in the file.
 def _suffix(name):
     import re
     m = re.search(r"_(\d+)$", name)
@@ -217,6 +219,93 @@ def net_from_keras_named_arrays(arrays):
     return net.eval()
 
 
+def keras_layers(net):
+    """The layers of the reference's graph (agent/model.py:28-72) for `net`'s architecture, in the order of Keras'
+    `model.layers`, as [(layer name, class name, inbound layer names)], named as a fresh Keras session names them.
+
+    Keras 2.1.2 (keras/engine/topology.py Container.__init__, restated - Keras is not part of the reference tree) sorts
+    layers by depth = longest path to an output, deepest first, ties in the order a depth-first walk from the outputs
+    (policy_out, then value_out) first meets them.  The trunk is a chain of distinct depths (creation order); the two
+    heads tie: the value head is one Dense longer, so its layers sit one level deeper than the policy head's."""
+    R = net.res_layers
+    out = [("input_1", "InputLayer", []), ("conv2d_1", "Conv2D", ["input_1"]),
+           ("batch_normalization_1", "BatchNormalization", ["conv2d_1"]), ("activation_1", "Activation", ["batch_normalization_1"])]
+    for k in range(1, R + 1):
+        a, b, prev = 2 * k, 2 * k + 1, f"activation_{2 * k - 1}"
+        out += [(f"conv2d_{a}", "Conv2D", [prev]), (f"batch_normalization_{a}", "BatchNormalization", [f"conv2d_{a}"]),
+                (f"activation_{a}", "Activation", [f"batch_normalization_{a}"]), (f"conv2d_{b}", "Conv2D", [f"activation_{a}"]),
+                (f"batch_normalization_{b}", "BatchNormalization", [f"conv2d_{b}"]),
+                (f"add_{k}", "Add", [prev, f"batch_normalization_{b}"]), (f"activation_{b}", "Activation", [f"add_{k}"])]
+    p, v, trunk = 2 * R + 2, 2 * R + 3, f"activation_{2 * R + 1}"
+    out += [(f"conv2d_{v}", "Conv2D", [trunk]),                                                                  # depth 5
+            (f"conv2d_{p}", "Conv2D", [trunk]), (f"batch_normalization_{v}", "BatchNormalization", [f"conv2d_{v}"]),   # 4
+            (f"batch_normalization_{p}", "BatchNormalization", [f"conv2d_{p}"]),
+            (f"activation_{v}", "Activation", [f"batch_normalization_{v}"]),                                     # 3
+            (f"activation_{p}", "Activation", [f"batch_normalization_{p}"]), ("flatten_2", "Flatten", [f"activation_{v}"]),   # 2
+            ("flatten_1", "Flatten", [f"activation_{p}"]), ("dense_1", "Dense", ["flatten_2"]),                  # 1
+            ("policy_out", "Dense", ["flatten_1"]), ("value_out", "Dense", ["dense_1"])]                         # 0
+    return out
+
+
+_WEIGHTS_OF = {"Conv2D": ("kernel:0", "bias:0"), "Dense": ("kernel:0", "bias:0"),
+               "BatchNormalization": ("gamma:0", "beta:0", "moving_mean:0", "moving_variance:0")}
+
+
+def keras_weight_layers(net):
+    """[(layer name, [(weight name, array), ...])] for lib/keras_h5.write_keras_weights: every layer of keras_layers(net),
+    the weightless ones with an empty list (Keras' save_weights lists them too)."""
+    arrays = keras_named_arrays(net)
+    return [(name, [(f"{name}/{w}", arrays[f"{name}/{w}"]) for w in _WEIGHTS_OF.get(cls, ())]) for name, cls, _ in keras_layers(net)]
+
+
+def keras_model_config(net, l2_reg=1e-4):
+    """What Keras 2.1.2 `Model.get_config()` returns for the reference's graph (agent/model.py:28-58) - the JSON the
+    reference writes next to the weights and feeds to `Model.from_config` (agent/model.py:86,96).  Restated from Keras'
+    layer `get_config` methods; Keras is absent here, so this is checked for structure only (tests/test_keras_h5.py)."""
+    l2 = float(np.float32(l2_reg))   # keras.regularizers.L1L2 stores K.cast_to_floatx(l2)
+    glorot = {"class_name": "VarianceScaling", "config": {"scale": 1.0, "mode": "fan_avg", "distribution": "uniform", "seed": None}}
+    zeros, ones = {"class_name": "Zeros", "config": {}}, {"class_name": "Ones", "config": {}}
+    reg = {"class_name": "L1L2", "config": {"l1": 0.0, "l2": l2}}
+
+    def conv(name, filters, k, padding):
+        return {"name": name, "trainable": True, "filters": filters, "kernel_size": [k, k], "strides": [1, 1], "padding": padding,
+                "data_format": "channels_first", "dilation_rate": [1, 1], "activation": "linear", "use_bias": True,
+                "kernel_initializer": glorot, "bias_initializer": zeros, "kernel_regularizer": reg, "bias_regularizer": None,
+                "activity_regularizer": None, "kernel_constraint": None, "bias_constraint": None}
+
+    def dense(name, units, activation):
+        return {"name": name, "trainable": True, "units": units, "activation": activation, "use_bias": True,
+                "kernel_initializer": glorot, "bias_initializer": zeros, "kernel_regularizer": reg, "bias_regularizer": None,
+                "activity_regularizer": None, "kernel_constraint": None, "bias_constraint": None}
+
+    def bn(name):
+        return {"name": name, "trainable": True, "axis": 1, "momentum": 0.99, "epsilon": BN_EPS, "center": True, "scale": True,
+                "beta_initializer": zeros, "gamma_initializer": ones, "moving_mean_initializer": zeros,
+                "moving_variance_initializer": ones, "beta_regularizer": None, "gamma_regularizer": None,
+                "beta_constraint": None, "gamma_constraint": None}
+
+    F, R, V, ks = net.filters, net.res_layers, net.value_fc, net.filter_size
+    heads = {f"conv2d_{2 * R + 2}": (2, 1, "valid"), f"conv2d_{2 * R + 3}": (1, 1, "valid")}
+    layers = []
+    for name, cls, inbound in keras_layers(net):
+        if cls == "InputLayer":
+            cfg = {"batch_input_shape": [None, 2, 8, 8], "dtype": "float32", "sparse": False, "name": name}
+        elif cls == "Conv2D":
+            cfg = conv(name, *heads.get(name, (F, ks, "same")))
+        elif cls == "BatchNormalization":
+            cfg = bn(name)
+        elif cls == "Activation":
+            cfg = {"name": name, "trainable": True, "activation": "relu"}
+        elif cls == "Dense":
+            cfg = dense(name, *{"policy_out": (64, "softmax"), "dense_1": (V, "relu"), "value_out": (1, "tanh")}[name])
+        else:   # Add, Flatten
+            cfg = {"name": name, "trainable": True}
+        layers.append({"name": name, "class_name": cls, "config": cfg,
+                       "inbound_nodes": [[[i, 0, 0, {}] for i in inbound]] if inbound else []})
+    return {"name": "reversi_model", "layers": layers, "input_layers": [["input_1", 0, 0]],
+            "output_layers": [["policy_out", 0, 0], ["value_out", 0, 0]]}
+
+
 HDF5_MAGIC = b"\x89HDF\r\n\x1a\n"
 NPZ_MAGIC = b"PK"
 
@@ -224,9 +313,10 @@ NPZ_MAGIC = b"PK"
 class ReversiModel:
     """Same role and method names as the reference's ReversiModel (agent/model.py:22-101).  `self.model` is the torch
     module.  Weight files, told apart by their first bytes whatever the (reference-fixed) file name says:
-      * a Keras-named .npz (see above): the interchange format with the reference's opt / eval workers;
-      * a torch state-dict (what save() wrote before the bridge existed);
-      * a Keras HDF5 file -> ValueError telling the operator to run tools/keras_npz_bridge.py (no h5py here)."""
+      * a Keras HDF5 weight file (`save_weights`, agent/model.py:94-101) - what the reference's workers write and read;
+        read and written through lib/keras_h5.py;
+      * a Keras-named .npz (see above): the bridge format of earlier versions, still read;
+      * a torch state-dict (what save() wrote before either existed)."""
 
     def __init__(self, config):
         self.config = config
@@ -247,38 +337,50 @@ class ReversiModel:
             return m.hexdigest()
 
     def load(self, config_path, weight_path):
+        """agent/model.py:82-92.  The architecture is taken from the weights themselves (layer kinds and shapes), so the
+        Keras config JSON is only required to exist, as in the reference."""
         if not (os.path.exists(config_path) and os.path.exists(weight_path)):
             return False
         with open(weight_path, "rb") as f:
             magic = f.read(8)
         if magic == HDF5_MAGIC:
-            raise ValueError(f"{weight_path} is a Keras HDF5 weight file; this package reads the Keras-named .npz bridge "
-                             f"format instead (h5py is not available here): convert it where keras is installed with "
-                             f"`python tools/keras_npz_bridge.py h5-to-npz {config_path} {weight_path} {weight_path}`")
-        if magic[:2] == NPZ_MAGIC and not _is_torch_zip(weight_path):
+            from ..lib.keras_h5 import read_keras_weights
+            arrays, _ = read_keras_weights(weight_path)
+            self.model = net_from_keras_named_arrays(arrays)
+        elif magic[:2] == NPZ_MAGIC and not _is_torch_zip(weight_path):
             with np.load(weight_path) as z:
                 self.model = net_from_keras_named_arrays({k: z[k] for k in z.files})
-        else:
-            with open(config_path, "rt") as f:
-                c = json.load(f)
-            if "cnn_filter_num" not in c:
-                raise ValueError(f"{config_path} is a Keras model config but {weight_path} is not a Keras-named .npz")
-            self.model = ReversiNet(c["cnn_filter_num"], c["res_layer_num"], c["value_fc_size"], c.get("cnn_filter_size", 3))
-            self.model.load_state_dict(torch.load(weight_path, map_location="cpu"))
+        else:   # a torch state-dict: the architecture is in the tensor shapes
+            try:
+                sd = torch.load(weight_path, map_location="cpu")
+                w0 = sd["stem.conv.weight"]
+                blocks = {int(k.split(".")[1]) for k in sd if k.startswith("res.")}
+                self.model = ReversiNet(w0.shape[0], len(blocks), sd["value_fc1.weight"].shape[0], w0.shape[2])
+                self.model.load_state_dict(sd)
+            except Exception as e:
+                raise ValueError(f"{weight_path} is neither a Keras HDF5 weight file, a Keras-named .npz nor a torch "
+                                 f"state-dict of ReversiNet ({type(e).__name__}: {e})")
             self.model.eval()
         self.digest = self.fetch_digest(weight_path)
         return True
 
-    def save(self, config_path, weight_path):
-        """Config JSON (the architecture numbers; the reference's Keras get_config() dump is rebuilt by the bridge
-        script from them) + the Keras-named .npz under the reference's file name."""
+    def save(self, config_path, weight_path, weight_format="h5"):
+        """agent/model.py:94-101: the Keras model config JSON (`get_config()`) + the Keras weight file (`save_weights`),
+        both in the reference's formats, so that its opt / eval workers and GUI load what this package saved.
+        weight_format="npz" writes the Keras-named .npz bridge instead."""
         m = self.model
+        l2 = getattr(getattr(self.config, "model", None), "l2_reg", 1e-4)
         with open(config_path, "wt") as f:
-            json.dump({"cnn_filter_num": m.filters, "res_layer_num": m.res_layers,
-                       "value_fc_size": m.value_fc, "cnn_filter_size": m.filter_size,
-                       "format": "keras-named npz (reversi_alpha_zero_amd.agent.model)"}, f)
-        tmp = weight_path + ".tmp.npz"
-        np.savez(tmp, **keras_named_arrays(m))
+            json.dump(keras_model_config(m, l2), f)
+        tmp = weight_path + ".tmp"
+        if weight_format == "h5":
+            from ..lib.keras_h5 import write_keras_weights
+            write_keras_weights(tmp, keras_weight_layers(m))
+        elif weight_format == "npz":
+            np.savez(tmp + ".npz", **keras_named_arrays(m))
+            tmp += ".npz"
+        else:
+            raise ValueError(f"weight_format {weight_format!r}: 'h5' or 'npz'")
         os.replace(tmp, weight_path)   # readers poll the digest (api.py:117-125): never expose a half-written file
         self.digest = self.fetch_digest(weight_path)
 

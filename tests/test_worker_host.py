@@ -420,10 +420,10 @@ def _model_config(tmp_path):
 
 
 def test_keras_named_npz_bridge_round_trip(tmp_path):
-    """SURVEY 8(f)3 weight interchange without h5py: torch module -> Keras-named arrays (Keras layouts) -> .npz under the
+    """SURVEY 8(f)3 weight interchange: torch module -> Keras-named arrays (Keras layouts) -> .npz under the
     reference's file name -> module -> blob, bit-exact; layer names with an arbitrary creation-number offset (a second
-    model built in one Keras session) still load; a torch state-dict file still loads; an HDF5 file is refused with the
-    conversion command."""
+    model built in one Keras session) still load; a torch state-dict file still loads; a damaged HDF5 file is refused
+    (real ones: tests/test_keras_h5.py)."""
     import re
     import torch
     from reversi_alpha_zero_amd.agent.model import (ReversiNet, ReversiModel, keras_named_arrays, net_from_keras_named_arrays)
@@ -443,7 +443,7 @@ def test_keras_named_npz_bridge_round_trip(tmp_path):
     cpath, wpath = str(tmp_path / "c.json"), str(tmp_path / "model_weight.h5")
     m = ReversiModel(cfg)
     m.model = net
-    m.save(cpath, wpath)
+    m.save(cpath, wpath, weight_format="npz")
     with np.load(wpath) as z:
         assert set(z.files) == set(arrs)
     m2 = ReversiModel(cfg)
@@ -452,7 +452,7 @@ def test_keras_named_npz_bridge_round_trip(tmp_path):
     m3 = ReversiModel(cfg)
     assert m3.load(cpath, str(tmp_path / "legacy.h5")) and m3.model.to_blob() == net.to_blob()
     (tmp_path / "keras.h5").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(ValueError, match="keras_npz_bridge"):
+    with pytest.raises(ValueError, match="offset/length|truncated"):
         ReversiModel(cfg).load(cpath, str(tmp_path / "keras.h5"))
     with pytest.raises(ValueError):
         net_from_keras_named_arrays({k: v for k, v in arrs.items() if not k.startswith("dense_1")})

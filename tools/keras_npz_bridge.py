@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""tools/keras_npz_bridge.py - weight interchange between the reference's Keras files and this package.
-RUNS ON THE REFERENCE SIDE (needs keras + h5py, which this repo's environment does not have):
+"""tools/keras_npz_bridge.py - weight interchange between the reference's Keras files and this package THROUGH KERAS.
+The package reads and writes Keras h5 files by itself (lib/keras_h5.py); this script is the fallback that lets Keras do
+the conversion.  RUNS ON THE REFERENCE SIDE (needs keras + h5py, which this repo's environment does not have):
 
     python tools/keras_npz_bridge.py h5-to-npz model_config.json model_weight.h5 out.npz
     python tools/keras_npz_bridge.py npz-to-h5 in.npz model_config.json model_weight.h5
