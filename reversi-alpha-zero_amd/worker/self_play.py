@@ -105,7 +105,7 @@ def drop_draw_uniform(seed, game_id):
     return rng_pair(seed, game_id, 3, 0)[1]
 
 
-def game_rows_json(headers, root_n, n_plies, winner, change_tau_turn, save_policy_of_tau_1):
+def game_rows_json(headers, root_n, n_plies, winner, change_tau_turn, save_policy_of_tau_1, as_bytes=False):
     """The JSON text of one finished game's rows (rows joined by ", ", no enclosing brackets) and their number,
     produced by libraz (csrc/raz_emit.hip) from the engine's raw records: byte for byte what
     json.dumps(rows_of_game(plies, winner)) yields minus the outer "[" "]"."""
@@ -121,13 +121,14 @@ def game_rows_json(headers, root_n, n_plies, winner, change_tau_turn, save_polic
                                     int(bool(save_policy_of_tau_1)), buf, cap, ctypes.byref(nrows))
     if n < 0:
         raise RuntimeError("raz_emit_game_rows_json: " + last_error())
-    return buf.raw[:n].decode("ascii"), nrows.value
+    return (buf.raw[:n] if as_bytes else buf.raw[:n].decode("ascii")), nrows.value
 
 
 def plies_for_ggf(headers, n_plies):
     """The per-ply facts MoveHistory needs (worker/self_play.py:279-296) from raw ply headers."""
-    return [{"action": int(h["action"]), "player": int(h["player"]), "solved": bool(int(h["flags"]) & 1),
-             "q": float(h["q"]), "n": float(h["n"])} for h in headers[:int(n_plies)]]
+    h = headers[:int(n_plies)]
+    return [{"action": a, "player": pl, "solved": bool(f & 1), "q": q, "n": n} for a, pl, f, q, n in
+            zip(h["action"].tolist(), h["player"].tolist(), h["flags"].tolist(), h["q"].tolist(), h["n"].tolist())]
 
 
 RAW_KEYS = ("headers", "root_n", "n_plies", "status", "resigned", "game_id", "enable_resign", "final_black", "final_white")
@@ -208,7 +209,9 @@ class BatchedSelfPlayWorker:
         self.device = device
         self.rank, self.world = rank, world
         self.buffer = []
-        self.buffer_json = []          # the same rows as JSON text fragments, one per game (emit_raw)
+        self.buffer_json = []          # the same rows as JSON text fragments (bytes), one per game (write_raw)
+        self._emit_executor = None
+        self._emit_executor_threads = 0
         self.move_history_buffer = []
         self.false_positive_count_of_resign = 0
         self.resign_test_game_count = 0
@@ -346,42 +349,77 @@ class BatchedSelfPlayWorker:
 
     def emit_raw(self, raw, first_local_idx=1, threads=None):
         """emit() on raw record arrays: the same files, with the rows' JSON text produced natively
-        (csrc/raz_emit.hip; one call per game, spread over host threads - ctypes releases the GIL)."""
+        (csrc/raz_emit.hip; one call per game, spread over host threads - ctypes releases the GIL).
+        = bookkeep_raw (resignation accounting, one threshold step per batch) + write_raw (the files)."""
+        self.bookkeep_raw(raw)
+        return self.write_raw(raw, first_local_idx, threads)
+
+    def bookkeep_raw(self, raw):
+        """finish_game (self_play.py:219-260) for every game of a batch, then ONE threshold step: all that the next
+        batch needs from this one.  Cheap (no rows are touched), so run() does it before handing the batch's arrays to
+        the background writer."""
+        self._defer_threshold_update = True
+        for st, rb, rw, er in zip(raw["status"].tolist(), raw["resigned"][:, 0].tolist(), raw["resigned"][:, 1].tolist(),
+                                  raw["enable_resign"].tolist()):
+            self.finish_game({"winner": int(st) & 0x0f, "resigned_black": int(rb), "resigned_white": int(rw), "enable_resign": int(er)})
+        self._defer_threshold_update = False
+        self.check_and_update_resignation_threshold()
+
+    def _emit_pool(self, threads=None):
         import concurrent.futures as cf
-        pd, pc = self.config.play_data, self.config.play
+        want = threads or min(32, os.cpu_count() or 1)
+        if self._emit_executor is None or self._emit_executor_threads != want:
+            if self._emit_executor is not None:
+                self._emit_executor.shutdown(wait=True)
+            self._emit_executor, self._emit_executor_threads = cf.ThreadPoolExecutor(max_workers=want), want
+        return self._emit_executor
+
+    def write_raw(self, raw, first_local_idx=1, threads=None, ahead=128):
+        """The files of a batch of finished games (self_play.py:180-207), streamed: the JSON text of at most `ahead`
+        games is in flight on the host threads while the games before them are written, so memory stays bounded by
+        nb_game_in_file + ahead games (a game's rows are ~0.7 MB of text) whatever the batch size."""
+        from collections import deque
+        pd, pc, rc = self.config.play_data, self.config.play, self.config.resource
         n = len(raw["n_plies"])
-        winners = [int(s) & 0x0f for s in raw["status"]]
+        winners = [int(v) & 0x0f for v in raw["status"].tolist()]
+        game_ids = raw["game_id"].tolist()
+        ex = self._emit_pool(threads)
 
         def frag(g):
             return game_rows_json(raw["headers"][g], raw["root_n"][g], raw["n_plies"][g], winners[g],
-                                  pc.change_tau_turn, pd.save_policy_of_tau_1)
-        with cf.ThreadPoolExecutor(max_workers=threads or min(32, os.cpu_count() or 1)) as ex:
-            frags = list(ex.map(frag, range(n)))
+                                  pc.change_tau_turn, pd.save_policy_of_tau_1, as_bytes=True)
+        futs, submitted = deque(), 0
         paths = []
-        self._defer_threshold_update = True
+        known_files = None   # the directory is listed once per batch, then tracked (the reference lists it after every game)
         for g in range(n):
+            while submitted < min(n, g + ahead):
+                futs.append(ex.submit(frag, submitted))
+                submitted += 1
+            text, nrows = futs.popleft().result()
             local_idx = first_local_idx + g
-            gid = int(raw["game_id"][g])
-            self.finish_game({"winner": winners[g], "resigned_black": int(raw["resigned"][g, 0]),
-                              "resigned_white": int(raw["resigned"][g, 1]), "enable_resign": int(raw["enable_resign"][g])})
-            text, nrows = frags[g]
             is_draw = nrows > 0 and winners[g] == 3          # rows[0][-1] == 0 (self_play.py:181)
-            if nrows and (not is_draw or pd.drop_draw_game_rate <= drop_draw_uniform(self.seed, gid)):
+            if nrows and (not is_draw or pd.drop_draw_game_rate <= drop_draw_uniform(self.seed, int(game_ids[g]))):
                 self.buffer_json.append(text)
             if local_idx % pd.nb_game_in_file == 0 and self.buffer_json:
-                rc = self.config.resource
                 stamp = datetime.now().strftime("%Y%m%d-%H%M%S.%f")
                 path = os.path.join(rc.play_data_dir, rc.play_data_filename_tmpl % stamp)
-                with open(path, "wt") as f:
-                    f.write("[" + ", ".join(self.buffer_json) + "]")
+                with open(path, "wb") as f:
+                    f.write(b"[")
+                    for i, t in enumerate(self.buffer_json):
+                        if i:
+                            f.write(b", ")
+                        f.write(t)
+                    f.write(b"]")
                 self.buffer_json = []
                 paths.append(path)
-                self.remove_play_data()   # (the reference lists the directory after every game; only a write changes it)
+                if known_files is None:
+                    known_files = get_game_data_filenames(rc)
+                elif not known_files or known_files[-1] != path:
+                    known_files.append(path)
+                known_files = self.remove_play_data(known_files)
             if pd.enable_ggf_data:
                 self.save_ggf_data(plies_for_ggf(raw["headers"][g], raw["n_plies"][g]),
                                    write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
-        self._defer_threshold_update = False
-        self.check_and_update_resignation_threshold()
         return paths
 
     # -- bookkeeping identical to the reference worker ---------------------------------------------
@@ -442,16 +480,19 @@ class BatchedSelfPlayWorker:
         self.move_history_buffer = []
         return path
 
-    def remove_play_data(self):
-        """self_play.py:209-217."""
-        files = get_game_data_filenames(self.config.resource)
-        if len(files) < self.config.play_data.max_file_num:
-            return
-        for i in range(len(files) - self.config.play_data.max_file_num):
+    def remove_play_data(self, files=None):
+        """self_play.py:209-217.  `files`: the sorted listing if the caller tracks it; returns what is left."""
+        if files is None:
+            files = get_game_data_filenames(self.config.resource)
+        extra = len(files) - self.config.play_data.max_file_num
+        if extra <= 0:
+            return files
+        for i in range(extra):
             try:
                 os.remove(files[i])
             except OSError:
                 pass
+        return files[extra:]
 
     def emit(self, records, first_local_idx=1):
         """Write one batch of finished games the way the reference loop would, game by game."""
@@ -471,12 +512,15 @@ class BatchedSelfPlayWorker:
         self.check_and_update_resignation_threshold()
         return paths
 
-    def run(self, total_games=None, reload_model=None):
+    def run(self, total_games=None, reload_model=None, background_emit=True):
         """_start (self_play.py:95-137): play batches until total_games (None = forever).
         Per batch: every rank plays its id range; the finished games' records are packed in HBM and gathered on
-        rank 0 (the path's single collective), which writes the files, does the resignation bookkeeping and
-        broadcasts what every rank needs for the next batch: the game index and the resign threshold (so that all
-        ranks keep playing under the same rule and results stay independent of the sharding).
+        rank 0 (the path's single collective), which does the resignation bookkeeping, broadcasts what every rank needs
+        for the next batch - the game index and the resign threshold (so that all ranks keep playing under the same
+        rule and results stay independent of the sharding) - and writes the files.  With background_emit the files of
+        batch k are written by a host thread while batch k + 1 is played (the text of 65 536 games is ~45 GB: minutes
+        of host work that would otherwise idle every GPU); data/.self-play-game-idx is advanced after a batch's files
+        are on disk, and run() returns only when everything is written.
         reload_model (optional): callable returning a new net blob or None, polled between batches (api.py:117-125)."""
         import torch.distributed as dist
         from ..engine import raw_from_packed
@@ -485,35 +529,47 @@ class BatchedSelfPlayWorker:
             rc.create_directories()
         game_idx = read_as_int(rc.self_play_game_idx_file) or 0
         local_idx = 1
-        while total_games is None or local_idx <= total_games:
-            continuous = self.block_games > self.games_in_flight and self._series_length() == 1
-            if continuous:
-                packed = self.play_block_continuous(game_idx)
-            else:
-                eng, n = self.play_batch_raw(game_idx, device_records=True)
-                packed = lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)
-            if not self._net.range_ok():
-                raise RuntimeError("an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2): "
-                                   "this block's games are not trustworthy - run the worker with net_kernel='f32'")
-            if self.world > 1:
-                allraw, _ = gather_packed(packed, self.rank, self.world)
-            else:
-                pk = packed(None)
-                allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
-            if self.rank == 0:
-                self.emit_raw(allraw, local_idx)
-                game_idx += len(allraw["n_plies"])
-                with open(rc.self_play_game_idx_file, "wt") as f:
-                    f.write(str(game_idx))
-            if self.world > 1:
-                t = [game_idx, self.config.play.resign_threshold]
-                dist.broadcast_object_list(t, src=0)
-                game_idx, self.config.play.resign_threshold = t
-            local_idx += (self.block_games if continuous else self.games_in_flight) * self.world
-            if reload_model is not None:
-                blob = reload_model()
-                if blob is not None:   # every rank polls the same files: the digest decides
-                    self.set_net_blob(blob)
+        writer = _BackgroundWriter(self) if (background_emit and self.rank == 0) else None
+        try:
+            while total_games is None or local_idx <= total_games:
+                continuous = self.block_games > self.games_in_flight and self._series_length() == 1
+                if continuous:
+                    packed = self.play_block_continuous(game_idx)
+                else:
+                    eng, n = self.play_batch_raw(game_idx, device_records=True)
+                    packed = lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)
+                if not self._net.range_ok():
+                    raise RuntimeError("an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2): "
+                                       "this block's games are not trustworthy - run the worker with net_kernel='f32'")
+                if self.world > 1:
+                    allraw, _ = gather_packed(packed, self.rank, self.world)
+                else:
+                    pk = packed(None)
+                    allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
+                if self.rank == 0:
+                    self.bookkeep_raw(allraw)
+                    game_idx += len(allraw["n_plies"])
+                    if writer is not None:
+                        writer.submit(allraw, local_idx, game_idx)
+                    else:
+                        self.write_raw(allraw, local_idx)
+                        self._write_game_idx(game_idx)
+                if self.world > 1:
+                    t = [game_idx, self.config.play.resign_threshold]
+                    dist.broadcast_object_list(t, src=0)
+                    game_idx, self.config.play.resign_threshold = t
+                local_idx += (self.block_games if continuous else self.games_in_flight) * self.world
+                if reload_model is not None:
+                    blob = reload_model()
+                    if blob is not None:   # every rank polls the same files: the digest decides
+                        self.set_net_blob(blob)
+        finally:
+            if writer is not None:
+                writer.close()
+
+    def _write_game_idx(self, game_idx):
+        with open(self.config.resource.self_play_game_idx_file, "wt") as f:
+            f.write(str(game_idx))
 
     def set_net_blob(self, blob):
         """A new generation of weights between two batches (agent/api.py:117-125 try_reload_model): the engine is
@@ -523,6 +579,48 @@ class BatchedSelfPlayWorker:
         self._engine = None
         self._engine_key = None
         self._series_pos = 0
+
+
+class _BackgroundWriter:
+    """One host thread that writes finished batches, in submission order, while the next batch is played.  At most one
+    batch waits behind the one being written (submit blocks beyond that), so at most three batches' record arrays are
+    alive.  An error in the thread is raised in the caller at the next submit() / close()."""
+
+    def __init__(self, worker):
+        import queue
+        import threading
+        self.worker, self.error = worker, None
+        self.queue = queue.Queue(maxsize=1)
+        self.thread = threading.Thread(target=self._loop, name="raz-play-data-writer", daemon=True)
+        self.thread.start()
+
+    def _loop(self):
+        while True:
+            item = self.queue.get()
+            if item is None:
+                return
+            if self.error is not None:
+                continue   # keep draining so that submit() never blocks forever
+            raw, local_idx, game_idx = item
+            try:
+                self.worker.write_raw(raw, local_idx)
+                self.worker._write_game_idx(game_idx)
+            except BaseException as e:   # noqa: B902 - reported to the caller
+                self.error = e
+
+    def _check(self):
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise RuntimeError(f"writing play data failed: {err!r}") from err
+
+    def submit(self, raw, local_idx, game_idx):
+        self._check()
+        self.queue.put((raw, local_idx, game_idx))
+
+    def close(self):
+        self.queue.put(None)
+        self.thread.join()
+        self._check()
 
 
 # ---- the single collective: finished-game records -> rank 0 ------------------------------------------

@@ -1,0 +1,195 @@
+"""BatchedSelfPlayWorker.run() (worker/self_play.py:95-137 of the reference) on the HOST: the control flow around the
+engine - gather, resignation bookkeeping, broadcast, background file writing, game-index file - with the engine replaced
+by a stub that hands out prepared records.  The real engine under run() is covered on the GPU (tests/test_multirank_gpu.py,
+tests/test_worker_scale_gpu.py); this is the CPU (gloo, world_size 2) coverage of the N > 1 path."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def stub_games(first_id, n, seed=7):
+    """Deterministic fake finished games keyed by GLOBAL game id (so that any sharding yields the same games)."""
+    games = []
+    for gid in range(first_id, first_id + n):
+        rng = np.random.default_rng(seed * 100003 + gid)
+        plies = []
+        for j in range(int(rng.integers(3, 10))):
+            own = int(rng.integers(0, 2**62)) * 2 + 1
+            rn = [float(v) for v in rng.integers(0, 40, 64) * (rng.random(64) < 0.3)]
+            if sum(rn) == 0:
+                rn[5] = 3.0
+            plies.append({"player": 1 + j % 2, "turn": j, "own": own, "enemy": int(rng.integers(0, 2**62)) & ~own, "action": int(rng.integers(0, 64)),
+                          "has_row": bool(j % 4), "solved": False, "sims": 10, "loops": 1, "n": float(rng.integers(1, 9)),
+                          "q": float(rng.random() * 2 - 1), "root_n": rn, "root_w": None})
+        games.append((plies, {"winner": int(rng.integers(1, 4)), "status": 1, "plies": len(plies), "game_id": gid,
+                              "enable_resign": int(gid % 2), "resigned_black": int(gid % 2), "resigned_white": int(gid % 5 == 0)}))
+    return games
+
+
+def make_stub_worker(cfg, games_in_flight, rank=0, world=1, seed=4):
+    import torch
+    from reversi_alpha_zero_amd.engine import GAME_SUMMARY, PLY_HEADER
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+
+    class StubEngine:
+        def __init__(self, games):
+            self.games = games
+
+        def pack_records(self, g0, n, plies=None):   # SelfPlayEngine.pack_records' result, as CPU tensors
+            games = self.games[g0:g0 + n]
+            ext = max(len(p) for p, _ in games) if plies is None else plies
+            hdr = np.zeros((n, ext), dtype=PLY_HEADER)
+            rn = np.zeros((n, ext, 64), dtype=np.uint32)
+            sm = np.zeros(n, dtype=GAME_SUMMARY)
+            for g, (pl, s) in enumerate(games):
+                for j, p in enumerate(pl):
+                    h = hdr[g, j]
+                    h["own"], h["enemy"], h["n"], h["q"] = p["own"], p["enemy"], p["n"], p["q"]
+                    h["action"], h["player"], h["turn"], h["has_row"] = p["action"], p["player"], p["turn"], int(p["has_row"])
+                    rn[g, j] = np.asarray(p["root_n"], dtype=np.uint32)
+                sm[g]["game_id"], sm[g]["n_plies"], sm[g]["status"] = s["game_id"], len(pl), s["winner"]
+                sm[g]["resigned_black"], sm[g]["resigned_white"], sm[g]["enable_resign"] = s["resigned_black"], s["resigned_white"], s["enable_resign"]
+            return {"headers": torch.from_numpy(hdr.view(np.uint8).reshape(n, ext, 48)), "root_n": torch.from_numpy(rn.view(np.int32)),
+                    "summary": torch.from_numpy(sm.view(np.uint8).reshape(n, 32))}
+
+    class StubNet:
+        def range_ok(self):
+            return True
+
+    class StubWorker(BatchedSelfPlayWorker):
+        thresholds_seen = []
+
+        def play_batch_raw(self, first_game_idx=0, device_records=False):
+            # a rank plays ids [first + rank * B, first + (rank + 1) * B)  (worker/self_play.py of this package: play_batch_raw)
+            self._net = StubNet()
+            self.thresholds_seen = self.thresholds_seen + [self.config.play.resign_threshold]
+            first = first_game_idx + self.rank * self.games_in_flight
+            return StubEngine(stub_games(first, self.games_in_flight)), self.games_in_flight
+
+    return StubWorker(cfg, b"", games_in_flight=games_in_flight, seed=seed, device="cpu", rank=rank, world=world)
+
+
+def make_config(root):
+    from reversi_alpha_zero_amd.config import Config
+    cfg = Config()
+    cfg.play_data.update(dict(nb_game_in_file=3, nb_game_in_ggf_file=4, drop_draw_game_rate=0.5, max_file_num=1000))
+    cfg.play.resign_threshold = -0.8
+    rc = cfg.resource
+    rc.data_dir, rc.play_data_dir, rc.self_play_ggf_data_dir = str(root), str(root / "play"), str(root / "ggf")
+    rc.self_play_game_idx_file = str(root / ".self-play-game-idx")
+    rc.create_directories = lambda: [os.makedirs(d, exist_ok=True) for d in (rc.play_data_dir, rc.self_play_ggf_data_dir)]
+    return cfg
+
+
+def outputs(cfg):
+    rc = cfg.resource
+    play = [open(os.path.join(rc.play_data_dir, f), "rb").read() for f in sorted(os.listdir(rc.play_data_dir))]
+    ggf = [re.sub(r"DT\[[^\]]*\]", "DT[]", open(os.path.join(rc.self_play_ggf_data_dir, f)).read())
+           for f in sorted(os.listdir(rc.self_play_ggf_data_dir))]
+    return play, ggf, open(rc.self_play_game_idx_file).read()
+
+
+def test_run_background_writer_equals_inline(tmp_path):
+    """run() with the files written by the background thread == written inline: same file contents in the same order,
+    same game index, same threshold trajectory; rows load as JSON; memory-bounded streaming (ahead < games)."""
+    res = {}
+    for mode in (True, False):
+        cfg = make_config(tmp_path / f"bg{int(mode)}")
+        w = make_stub_worker(cfg, games_in_flight=50)
+        w.run(total_games=250, background_emit=mode)
+        res[mode] = outputs(cfg) + (w.thresholds_seen, cfg.play.resign_threshold, w.resign_test_game_count)
+    assert res[True] == res[False]
+    play, ggf, idx, thr, final_thr, _ = res[True]
+    assert idx == "250" and len(play) >= 60 and len(ggf) >= 60
+    assert len(thr) == 5 and len(set(thr)) > 1           # 25 no-resign test games per batch: the threshold moved after 100 of them
+    rows = json.loads(play[0])
+    assert len(rows) % 8 == 0 and len(rows[0]) == 3 and len(rows[0][1]) == 64
+    # the streamed writer with a small look-ahead window writes the same bytes
+    cfg = make_config(tmp_path / "ahead")
+    w = make_stub_worker(cfg, games_in_flight=50)
+    from reversi_alpha_zero_amd.engine import raw_from_packed
+    eng, n = w.play_batch_raw(0)
+    pk = eng.pack_records(0, n)
+    raw = raw_from_packed(*(pk[k].numpy() for k in ("headers", "root_n", "summary")))
+    cfg.resource.create_directories()
+    w.write_raw(raw, 1, threads=2, ahead=3)
+    first = [open(os.path.join(cfg.resource.play_data_dir, f), "rb").read() for f in sorted(os.listdir(cfg.resource.play_data_dir))]
+    assert first == play[:len(first)] and len(first) >= 12
+
+
+def test_run_reports_writer_errors(tmp_path):
+    """A failure in the background writer surfaces in run() (not silently lost), and the game index is not advanced past
+    the batch whose files are missing."""
+    cfg = make_config(tmp_path / "err")
+    w = make_stub_worker(cfg, games_in_flight=20)
+    real = w.write_raw
+    calls = []
+
+    def failing(raw, first_local_idx=1, threads=None, ahead=128):
+        calls.append(first_local_idx)
+        if len(calls) == 2:
+            raise OSError("disk full")
+        return real(raw, first_local_idx, threads, ahead)
+    w.write_raw = failing
+    with pytest.raises(RuntimeError, match="disk full"):
+        w.run(total_games=100)
+    assert open(cfg.resource.self_play_game_idx_file).read() == "20"
+
+
+def test_max_file_num_is_enforced_from_a_tracked_listing(tmp_path):
+    """remove_play_data (self_play.py:209-217) with the directory listed once per batch: only the newest max_file_num
+    files survive, older files of earlier runs included."""
+    cfg = make_config(tmp_path / "cap")
+    cfg.play_data.max_file_num = 7
+    cfg.resource.create_directories()
+    for i in range(3):
+        open(os.path.join(cfg.resource.play_data_dir, cfg.resource.play_data_filename_tmpl % f"20000101-00000{i}.000000"), "w").write("[]")
+    w = make_stub_worker(cfg, games_in_flight=40)
+    w.run(total_games=40)
+    names = sorted(os.listdir(cfg.resource.play_data_dir))
+    assert len(names) == 7 and not any(n.startswith("play_2000") for n in names)
+
+
+_RUN2_SCRIPT = r'''
+import os, sys, pathlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch.distributed as dist
+from test_worker_run_host import make_config, make_stub_worker
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = make_config(pathlib.Path({out!r}))
+w = make_stub_worker(cfg, games_in_flight=25, rank=rank, world=world)
+w.run(total_games=200)
+print("RANK", rank, "THRESHOLDS", w.thresholds_seen, cfg.play.resign_threshold)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_run_two_ranks_gloo_equals_one_rank(tmp_path):
+    """SURVEY 8(d) Config 4's acceptance on the host logic: 2 ranks x 25 games per batch write the files 1 rank x 50
+    games per batch writes, and both ranks play every batch under the same (broadcast) resign threshold."""
+    script = tmp_path / "run2.py"
+    script.write_text(_RUN2_SCRIPT.format(root=ROOT, out=str(tmp_path / "two")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29551", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    thr = dict(re.findall(r"RANK (\d) THRESHOLDS (\[[^\]]*\] \S+)", r.stdout))
+    assert set(thr) == {"0", "1"} and thr["0"] == thr["1"], r.stdout[-1000:]
+    cfg1 = make_config(tmp_path / "one")
+    w = make_stub_worker(cfg1, games_in_flight=50)
+    w.run(total_games=200)
+    two = outputs(make_config(tmp_path / "two"))
+    one = outputs(cfg1)
+    assert one[2] == two[2] == "200" and len(one[0]) >= 50
+    assert [hashlib.sha256(b).hexdigest() for b in one[0]] == [hashlib.sha256(b).hexdigest() for b in two[0]] and one[1] == two[1]
+    assert f"{w.thresholds_seen} {cfg1.play.resign_threshold}" == thr["0"]
