@@ -231,3 +231,20 @@ def test_refusals(tmp_path):
         assert r.returncode == 0
         with pytest.raises(H5FormatError, match="libver|version"):
             H5File(p)["x"]
+
+
+def test_model_save_style_file_is_read(tmp_path):
+    """A Keras `model.save()` file keeps the same layout one level down, in the group `model_weights`: read too."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet, keras_named_arrays, keras_weight_layers, net_from_keras_named_arrays
+    from reversi_alpha_zero_amd.lib.keras_h5 import H5File, read_keras_weights, write_h5, write_keras_weights
+    net = ReversiNet(16, 1, 16).keras_init_(9).randomize_bn_(10)
+    inner = H5File(write_keras_weights(None, keras_weight_layers(net)))
+
+    def tree(g):   # re-nest the plain weight file under /model_weights
+        from reversi_alpha_zero_amd.lib.keras_h5 import Dataset
+        return {k: (g[k].read() if isinstance(g[k], Dataset) else (dict(g[k].attrs), tree(g[k]))) for k in g.keys()}
+    raw = write_h5(None, {"keras_version": "2.1.2", "model_config": "{}"}, {"model_weights": (dict(inner.attrs), tree(inner.root))})
+    arrays, info = read_keras_weights(raw)
+    want = keras_named_arrays(net)
+    assert set(arrays) == set(want) and all(np.array_equal(arrays[k], want[k]) for k in want)
+    assert net_from_keras_named_arrays(arrays).to_blob() == net.to_blob()
