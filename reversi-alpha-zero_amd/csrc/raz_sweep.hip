@@ -2,8 +2,9 @@
 //
 // These are the reference's per-position integer ops (lib/bitboard.py find_correct_moves /
 // calc_flip, env/reversi_env.py step / _game_over) applied to n independent positions.  They are
-// pure streaming integer kernels: ~150 VALU ops against 24-45 bytes per board, so the bound is
-// HBM bandwidth, not ALU (no MFMA, no LDS: there is no reuse to stage).  Layout choices:
+// pure streaming integer kernels (no MFMA, no LDS: there is no reuse to stage) - but with a board
+// per lane every u64 op costs vector instructions, and it is VALU issue, not HBM, that bounds
+// k_step / k_legal_moves: hence the VALU-shaped primitives of raz_bitboard_valu.h.  Layout choices:
 //   * SoA u64 arrays so that a wave's 64 lanes read 64 consecutive boards: every load/store is
 //     fully coalesced;
 //   * each thread owns TWO adjacent boards so the u64 streams move as 16 B/lane
@@ -13,6 +14,7 @@
 //     sharing, so no XCD remap is needed.
 #include <hip/hip_runtime.h>
 #include "raz_bitboard.h"
+#include "raz_bitboard_valu.h"
 #include "raz_internal.h"
 
 namespace {
@@ -53,10 +55,10 @@ __global__ __launch_bounds__(kBlock) void k_legal_moves(const ulonglong2* __rest
             no0 = own2[k]; no1 = own2[k + 64]; ne0 = enemy2[k]; ne1 = enemy2[k + 64];
         }
         ulonglong2 r0, r1;
-        r0.x = bb_legal_moves(o0.x, e0.x);
-        r0.y = bb_legal_moves(o0.y, e0.y);
-        r1.x = bb_legal_moves(o1.x, e1.x);
-        r1.y = bb_legal_moves(o1.y, e1.y);
+        r0.x = bbv_legal_moves(o0.x, e0.x);
+        r0.y = bbv_legal_moves(o0.y, e0.y);
+        r1.x = bbv_legal_moves(o1.x, e1.x);
+        r1.y = bbv_legal_moves(o1.y, e1.y);
         legal2[i] = r0;
         legal2[i + 64] = r1;
         o0 = no0; o1 = no1; e0 = ne0; e1 = ne1;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_legal_moves(const ulonglong2* __rest
     }
     // ragged tail: the boards after the last full block
     for (size_t t = (nblocks << 8) + (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock)
-        legal[t] = bb_legal_moves(own[t], enemy[t]);
+        legal[t] = bbv_legal_moves(own[t], enemy[t]);
 }
 
 __global__ __launch_bounds__(kBlock) void k_calc_flip(const uint8_t* __restrict__ pos,
@@ -80,28 +82,46 @@ __global__ __launch_bounds__(kBlock) void k_calc_flip(const uint8_t* __restrict_
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += stride) {
         ulonglong2 o = own2[i], e = enemy2[i], r;
         uchar2 p = pos2[i];
-        r.x = p.x < 64 ? bb_calc_flip(p.x, o.x, e.x) : 0;
-        r.y = p.y < 64 ? bb_calc_flip(p.y, o.y, e.y) : 0;
+        r.x = p.x < 64 ? bbv_calc_flip(p.x, o.x, e.x) : 0;
+        r.y = p.y < 64 ? bbv_calc_flip(p.y, o.y, e.y) : 0;
         out2[i] = r;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         uint8_t p = pos[n - 1];
-        flipped[n - 1] = p < 64 ? bb_calc_flip(p, own[n - 1], enemy[n - 1]) : 0;
+        flipped[n - 1] = p < 64 ? bbv_calc_flip(p, own[n - 1], enemy[n - 1]) : 0;
     }
 }
 
-__device__ __forceinline__ void step_one(raz_bb& b, raz_bb& w, uint8_t& pl, uint8_t& st, raz_bb& lg,
-                                         uint8_t act) {
+// ReversiEnv.step on one board, first part: returns true when the opponent has no move after it - the board then
+// still needs step_rest (the mover's own mobility, else the final count).  That case is rare (a pass or the end of a
+// game: ~2 % of the steps of a game), so k_step does it out of line for the few boards concerned.
+__device__ __forceinline__ bool step_first(raz_bb& b, raz_bb& w, uint8_t& pl, uint8_t& st, raz_bb& lg, uint8_t act) {
     if (st != 0) {
         lg = 0;
-        return;
+        return false;
     }
-    raz_step_result r = bb_env_step(b, w, pl, act);
+    raz_step_result r = bbv_env_step_first(b, w, pl, act);
     b = r.black;
     w = r.white;
     pl = r.player;
+    lg = r.legal;
+    const bool stuck = r.status == RAZ_STEP_OPP_STUCK;
+    st = stuck ? 0 : r.status;
+    return stuck;
+}
+__device__ __forceinline__ void step_rest(raz_bb b, raz_bb w, uint8_t pl, uint8_t& st, raz_bb& lg) {
+    raz_step_result r;
+    r.black = b;
+    r.white = w;
+    r.player = pl;
+    r.legal = 0;
+    r.status = RAZ_STEP_OPP_STUCK;
+    bbv_env_step_finish(r);
     st = r.status;
     lg = r.legal;
+}
+__device__ __forceinline__ void step_one(raz_bb& b, raz_bb& w, uint8_t& pl, uint8_t& st, raz_bb& lg, uint8_t act) {
+    if (step_first(b, w, pl, st, lg, act)) step_rest(b, w, pl, st, lg);
 }
 
 // Blocks of 256 adjacent boards per wave as in k_legal_moves (lane l: pairs l and 64 + l), next block prefetched: four
@@ -142,10 +162,28 @@ __global__ __launch_bounds__(kBlock) void k_step(raz_bb* __restrict__ black,
         StepRegs nx;
         if (nb < nblocks) nx = step_load(black2, white2, player2, status2, action2, (nb << 7) + lane);
         ulonglong2 l0, l1;
-        step_one(c.b0.x, c.w0.x, c.p0.x, c.s0.x, l0.x, c.a0.x);
-        step_one(c.b0.y, c.w0.y, c.p0.y, c.s0.y, l0.y, c.a0.y);
-        step_one(c.b1.x, c.w1.x, c.p1.x, c.s1.x, l1.x, c.a1.x);
-        step_one(c.b1.y, c.w1.y, c.p1.y, c.s1.y, l1.y, c.a1.y);
+        unsigned stuck = (unsigned)step_first(c.b0.x, c.w0.x, c.p0.x, c.s0.x, l0.x, c.a0.x);
+        stuck |= (unsigned)step_first(c.b0.y, c.w0.y, c.p0.y, c.s0.y, l0.y, c.a0.y) << 1;
+        stuck |= (unsigned)step_first(c.b1.x, c.w1.x, c.p1.x, c.s1.x, l1.x, c.a1.x) << 2;
+        stuck |= (unsigned)step_first(c.b1.y, c.w1.y, c.p1.y, c.s1.y, l1.y, c.a1.y) << 3;
+        // the rare second half, once per lane and round for the lane's lowest board that needs it (a wave's 256 boards
+        // hold ~6 such boards: one round almost always, instead of a second mobility computation on every board)
+        while (__any(stuck != 0)) {
+            if (stuck) {
+                const unsigned k = __ffs(stuck) - 1;
+                const raz_bb b = k == 0 ? c.b0.x : (k == 1 ? c.b0.y : (k == 2 ? c.b1.x : c.b1.y));
+                const raz_bb w = k == 0 ? c.w0.x : (k == 1 ? c.w0.y : (k == 2 ? c.w1.x : c.w1.y));
+                const uint8_t pl = k == 0 ? c.p0.x : (k == 1 ? c.p0.y : (k == 2 ? c.p1.x : c.p1.y));
+                uint8_t st;
+                raz_bb lg;
+                step_rest(b, w, pl, st, lg);
+                if (k == 0) { c.s0.x = st; l0.x = lg; }
+                else if (k == 1) { c.s0.y = st; l0.y = lg; }
+                else if (k == 2) { c.s1.x = st; l1.x = lg; }
+                else { c.s1.y = st; l1.y = lg; }
+                stuck &= stuck - 1;
+            }
+        }
         black2[i] = c.b0; black2[i + 64] = c.b1;
         white2[i] = c.w0; white2[i + 64] = c.w1;
         legal2[i] = l0; legal2[i + 64] = l1;

@@ -118,3 +118,16 @@ def test_engine_workspace_scales_with_parallel_search_num():
                                                  play_data=cfg.play_data), n_games=64, seed=0, nodes_per_game=256)
     c.parallel_search_num = 17
     assert N.lib.raz_engine_workspace_bytes(ctypes.byref(c)) == 0 and b"parallel_search_num" in N.lib.raz_last_error()
+
+
+def test_valu_shaped_bitboard_ops_equal_the_reference_shaped_ones(tmp_path):
+    """csrc/raz_bitboard_valu.h (what the sweep kernels compute with: three-input logic, carry-propagation rows, the
+    step split into first / finish) == csrc/raz_bitboard.h (pinned by the goldens and the oracle) on the host, for
+    playout positions x every action and for garbage inputs: tests/native/bbv_check.cpp, built here with g++."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "bbv_check.cpp")
+    exe = str(tmp_path / "bbv_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "1500000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BBV_OK" in r.stdout, r.stdout[-2000:]
