@@ -9,9 +9,12 @@
 //     fully coalesced;
 //   * each thread owns TWO adjacent boards so the u64 streams move as 16 B/lane
 //     (global_load_dwordx4, 1 KiB per wave instruction) and the u8 streams as 2 B/lane;
-//   * grid = min(needed, 2048) workgroups of 256 threads, grid-stride loop — 8 workgroups per CU
-//     on 256 CUs, consecutive workgroups land on consecutive XCDs and there is no inter-block
-//     sharing, so no XCD remap is needed.
+//   * grid = one workgroup of 256 threads per 1024 boards (k_step, k_legal_moves: one 256-board block per wave), capped
+//     at 65536 workgroups; the grid-stride loops only matter beyond that.  Measured on 2^24 boards
+//     (profiles/r2/sweep_grid_tuning.txt): caps of 512 / 2048 / 4096 / 16384 workgroups give k_step 0.193 / 0.167 / 0.161 /
+//     0.150 ms and k_legal_moves 0.088 / 0.084 / 0.082 / 0.076 ms - many short workgroups beat few persistent ones with
+//     software prefetch (the hardware dispatcher overlaps the next workgroup's loads with the current one's arithmetic).
+//     Consecutive workgroups land on consecutive XCDs and there is no inter-block sharing, so no XCD remap is needed.
 #include <hip/hip_runtime.h>
 #include "raz_bitboard.h"
 #include "raz_bitboard_valu.h"
@@ -20,7 +23,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 2048;
+constexpr int kMaxGrid = 65536;
 
 inline unsigned grid_for(size_t work_items) {
     size_t g = (work_items + kBlock - 1) / kBlock;
@@ -302,7 +305,7 @@ extern "C" int raz_legal_moves_batch(const uint64_t* own, const uint64_t* enemy,
     RAZ_REQUIRE(own && enemy && legal, "raz_legal_moves_batch: NULL array");
     RAZ_REQUIRE(aligned16(own) && aligned16(enemy) && aligned16(legal),
                 "raz_legal_moves_batch: arrays must be 16-byte aligned");
-    hipLaunchKernelGGL(k_legal_moves, dim3(grid_for(n / 2 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_legal_moves, dim3(grid_for(n / 4 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const ulonglong2*)own, (const ulonglong2*)enemy, (ulonglong2*)legal,
                        (const raz_bb*)own, (const raz_bb*)enemy, (raz_bb*)legal, n);
     return raz_check_launch("raz_legal_moves_batch");
