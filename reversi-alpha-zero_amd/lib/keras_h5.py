@@ -497,6 +497,8 @@ def _u64(x):
 
 def _msg(mtype, data, flags=0):
     data = _pad8(data)
+    if len(data) > 0xFFF8:   # the size field of a version-1 header message is 16 bits (HDF5's 64 KiB attribute limit)
+        raise H5FormatError(f"header message of {len(data)} bytes: attributes are limited to 64 KiB in this file format")
     return _u16(mtype) + _u16(len(data)) + bytes([flags, 0, 0, 0]) + data
 
 

@@ -248,3 +248,10 @@ def test_model_save_style_file_is_read(tmp_path):
     want = keras_named_arrays(net)
     assert set(arrays) == set(want) and all(np.array_equal(arrays[k], want[k]) for k in want)
     assert net_from_keras_named_arrays(arrays).to_blob() == net.to_blob()
+
+
+def test_writer_refuses_attributes_beyond_the_format_limit():
+    """HDF5's classic object headers hold attributes of < 64 KiB (h5py fails the same way): a clear error, not a corrupt file."""
+    from reversi_alpha_zero_amd.lib.keras_h5 import H5FormatError, write_h5
+    with pytest.raises(H5FormatError, match="64 KiB"):
+        write_h5(None, {"layer_names": np.array([b"x" * 40] * 2000, dtype="S")}, {})
