@@ -347,3 +347,75 @@ def test_reader_on_random_h5py_files(tmp_path):
             assert np.array_equal(g, w), (seed, k)
             total += 1
     assert total > 150
+
+
+H5PY_DUMP = r"""
+import sys, numpy as np, h5py
+out = {}
+def visit(name, obj):
+    for k, v in obj.attrs.items():
+        out[name + '@' + k] = np.asarray(v)
+    if isinstance(obj, h5py.Dataset):
+        out[name] = np.asarray(obj[...])
+with h5py.File(sys.argv[1], 'r') as f:
+    for k, v in f.attrs.items():
+        out['@' + k] = np.asarray(v)
+    f.visititems(visit)
+np.savez(sys.argv[2], **{k.replace('/', '|'): v for k, v in out.items()})
+"""
+
+
+@needs_h5py
+def test_writer_on_random_trees_read_by_h5py(tmp_path):
+    """The other direction: random trees (nested groups of any size, float / int arrays of rank 0..3 incl. empty ones,
+    string and numeric attributes) written by write_h5, read back through h5py / libhdf5."""
+    from reversi_alpha_zero_amd.lib.keras_h5 import write_h5
+    total = 0
+    for seed in range(int(os.environ.get("RAZ_H5_FUZZ_SEEDS", "8"))):
+        rng = np.random.default_rng(1000 + seed)
+        want = {}
+
+        def rand(nd=None):
+            dt = ["<f4", "<f8", "<i4", "<i8", "<u1", "<i2"][rng.integers(6)]
+            nd = int(rng.integers(0, 4)) if nd is None else nd
+            shape = tuple(int(rng.integers(0 if nd == 1 else 1, 7)) for _ in range(nd))
+            if dt[1] == "f":
+                return rng.standard_normal(shape).astype(dt)
+            info = np.iinfo(np.dtype(dt))
+            return rng.integers(info.min, info.max, shape, dtype=np.dtype(dt))
+
+        def attrs(path):
+            a = {}
+            for i in range(rng.integers(0, 4)):
+                k = f"a{i}"
+                kind = rng.integers(3)
+                a[k] = rand() if kind == 0 else ("text %d" % rng.integers(1000) if kind == 1 else
+                                                 np.array([b"n%d" % j for j in range(rng.integers(1, 5))], dtype="S"))
+                want[path + "@" + k] = np.asarray(a[k].encode() if isinstance(a[k], str) else a[k])
+            return a
+
+        def tree(path, depth):
+            kids = {}
+            for i in range(rng.integers(0, 40 if depth == 0 else 6)):
+                name = f"k{i}_" + "y" * int(rng.integers(0, 12))
+                if depth < 2 and rng.integers(4) == 0:
+                    p = (path + "/" + name).lstrip("/")
+                    a = attrs(p)
+                    kids[name] = (a, tree(p, depth + 1))
+                else:
+                    kids[name] = rand()
+                    want[(path + "/" + name).lstrip("/")] = kids[name]
+            return kids
+        root_attrs = attrs("")
+        path = str(tmp_path / f"w{seed}.h5")
+        write_h5(path, root_attrs, tree("", 0))
+        r = subprocess.run([H5PY_PYTHON, "-c", H5PY_DUMP, path, str(tmp_path / f"w{seed}.npz")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        with np.load(str(tmp_path / f"w{seed}.npz")) as z:
+            got = {k.replace("|", "/"): z[k] for k in z.files}
+        assert set(got) == set(want), (seed, sorted(set(got) ^ set(want))[:6])
+        for k, w in want.items():
+            g = got[k]
+            assert g.shape == w.shape and g.dtype.kind == w.dtype.kind and np.array_equal(g, w), (seed, k, g.dtype, w.dtype)
+            total += 1
+    assert total > 100
