@@ -584,12 +584,18 @@ class BatchedSelfPlayWorker:
 class _BackgroundWriter:
     """One host thread that writes finished batches, in submission order, while the next batch is played.  At most one
     batch waits behind the one being written (submit blocks beyond that), so at most three batches' record arrays are
-    alive.  An error in the thread is raised in the caller at the next submit() / close()."""
+    alive.  An error in the thread is raised in the caller at the next submit() / close().  Once a batch has failed the
+    writer is dead for good (`failed` is sticky and owned by the thread; the caller only ever takes the exception out of
+    `error`): every batch queued behind the failed one is dropped, so data/.self-play-game-idx can never advance past a
+    batch whose files are missing."""
 
     def __init__(self, worker):
         import queue
         import threading
         self.worker, self.error = worker, None
+        self.failed = False            # written by the writer thread only, never cleared
+        self._reported = False         # the caller has been handed the exception
+        self._lock = threading.Lock()  # guards `error` (handed from the thread to the caller exactly once)
         self.queue = queue.Queue(maxsize=1)
         self.thread = threading.Thread(target=self._loop, name="raz-play-data-writer", daemon=True)
         self.thread.start()
@@ -599,19 +605,25 @@ class _BackgroundWriter:
             item = self.queue.get()
             if item is None:
                 return
-            if self.error is not None:
+            if self.failed:
                 continue   # keep draining so that submit() never blocks forever
             raw, local_idx, game_idx = item
             try:
                 self.worker.write_raw(raw, local_idx)
                 self.worker._write_game_idx(game_idx)
             except BaseException as e:   # noqa: B902 - reported to the caller
-                self.error = e
+                with self._lock:
+                    self.error = e
+                self.failed = True
 
-    def _check(self):
-        if self.error is not None:
+    def _check(self, closing=False):
+        with self._lock:
             err, self.error = self.error, None
+        if err is not None:
+            self._reported = True
             raise RuntimeError(f"writing play data failed: {err!r}") from err
+        if self.failed and not (closing and self._reported):   # (close() after the error was raised: nothing new to say)
+            raise RuntimeError("writing play data failed earlier: the writer is stopped")
 
     def submit(self, raw, local_idx, game_idx):
         self._check()
@@ -620,7 +632,7 @@ class _BackgroundWriter:
     def close(self):
         self.queue.put(None)
         self.thread.join()
-        self._check()
+        self._check(closing=True)
 
 
 # ---- the single collective: finished-game records -> rank 0 ------------------------------------------

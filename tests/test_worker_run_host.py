@@ -127,7 +127,7 @@ def test_run_background_writer_equals_inline(tmp_path):
 
 def test_run_reports_writer_errors(tmp_path):
     """A failure in the background writer surfaces in run() (not silently lost), and the game index is not advanced past
-    the batch whose files are missing."""
+    the batch whose files are missing - whatever the interleaving of the caller and the writer thread."""
     cfg = make_config(tmp_path / "err")
     w = make_stub_worker(cfg, games_in_flight=20)
     real = w.write_raw
@@ -142,6 +142,40 @@ def test_run_reports_writer_errors(tmp_path):
     with pytest.raises(RuntimeError, match="disk full"):
         w.run(total_games=100)
     assert open(cfg.resource.self_play_game_idx_file).read() == "20"
+    assert calls == [1, 21]   # nothing queued behind the failed batch was written
+
+
+def test_background_writer_drops_everything_behind_a_failed_batch():
+    """The race the sticky flag closes, forced: the caller takes the exception out of the writer (its _check() at the next
+    submit) BEFORE the thread looks at the batch queued behind the failed one; that batch must still be dropped."""
+    import threading
+    from reversi_alpha_zero_amd.worker.self_play import _BackgroundWriter
+    written, idx = [], []
+    failed_once, go_on = threading.Event(), threading.Event()
+
+    class Stub:
+        def write_raw(self, raw, local_idx):
+            if raw == "bad":
+                failed_once.set()
+                raise OSError("disk full")
+            go_on.wait(10)       # (only reached if the writer wrongly keeps going)
+            written.append(raw)
+
+        def _write_game_idx(self, game_idx):
+            idx.append(game_idx)
+    bw = _BackgroundWriter(Stub())
+    bw.submit("bad", 1, 20)
+    assert failed_once.wait(10)
+    while not bw.failed:         # the thread has recorded the failure
+        pass
+    with pytest.raises(RuntimeError, match="disk full"):
+        bw.submit("next", 21, 40)          # the caller is told here: this clears writer.error
+    bw.queue.put(("late", 41, 60))         # a batch that slips in behind the failure (what the old flag let through)
+    go_on.set()
+    bw.close()                             # the error was already raised: close() has nothing new to report
+    assert written == [] and idx == []
+    with pytest.raises(RuntimeError, match="stopped"):
+        bw.submit("again", 61, 80)
 
 
 def test_max_file_num_is_enforced_from_a_tracked_listing(tmp_path):
