@@ -1959,6 +1959,7 @@ int launch_steps_direct(raz_engine* e, uint32_t n_steps, hipStream_t s) {
 // Capture kGraphSteps steps on (s, aux streams).  On any failure the engine keeps launching directly.
 bool ensure_graph(raz_engine* e, hipStream_t s) {
     if (e->graph_off) return false;
+    if (e->cache.tags) return false;   // the cache's step stamp is a host-side kernel argument: a replayed graph would freeze it
     if (e->graph_exec && e->graph_stream == s && e->graph_parts == e->parts) return true;
     drop_graph(e);
     hipGraph_t g = nullptr;

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void k_leaf_resolve(raz_leaf_cache_dev C, cons
     if (kind == ROLE_FOLLOW) {
         const bool same = C.keys[2 * (size_t)i] == own[r] && C.keys[2 * (size_t)i + 1] == enemy[r];
         const uint32_t ow = C.owner[i];
-        if (same && C.ready[i]) {   // HIT
+        // Slices run concurrently on other streams and publish into the same table: the flag is read with ACQUIRE at agent
+        // scope (invalidates this CU's L1), so the answer read below cannot come from a line fetched before it was filled.
+        if (same && __hip_atomic_load(&C.ready[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {   // HIT
             policy[(size_t)r * 64 + lane] = C.pv[(size_t)i * 72 + lane];
             if (lane == 0) {
                 value[r] = C.pv[(size_t)i * 72 + 64];
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(256) void k_leaf_fill(raz_leaf_cache_dev C, float* 
         C.pv[(size_t)i * 72 + lane] = policy[(size_t)r * 64 + lane];
         if (lane == 0) {
             C.pv[(size_t)i * 72 + 64] = value[r];
-            __threadfence();
-            C.ready[i] = 1;
+            // RELEASE at agent scope: the wave's pv stores above (all lanes: one wave, program order) are visible before the flag
+            __hip_atomic_store(&C.ready[i], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (kind == ROLE_WAIT) {
         const uint32_t ow = C.owner[i];

@@ -13,6 +13,8 @@ import numpy as np
 from . import _native as N
 from ._native import lib, check
 
+NODE_POOL_BYTES_PER_NODE = 1408   # csrc/raz_engine.h RAZ_NODE_BYTES: what one tree node costs in a game's pool
+
 PLY_HEADER = np.dtype([("own", "<u8"), ("enemy", "<u8"), ("n", "<f8"), ("q", "<f8"), ("action", "i1"),
                        ("player", "u1"), ("turn", "u1"), ("has_row", "u1"), ("sims", "<u4"),
                        ("loops", "<u4"), ("flags", "<u4")])

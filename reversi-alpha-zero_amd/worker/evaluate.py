@@ -142,12 +142,13 @@ class EvaluateWorker:
                 own, enemy = env.get_own_and_enemy()
                 mover_is_best = (env.next_player == Player.black) == best_is_black[g]
                 sides[mover_is_best].ask(g, own, enemy)
-            while True:
-                for s in sides.values():
-                    if s.armed:
-                        s.engine.step(64)
-                if not any(s.armed and s.busy() for s in sides.values()):
-                    break
+            stepping = [s for s in sides.values() if s.armed]
+            while stepping:
+                for s in stepping:
+                    s.engine.step(64)
+                # every side's busy() runs each round (it also does the side's pool and error-flag checks); a side whose
+                # slots have all decided is no longer stepped
+                stepping = [s for s, b in [(s, s.busy()) for s in stepping] if b]
             for s in sides.values():
                 for g, action in s.answers().items():
                     envs[g].step(action)

@@ -227,6 +227,9 @@ class BatchedSelfPlayWorker:
         # threshold: stepping once per 100 of them would multiply the control gain by the batch size, so the emitters
         # defer the check and apply it once per emitted batch (>= 100 test games accumulated, as in the reference).
         self._defer_threshold_update = False
+        # raznet-forward-v2 reported an activation outside the f16 range: this net runs on the exact-f32 kernels from now on
+        # (until the next set_net_blob)
+        self._f32_fallback = False
 
     # -- engine life cycle -------------------------------------------------------------------
     def _series_length(self):
@@ -244,29 +247,30 @@ class BatchedSelfPlayWorker:
         # (resign_threshold is a run-time parameter of the engine - raz_engine_set_resign_threshold - not part of
         #  its identity: the reference keeps mtcs_info across threshold updates, worker/self_play.py:250-260)
         key = (max_sims, self.config.play.thinking_loop)
+        if self._engine is not None and self._engine_key != key:
+            self._drop_engine()   # BEFORE the new pools are sized: the old workspace must be back in the free list
         if self._net is None:
-            self._net = DeviceNet(self.net_blob, self.device, kernel=self.net_kernel)
-        if self._engine is None or self._engine_key != key:
-            self._engine = None
+            self._net = DeviceNet(self.net_blob, self.device, kernel="f32" if self._f32_fallback else self.net_kernel)
+        if self._engine is None:
             self._series_pos = 0   # a new engine starts from empty trees
             r = self._series_length()
             p = self.config.play
             whole = (max_sims * max(1, p.thinking_loop) * 62 + 128) * 2   # a whole game's tree (two nodes per simulation at most)
+            cache = self.leaf_cache_log2
+            if cache == "auto":
+                cache = 26 if self._net.filters >= 128 else None
             nodes = None
             if r > 1:   # the tree of a series is never pruned (its early positions are searched again): room for r games
                 nodes = r * whole
             else:
                 # 8192 games x 800 sims/move would need 1.1 TB for whole-game trees: size the pools for the HBM that is
                 # there (k_gc prunes the positions the real game has left behind; pools of ~16 x sims nodes suffice)
-                cap = self._pool_nodes_that_fit()
+                cap = self._pool_nodes_that_fit(cache_log2=cache)
                 if cap is not None and cap < whole:
                     if cap < 12 * max_sims:
                         raise RuntimeError(f"{self.games_in_flight} games in flight at {max_sims} sims/move leave {cap} tree nodes per "
                                            f"game in this GPU's free memory (< 12 x sims): lower games_in_flight")
                     nodes = cap
-            cache = self.leaf_cache_log2
-            if cache == "auto":
-                cache = 26 if self._net.filters >= 128 else None
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=cache,
                                           leaf_cache_max_discs=self.leaf_cache_max_discs)
@@ -274,16 +278,52 @@ class BatchedSelfPlayWorker:
         self._engine.set_resign_threshold(self.config.play.resign_threshold)
         return self._engine
 
-    def _pool_nodes_that_fit(self, fraction=0.7):
-        """Tree nodes per game that fit in `fraction` of the device's free memory (node 1408 B + 2 table slots of 32 B + a
-        prune-map word; include/raz.h raz_engine_workspace_bytes is the exact figure).  None when torch cannot tell."""
+    def _drop_engine(self, net_too=False):
+        """Give the engine's workspace (node pools, tables, evaluation cache, net scratch) back to the device: drop every
+        reference, collect, and empty torch's caching allocator - torch.cuda.mem_get_info, which sizes the next engine's
+        pools, only sees memory the allocator has returned to the driver."""
+        import gc
+        self._engine = None
+        self._engine_key = None
+        self._series_pos = 0
+        if net_too:
+            self._net = None
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+    def _fixed_device_bytes(self, cache_log2):
+        """What the engine allocates beside the node pools, tables and prune maps: the evaluation cache, the net's scratch
+        and the id-ordered outbox of a block (include/raz.h: raz_leaf_cache_bytes, raz_net_scratch_bytes; outbox rows of
+        max_plies x (48 + 256) B + a 32-byte summary + a done flag)."""
+        from .._native import lib
+        rows = self.games_in_flight * max(1, int(getattr(self.config.play, "parallel_search_num", 1) or 1))
+        total = 0
+        if cache_log2:
+            total += int(lib.raz_leaf_cache_bytes(int(cache_log2), rows)) + 256
+        if self._net is not None:
+            total += int(lib.raz_net_scratch_bytes(self._net.filters, self._net.value_fc, rows))
+        if self.block_games > self.games_in_flight:
+            total += self.block_games * (72 * (48 + 256) + 33)
+        return total
+
+    def _pool_nodes_that_fit(self, fraction=0.7, cache_log2=None):
+        """Tree nodes per game that fit in `fraction` of the device's free memory once the evaluation cache, the net scratch
+        and the outbox are taken out (node RAZ_NODE_POOL_BYTES_PER_NODE B of pool + up to 4 table slots of 32 B + a prune-map
+        word; include/raz.h raz_engine_workspace_bytes is the exact figure).  None when torch cannot tell."""
         try:
             import torch
             free, _ = torch.cuda.mem_get_info(torch.device(self.device))
         except Exception:
             return None
-        per_node = 1408 + 2 * 32 * 2 + 4   # (table_slots is the next power of two >= 2 x nodes: up to 4 slots per node)
-        return int(free * fraction) // (self.games_in_flight * per_node)
+        from ..engine import NODE_POOL_BYTES_PER_NODE
+        per_node = NODE_POOL_BYTES_PER_NODE + 2 * 32 * 2 + 4   # (table_slots is the next power of two >= 2 x nodes: up to 4 slots per node)
+        budget = int(free * fraction) - self._fixed_device_bytes(cache_log2)
+        return max(0, budget) // (self.games_in_flight * per_node)
 
     def play_batch(self, first_game_idx, n_games=None):
         """Play global game ids first_game_idx + rank*B .. on this rank.  Returns [(plies, summary)]."""
@@ -512,6 +552,55 @@ class BatchedSelfPlayWorker:
         self.check_and_update_resignation_threshold()
         return paths
 
+    def _play_block(self, game_idx):
+        """This rank's ids of the block that starts at game_idx.  Returns (packed, ids per rank): `packed` is the
+        `plies -> packed device tensors` callable gather_packed wants."""
+        continuous = self.block_games > self.games_in_flight and self._series_length() == 1
+        if continuous:
+            return self.play_block_continuous(game_idx), self.block_games
+        eng, n = self.play_batch_raw(game_idx, device_records=True)
+        return (lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)), self.games_in_flight
+
+    def _play_block_checked(self, game_idx):
+        """_play_block + the net's range flag.  A search fed with out-of-range priors may also trip an engine error flag
+        before the block ends: that is the same event, reported as ok = False (the block is void either way)."""
+        try:
+            packed, per_rank = self._play_block(game_idx)
+            return packed, per_rank, bool(self._net.range_ok())
+        except RuntimeError:
+            if self._net is None or self._net.range_ok():
+                raise
+            return None, 0, False
+
+    def _all_ranks_agree(self, ok):
+        """AND of a per-rank flag over all ranks (every rank must take the same branch before the next collective)."""
+        if self.world == 1:
+            return bool(ok)
+        import torch
+        import torch.distributed as dist
+        dev = torch.device(self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def _broadcast_blob(self, blob):
+        """Rank 0's decision about a new generation of weights, and the weights themselves, to every rank: ranks polling
+        the model files on their own could see the optimizer's half-written file, or see it at different times, and play
+        the same block with different nets."""
+        import torch
+        import torch.distributed as dist
+        meta = [len(blob) if blob is not None else 0]
+        dist.broadcast_object_list(meta, src=0)
+        if not meta[0]:
+            return None
+        dev = torch.device(self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        if self.rank == 0:
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        else:
+            t = torch.empty(meta[0], dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        return blob if self.rank == 0 else t.cpu().numpy().tobytes()
+
     def run(self, total_games=None, reload_model=None, background_emit=True):
         """_start (self_play.py:95-137): play batches until total_games (None = forever).
         Per batch: every rank plays its id range; the finished games' records are packed in HBM and gathered on
@@ -521,7 +610,10 @@ class BatchedSelfPlayWorker:
         batch k are written by a host thread while batch k + 1 is played (the text of 65 536 games is ~45 GB: minutes
         of host work that would otherwise idle every GPU); data/.self-play-game-idx is advanced after a batch's files
         are on disk, and run() returns only when everything is written.
-        reload_model (optional): callable returning a new net blob or None, polled between batches (api.py:117-125)."""
+        reload_model (optional): callable returning a new net blob or None, polled by RANK 0 between batches
+        (api.py:117-125); its answer - and the weights - are broadcast, so every rank plays a block with the same net.
+        A block during which an activation of the split-f16 trunk left the f16 range (raz_net_range_check) is discarded
+        on every rank and played again on the exact-f32 kernels, which the net then stays on (include/raz.h)."""
         import torch.distributed as dist
         from ..engine import raw_from_packed
         rc = self.config.resource
@@ -532,20 +624,25 @@ class BatchedSelfPlayWorker:
         writer = _BackgroundWriter(self) if (background_emit and self.rank == 0) else None
         try:
             while total_games is None or local_idx <= total_games:
-                continuous = self.block_games > self.games_in_flight and self._series_length() == 1
-                if continuous:
-                    packed = self.play_block_continuous(game_idx)
-                else:
-                    eng, n = self.play_batch_raw(game_idx, device_records=True)
-                    packed = lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)
-                if not self._net.range_ok():
-                    raise RuntimeError("an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2): "
-                                       "this block's games are not trustworthy - run the worker with net_kernel='f32'")
+                packed, per_rank, ok = self._play_block_checked(game_idx)
+                while not self._all_ranks_agree(ok):
+                    if self._f32_fallback or self._series_length() > 1:
+                        raise RuntimeError("the net left its numeric range on the exact-f32 kernels too" if self._f32_fallback else
+                                           "an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2) "
+                                           "inside a series of games on a carried tree: run the worker with net_kernel='f32'")
+                    logger.warning("an activation left the f16 range of the split-operand trunk (raznet-forward-v2): the block at "
+                                   f"game index {game_idx} is played again on the exact-f32 kernels, which this net stays on")
+                    del packed
+                    self._f32_fallback = True
+                    self._drop_engine(net_too=True)
+                    packed, per_rank, ok = self._play_block_checked(game_idx)
                 if self.world > 1:
                     allraw, _ = gather_packed(packed, self.rank, self.world)
                 else:
                     pk = packed(None)
                     allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
+                    del pk
+                del packed   # (holds the engine / the outbox: nothing of this block may pin device memory past this point)
                 if self.rank == 0:
                     self.bookkeep_raw(allraw)
                     game_idx += len(allraw["n_plies"])
@@ -558,10 +655,12 @@ class BatchedSelfPlayWorker:
                     t = [game_idx, self.config.play.resign_threshold]
                     dist.broadcast_object_list(t, src=0)
                     game_idx, self.config.play.resign_threshold = t
-                local_idx += (self.block_games if continuous else self.games_in_flight) * self.world
+                local_idx += per_rank * self.world
                 if reload_model is not None:
-                    blob = reload_model()
-                    if blob is not None:   # every rank polls the same files: the digest decides
+                    blob = reload_model() if self.rank == 0 else None   # rank 0 decides; the digest of ITS read is what counts
+                    if self.world > 1:
+                        blob = self._broadcast_blob(blob)
+                    if blob is not None:
                         self.set_net_blob(blob)
         finally:
             if writer is not None:
@@ -573,12 +672,11 @@ class BatchedSelfPlayWorker:
 
     def set_net_blob(self, blob):
         """A new generation of weights between two batches (agent/api.py:117-125 try_reload_model): the engine is
-        rebuilt on the new net at the next batch (a tree searched with the old priors is not carried over)."""
+        rebuilt on the new net at the next batch (a tree searched with the old priors is not carried over).  The old
+        engine's device memory is released first, so that the new pools are sized against what is really free."""
         self.net_blob = blob
-        self._net = None
-        self._engine = None
-        self._engine_key = None
-        self._series_pos = 0
+        self._f32_fallback = False
+        self._drop_engine(net_too=True)
 
 
 class _BackgroundWriter:

@@ -178,6 +178,62 @@ def test_background_writer_drops_everything_behind_a_failed_batch():
         bw.submit("again", 61, 80)
 
 
+def test_block_is_replayed_on_f32_when_the_f16_range_flag_is_raised(tmp_path):
+    """raz_net_range_check says an activation left the f16 range during a block: run() discards the block, rebuilds net and
+    engine on the exact-f32 kernels (include/raz.h: "run the net with reserved = 0 then"), replays the SAME ids and goes on;
+    the files are those of a run that never overflowed."""
+    cfg = make_config(tmp_path / "ovf")
+    w = make_stub_worker(cfg, games_in_flight=30)
+    played, dropped = [], []
+
+    class Net:
+        def __init__(self, ok):
+            self.ok = ok
+
+        def range_ok(self):
+            return self.ok
+    stub_play = type(w).play_batch_raw
+
+    def play(first_game_idx=0, device_records=False):
+        out = stub_play(w, first_game_idx, device_records)
+        played.append((first_game_idx, w._f32_fallback))
+        w._net = Net(ok=not (first_game_idx == 30 and not w._f32_fallback))   # the second block overflows on the f16 path
+        return out
+    w.play_batch_raw = play
+    w._drop_engine = lambda net_too=False: dropped.append(net_too)
+    w.run(total_games=90)
+    assert played == [(0, False), (30, False), (30, True), (60, True)] and dropped == [True]
+    ref_cfg = make_config(tmp_path / "plain")
+    make_stub_worker(ref_cfg, games_in_flight=30).run(total_games=90)
+    assert outputs(cfg) == outputs(ref_cfg)
+    # a second overflow - now on the f32 kernels - is an error, not a loop
+    w2 = make_stub_worker(make_config(tmp_path / "ovf2"), games_in_flight=30)
+    stub2 = type(w2).play_batch_raw
+
+    def always_bad(first_game_idx=0, device_records=False):
+        out = stub2(w2, first_game_idx, device_records)
+        w2._net = Net(ok=False)
+        return out
+    w2.play_batch_raw = always_bad
+    w2._drop_engine = lambda net_too=False: None
+    with pytest.raises(RuntimeError, match="numeric range"):
+        w2.run(total_games=30)
+
+
+def test_rank0_decides_model_reloads(tmp_path):
+    """reload_model is polled on rank 0 only and what it returns is what every rank loads (world 1: plain call)."""
+    cfg = make_config(tmp_path / "reload")
+    w = make_stub_worker(cfg, games_in_flight=10)
+    seen, polls = [], []
+    w.set_net_blob = lambda blob: seen.append(blob)
+
+    def reload_model():
+        polls.append(1)
+        return b"gen2" if len(polls) == 2 else None
+    w.run(total_games=30, reload_model=reload_model)
+    assert len(polls) == 3 and seen == [b"gen2"]
+
+
 def test_max_file_num_is_enforced_from_a_tracked_listing(tmp_path):
     """remove_play_data (self_play.py:209-217) with the directory listed once per batch: only the newest max_file_num
     files survive, older files of earlier runs included."""
@@ -201,7 +257,14 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = make_config(pathlib.Path({out!r}))
 w = make_stub_worker(cfg, games_in_flight=25, rank=rank, world=world)
-w.run(total_games=200)
+loaded, polls = [], []
+w.set_net_blob = lambda blob: loaded.append(bytes(blob))
+def reload_model():   # only rank 0 may be asked; what it answers is what BOTH ranks load
+    assert rank == 0
+    polls.append(1)
+    return bytes(range(256)) * 40 if len(polls) == 2 else None
+w.run(total_games=200, reload_model=reload_model)
+assert loaded == [bytes(range(256)) * 40], (rank, len(loaded))
 print("RANK", rank, "THRESHOLDS", w.thresholds_seen, cfg.play.resign_threshold)
 dist.barrier(); dist.destroy_process_group()
 '''
