@@ -184,6 +184,8 @@ def load_ext():
         lib.orc_selfplay_game_on.argtypes = [c_void_p] + lib.orc_selfplay_game.argtypes
         lib.orc_selfplay_game_ex.argtypes = [c_void_p, POINTER(OrcPlayCfg), c_char_p, c_size_t, NN_FN, c_void_p, c_uint32,
                                              c_uint32, c_int, POINTER(OrcPlyRecord), c_int, c_int, POINTER(OrcGameSummary)]
+        lib.orc_selfplay_game_from.argtypes = [POINTER(OrcPlayCfg), c_char_p, c_size_t, NN_FN, c_void_p, c_uint32, c_uint32, c_int,
+                                               c_uint64, c_uint64, c_int, POINTER(OrcPlyRecord), c_int, c_int, POINTER(OrcGameSummary)]
         _ext_done = True
     return lib
 
@@ -223,10 +225,11 @@ class Tree:
             self.h = None
 
 
-def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128, tree=None, nn=None, stop_after_plies=0):
+def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128, tree=None, nn=None, stop_after_plies=0, start=None):
     """Run one oracle self-play game.  Returns (list of ply dicts, summary dict).
     nn (optional): callable (own, enemy) -> (policy64 float32 array, value float): the injected NN seam
-    (ReversiPlayer(api=...)); blob may then be None.  stop_after_plies > 0: only the game's first plies."""
+    (ReversiPlayer(api=...)); blob may then be None.  stop_after_plies > 0: only the game's first plies.
+    start (optional): (black, white, next_player) - take the game up at that position (orc_selfplay_game_from)."""
     import numpy as np
     lib = load_ext()
     plies = (OrcPlyRecord * max_plies)()
@@ -240,9 +243,14 @@ def selfplay_game(cfg, blob, seed, game_id, sims_per_move, max_plies=128, tree=N
         cb = NN_FN(_cb)
     else:
         cb = ctypes.cast(None, NN_FN)
-    n = lib.orc_selfplay_game_ex(tree.h if tree is not None else None, ctypes.byref(cfg), blob, len(blob) if blob else 0,
-                                 cb, None, seed, game_id, sims_per_move, plies, max_plies, stop_after_plies,
-                                 ctypes.byref(summ))
+    if start is not None:
+        assert tree is None
+        n = lib.orc_selfplay_game_from(ctypes.byref(cfg), blob, len(blob) if blob else 0, cb, None, seed, game_id, sims_per_move,
+                                       int(start[0]), int(start[1]), int(start[2]), plies, max_plies, stop_after_plies, ctypes.byref(summ))
+    else:
+        n = lib.orc_selfplay_game_ex(tree.h if tree is not None else None, ctypes.byref(cfg), blob, len(blob) if blob else 0,
+                                     cb, None, seed, game_id, sims_per_move, plies, max_plies, stop_after_plies,
+                                     ctypes.byref(summ))
     if n < 0:
         raise RuntimeError("orc_selfplay_game failed (unsupported config or too many plies)")
     out = []

@@ -524,9 +524,9 @@ void orc_tree_free(orc_tree* t) {
  * tree (nullable): the worker's MCTSInfo; used - and left holding this game's statistics too - when
  * share_mtcs_info.  The game's two new ReversiPlayers start with expanded = set(var_p.keys())
  * (agent/player.py:47) and an empty now_expanding. */
-int orc_selfplay_game_ex(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, orc_nn_fn nn,
+static int selfplay_impl(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, orc_nn_fn nn,
                          void* nn_ctx, uint32_t seed, uint32_t game_id, int sims_per_move, orc_ply_record* plies,
-                         int max_plies, int stop_after_plies, orc_game_summary* sum) {
+                         int max_plies, int stop_after_plies, orc_game_summary* sum, const orc_env* start) {
     ogame g;
     memset(&g, 0, sizeof g);
     g.cfg = cfg; g.blob = blob; g.blob_bytes = blob_bytes; g.seed = seed; g.game_id = game_id;
@@ -552,7 +552,8 @@ int orc_selfplay_game_ex(orc_tree* tree, const orc_play_cfg* cfg, const void* bl
     orc_rng_pair(seed, game_id, 3, 0, 0, 0, d);
     int enable_resign = cfg->disable_resignation_rate <= d[0]; /* self_play.py:144 */
     orc_env env;
-    orc_env_reset(&env);
+    if (start) env = *start;   /* a game taken up at a position (ReversiEnv.update, env/reversi_env.py:33-40): fresh players, fresh streams */
+    else orc_env_reset(&env);
     int np = 0;
     while (!env.done) {
         if (stop_after_plies > 0 && np >= stop_after_plies) break; /* partial replay (spot checks): the prefix is the game's */
@@ -584,6 +585,25 @@ int orc_selfplay_game_ex(orc_tree* tree, const orc_play_cfg* cfg, const void* bl
     else table_free(&g.tables[0]);
     if (!cfg->share_mtcs_info) table_free(&g.tables[1]);
     return np;
+}
+
+int orc_selfplay_game_ex(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, orc_nn_fn nn,
+                         void* nn_ctx, uint32_t seed, uint32_t game_id, int sims_per_move, orc_ply_record* plies,
+                         int max_plies, int stop_after_plies, orc_game_summary* sum) {
+    return selfplay_impl(tree, cfg, blob, blob_bytes, nn, nn_ctx, seed, game_id, sims_per_move, plies, max_plies, stop_after_plies, sum, NULL);
+}
+
+/* The same loop taken up at (black, white, next_player) instead of the initial position: what SelfPlayWorker.start_game
+ * would do on an env put there by ReversiEnv.update (env/reversi_env.py:33-40) - two new players, empty trees, the game's
+ * random streams at their first events.  Used to check games the engine continues from a given position
+ * (raz_engine_set_position with one_move = 0: bench.py's steady-state batch). */
+int orc_selfplay_game_from(const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, orc_nn_fn nn, void* nn_ctx,
+                           uint32_t seed, uint32_t game_id, int sims_per_move, u64 black, u64 white, int next_player,
+                           orc_ply_record* plies, int max_plies, int stop_after_plies, orc_game_summary* sum) {
+    orc_env start;
+    orc_env_reset(&start);
+    orc_env_update(&start, black, white, next_player);
+    return selfplay_impl(NULL, cfg, blob, blob_bytes, nn, nn_ctx, seed, game_id, sims_per_move, plies, max_plies, stop_after_plies, sum, &start);
 }
 
 int orc_selfplay_game_on(orc_tree* tree, const orc_play_cfg* cfg, const void* blob, size_t blob_bytes, uint32_t seed,

@@ -3,8 +3,10 @@
 
 TEST INFRASTRUCTURE ONLY.  Nothing under reversi-alpha-zero_amd/ may import this module, and it
 must never be needed at run time on the GPU box (where /root/reference does not exist): its only
-consumers are tests/golden/make_golden*.py (run here, outputs committed under tests/golden/) and
-CPU tests marked `needs_reference` (auto-skipped when the reference tree is absent).
+consumers are tests/golden/make_golden*.py (run here, outputs committed under tests/golden/), CPU tests marked
+`needs_reference` (auto-skipped when the reference tree is absent) and bench.py's `cpu_baseline` leg, which times the
+reference's own self-play on the bench box's host cores from the byte-compiled copy oracle/build_ref.py stages
+under oracle/_ref/ (build output, git-ignored).
 
 No reference file is edited or copied.  What is shimmed, and why:
   * keras.* / tensorflow: un-vendored third-party deps of agent/model.py, agent/api.py
@@ -22,7 +24,19 @@ import sys
 import types
 from unittest.mock import MagicMock
 
-REFERENCE_ROOT = os.environ.get("RAZ_REFERENCE_ROOT", "/root/reference")
+def _reference_root():
+    """/root/reference where it exists (the build container); else oracle/_ref - the same modules byte-compiled from
+    there by oracle/build_ref.py (git-ignored build output that travels to the GPU box, where bench.py's cpu_baseline
+    leg times the reference's own self-play on the host cores).  RAZ_REFERENCE_ROOT overrides."""
+    env = os.environ.get("RAZ_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/src/reversi_zero"):
+        return "/root/reference"
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+REFERENCE_ROOT = _reference_root()
 REFERENCE_SRC = os.path.join(REFERENCE_ROOT, "src")
 
 

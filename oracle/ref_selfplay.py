@@ -108,11 +108,13 @@ def injected(stream):
          rp.ReversiPlayer.__init__) = saved
 
 
-def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False, carry=None, api=None):
+def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None, virtual_time=False, carry=None, api=None, start=None):
     """One game through the reference's SelfPlayWorker.start_game.  Returns a dict with per-ply
     captures (root N/W, action, n, q, emitted rows) and the play_*.json content the reference wrote.
     carry (dict, optional): holds the worker's MCTSInfo from call to call, the way SelfPlayWorker.start
-    keeps `mtcs_info` for reset_mtcs_info_per_game games (worker/self_play.py:109-111,132-134)."""
+    keeps `mtcs_info` for reset_mtcs_info_per_game games (worker/self_play.py:109-111,132-134).
+    start (optional): (black, white, next_player) - the worker's env is put on that position by ReversiEnv.update
+    (env/reversi_env.py:33-40) where start_game resets it (worker/self_play.py:143), i.e. the game is taken up there."""
     rh.install()
     import reversi_zero.agent.player as rp
     from reversi_zero.env.reversi_env import ReversiEnv, Player
@@ -156,7 +158,10 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
     with injected(stream):
         rp.ReversiPlayer.action_with_evaluation = capture
         try:
-            worker = SelfPlayWorker(config, env=ReversiEnv(), api=api, shared_var=None, worker_index=0)
+            the_env = ReversiEnv()
+            if start is not None:
+                the_env.reset = lambda: the_env.update(int(start[0]), int(start[1]), Player(int(start[2])))
+            worker = SelfPlayWorker(config, env=the_env, api=api, shared_var=None, worker_index=0)
             mtcs_info = carry.get("mtcs_info") if carry is not None else None
             if mtcs_info is None and config.play.share_mtcs_info_in_self_play:   # self_play.py:109-111
                 mtcs_info = rp.ReversiPlayer.create_mtcs_info()
@@ -175,7 +180,7 @@ def run_reference_game(config, blob, seed, game_id, sims_per_move, data_dir=None
         with open(os.path.join(rc.play_data_dir, files[-1])) as f:
             play_rows = json.load(f)
     players = []
-    e2 = ReversiEnv().reset()
+    e2 = ReversiEnv().reset() if start is None else ReversiEnv().update(int(start[0]), int(start[1]), Player(int(start[2])))
     for p in plies:  # recover who moved at each ply by replaying
         players.append(e2.next_player.value)
         e2.step(None if p["action"] < 0 else p["action"])

@@ -2,9 +2,11 @@
 played by the UNMODIFIED reference (tests/golden/mcts_games.json) — bit-exact: every action, every
 root N and W (float64), ActionWithEvaluation n/q, every saved policy, resignation flags, and the
 play_*.json rows the reference worker wrote (sha256 of the JSON text)."""
+import ctypes
 import hashlib
 import json
 
+import numpy as np
 import pytest
 
 import oracle as O
@@ -184,6 +186,41 @@ def test_live_reference_game_matches_oracle(blob):
     for a, b in zip(plies, ref["plies"]):
         assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"]
     assert summ["winner"] == ref["winner"]
+
+
+@pytest.mark.needs_reference
+def test_game_taken_up_at_a_position_matches_the_reference(blob):
+    """orc_selfplay_game_from (bench.py's check of its steady-state batch): the reference worker whose env is put on a
+    mid-game position by ReversiEnv.update (env/reversi_env.py:33-40) instead of reset() plays, with fresh players and
+    fresh random streams, the game the oracle plays from that position - white and black to move, with a pass on the way."""
+    import ref_harness as rh
+    import ref_selfplay as rs
+    cfg = rh.load_config("ch5.yml", {"play": {"parallel_search_num": 1, "thinking_loop": 1, "use_solver_turn": 0,
+                                              "use_solver_turn_in_simulation": 0}})
+    env = O.OrcEnv()
+    lib = O.load()
+    rng = np.random.default_rng(3)
+    starts = []
+    for plies_in in (7, 30, 52):   # reach positions by random playouts
+        lib.orc_env_reset(ctypes.byref(env))
+        for _ in range(plies_in):
+            own, enemy = (env.black, env.white) if env.next_player == 1 else (env.white, env.black)
+            legal = lib.orc_find_correct_moves(own, enemy)
+            moves = [i for i in range(64) if legal >> i & 1]
+            lib.orc_env_step(ctypes.byref(env), int(rng.choice(moves)))
+            assert not env.done
+        starts.append((int(env.black), int(env.white), int(env.next_player)))
+    assert {s[2] for s in starts} == {1, 2}
+    for k, st in enumerate(starts):
+        ref = rs.run_reference_game(cfg, blob, seed=5, game_id=900 + k, sims_per_move=14, start=st)
+        plies, summ = O.selfplay_game(O.play_cfg_from_config(cfg), blob, 5, 900 + k, 14, start=st)
+        assert [p["action"] for p in plies] == [p["action"] for p in ref["plies"]] and len(plies) >= 5
+        for a, b in zip(plies, ref["plies"]):
+            assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"] and a["player"] == b["player"]
+        assert summ["winner"] == ref["winner"]
+    # from the initial position it is the ordinary game
+    a = O.selfplay_game(O.play_cfg_from_config(cfg), blob, 5, 77, 9, start=(0x0000000810000000, 0x0000001008000000, 1))
+    assert a == O.selfplay_game(O.play_cfg_from_config(cfg), blob, 5, 77, 9)
 
 
 @pytest.mark.needs_reference
