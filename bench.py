@@ -23,9 +23,14 @@ long run holds at any instant; --tree-warm + W warm-up steps are run on that sta
 search trees that already hold a few dozen simulations.  metric = MCTS simulations/sec = start_search_my_move invocations / wall time, NN included,
 inputs resident in HBM, whole job over all GPUs.  games/hour is extrapolated from it (labelled).
 
-The same line carries, at N = 1: the parity spot check (8 sampled games of the 8192-game batch against the CPU
-oracle fed with the device net's outputs), BASELINE configs[1] (4096 games x mini net x 200 sims/move, WHOLE
-games, with its own spot check), the bitboard-sweep HBM leg, and the CPU baselines.
+The same line carries, at N = 1: the parity spot checks (8 sampled games of the 8192-game batch from the opening AND 8
+sampled slots of the TIMED steady-state batch, root N / W bit for bit against the CPU oracle fed with the device net's
+outputs), a WHOLE-GAME leg on the headline settings (1024 slots, continuous batching over 1536 game ids, ~4 min: games/hour
+and sims/s measured on complete games, two complete games == the oracle), `cpu_baseline` = the reference's own pure-Python
+self-play timed in this run on this box's host cores (oracle/_ref, tools/ref_python_baseline.py), BASELINE configs[1]
+(4096 games x mini net x 200 sims/move, whole games, with its own spot check) and the bitboard-sweep HBM leg.
+At N > 1: the record gather over RCCL is timed and its payload verified (per-rank checksums), and a small whole-game batch is
+played sharded AND on rank 0 alone: the gathered records must be byte-identical (SURVEY 8(d) Config 4's acceptance).
 """
 import argparse
 import json
@@ -125,6 +130,43 @@ def spotcheck_partial_search(eng, cfg, dnet, seed, first_id, slots):
     return checked
 
 
+def spotcheck_steady_state(eng, cfg, dnet, seed, first_id, start, n_check=8):
+    """The batch that was TIMED: slot g was put on the position start[g] = (black, white, player) (raz_engine_set_position,
+    fresh tree, the game's random streams at their first events) and has since completed some simulations of its first
+    move.  Its root statistics (N u32, W f64 bits) must equal the oracle's after the same number of simulations of game id
+    first_id + g taken up at that position (orc_selfplay_game_from, pinned to the reference's worker in
+    tests/test_oracle_mcts.py), the oracle evaluating leaves through the device net."""
+    import numpy as np
+    import oracle as O
+    from reversi_alpha_zero_amd.engine import GAME_SUMMARY
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
+    nn = device_nn(dnet)
+    b, w, p = start
+    summ = eng.pack_records(0, eng.n_games, plies=1)["summary"].cpu().numpy().view(GAME_SUMMARY).reshape(-1)
+    discs = np.unpackbits((b.view(np.uint64) | w.view(np.uint64)).view(np.uint8)).reshape(len(b), 64).sum(1)
+    cand = np.nonzero((summ["n_plies"] == 0) & (discs > 4))[0]   # still in the first move; turn 0 is bypassed (player.py:143-148)
+    if len(cand) < n_check:
+        raise AssertionError("steady-state spot check: too few slots are still in their first move")
+    order = np.argsort(discs[cand], kind="stable")   # spread the sample over the plies of the batch
+    slots = [int(cand[order[i]]) for i in np.linspace(0, len(cand) - 1, n_check).astype(int)]
+    checked = []
+    for g in slots:
+        own, enemy = (int(b[g]), int(w[g])) if int(p[g]) == 1 else (int(w[g]), int(b[g]))
+        own, enemy = own & (2**64 - 1), enemy & (2**64 - 1)
+        found, w64, n64, _ = eng.read_node(g, own, enemy, 1, 0)
+        if not found or int(n64.sum()) == 0:
+            raise AssertionError(f"steady-state spot check: slot {g} has no root statistics")
+        done = int(n64.sum()) + 1   # the first simulation on a fresh tree expands the root and backs nothing up
+        plies, _ = O.selfplay_game(ocfg, None, seed, first_id + g, done, nn=nn, stop_after_plies=1,
+                                   start=(int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g])))
+        on, ow = np.array(plies[0]["root_n"]), np.array(plies[0]["root_w"])
+        if not (np.array_equal(on, n64.astype(np.float64)) and np.array_equal(ow.view(np.uint64), w64.view(np.uint64))):
+            raise AssertionError(f"parity spot check FAILED: timed steady-state batch, slot {g} (game id {first_id + g}, ply {int(discs[g]) - 4}, "
+                                 f"{done} simulations): root N/W differ from the oracle")
+        checked.append({"game_id": first_id + g, "ply": int(discs[g]) - 4, "sims": done})
+    return checked
+
+
 def spotcheck_whole_games(eng, cfg, blob, seed, first_id, slots, sims):
     """Finished games of the batch against complete oracle games (C net): every action and every root visit count."""
     import concurrent.futures as cf
@@ -158,6 +200,7 @@ def stagger(eng, n, sims, seed, dev, ply_weights=None):
     for g in range(n):
         eng.set_position(g, int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g]), sims, enable_resign=True, one_move=False)
     occ = np.unpackbits((b.view(np.uint64) | w.view(np.uint64)).view(np.uint8)).reshape(n, 64).sum(1)
+    eng._staggered = (b, w, p)   # where every slot was put (the steady-state spot check starts the oracle there)
     return occ.astype(np.int64) - 4
 
 
@@ -191,12 +234,25 @@ def calibrate_ply_weights(eng, n, sims, seed, dev, first_id, steps=12):
 def conv_traffic():
     """HBM bytes per net forward from the committed PMC passes (separate rocprofv3 --pmc runs of this command:
     tools/run_profiles.sh -> tools/pmc_summary.py); None when no pass is committed for this build."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc", "headline_config3_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc", "headline_config3_traffic.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         t = json.load(f)
-    return t.get("net_forward_hbm_bytes_per_launch"), "profiles/r2_pmc/headline_config3_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE over the launches of one net forward)"
+    if not t.get("fetch_pass_present") or not t.get("write_pass_present"):   # never report half a measurement
+        return None, None
+    return t.get("net_forward_hbm_bytes_per_launch"), ("profiles/r3_pmc/headline_config3_traffic.json (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes "
+                                                       "of this command, summed over the launches of one net forward; FETCH doubled as MI355X_MICROARCH.md prescribes)")
+
+
+def sweep_traffic():
+    """HBM bytes per launch of k_step / k_legal_moves from the committed PMC passes of tools/bench_sweep.py
+    (tools/run_profiles.sh sweep -> tools/pmc_summary.py)."""
+    path = os.path.join(ROOT, "profiles", "r3_pmc", "sweep_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
 
 
 def headline_leg(args, dev, rank, world, cdev):
@@ -273,15 +329,41 @@ def headline_leg(args, dev, rank, world, cdev):
     t1 = time.perf_counter()
     gather = {"collective": "none (1 GPU)", "bytes": 0}
     if world > 1:
+        import numpy as np
         from reversi_alpha_zero_amd.worker.self_play import gather_packed
-        raw, moved = gather_packed(lambda plies: eng.pack_records(0, args.games, plies), rank, world)
+        last = {}
+
+        def packed(plies):
+            last["pk"] = eng.pack_records(0, args.games, plies)
+            return last["pk"]
+        raw, moved = gather_packed(packed, rank, world)
         torch.cuda.synchronize()
         gather = {"collective": f"{dist.get_backend()} gather of packed records from HBM ({world} ranks)", "bytes": moved,
-                  "games": (len(raw["n_plies"]) if raw is not None else None)}
-    gather["seconds"] = time.perf_counter() - t1
+                  "games": (len(raw["n_plies"]) if raw is not None else None), "seconds": time.perf_counter() - t1}
+        # payload check (outside the timed figure): every rank's byte sums of what it packed, against the sums of its slice of
+        # what arrived on rank 0
+        mine = [int(last["pk"][k].contiguous().view(torch.uint8).to(torch.int64).sum().item()) for k in ("headers", "root_n")]
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        if rank == 0:
+            n = args.games
+            for r in range(world):
+                got = [int(np.ascontiguousarray(raw[k][r * n:(r + 1) * n]).view(np.uint8).astype(np.int64).sum()) for k in ("headers", "root_n")]
+                if got != sums[r]:
+                    raise AssertionError(f"record gather: the bytes that arrived from rank {r} differ from what it packed ({got} != {sums[r]})")
+            gather["payload_check"] = f"byte sums of headers and root N of all {world} shards == what each rank packed"
+    gather.setdefault("seconds", time.perf_counter() - t1)
 
     if rank != 0:
         return None
+    spot_timed = None
+    if not args.no_spotcheck and not args.opening:
+        t2 = time.perf_counter()
+        checked = spotcheck_steady_state(eng, cfg, net, 0, first_id, eng._staggered)
+        spot_timed = {"result": "ok", "what": f"{len(checked)} slots of the TIMED steady-state batch (sampled across its plies), after the timed steps: root N (u32) "
+                                              "and W (f64 bits) == the CPU oracle taking game id first_id + slot up at the slot's position, same number of "
+                                              "simulations, leaves evaluated by the device net",
+                      "games": checked, "seconds": time.perf_counter() - t2}
     macs = macs_per_position(F, R, V)
     launches = args.steps * parts
     leaves_per_launch = (leaves / world - served) / launches   # rows the net evaluated on this rank (the cache serves the rest)
@@ -309,7 +391,7 @@ def headline_leg(args, dev, rank, world, cdev):
                    "kernel_launches_per_step": parts * (2 if args.net == "mini" else 23), "slices": parts},
         "sims_per_sec_per_gpu": value / world, "leaves_per_sec": leaves / elapsed,
         "games_per_hour": value / (args.sims * MEAN_SEARCHED_PLIES) * 3600.0,
-        "games_per_hour_note": f"extrapolated: sims/s / ({args.sims} sims/move x {MEAN_SEARCHED_PLIES} searched plies/game); a whole batch is ~50 000 steps",
+        "games_per_hour_note": f"EXTRAPOLATED (the whole-game leg did not run): sims/s / ({args.sims} sims/move x {MEAN_SEARCHED_PLIES} searched plies/game)",
         "total_sims": total_sims, "nn_leaves": leaves, "leaf_slot_occupancy": leaves / world / (args.steps * args.games),
         "mean_selections_per_sim": selections / max(total_sims, 1.0),
         "roofline": {"bound": "mfma", "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
@@ -330,21 +412,8 @@ def headline_leg(args, dev, rank, world, cdev):
                                 "self-play from the opening shares more (profiles/r2/whole_games_config3_1024slots_leaf_cache.json)"}
                        if cache_log2 else None),
         "record_gather": gather, "parity_spotcheck": spot if spot else "skipped",
+        "parity_spotcheck_timed_batch": spot_timed if spot_timed else "skipped",
     })
-    wg = os.path.join(ROOT, "profiles", "r2", "whole_games_config3_8192slots.json")
-    if args.net == "ch5" and os.path.exists(wg):   # committed measurement of the WHOLE batch (tools/whole_games_config3.py, 19 min)
-        with open(wg) as f:
-            w = json.load(f)
-        lpg = w["nn_leaves"] / float(w["workload"].split(" ")[0])
-        out["whole_batch_measured"] = {
-            "source": "profiles/r2/whole_games_config3_8192slots.json: this workload played to the end - 8192 complete games, one batch, "
-                      "1153 s on one MI355X (tools/whole_games_config3.py --slots 8192 --games 8192; first plies == oracle)",
-            "sims_per_s": w["sims_per_s_at_this_batch"], "games_per_hour": w["games_per_hour_at_this_batch"],
-            "net_evaluations_per_s": w["leaves_per_s_at_this_batch"], "ms_per_step": w["ms_per_step"], "steps": w["steps"],
-            "sims_per_net_evaluation": w["sims_per_net_evaluation"], "searched_plies_per_game": w["searched_plies_per_game"],
-            "leaf_slot_occupancy_incl_ramp_down": w["leaf_slot_occupancy"],
-            "this_runs_sims_per_s_at_the_whole_batch_sims_per_evaluation": leaves / elapsed * w["sims_per_net_evaluation"],
-            "this_runs_games_per_hour_from_net_evaluations": leaves / elapsed / lpg * 3600.0}
     k = out["kernels"]["k_tree"]
     k["achieved"] = k["algorithmic_bytes_per_launch"] / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None
     k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"
@@ -384,6 +453,159 @@ def exact_f32_leg(args, dev, blob, cfg, weights, steps=8):
                         "frac": ach / FP32_PEAK_TFLOPS}}
     del eng, net
     torch.cuda.empty_cache()
+    return out
+
+
+
+# ------------------------------------------------------------------------------------------------------------
+# whole games on the headline settings (driver-timed: measured, not extrapolated)
+# ------------------------------------------------------------------------------------------------------------
+def whole_games_leg(args, dev, blob, cfg, slots=1024, ids=1536):
+    """COMPLETE games of the headline search (256x10 net on the split-f16 trunk, 800 sims/move, ch5.yml play settings,
+    thinking_loop 1, solver off, parallel_search_num 1) at a reduced number of slots so that it fits the bench's time budget:
+    `slots` resident games, continuous batching over `ids` game ids (a finished slot restarts on the next id at once),
+    node pools of 16 x sims pruned by k_gc, the evaluation cache attached as the worker attaches it.  games/hour and sims/s
+    are MEASURED on complete games, including the ramp-down of the last games; the steady window (first refill .. last
+    refill) is reported beside it.  Returns (result dict, records of the sampled ids for the complete-game check)."""
+    import numpy as np
+    import torch
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine, raw_from_packed
+    net = DeviceNet(blob, dev, kernel=args.net_kernel)
+    cache_log2 = None if args.no_leaf_cache else 26
+    eng = SelfPlayEngine(cfg, net, n_games=slots, seed=0, sims_hint=args.sims, nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=1,
+                         leaf_cache_log2=cache_log2, leaf_cache_max_discs=24)
+    marks = []
+
+    def on_chunk(steps, done, st):
+        marks.append((time.perf_counter(), steps, done, st["total_sims"], st["nn_leaves"]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outbox, st = eng.play_continuous(0, ids, lambda gid: args.sims, chunk=256, on_chunk=on_chunk)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pk = {k: outbox[k].cpu().numpy() for k in ("headers", "root_n", "summary")}
+    raw = raw_from_packed(pk["headers"], pk["root_n"], pk["summary"])
+    searched = int((raw["headers"]["sims"] > 0).sum())
+    # steady window: from the first chunk after which a slot had been refilled to the last chunk that still had unplayed ids
+    first_refill = next((i for i, m in enumerate(marks) if m[2] > 0), None)
+    last_full = max((i for i, m in enumerate(marks) if m[2] <= ids - slots), default=None)
+    steady = None
+    if first_refill is not None and last_full is not None and last_full > first_refill:
+        a, b = marks[first_refill], marks[last_full]
+        steady = {"seconds": b[0] - a[0], "sims_per_s": (b[3] - a[3]) / (b[0] - a[0]), "games_per_hour": (b[2] - a[2]) / (b[0] - a[0]) * 3600.0,
+                  "net_evaluations_per_s": (b[4] - a[4]) / (b[0] - a[0]), "leaf_slot_occupancy": (b[4] - a[4]) / ((b[1] - a[1]) * slots),
+                  "what": "between the first refill and the last chunk that still had unplayed ids: every slot busy"}
+    cs = eng.leaf_cache_stats()
+    out = {"workload": f"{ids} COMPLETE self-play games on {slots} slots (continuous batching), 256x10 net ({net.kernel_name}), {args.sims} sims/move, "
+                       "ch5.yml play settings, thinking_loop=1, solver off, parallel_search_num=1, node pools 16 x sims (k_gc between harvests)",
+           "measured": "in this run, on complete games (not extrapolated)",
+           "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": ids / dt * 3600.0, "seconds": dt, "steps": st["steps"],
+           "ms_per_step": 1e3 * dt / st["steps"], "net_evaluations_per_s": st["nn_leaves"] / dt,
+           "sims_per_net_evaluation": st["total_sims"] / st["nn_leaves"], "searched_plies_per_game": searched / ids,
+           "plies_per_game": float(raw["n_plies"].mean()), "leaf_slot_occupancy_incl_ramp_down": st["leaf_slot_occupancy"],
+           "gc_runs": st["gc_runs"], "steady_window": steady,
+           "winners_black_white_draw": [int((raw["status"] & 0x0f == w).sum()) for w in (1, 2, 3)],
+           "resigned_games": int(((raw["status"] & 0x20) != 0).sum()), "range_ok": net.range_ok(),
+           "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table": int(cs["hits"] + cs["in_batch_duplicates"]),
+                           "share_of_leaf_requests": (cs["hits"] + cs["in_batch_duplicates"]) / max(1, st["nn_leaves"])} if cache_log2 else None),
+           "pool_bytes": int(eng.workspace_bytes)}
+    sample = [0, ids - 1]   # one game of the first wave, one that was started by a refill
+    recs = {gid: (raw["headers"][gid, :int(raw["n_plies"][gid])].copy(), raw["root_n"][gid, :int(raw["n_plies"][gid])].copy(), int(raw["status"][gid]))
+            for gid in sample}
+    del eng, net, outbox
+    torch.cuda.empty_cache()
+    return out, recs
+
+
+def start_complete_game_checks(dev, args, blob, cfg, recs):
+    """Complete games of the whole-game leg against complete oracle games, the oracle evaluating every leaf (~45 000 per game)
+    through a device net of its own (the reference's NN seam, batch of 1) on its own stream: one host thread per game,
+    started here and joined by the caller after the CPU-baseline leg (the GPU is idle meanwhile)."""
+    import threading
+    import numpy as np
+    import torch
+    import oracle as O
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
+    results = {}
+
+    def check(gid):
+        try:
+            t0 = time.perf_counter()
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                dnet = DeviceNet(blob, dev, kernel=args.net_kernel)
+                plies, summ = O.selfplay_game(ocfg, None, 0, gid, args.sims, nn=device_nn(dnet))
+            hdr, rn, status = recs[gid]
+            ok = len(plies) == len(hdr) and (status & 0x0f) == summ["winner"] and \
+                [int(a) for a in hdr["action"]] == [p["action"] for p in plies] and \
+                all(np.array_equal(rn[i].astype(np.float64), np.array(p["root_n"])) for i, p in enumerate(plies))
+            results[gid] = {"ok": bool(ok), "plies": len(plies), "leaf_evaluations": int(summ["n_expand"]), "seconds": time.perf_counter() - t0}
+        except BaseException as e:   # noqa: B902 - reported by the joiner
+            results[gid] = {"ok": False, "error": repr(e)}
+    threads = [threading.Thread(target=check, args=(gid,), daemon=True) for gid in recs]
+    for t in threads:
+        t.start()
+    return threads, results
+
+
+def join_complete_game_checks(threads, results, timeout=900.0):
+    for t in threads:
+        t.join(timeout)
+    if any(t.is_alive() for t in threads):
+        raise AssertionError("complete-game parity check did not finish")
+    bad = {g: r for g, r in results.items() if not r.get("ok")}
+    if bad:
+        raise AssertionError(f"parity check FAILED: complete games of the whole-game leg differ from the oracle: {bad}")
+    return {"result": "ok", "what": "complete games of this leg (one of the first wave, one started by a refill): every action, the winner and every "
+                                    "ply's root N == the complete game the CPU oracle plays for that id with the device net's outputs (800 sims/move)",
+            "games": [dict(game_id=g, **{k: v for k, v in r.items() if k != "ok"}) for g, r in sorted(results.items())]}
+
+
+def config4_acceptance(dev, rank, world, cdev):
+    """SURVEY 8(d) Config 4's acceptance on the real collective, scaled down: every rank plays its shard of a small
+    whole-game batch (ids [64 r, 64 r + 64), mini net, 20 sims/move) and the records are gathered on rank 0 (RCCL under
+    nccl); rank 0 then plays ALL world x 64 ids alone and the two packed record sets must be byte-identical."""
+    import numpy as np
+    import torch
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    from reversi_alpha_zero_amd.worker.self_play import gather_packed
+    per, sims = 64, 20
+    cfg = mini_config(sims, 1)
+    blob = ReversiNet(*NETS["mini"]).keras_init_(0).to_blob()
+
+    def play(first, n):
+        eng = SelfPlayEngine(cfg, DeviceNet(blob, dev), n_games=n, seed=0, sims_hint=sims)
+        eng.start(first, sims)
+        eng.run(chunk=128)
+        return eng
+    eng = play(rank * per, per)
+    raw, moved = gather_packed(lambda plies: eng.pack_records(0, per, plies), rank, world)
+    if rank != 0:
+        return None
+    alone = play(0, per * world)
+    pk = alone.pack_records(0, per * world, plies=raw["headers"].shape[1])
+    from reversi_alpha_zero_amd.engine import raw_from_packed
+    one = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
+    same = all(np.array_equal(np.asarray(raw[k]).view(np.uint8), np.asarray(one[k]).view(np.uint8))
+               for k in ("headers", "root_n", "n_plies", "status", "game_id", "final_black", "final_white", "resigned"))
+    if not same:
+        raise AssertionError("Config 4 acceptance FAILED: the gathered records of the sharded batch differ from rank 0 playing all ids alone")
+    return {"result": "ok", "what": f"{per * world} complete games (mini net, {sims} sims/move): {world} ranks x {per} ids gathered on rank 0 == rank 0 playing all "
+                                    "ids alone, byte for byte (headers, root N, summaries)", "gathered_bytes": moved}
+
+
+def cpu_baseline_reference(windows=(("ch5", 20.0), ("mini", 10.0))):
+    """`cpu_baseline`: the reference's own pure-Python self-play on THIS box's host cores, in this run
+    (tools/ref_python_baseline.py; modules from /root/reference or, on the GPU box, oracle/_ref)."""
+    import ref_harness
+    if not ref_harness.reference_available():
+        return None
+    import ref_python_baseline
+    r = ref_python_baseline.measure(list(windows))
+    out = dict(r["ch5"])
+    out["configs1_mini_200sims"] = r.get("mini")
+    out["wall_seconds_incl_process_start"] = r["wall_seconds_incl_process_start"]
     return out
 
 
@@ -500,13 +722,34 @@ def continuous_leg(dev, args, rounds=3):
     return out
 
 
-def sweep_leg(dev, boards=1 << 24, steps=10):
-    """The bitboard-sweep HBM leg of the north star: k_step / k_legal_moves GB/s (tools/bench_sweep.py)."""
+def sweep_leg(dev):
+    """The bitboard-sweep HBM leg of the north star: k_step / k_legal_moves GB/s (tools/bench_sweep.py) at 2^24 boards (the
+    size SURVEY 8(d) names; its 256 MiB of inputs equal the Infinity Cache) and at 2^26 boards (1 GiB of inputs: nothing is
+    cache-resident), with the counter traffic of the committed PMC passes beside the algorithmic bytes."""
     import bench_sweep
-    a = types.SimpleNamespace(boards=boards, steps=steps, warmup=3, no_cpu_baseline=True, cpu_budget=0.0)
-    o = bench_sweep.run_sweep(a, 0, 1, dev)
-    return {"workload": o["config"]["workload"], "k_step": o["roofline"], "k_legal_moves": o["k_legal_moves"],
-            "boards_per_s": o["value"]}
+    tr = sweep_traffic()
+    res = {}
+    for boards, steps in ((1 << 24, 10), (1 << 26, 4)):
+        a = types.SimpleNamespace(boards=boards, steps=steps, warmup=2, no_cpu_baseline=True, cpu_budget=0.0)
+        o = bench_sweep.run_sweep(a, 0, 1, dev)
+        ks, kl = o["roofline"], o["k_legal_moves"]
+        for k, name in ((ks, "k_step"), (kl, "k_legal_moves")):
+            t = tr.get(f"{name}@{boards}")
+            if t:
+                # FETCH_SIZE counts the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B on gfx950 and is "uncalibrated" for
+                # other widths (MI355X_MICROARCH.md): these kernels read 8 B/lane, and their inputs are a known byte count that must
+                # be fetched at least once - so the raw figure is used where it covers the algorithmic reads, the doubled one where not
+                read_alg = {"k_step": 19, "k_legal_moves": 16}[name] * boards
+                doubled = t["fetch_bytes_raw"] < 0.98 * read_alg
+                k["traffic"] = (2.0 if doubled else 1.0) * t["fetch_bytes_raw"] + t["write_bytes"]
+                k["traffic_over_algorithmic"] = k["traffic"] / k["algorithmic_bytes_per_launch"]
+                k["traffic_detail"] = {"fetch_bytes_raw": t["fetch_bytes_raw"], "fetch_doubled": doubled, "write_bytes": t["write_bytes"],
+                                       "algorithmic_read_bytes": read_alg, "dispatches_averaged": t.get("dispatches_averaged")}
+                k["traffic_source"] = "profiles/r3_pmc/sweep_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/bench_sweep.py)"
+        res[f"boards_2^{boards.bit_length() - 1}"] = {"workload": o["config"]["workload"], "k_step": ks, "k_legal_moves": kl, "boards_per_s": o["value"]}
+    out = dict(res["boards_2^24"])
+    out["beyond_the_infinity_cache_2^26_boards"] = res["boards_2^26"]
+    return out
 
 
 def cpu_baseline_port(cfg, blob, sims, threads, stop_after_plies=0, what=""):
@@ -523,16 +766,6 @@ def cpu_baseline_port(cfg, blob, sims, threads, stop_after_plies=0, what=""):
     return {"value": total / dt, "unit": "sims/s", "cores": threads, "kind": "port",
             "sample": f"{what}; oracle/orc_mcts.c + orc_net.c (C port of the reference player and net), one game per host thread; "
                       f"{total} sims in {dt:.1f} s"}
-
-
-def committed_reference_baseline():
-    """The reference's own pure-Python self-play (SelfPlayWorker.start_game, unmodified source) timed in the BUILD
-    container by tools/ref_python_baseline.py (the GPU box has no /root/reference): a committed measurement."""
-    path = os.path.join(ROOT, "profiles", "r2_cpu_baseline_reference_python.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -568,7 +801,10 @@ def main():
     ap.add_argument("--no-spotcheck", action="store_true")
     ap.add_argument("--no-leaf-cache", action="store_true", help="headline engine without the cross-game evaluation cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (configs[1], par-4 and sweep legs skipped)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (whole-game, configs[1], par-4 and sweep legs skipped)")
+    ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
+    ap.add_argument("--whole-slots", type=int, default=1024, help="slots of the whole-game leg")
+    ap.add_argument("--whole-ids", type=int, default=1536, help="game ids the whole-game leg plays to the end")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -603,12 +839,48 @@ def main():
         dist.barrier()
     g.build()
 
+    acceptance = None
+    if world > 1 and not args.no_extra_legs:
+        acceptance = config4_acceptance(dev, rank, world, cdev)
     res = headline_leg(args, dev, rank, world, cdev)
     if rank == 0:
         out, blob, cfg = res
         ply_weights = out.pop("_ply_weights", None)
+        if acceptance:
+            out["config4_acceptance"] = acceptance
         if shared_gpu:
             out["config"]["test_rig"] = "RAZ_BENCH_SHARED_GPU=1: ranks share GPUs, gloo collectives - not a scaling measurement"
+        import gc
+        checks = None
+        if world == 1 and not args.no_extra_legs and args.net == "ch5" and not args.no_whole_games:
+            gc.collect()
+            torch.cuda.empty_cache()
+            wg, recs = whole_games_leg(args, dev, blob, cfg, slots=args.whole_slots, ids=args.whole_ids)
+            out["whole_games_measured"] = wg
+            # the line's games/hour is what was measured on complete games; the steady-state extrapolation stays beside it
+            out["games_per_hour_extrapolated_from_the_timed_steps"] = out["value"] / (args.sims * wg["searched_plies_per_game"]) * 3600.0
+            out["games_per_hour"] = wg["games_per_hour"]
+            out["games_per_hour_note"] = (f"MEASURED in this run on {args.whole_ids} complete games at {args.whole_slots} slots (whole_games_measured); at 8192 slots the "
+                                          "timed steps extrapolate to games_per_hour_extrapolated_from_the_timed_steps (sims/s / (sims/move x searched plies/game "
+                                          "measured on those complete games))")
+            out["headline_over_whole_games_sims_per_s"] = out["value"] / wg["value"]
+            if not args.no_spotcheck:
+                checks = start_complete_game_checks(dev, args, blob, cfg, recs)
+        if world == 1 and not args.no_cpu_baseline:
+            # the reference's own pure-Python self-play on this box's host cores, in this run (the complete-game checks above
+            # keep two host threads and an otherwise idle GPU busy meanwhile)
+            ref = cpu_baseline_reference()
+            if ref is not None:
+                out["cpu_baseline"] = ref
+            else:   # no reference modules on this box (oracle/_ref not staged): the C port, labelled as such
+                threads = min(os.cpu_count() or 1, 128)
+                per_thread = 2 if args.net == "ch5" else 400
+                out["cpu_baseline"] = cpu_baseline_port(
+                    cfg, blob, per_thread, threads, stop_after_plies=2,
+                    what=f"oracle/_ref absent: C port instead of the reference; bounded sample: the first {per_thread} simulations of the first searched "
+                         f"move of {threads} games")
+        if checks is not None:
+            out["whole_games_measured"]["parity_check_complete_games"] = join_complete_game_checks(*checks)
         if world == 1 and not args.no_extra_legs:
             legs = ((("headline_on_exact_f32_kernels", lambda: exact_f32_leg(args, dev, blob, cfg, ply_weights)),)
                     if "f16x3" in out["dtype"] else ()) + (
@@ -617,7 +889,6 @@ def main():
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             for key, leg in legs:
-                import gc
                 gc.collect()
                 torch.cuda.empty_cache()
                 try:
@@ -626,21 +897,6 @@ def main():
                     raise
                 except Exception as ex:   # never lose the main line over an extra leg
                     out[key] = {"error": repr(ex)}
-            spp = out.get("config1_4096x200_mini", {}).get("searched_plies_per_game")
-            if spp:
-                out["games_per_hour"] = out["value"] / (args.sims * spp) * 3600.0
-                out["games_per_hour_note"] = (f"extrapolated: sims/s / ({args.sims} sims/move x {spp:.2f} searched plies/game, the figure "
-                                              "measured on the whole-game configs[1] leg of this run); a whole batch is ~50 000 steps")
-        if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 128)
-            per_thread = 2 if args.net == "ch5" else 400
-            out["cpu_baseline"] = cpu_baseline_port(
-                cfg, blob, per_thread, threads, stop_after_plies=2,
-                what=f"same workload (net, play settings), bounded sample: the first {per_thread} simulations of the first searched move of "
-                     f"{threads} games")
-            ref = committed_reference_baseline()
-            if ref:
-                out["cpu_baseline_reference_python"] = ref
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

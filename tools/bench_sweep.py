@@ -141,8 +141,11 @@ def run_sweep(args, rank, world, dev):
     e1.record()
     torch.cuda.synchronize()
     lm_ms = e0.elapsed_time(e1) / 10
-    out["k_legal_moves"] = {"avg_kernel_ms": lm_ms, "achieved": 24 * n / (lm_ms * 1e-3) / 1e9, "unit": "GB/s",
-                            "frac": 24 * n / (lm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "inputs (256 MiB) partly Infinity-Cache resident"}
+    out["k_legal_moves"] = {"bound": "hbm", "kernel": "k_legal_moves", "avg_kernel_ms": lm_ms, "achieved": 24 * n / (lm_ms * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 24 * n,
+                            "frac": 24 * n / (lm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": f"the same {16 * n >> 20} MiB of inputs every launch: " + ("Infinity-Cache (256 MiB) resident in part" if 16 * n <= (512 << 20)
+                                                                                              else "4x the 256 MiB Infinity Cache, streamed from HBM")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_sweep(black, white, player, action, args.cpu_budget)
     return out

@@ -1,8 +1,14 @@
 """Average the rocprofv3 PMC passes written by tools/run_profiles.sh per kernel and per dispatch.
 
-usage: python tools/pmc_summary.py gpurun_out/prof_final profiles/r1_pmc/final
-writes <out>_pmc_per_dispatch.json (counter averages) and <out>_traffic.json (HBM bytes per launch,
-FETCH_SIZE / WRITE_SIZE are reported in KiB; bench.py reads the latter for roofline.traffic)."""
+usage: python tools/pmc_summary.py gpurun_out/prof_final profiles/r3_pmc/headline [--last K] [--sweep BOARDS]
+writes <out>_pmc_per_dispatch.json (counter averages) and, when BOTH traffic passes are present, <out>_traffic.json (HBM bytes
+per launch; FETCH_SIZE / WRITE_SIZE are reported in KiB) plus <out>_config3_traffic.json (one net forward; bench.py reads it
+for roofline.traffic).  A traffic pass that is missing for a kernel is an ERROR (exit code 2), never a silent zero: round 2
+shipped a WRITE-only figure that was below the algorithmic bytes.
+--last K: average only the last K dispatches of every kernel (the timed launches of tools/bench_sweep.py come after the
+harvest's launches of the same kernels).  --sweep BOARDS: also write <out-dir>/sweep_traffic.json entries "k_step@BOARDS" /
+"k_legal_moves@BOARDS" (merged into an existing file), FETCH doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads."""
+import argparse
 import collections
 import csv
 import glob
@@ -10,22 +16,28 @@ import json
 import os
 import sys
 
-SHORT = {"k_tree_par": "k_tree_par", "k_tree": "k_tree", "k_net_mfma": "k_net_mfma", "k_conv3x3_wide": "k_conv3x3_wide", "k_heads_wide": "k_heads_wide",
-         "k_conv0_wide": "k_conv0_wide", "k_conv3x3_f16x3": "k_conv3x3_f16x3", "k_conv0_split": "k_conv0_split", "k_heads_split": "k_heads_split",
-         "k_stats": "k_stats", "k_start": "k_start", "k_gc": "k_gc"}
+SHORT = ["k_tree_par", "k_tree", "k_net_mfma", "k_conv3x3_wide", "k_heads_wide", "k_conv0_wide", "k_conv3x3_f16x3", "k_conv0_split",
+         "k_heads_split", "k_stats", "k_start", "k_gc", "k_step", "k_legal_moves", "k_leaf_claim", "k_leaf_resolve", "k_leaf_fill"]
+TRAFFIC = ("FETCH_SIZE", "WRITE_SIZE")
 
 
 def short(name):
     for k in SHORT:
         if k in name:
-            return SHORT[k]
+            return k
     return None
 
 
-def main(src, out):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    cnt = collections.defaultdict(lambda: collections.defaultdict(set))
-    for path in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("out")
+    ap.add_argument("--last", type=int, default=0)
+    ap.add_argument("--sweep", type=int, default=0)
+    a = ap.parse_args()
+    rows = collections.defaultdict(lambda: collections.defaultdict(dict))   # kernel@grid -> counter -> {dispatch id: value}
+    passes = set()
+    for path in sorted(glob.glob(os.path.join(a.src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
         with open(path) as f:
             for r in csv.DictReader(f):
                 k = short(r.get("Kernel_Name", ""))
@@ -33,43 +45,80 @@ def main(src, out):
                     continue
                 k = f"{k}@grid{r.get('Grid_Size')}"   # slices and whole-batch launches are different workloads
                 c = r["Counter_Name"]
-                acc[k][c] += float(r["Counter_Value"])
-                cnt[k][c].add(r.get("Dispatch_Id"))
-    res = {k: {c: acc[k][c] / max(len(cnt[k][c]), 1) for c in acc[k]} for k in acc}
-    for k in res:
-        res[k]["dispatches"] = max(len(v) for v in cnt[k].values())
+                passes.add(c)
+                d = rows[k][c]
+                did = int(r.get("Dispatch_Id") or 0)
+                d[did] = d.get(did, 0.0) + float(r["Counter_Value"])   # (a counter may be split over several rows of one dispatch)
+    if not rows:
+        print(f"pmc_summary: no counter_collection.csv with known kernels under {a.src}/pmc*", file=sys.stderr)
+        return 2
+    res = {}
+    for k, cs in rows.items():
+        res[k] = {}
+        for c, d in cs.items():
+            ids = sorted(d)
+            if a.last:
+                ids = ids[-a.last:]
+            res[k][c] = sum(d[i] for i in ids) / len(ids)
+        res[k]["dispatches"] = max(len(d) for d in cs.values())
     # the most frequent grid of each kernel (the in-run slice launches) also goes under the bare kernel name
     for base in sorted({k.split("@")[0] for k in res}):
         modal = max((k for k in res if k.startswith(base + "@")), key=lambda k: res[k]["dispatches"])
         res[base] = dict(res[modal], grid=modal.split("@grid")[1])
-    with open(out + "_pmc_per_dispatch.json", "w") as f:
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    with open(a.out + "_pmc_per_dispatch.json", "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
-    traffic = {k: {"fetch_bytes": v.get("FETCH_SIZE", 0.0) * 1024.0, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024.0,
-                   "hbm_bytes_per_launch": (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0}
-               for k, v in res.items() if "@" not in k and ("FETCH_SIZE" in v or "WRITE_SIZE" in v)}
-    with open(out + "_traffic.json", "w") as f:
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profiles.sh), KiB -> bytes, "
-                             "average per dispatch; FETCH_SIZE under-reports wide coalesced reads on gfx950 (guide)",
-                   "kernels": traffic}, f, indent=1, sort_keys=True)
+    print(json.dumps({k: {c: (round(v, 1) if isinstance(v, float) else v) for c, v in res[k].items()}
+                      for k in ("k_tree", "k_tree_par", "k_net_mfma", "k_conv3x3_f16x3", "k_conv3x3_wide", "k_step", "k_legal_moves") if k in res}, indent=1))
+
+    have = [c for c in TRAFFIC if c in passes]
+    if not have:
+        print("pmc_summary: no FETCH_SIZE / WRITE_SIZE pass in this directory: no traffic file written")
+        return 0
+    missing = sorted({f"{k}: {c}" for k, v in res.items() if "@" not in k for c in TRAFFIC if c not in v and any(t in v for t in TRAFFIC)}
+                     | {f"(whole pass) {c}" for c in TRAFFIC if c not in passes})
+    if missing:
+        print("pmc_summary: ERROR - traffic pass incomplete, refusing to write a traffic figure:\n  " + "\n  ".join(missing), file=sys.stderr)
+        return 2
+    traffic = {k: {"fetch_bytes_raw": v["FETCH_SIZE"] * 1024.0, "write_bytes": v["WRITE_SIZE"] * 1024.0,
+                   # FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 B on gfx950 (MI355X_MICROARCH.md): doubled
+                   "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
+                   "hbm_bytes_per_launch_uncorrected": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "dispatches_averaged": v["dispatches"] if not a.last else min(a.last, v["dispatches"])}
+               for k, v in res.items() if "@" not in k and all(t in v for t in TRAFFIC)}
+    with open(a.out + "_traffic.json", "w") as f:
+        json.dump({"source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/run_profiles.sh), KiB -> bytes, average per dispatch; "
+                             "hbm_bytes_per_launch = 2 x FETCH + WRITE (FETCH_SIZE under-reports wide coalesced reads by 2 on gfx950, MI355X_MICROARCH.md)",
+                   "fetch_pass_present": True, "write_pass_present": True, "kernels": traffic}, f, indent=1, sort_keys=True)
     # one net forward of the wide nets = conv0 + 2R conv launches + heads: HBM bytes per forward for bench.py's roofline.traffic
     for conv, c0, hd in (("k_conv3x3_f16x3", "k_conv0_split", "k_heads_split"), ("k_conv3x3_wide", "k_conv0_wide", "k_heads_wide")):
         if conv in traffic and c0 in traffic and hd in traffic and res[c0]["dispatches"]:
             per_fwd = res[conv]["dispatches"] / res[c0]["dispatches"]
-            fwd = traffic[c0]["hbm_bytes_per_launch"] + per_fwd * traffic[conv]["hbm_bytes_per_launch"] + traffic[hd]["hbm_bytes_per_launch"]
-            with open(out + "_config3_traffic.json", "w") as f:
-                json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the headline bench command (tools/run_profiles.sh); "
-                                     "FETCH_SIZE is reported at 1/2 of the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md): "
-                                     "fetch bytes doubled here as the guide prescribes",
+            with open(a.out + "_config3_traffic.json", "w") as f:
+                json.dump({"source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the headline bench command (tools/run_profiles.sh); FETCH doubled "
+                                     "(MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads on gfx950)",
+                           "fetch_pass_present": True, "write_pass_present": True,
                            "conv_kernel": conv, "conv_launches_per_forward": per_fwd,
-                           "conv_fetch_bytes_per_launch_raw": traffic[conv]["fetch_bytes"], "conv_write_bytes_per_launch": traffic[conv]["write_bytes"],
-                           "net_forward_hbm_bytes_per_launch": traffic[c0]["hbm_bytes_per_launch"] + traffic[c0]["fetch_bytes"]
-                           + per_fwd * (traffic[conv]["hbm_bytes_per_launch"] + traffic[conv]["fetch_bytes"])
-                           + traffic[hd]["hbm_bytes_per_launch"] + traffic[hd]["fetch_bytes"],
-                           "net_forward_hbm_bytes_per_launch_uncorrected": fwd}, f, indent=1)
+                           "conv_fetch_bytes_per_launch_raw": traffic[conv]["fetch_bytes_raw"], "conv_write_bytes_per_launch": traffic[conv]["write_bytes"],
+                           "net_forward_hbm_bytes_per_launch": traffic[c0]["hbm_bytes_per_launch"] + per_fwd * traffic[conv]["hbm_bytes_per_launch"]
+                           + traffic[hd]["hbm_bytes_per_launch"],
+                           "net_forward_hbm_bytes_per_launch_uncorrected": traffic[c0]["hbm_bytes_per_launch_uncorrected"]
+                           + per_fwd * traffic[conv]["hbm_bytes_per_launch_uncorrected"] + traffic[hd]["hbm_bytes_per_launch_uncorrected"]}, f, indent=1)
             break
-    print(json.dumps({k: {c: (round(v, 1) if isinstance(v, float) else v) for c, v in res[k].items()}
-                      for k in ("k_tree", "k_tree_par", "k_net_mfma", "k_conv3x3_f16x3", "k_conv3x3_wide") if k in res}, indent=1))
+    if a.sweep:
+        path = os.path.join(os.path.dirname(os.path.abspath(a.out)), "sweep_traffic.json")
+        cur = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                cur = json.load(f)
+        for k in ("k_step", "k_legal_moves"):
+            if k not in traffic:
+                print(f"pmc_summary: ERROR - --sweep given but no traffic for {k}", file=sys.stderr)
+                return 2
+            cur[f"{k}@{a.sweep}"] = traffic[k]
+        with open(path, "w") as f:
+            json.dump(cur, f, indent=1, sort_keys=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    sys.exit(main())
