@@ -1,0 +1,159 @@
+// hip/hip_runtime.h — WAVE EMULATOR shim (tests/native/wave_emu): TEST INFRASTRUCTURE ONLY.
+//
+// Compiles csrc/raz_engine.hip (and friends) as HOST C++ so that the tree kernels can be stepped, debugged (gdb, asan) and
+// checked against the CPU oracle in the build container, which has no GPU.  It is NOT a CPU fallback of the product: the
+// library it produces (tests/native/libraz_emu.so) is loaded by tests/test_engine_emu.py alone, is far too slow for anything
+// but a few tiny games, and nothing under reversi-alpha-zero_amd/ knows it exists.
+//
+// Execution model: a kernel launch runs its workgroups one after the other; the threads of a workgroup are cooperative
+// FIBERS on the calling OS thread, switched only at cross-lane operations (readlane / DPP / ballot / shfl / barriers), where
+// the 64 lanes of a wavefront rendezvous and exchange values.  A cross-lane operation reached by some lanes of a wave while
+// others wait at a different one is reported (with source lines) and aborts: the emulator demands convergent waves there.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <functional>
+
+#define RAZ_WAVE_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
+
+namespace wave_emu {
+struct Ctx { dim3 tid, bid, bdim, gdim; };
+extern thread_local Ctx* cur;                       // the running fiber's indices
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// rendezvous of the calling lane's wave: publish v, wait for every live lane of the wave, return the value lane `src` published
+uint64_t exchange(uint64_t v, int src, const char* what, int line);
+uint64_t ballot(bool pred, const char* what, int line);
+void wave_barrier(const char* what, int line);
+void block_barrier(int line);
+unsigned long long clock64();
+}  // namespace wave_emu
+
+#define threadIdx (wave_emu::cur->tid)
+#define blockIdx (wave_emu::cur->bid)
+#define blockDim (wave_emu::cur->bdim)
+#define gridDim (wave_emu::cur->gdim)
+
+// ---- runtime API (device memory IS host memory; everything is synchronous) ----------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+#define hipErrorNotSupported 801
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+#define hipStreamCaptureModeThreadLocal 1
+static inline const char* hipGetErrorString(hipError_t) { return "wave_emu"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = (hipStream_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = (hipEvent_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, int) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    wave_emu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+// ---- device intrinsics -----------------------------------------------------------------------------------------------------
+static inline int emu_lane() { return (int)(wave_emu::cur->tid.x & 63u); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
+static inline double __longlong_as_double(long long u) { double d; memcpy(&d, &u, 8); return d; }
+using std::max;
+using std::min;
+
+#define __ballot(p) wave_emu::ballot((p), "__ballot", __LINE__)
+static inline int emu_shfl_i(uint64_t bits, int src, int line) { (void)bits; (void)src; (void)line; return 0; }
+template <typename T>
+static inline T emu_shfl(T v, int src, int line) {
+    uint64_t b = 0;
+    memcpy(&b, &v, sizeof(T));
+    b = wave_emu::exchange(b, src & 63, "__shfl", line);
+    T r;
+    memcpy(&r, &b, sizeof(T));
+    return r;
+}
+#define __shfl(v, src) emu_shfl((v), (src), __LINE__)
+#define __syncthreads() wave_emu::block_barrier(__LINE__)
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+#define __ATOMIC_EMU_SCOPE 0
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+
+// the gfx950 builtins the tree kernels use
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_barrier() wave_emu::wave_barrier("s_barrier", __LINE__)
+#define __builtin_amdgcn_s_memtime() wave_emu::clock64()
+// v_readfirstlane of a value every lane holds identically (that is how the kernels use it): no rendezvous needed.  With
+// RAZ_WAVE_EMU_CHECK_UNIFORM the lanes do meet and the emulator verifies that the value IS uniform.
+#ifdef RAZ_WAVE_EMU_CHECK_UNIFORM
+static inline uint32_t emu_readfirstlane(uint32_t v, int line) {
+    const uint32_t f = (uint32_t)wave_emu::exchange(v, 0, "readfirstlane", line);
+    if (f != v) {
+        fprintf(stderr, "wave_emu: readfirstlane at line %d of a NON-UNIFORM value (lane %d holds %u, lane 0 holds %u)\n", line, emu_lane(), v, f);
+        abort();
+    }
+    return f;
+}
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane((uint32_t)(v), __LINE__)
+#else
+#define __builtin_amdgcn_readfirstlane(v) ((uint32_t)(v))
+#endif
+#define __builtin_amdgcn_readlane(v, l) ((int)(uint32_t)wave_emu::exchange((uint32_t)(v), (int)(l) & 63, "readlane", __LINE__))
+static inline int emu_dpp_src(int lane, int ctrl) {
+    switch (ctrl) {
+        case 0xB1: return (lane & ~3) | ((lane & 3) ^ 1);          // quad_perm [1,0,3,2]
+        case 0x4E: return (lane & ~3) | ((lane & 3) ^ 2);          // quad_perm [2,3,0,1]
+        case 0x141: return (lane & ~7) | (7 - (lane & 7));         // row_half_mirror
+        case 0x140: return (lane & ~15) | (15 - (lane & 15));      // row_mirror
+        default: fprintf(stderr, "wave_emu: DPP control %#x not modelled\n", ctrl); abort();
+    }
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) \
+    ((int)(uint32_t)wave_emu::exchange((uint32_t)(src), emu_dpp_src(emu_lane(), (ctrl)), "dpp", __LINE__))
+// v_writelane_b32 (bound through the LLVM intrinsic in the product source): src and lane are wave-uniform
+static inline uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t old) { return (uint32_t)emu_lane() == (lane & 63u) ? src : old; }
