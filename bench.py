@@ -87,15 +87,32 @@ def ch5_config(sims, par=1):
 def device_nn(dnet):
     """The reference's NN seam (ReversiPlayer(api=...), agent/player.py:41,346) served by the device net, one position
     per call: the oracle's search is then checked GIVEN the net's outputs (the net itself is checked against fp32
-    torch in tests/)."""
+    torch in tests/).  One 16-byte upload, one raz_net_forward over a batch of 1 (the kernels are batch-invariant), one
+    260-byte download per leaf, on the calling thread's current stream."""
+    import ctypes
     import numpy as np
     import torch
+    from reversi_alpha_zero_amd._native import lib, check
+    dev = dnet.device
+    boards = torch.zeros(2, dtype=torch.int64, device=dev)
+    out = torch.zeros(65, dtype=torch.float32, device=dev)      # policy 64 | value
+    host_in = torch.zeros(2, dtype=torch.int64).pin_memory()
+    host_out = torch.zeros(65, dtype=torch.float32).pin_memory()
+    need = lib.raz_net_scratch_bytes(dnet.filters, dnet.value_fc, 1)
+    scratch = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    signed = lambda x: x - (1 << 64) if x >= 1 << 63 else x
 
     def nn(own, enemy):
-        o = torch.tensor([own - (1 << 64) if own >= 1 << 63 else own], dtype=torch.int64, device=dnet.device)
-        e = torch.tensor([enemy - (1 << 64) if enemy >= 1 << 63 else enemy], dtype=torch.int64, device=dnet.device)
-        p, v = dnet.predict_bitboards(o, e)
-        return p[0].cpu().numpy().astype(np.float32), float(v[0].item())
+        host_in[0], host_in[1] = signed(own), signed(enemy)
+        with torch.cuda.device(dev):
+            boards.copy_(host_in, non_blocking=True)
+            s = torch.cuda.current_stream().cuda_stream
+            check(lib.raz_net_forward(ctypes.byref(dnet.c), boards.data_ptr(), boards.data_ptr() + 8, None, out.data_ptr(), out.data_ptr() + 256,
+                                      1, scratch.data_ptr() if need else None, need, s), "raz_net_forward")
+            host_out.copy_(out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        a = host_out.numpy()
+        return a[:64].astype(np.float32, copy=True), float(a[64])
     return nn
 
 
@@ -492,7 +509,7 @@ def whole_games_leg(args, dev, blob, cfg, slots=1024, ids=1536):
     steady = None
     if first_refill is not None and last_full is not None and last_full > first_refill:
         a, b = marks[first_refill], marks[last_full]
-        steady = {"seconds": b[0] - a[0], "sims_per_s": (b[3] - a[3]) / (b[0] - a[0]), "games_per_hour": (b[2] - a[2]) / (b[0] - a[0]) * 3600.0,
+        steady = {"seconds": b[0] - a[0], "sims_per_s": (b[3] - a[3]) / (b[0] - a[0]), "games_finished_in_the_window": b[2] - a[2],
                   "net_evaluations_per_s": (b[4] - a[4]) / (b[0] - a[0]), "leaf_slot_occupancy": (b[4] - a[4]) / ((b[1] - a[1]) * slots),
                   "what": "between the first refill and the last chunk that still had unplayed ids: every slot busy"}
     cs = eng.leaf_cache_stats()
@@ -504,6 +521,7 @@ def whole_games_leg(args, dev, blob, cfg, slots=1024, ids=1536):
            "sims_per_net_evaluation": st["total_sims"] / st["nn_leaves"], "searched_plies_per_game": searched / ids,
            "plies_per_game": float(raw["n_plies"].mean()), "leaf_slot_occupancy_incl_ramp_down": st["leaf_slot_occupancy"],
            "gc_runs": st["gc_runs"], "steady_window": steady,
+           "games_per_hour_at_the_steady_rate": (steady["sims_per_s"] / (st["total_sims"] / ids) * 3600.0) if steady else None,
            "winners_black_white_draw": [int((raw["status"] & 0x0f == w).sum()) for w in (1, 2, 3)],
            "resigned_games": int(((raw["status"] & 0x20) != 0).sum()), "range_ok": net.range_ok(),
            "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table": int(cs["hits"] + cs["in_batch_duplicates"]),

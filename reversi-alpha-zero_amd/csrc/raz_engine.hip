@@ -253,7 +253,9 @@ __device__ __forceinline__ raz_bb G64(const Regs& R, int i) {  // (the builtin r
 // v_writelane_b32: this clang has no __builtin for it, so the LLVM intrinsic is bound by name; the
 // compiler then sees a VALU instruction and inserts the gfx950 wait states around it (VALU-written
 // SGPR -> VALU read: 2; VALU-written VGPR -> v_readlane: 1), which inline asm would hide from it.
+#ifndef RAZ_WAVE_EMU   // (tests/native/wave_emu steps these kernels on the host and supplies its own)
 extern "C" __device__ uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+#endif
 template <int I>
 __device__ __forceinline__ uint32_t writelane_c(uint32_t old, uint32_t v) {
     static_assert(I >= 0 && I < 64, "lane");
@@ -607,7 +609,8 @@ __device__ bool place_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
     } else {  // existing node: store the prior (and the expanded flag)
         unsigned char* p = node_ptr(E, g, node);
         node_P(p)[lane] = prior;
-        if (new_tag_bits && lane == 0) node_hdr(p)->tag = G32(R, GW(leaf_tag)) | new_tag_bits;
+        const uint32_t old_tag = G32(R, GW(leaf_tag));   // (read by all lanes: a cross-lane read stays outside the lane-0 branch)
+        if (new_tag_bits && lane == 0) node_hdr(p)->tag = old_tag | new_tag_bits;
         mirror = G32(R, GW(leaf_mirror));
     }
     if (!with_mirror) {
@@ -742,6 +745,7 @@ __device__ void finalize_move(const raz_engine_dev& E, Regs& R, uint32_t g, int 
     const size_t ri = (size_t)g * E.max_plies + ply;
     E.rec_n[ri * 64 + lane] = Ni;
     if (E.rec_w) E.rec_w[ri * 64 + lane] = Wi;
+    const uint32_t move_sims = G32(R, GW(move_sims));   // (cross-lane reads stay outside lane-0 branches)
     if (lane == 0) {
         raz_ply_header h;
         h.own = own;
@@ -752,7 +756,7 @@ __device__ void finalize_move(const raz_engine_dev& E, Regs& R, uint32_t g, int 
         h.player = (uint8_t)player;
         h.turn = (uint8_t)turn;
         h.has_row = has_row ? 1 : 0;
-        h.sims = G32(R, GW(move_sims));
+        h.sims = move_sims;
         h.loops = loops;
         h.flags = solved ? 1u : 0u;
         E.rec[ri] = h;
@@ -947,7 +951,9 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         const uint32_t Ci = node_child(p)[lane];
         if (RAZ_PROF_ON(E)) {
             const unsigned long long tl = prof_now();
+#ifndef RAZ_WAVE_EMU
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             prof_add(E, g, 6, tl, lane);
         }
         env.black = uni(hb);

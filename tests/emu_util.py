@@ -1,0 +1,144 @@
+"""Driver of the WAVE-EMULATOR build of the tree kernels (tests/native/wave_emu -> tests/native/libraz_emu.so): the engine's
+C ABI (include/raz.h) on host memory, so that csrc/raz_engine.hip can be stepped and checked against the CPU oracle in a
+container without a GPU.  TEST INFRASTRUCTURE ONLY - the product never loads this library, and the GPU parity tests
+(tests/test_engine_gpu.py ...) remain the tests of record; this is the debugging loop the build container otherwise lacks."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from conftest import ROOT
+
+EMU_DIR = os.path.join(ROOT, "tests", "native", "wave_emu")
+EMU_LIB = os.path.join(ROOT, "tests", "native", "libraz_emu.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        r = subprocess.run(["make", "-C", EMU_DIR], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("wave-emulator build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+        from reversi_alpha_zero_amd import _native as N
+        lib = ctypes.CDLL(EMU_LIB)
+        for name, (res, args) in N.SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {(lib.raz_last_error() or b'').decode()}")
+
+
+class EmuEngine:
+    """The subset of reversi_alpha_zero_amd.engine.SelfPlayEngine the parity tests use, on the emulated kernels."""
+
+    def __init__(self, config, blob, n_games, seed=0, nodes_per_game=None, sims_hint=None, max_plies=72, record_root_w=True,
+                 inner_max=0, force_slot_kernel=False, **cfg_overrides):
+        from reversi_alpha_zero_amd import _native as N
+        from reversi_alpha_zero_amd.engine import engine_config_from
+        self.lib = lib = load()
+        self.n_games, self.max_plies, self.record_root_w = n_games, max_plies, record_root_w
+        import struct
+        _, _, F, R, V = struct.unpack_from("<5i", blob, 0)
+        self._weights = np.zeros(lib.raz_net_weight_bytes(F, R, V), dtype=np.uint8)
+        self.net = N.RazNet()
+        _check(lib, lib.raz_net_load(ctypes.byref(self.net), blob, len(blob), self._weights.ctypes.data, self._weights.size, None), "raz_net_load")
+        if nodes_per_game is None:
+            s = sims_hint or config.play.simulation_num_per_move
+            share = bool(config.play.share_mtcs_info_in_self_play)
+            nodes_per_game = (s * max(1, config.play.thinking_loop) * 62 + 128) * (2 if share else 1)
+        self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, None, record_root_w, False, True, 1, inner_max,
+                                      force_slot_kernel=force_slot_kernel)
+        for k, v in cfg_overrides.items():
+            setattr(self.cfg, k, v)
+        self.slots = int(self.cfg.parallel_search_num) or 1
+        nbytes = lib.raz_engine_workspace_bytes(ctypes.byref(self.cfg))
+        if nbytes == 0:
+            raise ValueError("invalid engine config: " + (lib.raz_last_error() or b"").decode())
+        self.workspace_bytes = nbytes
+        self._ws = np.zeros(nbytes + 256, dtype=np.uint8)
+        base = (self._ws.ctypes.data + 255) // 256 * 256
+        self._h = ctypes.c_void_p()
+        _check(lib, lib.raz_engine_create(ctypes.byref(self.cfg), ctypes.byref(self.net), base, nbytes, None, 0, ctypes.byref(self._h)), "raz_engine_create")
+        self.nodes_per_step = 2 * (inner_max or 2) if (self.slots == 1 and not force_slot_kernel) else 3 * self.slots + (inner_max or 2)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.raz_engine_destroy(self._h)
+            self._h = None
+
+    def start(self, first_game_id, sims_per_move, n_active=None):
+        sims = np.full(self.n_games, sims_per_move, dtype=np.uint32) if np.isscalar(sims_per_move) else np.ascontiguousarray(sims_per_move, dtype=np.uint32)
+        self.n_active = self.n_games if n_active is None else n_active
+        _check(self.lib, self.lib.raz_engine_start(self._h, first_game_id, sims.ctypes.data, self.n_active, None), "raz_engine_start")
+
+    def next_game(self, first_game_id, sims_per_move, n_active=None):
+        sims = np.full(self.n_games, sims_per_move, dtype=np.uint32)
+        self.n_active = self.n_games if n_active is None else n_active
+        _check(self.lib, self.lib.raz_engine_next_game(self._h, first_game_id, sims.ctypes.data, self.n_active, None), "raz_engine_next_game")
+
+    def step(self, n=1):
+        _check(self.lib, self.lib.raz_engine_step(self._h, n, None), "raz_engine_step")
+
+    def gc(self, threshold=0):
+        _check(self.lib, self.lib.raz_engine_gc(self._h, threshold, None), "raz_engine_gc")
+
+    def stats(self):
+        from reversi_alpha_zero_amd import _native as N
+        st = N.RazEngineStats()
+        _check(self.lib, self.lib.raz_engine_stats_sync(self._h, ctypes.byref(st), None), "raz_engine_stats_sync")
+        if st.error_flags:
+            raise RuntimeError(f"engine error flags {st.error_flags:#x}")
+        return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves, "selections": st.selections,
+                "max_pool_used": st.max_pool_used, "idle_or_done": st.idle_or_done}
+
+    def run(self, chunk=16, max_steps=200000, allow_gc=True):
+        steps, cap, self.gc_runs = 0, int(self.cfg.nodes_per_game), 0
+        while True:
+            self.step(chunk)
+            steps += chunk
+            st = self.stats()
+            if allow_gc and st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
+                self.gc(cap // 4)
+                self.gc_runs += 1
+            if st["finished_games"] >= self.n_active:
+                st["steps"] = steps
+                return st
+            if steps >= max_steps:
+                raise RuntimeError("engine did not finish")
+
+    def set_position(self, slot, black, white, player, sims, enable_resign=True, one_move=True):
+        _check(self.lib, self.lib.raz_engine_set_position(self._h, slot, black, white, player, sims, int(enable_resign), int(one_move), None), "raz_engine_set_position")
+
+    def read_node(self, slot, black, white, next_player=1, owner=0):
+        w, n, p = np.zeros(64), np.zeros(64, dtype=np.uint32), np.zeros(64, dtype=np.float32)
+        found = ctypes.c_int(0)
+        _check(self.lib, self.lib.raz_engine_read_node(self._h, slot, black, white, next_player, owner, w.ctypes.data, n.ctypes.data, p.ctypes.data,
+                                                       ctypes.byref(found), None), "raz_engine_read_node")
+        return bool(found.value), w, n, p
+
+    def read_raw(self):
+        from reversi_alpha_zero_amd.engine import PLY_HEADER
+        B, MP = self.n_games, self.max_plies
+        hdr = np.zeros((B, MP), dtype=PLY_HEADER)
+        root_n = np.zeros((B, MP, 64), dtype=np.uint32)
+        root_w = np.zeros((B, MP, 64), dtype=np.float64) if self.record_root_w else None
+        n_plies, status, resigned = np.zeros(B, dtype=np.uint32), np.zeros(B, dtype=np.uint8), np.zeros((B, 2), dtype=np.uint8)
+        game_id, enable_resign = np.zeros(B, dtype=np.uint32), np.zeros(B, dtype=np.uint8)
+        fb, fw = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
+        _check(self.lib, self.lib.raz_engine_read_records(self._h, hdr.ctypes.data, root_n.ctypes.data, root_w.ctypes.data if root_w is not None else None,
+                                                          n_plies.ctypes.data, status.ctypes.data, resigned.ctypes.data, game_id.ctypes.data,
+                                                          enable_resign.ctypes.data, fb.ctypes.data, fw.ctypes.data, None), "raz_engine_read_records")
+        return dict(headers=hdr, root_n=root_n, root_w=root_w, n_plies=n_plies, status=status, resigned=resigned, game_id=game_id,
+                    enable_resign=enable_resign, final_black=fb, final_white=fw)
+
+    def records(self, save_policy_of_tau_1=True, change_tau_turn=None):
+        from reversi_alpha_zero_amd.engine import SelfPlayEngine
+        return SelfPlayEngine.records(self, save_policy_of_tau_1, change_tau_turn)

@@ -128,21 +128,21 @@ template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_barrier() wave_emu::wave_barrier("s_barrier", __LINE__)
 #define __builtin_amdgcn_s_memtime() wave_emu::clock64()
-// v_readfirstlane of a value every lane holds identically (that is how the kernels use it): no rendezvous needed.  With
-// RAZ_WAVE_EMU_CHECK_UNIFORM the lanes do meet and the emulator verifies that the value IS uniform.
-#ifdef RAZ_WAVE_EMU_CHECK_UNIFORM
+// v_readfirstlane: the lanes MEET here even though the kernels only apply it to wave-uniform values - a wave executes in
+// lockstep, so every lane has done its loads of the value before any lane goes on to overwrite it (e.g. a flag in LDS that
+// all lanes read and then clear); lanes that ran ahead through such a sequence would see each other's stores.
+// With RAZ_WAVE_EMU_CHECK_UNIFORM the emulator also verifies that the value IS uniform.
 static inline uint32_t emu_readfirstlane(uint32_t v, int line) {
     const uint32_t f = (uint32_t)wave_emu::exchange(v, 0, "readfirstlane", line);
+#ifdef RAZ_WAVE_EMU_CHECK_UNIFORM
     if (f != v) {
         fprintf(stderr, "wave_emu: readfirstlane at line %d of a NON-UNIFORM value (lane %d holds %u, lane 0 holds %u)\n", line, emu_lane(), v, f);
         abort();
     }
+#endif
     return f;
 }
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane((uint32_t)(v), __LINE__)
-#else
-#define __builtin_amdgcn_readfirstlane(v) ((uint32_t)(v))
-#endif
 #define __builtin_amdgcn_readlane(v, l) ((int)(uint32_t)wave_emu::exchange((uint32_t)(v), (int)(l) & 63, "readlane", __LINE__))
 static inline int emu_dpp_src(int lane, int ctrl) {
     switch (ctrl) {

@@ -1,0 +1,140 @@
+"""CPU: the tree kernels of csrc/raz_engine.hip (k_tree, k_tree_par, k_gc, the harvest / adopt / read-node kernels) stepped by
+the WAVE EMULATOR (tests/native/wave_emu: workgroups as cooperative fibers, the 64 lanes of a wave meeting at every readlane /
+DPP / ballot) against the CPU oracle, bit for bit, at sizes a CPU finishes in seconds.  Leaves are evaluated by the oracle's C
+net (bit-identical to the exact-f32 device kernels).  This is the build container's debugging loop for the kernels' LOGIC -
+node layout, pool / table / pruning, the simulation-slot schedule; the parity tests of record are the GPU tests through the
+real libraz.so (tests/test_engine_gpu.py, test_engine_par_gpu.py, test_continuous_gpu.py).  The emulator also verifies what
+the hardware would not: that every cross-lane operation is reached by all lanes of its wave together."""
+import numpy as np
+import pytest
+
+import oracle as O
+from emu_util import EmuEngine
+from oracle_util import load_mcts_golden, load_par_golden, golden_net_blob, config_of, dense
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return load_mcts_golden()
+
+
+@pytest.fixture(scope="module")
+def blob(golden):
+    return golden_net_blob(golden["net"])
+
+
+def _same(tag, plies, summ, ref_plies, ref_winner):
+    assert len(plies) == len(ref_plies), (tag, len(plies), len(ref_plies))
+    for i, (a, b) in enumerate(zip(plies, ref_plies)):
+        for k in ("player", "own", "enemy", "action", "has_row"):
+            assert a[k] == b[k], (tag, i, k, a[k], b[k])
+        assert a["root_n"] == b["root_n"], (tag, i, "root_n")
+        assert a["root_w"] == b["root_w"], (tag, i, "root_w")
+        assert a["solved"] == b.get("solved", False), (tag, i)
+        if a["action"] >= 0:
+            assert a["n"] == b["n"] and a["q"] == b["q"], (tag, i)
+    assert summ["winner"] == ref_winner, tag
+
+
+def _variant(golden, name):
+    return next(g for g in golden["games"] if g["variant"] == name)
+
+
+def test_emulated_kernel_replays_reference_golden_games(golden, blob):
+    """Two of the unmodified reference's golden games (shared tree with re-thinking loops; unshared AlphaGoZero tree)."""
+    done = set()
+    for g in golden["games"]:
+        if g["variant"] in done or g["variant"] not in ("mini_shared", "agz") or g["sims_per_move"] > 40:
+            continue
+        done.add(g["variant"])
+        cfg = config_of(g)
+        eng = EmuEngine(cfg, blob, n_games=1, seed=g["seed"], sims_hint=g["sims_per_move"])
+        eng.start(g["game_id"], g["sims_per_move"])
+        eng.run(chunk=64)
+        (plies, summ), = eng.records(save_policy_of_tau_1=g["resolved_play_data"]["save_policy_of_tau_1"])
+        ref = [dict(p, own=int(p["own"], 16), enemy=int(p["enemy"], 16), root_n=dense(p["root_n"]), root_w=dense(p["root_w"])) for p in g["plies"]]
+        _same(g["variant"], plies, summ, ref, g["winner"])
+        assert (summ["black"], summ["white"]) == (int(g["black"], 16), int(g["white"], 16))
+    assert done == {"mini_shared", "agz"}
+
+
+@pytest.mark.parametrize("variant,pool", [("mini_shared", None), ("mini_shared", 480), ("agz", 200)])
+def test_emulated_batch_equals_oracle_with_and_without_pruning(golden, blob, variant, pool):
+    """A small batch with mixed simulation counts == independent oracle games; with a node pool far too small for a whole
+    game k_gc prunes several times per game and nothing changes."""
+    cfg = config_of(_variant(golden, variant))
+    n = 3
+    sims = np.array([9, 12, 15], dtype=np.uint32)
+    eng = EmuEngine(cfg, blob, n_games=n, seed=31, sims_hint=15, nodes_per_game=pool)
+    eng.start(500, sims)
+    eng.run(chunk=8 if pool else 32)
+    assert pool is None or eng.gc_runs >= 2
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg)
+    for i in range(n):
+        plies, summ = O.selfplay_game(ocfg, blob, 31, 500 + i, int(sims[i]))
+        _same(f"{variant}/{pool}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
+
+
+def test_emulated_solver_games_equal_oracle(golden, blob):
+    """mini.yml as shipped: exact solver at the root, win/loss solver inside simulations (LDS frames, per-game memo)."""
+    cfg = config_of(_variant(golden, "mini_solver_noresign"))
+    eng = EmuEngine(cfg, blob, n_games=2, seed=41, sims_hint=10)
+    eng.start(900, 10)
+    eng.run(chunk=32)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg)
+    solved = 0
+    for i in range(2):
+        plies, summ = O.selfplay_game(ocfg, blob, 41, 900 + i, 10)
+        _same(f"solver/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        solved += sum(p["solved"] for p in plies)
+    assert solved > 0
+
+
+@pytest.mark.parametrize("k,pool", [(4, None), (3, 400)])
+def test_emulated_slot_kernel_equals_oracle(blob, k, pool):
+    """k_tree_par: parallel_search_num simulations in flight per game on the raz-sched-v1 rounds, with and without pruning."""
+    par = load_par_golden()
+    g0 = next(g for g in par["games"] if g["resolved_play"]["share_mtcs_info_in_self_play"])
+    cfg = config_of(g0)
+    cfg.play.parallel_search_num = k
+    cfg.play.use_solver_turn = cfg.play.use_solver_turn_in_simulation = 0
+    cfg.play.thinking_loop = 1
+    eng = EmuEngine(cfg, blob, n_games=2, seed=7, sims_hint=14, nodes_per_game=pool)
+    eng.start(40, 14)
+    eng.run(chunk=8 if pool else 32)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=k)
+    for i in range(2):
+        plies, summ = O.selfplay_game(ocfg, blob, 7, 40 + i, 14)
+        _same(f"par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
+
+
+def test_emulated_series_on_a_carried_tree_and_position_api(golden, blob):
+    """raz_engine_next_game (k_adopt_all: the next game of the slot on the slot's tree) == the oracle's series; then
+    raz_engine_set_position + raz_engine_read_node: a search armed at a mid-game position == the oracle taken up there."""
+    cfg = config_of(_variant(golden, "mini_shared"))
+    cfg.play.thinking_loop = 1
+    eng = EmuEngine(cfg, blob, n_games=1, seed=3, nodes_per_game=2 * (2 * (10 * 62 + 128)))
+    tree = O.Tree()
+    ocfg = O.play_cfg_from_config(cfg)
+    for r in range(2):
+        (eng.start if r == 0 else eng.next_game)(70 + r, 10)
+        eng.run(chunk=32, allow_gc=False)
+        (plies, summ), = eng.records(save_policy_of_tau_1=True)
+        oplies, osum = O.selfplay_game(ocfg, blob, 3, 70 + r, 10, tree=tree)
+        _same(f"series/{r}", plies, summ, oplies, osum["winner"])
+    # a game taken up at a position
+    start = (int(oplies[20]["own"]), int(oplies[20]["enemy"]), 1) if oplies[20]["player"] == 1 else (int(oplies[20]["enemy"]), int(oplies[20]["own"]), 2)
+    eng2 = EmuEngine(cfg, blob, n_games=2, seed=3, sims_hint=10)
+    eng2.start(200, 10, n_active=0)
+    eng2.set_position(1, start[0], start[1], start[2], 10, enable_resign=True, one_move=False)
+    for _ in range(6):
+        eng2.step(1)
+    found, w64, n64, _ = eng2.read_node(1, int(oplies[20]["own"]), int(oplies[20]["enemy"]), 1, 0)
+    assert found and int(n64.sum()) >= 1
+    done = int(n64.sum()) + 1
+    fplies, _ = O.selfplay_game(ocfg, blob, 3, 201, done, stop_after_plies=1, start=start)
+    assert np.array_equal(np.array(fplies[0]["root_n"]), n64.astype(np.float64))
+    assert np.array_equal(np.array(fplies[0]["root_w"]).view(np.uint64), w64.view(np.uint64))
