@@ -989,7 +989,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
             leaf_legal = env.legal;
             leaf_tag = uni(tag);
             leaf_mirror = uni(hmirror);
-            if (PAR && lane == 0) node_hdr(p)->tag = uni(tag) | (64u << pl);  // now_expanding.add(key) (:294)
+            if (PAR && lane == 0) node_hdr(p)->tag = leaf_tag | (64u << pl);  // now_expanding.add(key) (:294)
             break;
         }
         if (depth >= 64) {
