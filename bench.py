@@ -657,8 +657,8 @@ def config1_leg(dev, args, par=1):
             eng.step(chunk)
         steps += chunk
         st = eng.stats()
-        if st["max_pool_used"] + eng.nodes_per_step * chunk + 64 > eng.cfg.nodes_per_game:
-            eng.gc(eng.cfg.nodes_per_game // 4)
+        if eng.pool_nearly_full(st, chunk):
+            eng.gc(min(eng.cfg.nodes_per_game // 4, st["max_pool_used"] // 2))
         if st["finished_games"] >= games:
             break
         if steps > 80 * sims * 4 + 4000:

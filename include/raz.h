@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RAZ_ABI_VERSION 1
+#define RAZ_ABI_VERSION 2   /* 2: compact tree nodes - raz_engine_config.pool_bytes_per_game, raz_engine_stats.max_pool_bytes */
 
 #define RAZ_OK 0
 #define RAZ_EINVAL (-1)   /* bad argument (range, NULL, alignment)            */
@@ -150,7 +150,7 @@ typedef struct {
     double resign_threshold;                  /* :145 */
     double disable_resignation_rate;          /* :147 */
     uint32_t n_games;                         /* game slots in flight (B) */
-    uint32_t nodes_per_game;                  /* node pool capacity per game */
+    uint32_t nodes_per_game;                  /* most tree nodes a game's pool may hold (sizes the hash table and the node directory) */
     uint32_t table_slots;                     /* hash slots per game, power of two >= 2*nodes_per_game */
     uint32_t max_plies;                       /* record capacity per game (>= 64) */
     uint32_t seed;
@@ -166,6 +166,10 @@ typedef struct {
     uint32_t parallel_search_num;             /* config.py:142: simulations in flight per game; 0/1 = one (the reference's
                                                  reproducible mode), 2..16 = the asyncio loop in exact virtual time
                                                  (raz-sched-v1), bit-exact vs the reference on such a loop */
+    uint64_t pool_bytes_per_game;             /* bytes of a game's node pool.  Nodes are compact and variable-size: 40 B + 20 B per
+                                                 LEGAL move of the position (the reference keeps three f64[64] per key = 1536 B,
+                                                 agent/player.py:62-66), ~212 B on average over a game, 704 B at most.
+                                                 0 = nodes_per_game x 232 + 64 x 704; at most 256 MB */
 } raz_engine_config;
 
 typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */
@@ -176,8 +180,9 @@ typedef struct {
     uint64_t nn_leaves;       /* leaf positions sent to the net */
     uint64_t error_flags;     /* 0 = ok; 1 node pool full, 2 table full, 4 records full, 8 path overflow */
     uint64_t selections;      /* select_action_q_and_u calls (sum of descent depths) */
-    uint64_t max_pool_used;   /* largest node-pool fill over the running games */
+    uint64_t max_pool_used;   /* most nodes in a running game's pool (limit: nodes_per_game) */
     uint64_t idle_or_done;    /* slots that are idle (never started / one-move mode finished) or finished */
+    uint64_t max_pool_bytes;  /* most bytes used in a running game's pool (limit: pool_bytes_per_game) */
 } raz_engine_stats;
 
 size_t raz_engine_workspace_bytes(const raz_engine_config* cfg);
@@ -239,7 +244,9 @@ int raz_engine_read_node(raz_engine* e, uint32_t slot, uint64_t black, uint64_t 
                          int owner, double* w64, uint32_t* n64, float* p64, int* found, raz_stream_t stream);
 /* Prune the nodes no future search can reach (positions with fewer discs than the current real
  * position; the disc count only grows) in every game whose pool holds >= threshold nodes, compacting
- * the pool and rebuilding that game's table.  Does not change any result.  Asynchronous. */
+ * the pool and rebuilding that game's table.  Does not change any result.  Asynchronous.  A pool is full when EITHER its node
+ * count reaches nodes_per_game or its bytes reach pool_bytes_per_game (error flag 1): prune when
+ * max_pool_used / max_pool_bytes of raz_engine_stats_sync come close (a simulation adds at most two nodes of <= 704 B). */
 int raz_engine_gc(raz_engine* e, uint32_t threshold, raz_stream_t stream);
 /* Number of slices/streams a step is split into (1..8; 1 = one tree launch + one net launch over the
  * whole batch).  Call with the stream idle. */

@@ -71,7 +71,7 @@ class RazEngineConfig(ctypes.Structure):
                 ("n_games", c_uint32), ("nodes_per_game", c_uint32), ("table_slots", c_uint32),
                 ("max_plies", c_uint32), ("seed", c_uint32), ("reserved", c_uint32),
                 ("use_solver_turn", ctypes.c_int32), ("use_solver_turn_in_simulation", ctypes.c_int32),
-                ("solver_memo_slots", c_uint32), ("parallel_search_num", c_uint32)]
+                ("solver_memo_slots", c_uint32), ("parallel_search_num", c_uint32), ("pool_bytes_per_game", c_uint64)]
 
 
 class RazHarvestResult(ctypes.Structure):
@@ -80,7 +80,8 @@ class RazHarvestResult(ctypes.Structure):
 
 class RazEngineStats(ctypes.Structure):
     _fields_ = [("finished_games", c_uint64), ("total_sims", c_uint64), ("nn_leaves", c_uint64),
-                ("error_flags", c_uint64), ("selections", c_uint64), ("max_pool_used", c_uint64), ("idle_or_done", c_uint64)]
+                ("error_flags", c_uint64), ("selections", c_uint64), ("max_pool_used", c_uint64), ("idle_or_done", c_uint64),
+                ("max_pool_bytes", c_uint64)]
 
 
 SIGNATURES.update({
@@ -127,8 +128,8 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.raz_abi_version() != 1:
-    raise ImportError(f"libraz ABI version {lib.raz_abi_version()} != 1 (stale build?)")
+if lib.raz_abi_version() != 2:
+    raise ImportError(f"libraz ABI version {lib.raz_abi_version()} != 2 (stale build?)")
 
 
 def last_error() -> str:

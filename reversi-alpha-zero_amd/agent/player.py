@@ -164,8 +164,8 @@ class ReversiPlayer:
             st = eng.stats()   # raises on engine error flags (node pool / table / record overflow)
             if st["idle_or_done"] >= eng.n_games:
                 break
-            if st["max_pool_used"] + eng.nodes_per_step * chunk + 64 > cap:
-                eng.gc(threshold=cap // 4)
+            if eng.pool_nearly_full(st, chunk):
+                eng.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
             if callback_in_mtcs and callback_in_mtcs.callback:
                 callback_in_mtcs.callback(list(self.var_q(key)), list(self.var_n[key]))
             if self.requested_stop_thinking and not stop_sent:

@@ -6,12 +6,20 @@
 //
 // HBM layout (all arrays indexed by game slot g first, so one game's data is contiguous for the
 // wave that owns it and different games never share a cache line of mutable data):
-//   tree nodes   : node g,i = 1408-byte block [W f64 x64 | N u32 x64 | P f32 x64 | child u32 x64 | header];
-//                  P holds the prior already masked by the legal moves and normalised (what
-//                  select_action_q_and_u recomputes at every visit, player.py:404-413, depends only
-//                  on the node); child[a] links to the node reached by action a, so a descent costs
-//                  ONE dependent memory round trip per level; the header carries key, legal mask,
-//                  expanded flags and the index of the colour-mirrored node
+//   tree nodes   : COMPACT, variable-size: a node holds statistics for its position's L legal moves only (average 8.5 of
+//                  64 squares).  Node = 40-byte header {black, white, legal, tag, mirror link, creation index} followed by
+//                  four arrays of L entries - W f64 | N u32 | P f32 | child u32 - entry r belonging to the r-th legal
+//                  square in ascending order: 40 + 20 L bytes rounded up to 8 (~210 B on average; the reference's
+//                  per-key f64[64] x 3 is 1536 B, the fixed 64-lane block this replaces was 1408 B).  A game's nodes
+//                  are packed back to back in its byte pool.  A node is referred to by a LINK = (offset / 8) << 6 | L,
+//                  so whoever follows a link knows the node's size and array offsets before its header arrives: a
+//                  descent still costs ONE dependent memory round trip per level (header + the four arrays requested
+//                  together, lane r < L loading entry r).  P holds the prior already masked by the legal moves and
+//                  normalised (what select_action_q_and_u recomputes at every visit, player.py:404-413); child[r] is
+//                  the link of the node reached by the r-th legal move (0 = not linked yet, bit 31 = edge known to end
+//                  the game, low bits = winner).  PUCT runs in RANK space (lane r = r-th legal move): ascending rank
+//                  is ascending square, so numpy's first-maximum argmax and the Dirichlet sample order are unchanged.
+//   node dir     : link of the i-th node created in a game (creation order = ascending offset): k_gc walks it
 //   hash table   : H slots of 32 B {black, white, idx|tag}, open addressing, linear probing, probed
 //                  16 slots (512 B, one coalesced request) at a time; used only for first arrivals
 //   per-sim path : 64 x (node idx u32, action|np u8)
@@ -20,7 +28,11 @@
 #include <stdint.h>
 #include "../../include/raz.h"
 
-#define RAZ_NODE_BYTES 1408
+#define RAZ_NODE_HDR_BYTES 40
+#define RAZ_NODE_ENTRY_BYTES 20          // W f64 + N u32 + P f32 + child u32 per legal move
+#define RAZ_NODE_MAX_BYTES 704           // 40 + 20 x 33 legal moves (the most a Reversi position can have), rounded up to 8
+#define RAZ_NODE_DEFAULT_BYTES 232       // default pool budget per node of nodes_per_game (the whole-game average is ~212)
+#define RAZ_NODE_OUT_BYTES 1408          // staging of raz_engine_read_node: the node expanded to W f64 x64 | N u32 x64 | P f32 x64
 #define RAZ_SLOT_BYTES 32
 #define RAZ_PROBE 16
 
@@ -49,26 +61,26 @@
 // along an edge (afterwards the parent's child link leads straight to the node).
 struct raz_slot {  // 32 bytes
     unsigned long long black, white;
-    uint32_t idx_tag;  // node index << 8 | used<<7 | owner<<2 | next_player
-    uint32_t pad0;
+    uint32_t idx_tag;  // used<<7 | owner<<2 | next_player   (the solver memo packs its answer into the upper bits)
+    uint32_t link;     // the node's link
     unsigned long long pad1;
 };
 #define RAZ_SLOT_USED 0x80u
 #define RAZ_SLOT_KEYMASK 0x07u
 
-// Header stored inside the node block (one 32-byte broadcast load with the node's vectors).
+// Header at the start of a node (one 40-byte broadcast load, requested together with the node's arrays).
 struct raz_node_hdr {
     unsigned long long black, white;  // key
-    unsigned long long legal;         // legal moves of the side to move (computed once)
+    unsigned long long legal;         // legal moves of the side to move (computed once); L = popcount
     uint32_t tag;                     // next_player | owner<<2 | expanded_by_black<<4 | expanded_by_white<<5
                                       // | being expanded by black<<6 / white<<7 (now_expanding, parallel_search_num > 1)
-    uint32_t mirror;                  // node index of the colour-mirrored key, 0xffffffff = none yet
+    uint32_t mirror;                  // link of the colour-mirrored key's node, 0xffffffff = none yet
+    uint32_t index;                   // creation index in the game's node directory
+    uint32_t gc_index;                // scratch of k_gc: the index after compaction
 };
-#define RAZ_NODE_W 0
-#define RAZ_NODE_N 512
-#define RAZ_NODE_P 768
-#define RAZ_NODE_CHILD 1024   // u32 x64: node index + 1 of the position after action i, 0 = not linked yet
-#define RAZ_NODE_HDR 1280
+// A LINK names a node: bits 6..30 = byte offset in the game's pool / 8, bits 0..5 = L (legal moves = array length).
+// 0 = no link (offset 0 of a pool is never a node), bit 31 = not a node (RAZ_NO_NODE, or a terminal edge in child[]).
+#define RAZ_LINK_MAX_UNITS (1u << 25)    // pools of up to 256 MB per game
 #define RAZ_NO_NODE 0xffffffffu
 
 struct raz_ply_header {  // 48 bytes, one per recorded ply (== orc_ply_record minus the vectors)
@@ -94,7 +106,7 @@ struct raz_game {
     uint32_t enable_resign, resigned[2], one_move;  // resigned[p]: ReversiPlayer.resigned of black / white
     uint32_t ev_expand, ev_choice, ev_dirichlet, sims_per_move;  // raz-rng-v1 event counters
     int32_t sims_left;
-    uint32_t loops_done, move_sims, pool_used;
+    uint32_t loops_done, move_sims, pool_used;      // pool_used: next free offset of the node pool in 8-byte units (starts at 1)
     uint32_t n_plies, error, root_node, leaf_kind;
     uint32_t leaf_sym, leaf_np, depth, leaf_action; // D4 transform shown to the net, side to move at the leaf, path length
     uint32_t leaf_node, leaf_slot, leaf_tag, leaf_mirror;  // existing node of the leaf (or RAZ_NO_NODE) / empty slot found
@@ -108,7 +120,8 @@ struct raz_game {
     // under, so that its result does not depend on when other games finish (worker/self_play.py:250-260 mutates the value)
     unsigned long long resign_thr;                  // f64 bits, valid when resign_mode == 1
     uint32_t resign_mode;                           // 0 = the engine's run-time value (raz_engine_set_resign_threshold), 1 = resign_thr, 2 = no rule
-    uint32_t pad[11];
+    uint32_t node_count;                            // nodes in the pool (= entries of the node directory)
+    uint32_t pad[10];
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");
@@ -130,7 +143,8 @@ struct raz_leaf_cache_dev {
 // Pointers into the caller-provided workspace + the play parameters.  Passed BY VALUE to kernels.
 struct raz_engine_dev {
     raz_engine_config cfg;
-    uint32_t B, C, H, max_plies;
+    uint32_t B, C, H, max_plies;   // C: node COUNT capacity per game (directory / table sizing)
+    unsigned long long pool_bytes; // bytes of one game's node pool (multiple of 8, <= 8 x RAZ_LINK_MAX_UNITS)
     uint32_t K;                    // simulation slots per game: parallel_search_num (1 for the classic one-in-flight kernel)
     uint32_t par;                  // 1: k_tree_par drives the games (per-slot state in `sim`), 0: k_tree
     uint32_t* sim;                 // [B][K][64] slot blocks (raz_game layout), par only
@@ -141,10 +155,11 @@ struct raz_engine_dev {
     unsigned long long *nn_own, *nn_enemy;
     float *nn_policy /*[B*K][64]*/, *nn_value;
     uint32_t *path_node /*[B*K][64]*/, *path_mirror /*[B*K][64]*/;
-    uint8_t* path_act /*[B*K][64]*/;
+    uint16_t* path_act /*[B*K][64]: action | side to move << 6 | rank of the action among the node's legal moves << 8*/;
     // tree
     raz_slot* table;               // [B][H]
-    unsigned char* nodes;          // [B][C][1024]
+    unsigned char* nodes;          // [B][pool_bytes]
+    uint32_t* node_dir;            // [B][C] link of the i-th node created
     // records
     raz_ply_header* rec;           // [B][max_plies]
     uint32_t* rec_n;               // [B][max_plies][64]
@@ -152,8 +167,8 @@ struct raz_engine_dev {
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games, [6] idle or finished slots
     raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
     uint32_t M;
-    unsigned char* node_out;       // RAZ_NODE_BYTES + 64: staging of raz_engine_read_node
-    uint32_t* gc_remap;            // [B][C] old -> new node index during k_gc
+    unsigned char* node_out;       // RAZ_NODE_OUT_BYTES + 64: staging of raz_engine_read_node
+    uint32_t* gc_remap;            // [B][C] creation index -> link after compaction, during k_gc
     unsigned long long* counters;
     unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)
 };

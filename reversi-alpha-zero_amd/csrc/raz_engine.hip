@@ -1,8 +1,9 @@
 // raz_engine.hip — the batched MCTS self-play engine: ONE WAVEFRONT PER GAME, LANE = BOARD SQUARE.
 //
 // What the reference does per game in Python (agent/player.py) and what happens here:
-//   * the three 64-vectors N / W / P of a position are one 1 KiB node block in HBM; a wave loads
-//     them with three fully coalesced requests, lane i holding action i (player.py:62-69);
+//   * the three 64-vectors N / W / P of a position (player.py:62-69) are stored for its LEGAL moves only, in one
+//     compact variable-size node in HBM (raz_engine.h); a wave loads them in one round trip, lane r holding the
+//     r-th legal move;
 //   * PUCT (select_action_q_and_u, :395-428) is per-lane f32/f64 arithmetic in the reference's
 //     exact dtype order + wave reductions (exact integer sum of N, numpy's pairwise f32 sum of p,
 //     first-maximum argmax);
@@ -187,7 +188,7 @@ __device__ __forceinline__ uint32_t key_hash(raz_bb b, raz_bb w, uint32_t tagkey
 
 struct Found {        // all fields wave-uniform
     bool found;
-    uint32_t node;    // valid when found
+    uint32_t node;    // the node's link, valid when found
     uint32_t slot;    // first empty slot when !found; 0xffffffff = table full
 };
 
@@ -204,7 +205,7 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
         const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
         const raz_slot* s = tab + si;
         const raz_bb sb = s->black, sw = s->white;
-        const uint32_t it = s->idx_tag;
+        const uint32_t it = s->idx_tag, lk = s->link;
         const bool used = (it & RAZ_SLOT_USED) != 0;
         const bool match = used && sb == b && sw == w && (it & RAZ_SLOT_KEYMASK) == tagkey;
         const unsigned long long mm = __ballot(match) & 0xffffULL;
@@ -212,7 +213,7 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
         if (mm) {
             const int jj = __ffsll((long long)mm) - 1;
             f.found = true;
-            f.node = lane_u32(it, jj) >> 8;
+            f.node = lane_u32(lk, jj);
             return f;
         }
         if (em) {
@@ -223,14 +224,32 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
     return f;
 }
 
-__device__ __forceinline__ unsigned char* node_ptr(const raz_engine_dev& E, uint32_t g, uint32_t node) {
-    return E.nodes + ((size_t)g * E.C + node) * RAZ_NODE_BYTES;
+// ---- compact nodes (raz_engine.h): a LINK = (byte offset / 8) << 6 | L names a node and tells its array length
+__device__ __forceinline__ int link_L(uint32_t link) { return (int)(link & 63u); }
+__device__ __forceinline__ uint32_t link_make(uint32_t off8, int L) { return (off8 << 6) | (uint32_t)L; }
+__device__ __forceinline__ uint32_t node_units(int L) { return (uint32_t)(RAZ_NODE_HDR_BYTES + RAZ_NODE_ENTRY_BYTES * L + 7) >> 3; }
+__device__ __forceinline__ unsigned char* node_ptr(const raz_engine_dev& E, uint32_t g, uint32_t link) {
+    return E.nodes + (size_t)g * E.pool_bytes + (size_t)(link >> 6) * 8;
 }
-__device__ __forceinline__ double* node_W(unsigned char* p) { return (double*)(p + RAZ_NODE_W); }
-__device__ __forceinline__ uint32_t* node_N(unsigned char* p) { return (uint32_t*)(p + RAZ_NODE_N); }
-__device__ __forceinline__ float* node_P(unsigned char* p) { return (float*)(p + RAZ_NODE_P); }
-__device__ __forceinline__ uint32_t* node_child(unsigned char* p) { return (uint32_t*)(p + RAZ_NODE_CHILD); }
-__device__ __forceinline__ raz_node_hdr* node_hdr(unsigned char* p) { return (raz_node_hdr*)(p + RAZ_NODE_HDR); }
+__device__ __forceinline__ raz_node_hdr* node_hdr(unsigned char* p) { return (raz_node_hdr*)p; }
+__device__ __forceinline__ double* node_W(unsigned char* p, int L) { (void)L; return (double*)(p + RAZ_NODE_HDR_BYTES); }
+__device__ __forceinline__ uint32_t* node_N(unsigned char* p, int L) { return (uint32_t*)(p + RAZ_NODE_HDR_BYTES + 8 * L); }
+__device__ __forceinline__ float* node_P(unsigned char* p, int L) { return (float*)(p + RAZ_NODE_HDR_BYTES + 12 * L); }
+__device__ __forceinline__ uint32_t* node_child(unsigned char* p, int L) { return (uint32_t*)(p + RAZ_NODE_HDR_BYTES + 16 * L); }
+// rank of square `sq` among the set bits of `legal` (= index of its entry in the node's arrays)
+__device__ __forceinline__ int rank_of(raz_bb legal, int sq) { return __popcll(legal & ((1ULL << sq) - 1ULL)); }
+// the square of the r-th (0-based) legal move; r < popcount(legal).  Wave-uniform arguments: one ballot.
+__device__ __forceinline__ int square_of_rank(raz_bb legal, int r, int lane) {
+    return __ffsll((long long)__ballot(((legal >> lane) & 1ULL) && rank_of(legal, lane) == r)) - 1;
+}
+// A node's vectors in SQUARE space (lane = board square, zero off the legal moves): what the per-move controller and the
+// records want (player.py:62-69 indexes var_n / var_w by action).
+__device__ __forceinline__ void node_read_squares(unsigned char* p, int L, raz_bb legal, int lane, double& Wi, uint32_t& Ni) {
+    const bool on = (legal >> lane) & 1ULL;
+    const int rk = rank_of(legal, lane);
+    Wi = on ? node_W(p, L)[rk] : 0.0;
+    Ni = on ? node_N(p, L)[rk] : 0u;
+}
 
 // ------------------------------------------------------------------ the game's control block in registers
 // raz_game (raz_engine.h) is 64 dwords.  k_tree loads it with ONE coalesced request (lane i = dword
@@ -277,37 +296,67 @@ __device__ __forceinline__ void set64(Regs& R, raz_bb v) {
 #define ADD64(R, I, d) S64(R, I, G64(R, I) + (raz_bb)(d))
 __device__ __forceinline__ void flag_error(Regs& R, uint32_t f) { S32(R, GW(error), G32(R, GW(error)) | f); }
 
-// Allocate a zeroed node for key (b, w, np, owner) in the EMPTY table slot `slot`.
-// Returns RAZ_NO_NODE after flagging an error when out of space.
-__device__ uint32_t node_create_at(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t slot, raz_bb b, raz_bb w,
-                                   uint32_t np, uint32_t owner, raz_bb legal, int lane) {
-    const uint32_t used = G32(R, GW(pool_used));
-    if (slot == 0xffffffffu || used >= E.C) {
-        flag_error(R, (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
-        return RAZ_NO_NODE;
+// Reserve room for a node with L legal moves at the end of the game's pool: `used` (8-byte units) and `count` are the
+// caller's running copies of pool_used / node_count.  Returns the new node's link, or RAZ_NO_NODE when the pool's bytes
+// or its node count are exhausted (the caller flags the error).
+__device__ __forceinline__ uint32_t pool_take(const raz_engine_dev& E, int L, uint32_t& used, uint32_t& count) {
+    const uint32_t units = node_units(L);
+    if (count >= E.C || (unsigned long long)(used + units) * 8ULL > E.pool_bytes) return RAZ_NO_NODE;
+    const uint32_t link = link_make(used, L);
+    used += units;
+    ++count;
+    return link;
+}
+
+// Write node `link` (just taken from the pool as the game's node number `index`) for key (b, w, tag) into the EMPTY table
+// slot `slot`: statistics zero, prior `prior_sq` given in SQUARE space (lane = square; only the legal lanes store).
+// Pure stores: nothing is read back.
+__device__ __forceinline__ void node_init(const raz_engine_dev& E, uint32_t g, uint32_t link, uint32_t index, uint32_t slot,
+                                          raz_bb b, raz_bb w, uint32_t tag, raz_bb legal, uint32_t mirror,
+                                          float prior_sq, int lane) {
+    unsigned char* p = node_ptr(E, g, link);
+    const int L = link_L(link);
+    if ((legal >> lane) & 1ULL) {
+        const int rk = rank_of(legal, lane);
+        node_W(p, L)[rk] = 0.0;
+        node_N(p, L)[rk] = 0u;
+        node_P(p, L)[rk] = prior_sq;
+        node_child(p, L)[rk] = 0u;
     }
-    const uint32_t tagkey = np | (owner << 2);
-    unsigned char* p = node_ptr(E, g, used);
-    node_W(p)[lane] = 0.0;
-    node_N(p)[lane] = 0u;
-    node_P(p)[lane] = 0.0f;
-    node_child(p)[lane] = 0u;
     if (lane == 0) {
         raz_node_hdr h;
         h.black = b;
         h.white = w;
         h.legal = legal;
-        h.tag = tagkey;
-        h.mirror = RAZ_NO_NODE;
+        h.tag = tag;
+        h.mirror = mirror;
+        h.index = index;
+        h.gc_index = 0;
         *node_hdr(p) = h;
+        E.node_dir[(size_t)g * E.C + index] = link;
         raz_slot* s = E.table + (size_t)g * E.H + slot;
         s->black = b;
         s->white = w;
-        s->idx_tag = (used << 8) | RAZ_SLOT_USED | tagkey;
+        s->link = link;
+        s->idx_tag = RAZ_SLOT_USED | (tag & RAZ_SLOT_KEYMASK);
     }
-    S32(R, GW(pool_used), used + 1);
+}
+
+// Allocate a zeroed node for key (b, w, np, owner) in the EMPTY table slot `slot`.
+// Returns RAZ_NO_NODE after flagging an error when out of space.
+__device__ uint32_t node_create_at(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t slot, raz_bb b, raz_bb w,
+                                   uint32_t np, uint32_t owner, raz_bb legal, int lane) {
+    uint32_t used = G32(R, GW(pool_used)), count = G32(R, GW(node_count));
+    const uint32_t link = slot == 0xffffffffu ? RAZ_NO_NODE : pool_take(E, __popcll(legal), used, count);
+    if (link == RAZ_NO_NODE) {
+        flag_error(R, (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
+        return RAZ_NO_NODE;
+    }
+    node_init(E, g, link, count - 1, slot, b, w, np | (owner << 2), legal, RAZ_NO_NODE, 0.0f, lane);
+    S32(R, GW(pool_used), used);
+    S32(R, GW(node_count), count);
     wave_sync();
-    return used;
+    return link;
 }
 
 // defaultdict access: find the node of (b, w, np) for `owner`, creating a zeroed one if absent.
@@ -336,12 +385,17 @@ __device__ __forceinline__ void env_step(Env& e, int action) {
 }
 
 // ------------------------------------------------------------------ select (agent/player.py:395-428)
+// RANK space: lane r < k holds the statistics of the node's r-th legal move in ascending square order (the node's
+// arrays as they lie in memory), the other lanes hold zeros.  The reference masks by the legal moves (`* legal`), so
+// squares that are not legal never win the argmax; ascending rank is ascending square, so the first-maximum rule, the
+// order of the Dirichlet samples (sample j belongs to the j-th legal square) and every sum below are the reference's.
 // The node's P already holds normalize(P * legal) in float32 (player.py:404-413 gives the same
 // vector at every visit of a node, so it is computed once, when the net's policy is stored).
+// Returns the RANK of the chosen move.
 __device__ int select_action(const raz_engine_dev& E, Regs& R, uint32_t g, double Wi, uint32_t Ni, float p32,
-                             raz_bb legal, uint32_t np, bool is_root, uint32_t game_id, int lane) {
+                             int k, uint32_t np, bool is_root, uint32_t game_id, int lane) {
     const raz_engine_config& c = E.cfg;
-    const uint32_t bit = (uint32_t)((legal >> lane) & 1ULL);
+    const uint32_t bit = lane < k ? 1u : 0u;
     const uint32_t sumN = wave_sum_u32(Ni);
     double xx = sqrt((double)sumN);  // np.sqrt(np.sum(N)); correctly rounded on gfx950 (probe)
     if (xx < 1.0) xx = 1.0;           // max(xx_, 1)
@@ -350,26 +404,18 @@ __device__ int select_action(const raz_engine_dev& E, Regs& R, uint32_t g, doubl
     if (is_root && c.noise_eps > 0.0) {  // (1-eps) p + eps Dir(alpha), fresh at every root visit (:415-417)
         const unsigned long long tp = prof_now();
         const uint32_t ev = G32(R, GW(ev_dirichlet));
-        // Gamma(alpha) sample j belongs to the j-th legal square.  Attempts of the rejection
-        // sampler are independent Philox blocks, so lane l evaluates attempt t = l / k of sample
-        // j = l % k (k legal moves, up to 8 attempts per sample per round) and each legal square
-        // takes its sample's first accepted attempt: one evaluation deep instead of the slowest
-        // lane's rejection count.
-        const int k = __popcll(legal);
-        const uint32_t rank = (uint32_t)__popcll(legal & ((1ULL << lane) - 1ULL));
-        double gam = 0.0;
+        double gam = 0.0;   // Gamma(alpha) sample j belongs to the j-th legal move = lane j
         if (c.dirichlet_alpha == 0.5) {
             // Box-Muller pairs: lane m < ceil(k/2) turns one Philox block into the two Gamma(1/2)
             // variates of legal moves 2m and 2m+1 (no rejection, no divergence).
             double g0 = 0.0, g1 = 0.0;
             if (2 * lane < k) raz_gamma_half_pair(c.seed, game_id, ev, (uint32_t)lane, g0, g1);
-            const double s0 = __shfl(g0, (int)(rank >> 1)), s1 = __shfl(g1, (int)(rank >> 1));
-            if (bit) gam = (rank & 1u) ? s1 : s0;
+            const double s0 = __shfl(g0, lane >> 1), s1 = __shfl(g1, lane >> 1);
+            if (bit) gam = (lane & 1) ? s1 : s0;
         } else {
-            // Gamma(alpha) sample j belongs to the j-th legal square.  Attempts of the rejection
-            // sampler are independent Philox blocks, so lane l evaluates attempt t = l / k of sample
-            // j = l % k (up to 8 attempts per sample per round) and each legal square takes its
-            // sample's first accepted attempt.
+            // Attempts of the rejection sampler are independent Philox blocks, so lane l evaluates attempt t = l / k of
+            // sample j = l % k (up to 8 attempts per sample per round) and each legal move takes its sample's first
+            // accepted attempt: one evaluation deep instead of the slowest lane's rejection count.
             int A = 64 / k;
             if (A > 8) A = 8;
             int myt = 0;
@@ -385,7 +431,7 @@ __device__ int select_action(const raz_engine_dev& E, Regs& R, uint32_t g, doubl
                 int src = -1;
                 if (need) {
                     for (int t = 0; t < A; ++t) {
-                        const int l = (int)rank + k * t;
+                        const int l = lane + k * t;
                         if ((am >> l) & 1ULL) {
                             src = l;
                             break;
@@ -401,7 +447,7 @@ __device__ int select_action(const raz_engine_dev& E, Regs& R, uint32_t g, doubl
             }
         }
         double acc = 0.0;
-        for (raz_bb m = legal; m; m &= m - 1) acc += lane_f64(gam, __ffsll((long long)m) - 1);
+        for (int j = 0; j < k; ++j) acc += lane_f64(gam, j);
         const double noise = bit ? gam / acc : 0.0;
         const float keep = (float)(1.0 - c.noise_eps);
         const double p64 = (double)(keep * p32) + c.noise_eps * noise;
@@ -558,60 +604,38 @@ __device__ bool solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_
 }
 
 // ------------------------------------------------------------------ backup of the previous leaf
-// Allocate node `idx` (the caller tracks the pool counter) for key (b, w, np, owner) in the EMPTY
-// table slot `slot`, with prior P already known.  Pure stores: nothing is read back.
-__device__ __forceinline__ void node_init(const raz_engine_dev& E, uint32_t g, uint32_t idx, uint32_t slot,
-                                          raz_bb b, raz_bb w, uint32_t tag, raz_bb legal, uint32_t mirror,
-                                          float prior, int lane) {
-    unsigned char* p = node_ptr(E, g, idx);
-    node_W(p)[lane] = 0.0;
-    node_N(p)[lane] = 0u;
-    node_P(p)[lane] = prior;
-    node_child(p)[lane] = 0u;
-    if (lane == 0) {
-        raz_node_hdr h;
-        h.black = b;
-        h.white = w;
-        h.legal = legal;
-        h.tag = tag;
-        h.mirror = mirror;
-        *node_hdr(p) = h;
-        raz_slot* s = E.table + (size_t)g * E.H + slot;
-        s->black = b;
-        s->white = w;
-        s->idx_tag = (idx << 8) | RAZ_SLOT_USED | (tag & RAZ_SLOT_KEYMASK);
-    }
-}
-
 // Leaf node + its colour-mirrored node for a leaf that is being expanded (prior = the net's policy)
 // or was solved (prior = one-hot): create / update them and cross-link.  Returns false when out of
-// space.  `used` is the running pool counter.
+// space.  `used` / `count` are the running pool counters (8-byte units / nodes); `prior` is in SQUARE space.
 __device__ bool place_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, uint32_t owner, uint32_t np,
                            raz_bb kb, raz_bb kw, raz_bb lg, uint32_t new_tag_bits, float prior, bool with_mirror,
-                           int depth, uint32_t& node, uint32_t& mirror, uint32_t& used) {
+                           int depth, uint32_t& node, uint32_t& mirror, uint32_t& used, uint32_t& count) {
     node = G32(R, GW(leaf_node));
     mirror = RAZ_NO_NODE;
     const uint32_t tagkey = np | (owner << 2);
+    const int L = __popcll(lg);
+    const bool on = (lg >> lane) & 1ULL;
+    const int rk = rank_of(lg, lane);
+    const uint32_t old_tag = G32(R, GW(leaf_tag)), old_mirror = G32(R, GW(leaf_mirror));   // (cross-lane reads stay outside lane-0 branches)
     if (node == RAZ_NO_NODE) {  // first arrival at this position: create it in the slot select found
         uint32_t slot = G32(R, GW(leaf_slot));
         if (slot == 0xfffffffeu) slot = table_find(E, g, kb, kw, tagkey, lane).slot;  // table rebuilt by k_gc
-        if (slot == 0xffffffffu || used >= E.C) {
+        node = slot == 0xffffffffu ? RAZ_NO_NODE : pool_take(E, L, used, count);
+        if (node == RAZ_NO_NODE) {
             flag_error(R, (slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
             return false;
         }
-        node = used++;
-        node_init(E, g, node, slot, kb, kw, tagkey | new_tag_bits, lg, RAZ_NO_NODE, prior, lane);
+        node_init(E, g, node, count - 1, slot, kb, kw, tagkey | new_tag_bits, lg, RAZ_NO_NODE, prior, lane);
         if (depth > 0) {  // link the parent's edge to it
             const uint32_t parent = lane_u32(R.pnode, depth - 1);
             const uint32_t pa = lane_u32(R.pact, depth - 1);
-            if (lane == 0) node_child(node_ptr(E, g, parent))[pa & 63u] = node + 1;
+            if (lane == 0) node_child(node_ptr(E, g, parent), link_L(parent))[pa >> 8] = node;
         }
     } else {  // existing node: store the prior (and the expanded flag)
         unsigned char* p = node_ptr(E, g, node);
-        node_P(p)[lane] = prior;
-        const uint32_t old_tag = G32(R, GW(leaf_tag));   // (read by all lanes: a cross-lane read stays outside the lane-0 branch)
+        if (on) node_P(p, L)[rk] = prior;
         if (new_tag_bits && lane == 0) node_hdr(p)->tag = old_tag | new_tag_bits;
-        mirror = G32(R, GW(leaf_mirror));
+        mirror = old_mirror;
     }
     if (!with_mirror) {
         mirror = RAZ_NO_NODE;
@@ -622,19 +646,20 @@ __device__ bool place_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
         const Found f = table_find(E, g, kw, kb, (3 - np) | (owner << 2), lane);
         if (f.found) {
             mirror = f.node;
-            node_P(node_ptr(E, g, mirror))[lane] = prior;
-        } else if (f.slot == 0xffffffffu || used >= E.C) {
-            flag_error(R, (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
+            if (on) node_P(node_ptr(E, g, mirror), L)[rk] = prior;
         } else {
-            mirror = used++;
-            node_init(E, g, mirror, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, prior, lane);
+            mirror = f.slot == 0xffffffffu ? RAZ_NO_NODE : pool_take(E, L, used, count);
+            if (mirror == RAZ_NO_NODE)
+                flag_error(R, (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
+            else   // (the mirror key has the same side's moves on the same squares: same legal mask, same L)
+                node_init(E, g, mirror, count - 1, f.slot, kw, kb, (3 - np) | (owner << 2), lg, node, prior, lane);
         }
         if (mirror != RAZ_NO_NODE && lane == 0) {
             node_hdr(node_ptr(E, g, node))->mirror = mirror;
             node_hdr(node_ptr(E, g, mirror))->mirror = node;
         }
     } else {
-        node_P(node_ptr(E, g, mirror))[lane] = prior;
+        if (on) node_P(node_ptr(E, g, mirror), L)[rk] = prior;
     }
     return true;
 }
@@ -651,20 +676,22 @@ __device__ void backup_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, uint32
     if (kind == RAZ_LEAF_NONE) return;
     const uint32_t owner = c.share_mtcs_info ? 0u : pl;
     const int depth = (int)G32(R, GW(depth));
-    // the path cells: every level is an independent (node, action) cell
+    // the path cells: every level is an independent (node, rank of the action) cell; a node and its colour-mirrored
+    // node have the same legal mask, hence the same array length and the same rank for an action
     const uint32_t my_node = R.pnode, my_mirror = R.pmirror, my_pa = R.pact;
-    const uint32_t a = my_pa & 63u;
+    const uint32_t a = my_pa >> 8;
     const uint32_t m = c.mirror_updates ? my_mirror : RAZ_NO_NODE;
+    const int Lp = link_L(my_node);
     uint32_t n0 = 0, n1 = 0;
     double w0 = 0.0, w1 = 0.0;
     unsigned char *p = nullptr, *q = nullptr;
     if (lane < depth) {  // issued first: in flight while the leaf is placed
         p = node_ptr(E, g, my_node);
         q = node_ptr(E, g, m == RAZ_NO_NODE ? my_node : m);
-        n0 = node_N(p)[a];
-        w0 = node_W(p)[a];
-        n1 = node_N(q)[a];
-        w1 = node_W(q)[a];
+        n0 = node_N(p, Lp)[a];
+        w0 = node_W(p, Lp)[a];
+        n1 = node_N(q, Lp)[a];
+        w1 = node_W(q, Lp)[a];
     }
     double leaf_v;
     const unsigned long long te = prof_now();
@@ -676,52 +703,55 @@ __device__ void backup_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, uint32
         // the net saw T(board); its policy q is over T-squares, so p[s] = q[T(s)]
         const float pol = __shfl(R.pol_raw, bb_d4_square(lane, (sym >> 2) & 1, sym & 3));
         const float pn = masked_normalised_prior(pol, lg, lane, lds64);
-        uint32_t used = G32(R, GW(pool_used));
+        uint32_t used = G32(R, GW(pool_used)), count = G32(R, GW(node_count));
         uint32_t node, mirror;
-        place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 16u << pl, pn, c.mirror_updates != 0, depth, node, mirror, used);
+        place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 16u << pl, pn, c.mirror_updates != 0, depth, node, mirror, used, count);
         S32(R, GW(pool_used), used);
+        S32(R, GW(node_count), count);
     } else if (kind == RAZ_LEAF_SOLVED) {  // in-simulation solver hit (:239-251): the key and its mirror get
         // N += 1, W +-= sign(score), P = one-hot; the key is NOT marked expanded
         const uint32_t np = G32(R, GW(leaf_np)), act = G32(R, GW(leaf_action));
         const raz_bb lg = G64(R, GW(leaf_legal)), kb = G64(R, GW(leaf_b)), kw = G64(R, GW(leaf_w));
         leaf_v = (double)raz_bits_to_f32(G32(R, GW(leaf_term_v)));  // sign(score) in the searching player's view
         const float onehot = lane == (int)act ? 1.0f : 0.0f;
-        uint32_t used = G32(R, GW(pool_used));
+        uint32_t used = G32(R, GW(pool_used)), count = G32(R, GW(node_count));
         uint32_t node, mirror;
         // (:248-250) writes to the mirror key are dead without a shared tree
-        const bool ok = place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 0u, onehot, c.mirror_updates != 0, depth, node, mirror, used);
+        const bool ok = place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 0u, onehot, c.mirror_updates != 0, depth, node, mirror, used, count);
         if (ok) {
             wave_sync();
             if (lane == 0) {
+                const int L = __popcll(lg), ra = rank_of(lg, (int)act);
                 unsigned char* pp = node_ptr(E, g, node);
-                node_N(pp)[act] += 1u;
-                node_W(pp)[act] = node_W(pp)[act] + leaf_v;
+                node_N(pp, L)[ra] += 1u;
+                node_W(pp, L)[ra] = node_W(pp, L)[ra] + leaf_v;
                 if (mirror != RAZ_NO_NODE) {
                     unsigned char* qq = node_ptr(E, g, mirror);
-                    node_N(qq)[act] += 1u;
-                    node_W(qq)[act] = node_W(qq)[act] - leaf_v;
+                    node_N(qq, L)[ra] += 1u;
+                    node_W(qq, L)[ra] = node_W(qq, L)[ra] - leaf_v;
                 }
             }
         }
         S32(R, GW(pool_used), used);
+        S32(R, GW(node_count), count);
     } else {
         leaf_v = (double)raz_bits_to_f32(G32(R, GW(leaf_term_v)));
     }
     prof_add(E, g, 7, te, lane);
     if (lane < depth) {  // N += vl; W -= vlw; ...; N += -vl + 1; W += vlw + leaf_v  (:270-277)
         const double vl = (double)c.virtual_loss;
-        const uint32_t npd = my_pa >> 6;
+        const uint32_t npd = (my_pa >> 6) & 3u;
         const double vlw = npd == 1 ? vl : -vl;
         if (PAR) {
-            node_N(p)[a] = n0 + 1u - (uint32_t)c.virtual_loss;
-            node_W(p)[a] = w0 + (vlw + leaf_v);
+            node_N(p, Lp)[a] = n0 + 1u - (uint32_t)c.virtual_loss;
+            node_W(p, Lp)[a] = w0 + (vlw + leaf_v);
         } else {
-            node_N(p)[a] = n0 + 1u;
-            node_W(p)[a] = (w0 - vlw) + (vlw + leaf_v);
+            node_N(p, Lp)[a] = n0 + 1u;
+            node_W(p, Lp)[a] = (w0 - vlw) + (vlw + leaf_v);
         }
         if (m != RAZ_NO_NODE) {  // another_side_counter_key (:279-280); exists since the node's expansion
-            node_N(q)[a] = n1 + 1u;
-            node_W(q)[a] = w1 - leaf_v;
+            node_N(q, Lp)[a] = n1 + 1u;
+            node_W(q, Lp)[a] = w1 - leaf_v;
         }
     }
     S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
@@ -792,8 +822,9 @@ __device__ void decide_move(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         return;
     }
     unsigned char* p = node_ptr(E, g, node);
-    const uint32_t Ni = node_N(p)[lane];
-    const double Wi = node_W(p)[lane];
+    uint32_t Ni;   // the root's statistics by SQUARE (var_n[key][action], var_w[key][action]: zero off the legal moves)
+    double Wi;
+    node_read_squares(p, link_L(node), bb_legal_moves(own, enemy), lane, Wi, Ni);
     const double Nd = (double)Ni;
     const double q = Wi / (Nd + 1e-5);
     const uint32_t sumN = wave_sum_u32(Ni);
@@ -865,19 +896,22 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
     const raz_bb legal = bb_legal_moves(own, enemy);
     const uint32_t node = node_get(E, R, g, own, enemy, 1, owner, legal, lane);
     S32(R, GW(root_node), node);
+    const int L = __popcll(legal), rk = rank_of(legal, lane);
+    const bool on = (legal >> lane) & 1ULL;
     if (SOLVER && c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
         int sm, ss;
         if (solver_solve(E, g, lane, own, enemy, 1u, S, sm, ss)) {
             unsigned char* p = node_ptr(E, g, node);
             const double sg = ss > 0 ? 1.0 : (ss < 0 ? -1.0 : 0.0);
-            node_P(p)[lane] = lane == sm ? 1.0f : 0.0f;
-            uint32_t Ni = node_N(p)[lane];
-            double Wi = node_W(p)[lane];
+            if (on) node_P(p, L)[rk] = lane == sm ? 1.0f : 0.0f;
+            uint32_t Ni;
+            double Wi;
+            node_read_squares(p, L, legal, lane, Wi, Ni);
             if (lane == sm) {
                 Ni = 999u;
                 Wi = sg * 999.0;
-                node_N(p)[lane] = Ni;
-                node_W(p)[lane] = Wi;
+                node_N(p, L)[rk] = Ni;
+                node_W(p, L)[rk] = Wi;
             }
             wave_sync();
             finalize_move(E, R, g, lane, player, rb, rw, own, enemy, turn, sm, false, true, 999.0, sg, 0u, Ni, Wi);
@@ -890,12 +924,11 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
     } else {
         if (node != RAZ_NO_NODE) {
             unsigned char* p = node_ptr(E, g, node);
-            const int first = __ffsll((long long)legal) - 1;
             const int cnt = bb_popcount(legal);
-            node_P(p)[lane] = (float)((double)((legal >> lane) & 1ULL) / (double)cnt);
-            if (lane == first) {
-                node_N(p)[lane] = 1u;
-                node_W(p)[lane] = 0.0;
+            if (on) node_P(p, L)[rk] = (float)((double)((legal >> lane) & 1ULL) / (double)cnt);
+            if (on && rk == 0) {   // the first legal move
+                node_N(p, L)[0] = 1u;
+                node_W(p, L)[0] = 0.0;
             }
         }
         S32(R, GW(sims_left), 0u);
@@ -938,17 +971,20 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         return;
     }
     for (;;) {
-        // one round trip: header (broadcast) + the node's four vectors, lane i holding action i.
-        // The header carries the position itself, so following a linked edge needs no move
-        // generation: flips and legal moves are computed once, when an edge is first taken.
+        // one round trip: header (broadcast) + the node's four arrays, lane r < L holding the r-th legal move (the link
+        // carries L, so the arrays' addresses do not wait for the header).  The header carries the position itself, so
+        // following a linked edge needs no move generation: flips and legal moves are computed once, when an edge is
+        // first taken.
         unsigned char* p = node_ptr(E, g, node);
+        const int L = link_L(node);
         const raz_node_hdr* hp = node_hdr(p);
         const raz_bb hb = hp->black, hw = hp->white, legal = hp->legal;
         const uint32_t tag = hp->tag, hmirror = hp->mirror;
-        const double Wi = node_W(p)[lane];
-        const uint32_t Ni = node_N(p)[lane];
-        const float Pi = node_P(p)[lane];
-        const uint32_t Ci = node_child(p)[lane];
+        const bool have = lane < L;
+        const double Wi = have ? node_W(p, L)[lane] : 0.0;
+        const uint32_t Ni = have ? node_N(p, L)[lane] : 0u;
+        const float Pi = have ? node_P(p, L)[lane] : 0.0f;
+        const uint32_t Ci = have ? node_child(p, L)[lane] : 0u;
         if (RAZ_PROF_ON(E)) {
             const unsigned long long tl = prof_now();
 #ifndef RAZ_WAVE_EMU
@@ -996,17 +1032,18 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
             flag_error(R, RAZ_ERR_PATH_FULL);
             break;
         }
-        const int a = select_action(E, R, g, Wi, Ni, Pi, env.legal, env.np, depth == 0, game_id, lane);
-        if (PAR && lane == a) {  // var_n[key][action_t] += virtual_loss; var_w[key][action_t] -= virtual_loss_for_w (:270-271)
+        const int r = select_action(E, R, g, Wi, Ni, Pi, L, env.np, depth == 0, game_id, lane);   // rank of the move
+        const int a = square_of_rank(env.legal, r, lane);
+        if (PAR && lane == r) {  // var_n[key][action_t] += virtual_loss; var_w[key][action_t] -= virtual_loss_for_w (:270-271)
             const double vl = (double)c.virtual_loss;
-            node_N(p)[a] = Ni + (uint32_t)c.virtual_loss;
-            node_W(p)[a] = Wi - (env.np == 1 ? vl : -vl);
+            node_N(p, L)[r] = Ni + (uint32_t)c.virtual_loss;
+            node_W(p, L)[r] = Wi - (env.np == 1 ? vl : -vl);
         }
         R.pnode = writelane_r(R.pnode, node, depth, lane);
         R.pmirror = writelane_r(R.pmirror, hmirror, depth, lane);
-        R.pact = writelane_r(R.pact, (uint32_t)a | (env.np << 6), depth, lane);
+        R.pact = writelane_r(R.pact, (uint32_t)a | (env.np << 6) | ((uint32_t)r << 8), depth, lane);
         ++depth;
-        const uint32_t child = lane_u32(Ci, a);
+        const uint32_t child = lane_u32(Ci, r);
         if (child & 0x80000000u) {  // edge known to end the game: env.done (:226-232)
             const uint32_t w = child & 3u;
             kind = RAZ_LEAF_TERMINAL;
@@ -1014,7 +1051,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
             break;
         }
         if (child) {
-            node = child - 1;
+            node = child;
             continue;
         }
         // first time along this edge: play the move
@@ -1022,7 +1059,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         if (env.status) {  // env.done (:226-232); remember the result on the edge
             kind = RAZ_LEAF_TERMINAL;
             term_v = env.status == RAZ_WIN_BLACK ? 1.0f : (env.status == RAZ_WIN_WHITE ? -1.0f : 0.0f);
-            if (lane == 0) node_child(p)[a] = 0x80000000u | env.status;
+            if (lane == 0) node_child(p, L)[r] = 0x80000000u | env.status;
             break;
         }
         // the position may already exist (transposition / mirror write)
@@ -1030,7 +1067,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         const Found f = table_find(E, g, env.black, env.white, env.np | (owner << 2), lane);
         prof_add(E, g, 4, tq, lane);
         if (f.found) {
-            if (lane == 0) node_child(p)[a] = f.node + 1;
+            if (lane == 0) node_child(p, L)[r] = f.node;
             node = f.node;
             continue;
         }
@@ -1048,17 +1085,19 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
             }
         }
         if (PAR && kind == RAZ_LEAF_EXPAND) {  // the key enters now_expanding: it needs a node to carry the flag
-            const uint32_t used = G32(R, GW(pool_used));
-            if (f.slot == 0xffffffffu || used >= E.C) {
+            uint32_t used = G32(R, GW(pool_used)), count = G32(R, GW(node_count));
+            const uint32_t fresh = f.slot == 0xffffffffu ? RAZ_NO_NODE : pool_take(E, __popcll(env.legal), used, count);
+            if (fresh == RAZ_NO_NODE) {
                 flag_error(R, (f.slot == 0xffffffffu) ? RAZ_ERR_TABLE_FULL : RAZ_ERR_POOL_FULL);
                 kind = RAZ_LEAF_NONE;
                 break;
             }
             const uint32_t tagkey = env.np | (owner << 2);
-            node_init(E, g, used, f.slot, env.black, env.white, tagkey | (64u << pl), env.legal, RAZ_NO_NODE, 0.0f, lane);
-            if (lane == 0) node_child(p)[a] = used + 1;
-            S32(R, GW(pool_used), used + 1);
-            leaf_node = used;
+            node_init(E, g, fresh, count - 1, f.slot, env.black, env.white, tagkey | (64u << pl), env.legal, RAZ_NO_NODE, 0.0f, lane);
+            if (lane == 0) node_child(p, L)[r] = fresh;
+            S32(R, GW(pool_used), used);
+            S32(R, GW(node_count), count);
+            leaf_node = fresh;
             leaf_tag = tagkey;
         }
         break;
@@ -1164,7 +1203,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
     if (R.path_dirty) {
         E.path_node[(size_t)g * 64 + lane] = R.pnode;
         E.path_mirror[(size_t)g * 64 + lane] = R.pmirror;
-        E.path_act[(size_t)g * 64 + lane] = (uint8_t)R.pact;
+        E.path_act[(size_t)g * 64 + lane] = (uint16_t)R.pact;
     }
     if (lane == 0) E.nn_active[g] = (uint8_t)R.nn;
 }
@@ -1213,7 +1252,7 @@ __device__ __forceinline__ void slot_store(const raz_engine_dev& E, const Regs& 
     if ((kSimLanes >> lane) & 1ULL) E.sim[gi * 64 + lane] = R.cw;
     E.path_node[gi * 64 + lane] = R.pnode;
     E.path_mirror[gi * 64 + lane] = R.pmirror;
-    E.path_act[gi * 64 + lane] = (uint8_t)R.pact;
+    E.path_act[gi * 64 + lane] = (uint16_t)R.pact;
 }
 // the slot of `mask` with the smallest order number (K <= 16: a scalar scan)
 __device__ __forceinline__ int pick_min_seq(uint32_t sq, unsigned long long mask) {
@@ -1379,12 +1418,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // global atomics: 4096 waves hitting one address cost ~90 us per launch (one word saturates at
 // ~88 atomics/us on this chip).
 __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
-    __shared__ unsigned long long sh[7][256];
-    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0, maxpool = 0, idle = 0;
+    __shared__ unsigned long long sh[8][256];
+    unsigned long long fin = 0, sims = 0, err = 0, leaves = 0, sel = 0, maxpool = 0, idle = 0, maxbytes = 0;
     for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
         const raz_game& G = E.game[g];
-        const unsigned long long pu = G.status == 0 ? G.pool_used : 0;
+        const unsigned long long pu = G.status == 0 ? G.node_count : 0, pb = G.status == 0 ? 8ULL * G.pool_used : 0;
         maxpool = pu > maxpool ? pu : maxpool;
+        maxbytes = pb > maxbytes ? pb : maxbytes;
         fin += G.status != 0 ? 1 : 0;
         idle += (G.phase == RAZ_PHASE_IDLE || G.phase == RAZ_PHASE_DONE) ? 1 : 0;
         sims += G.sims;
@@ -1394,19 +1434,20 @@ __global__ __launch_bounds__(256) void k_stats(raz_engine_dev E) {
     }
     sh[0][threadIdx.x] = fin; sh[1][threadIdx.x] = sims; sh[2][threadIdx.x] = err;
     sh[3][threadIdx.x] = leaves; sh[4][threadIdx.x] = sel; sh[5][threadIdx.x] = maxpool; sh[6][threadIdx.x] = idle;
+    sh[7][threadIdx.x] = maxbytes;
     __syncthreads();
-    if (threadIdx.x < 7) {
+    if (threadIdx.x < 8) {
         unsigned long long a = 0;
         for (int i = 0; i < 256; ++i) {
             const unsigned long long x = sh[threadIdx.x][i];
-            a = (threadIdx.x == 2) ? (a | x) : (threadIdx.x == 5 ? (x > a ? x : a) : a + x);
+            a = (threadIdx.x == 2) ? (a | x) : ((threadIdx.x == 5 || threadIdx.x == 7) ? (x > a ? x : a) : a + x);
         }
         // + the games raz_engine_harvest took out of their slots since raz_engine_start: [8] finished, [9] sims, [10] leaves, [11] selections
         if (threadIdx.x == 0) a += E.counters[8];
         if (threadIdx.x == 1) a += E.counters[9];
         if (threadIdx.x == 3) a += E.counters[10];
         if (threadIdx.x == 4) a += E.counters[11];
-        E.counters[threadIdx.x] = a;
+        E.counters[threadIdx.x == 7 ? 16 : threadIdx.x] = a;   // ([8..15] belong to the harvest and the record extent)
     }
 }
 
@@ -1430,6 +1471,7 @@ __global__ void k_start(raz_engine_dev E, uint32_t first_game_id, const uint32_t
     G.root_node = RAZ_NO_NODE;
     G.leaf_node = RAZ_NO_NODE;
     G.leaf_mirror = RAZ_NO_NODE;
+    G.pool_used = 1;   // (8-byte units; offset 0 is never a node, so that a link is never 0)
     E.game[g] = G;
     if (!E.par) E.nn_active[g] = 0;   // (slot kernel: cleared by raz_engine_start, one flag per slot)
 }
@@ -1457,6 +1499,7 @@ __global__ void k_next_game(raz_engine_dev E, uint32_t first_game_id, const uint
     G.leaf_node = RAZ_NO_NODE;
     G.leaf_mirror = RAZ_NO_NODE;
     G.pool_used = E.game[g].pool_used;
+    G.node_count = E.game[g].node_count;
     G.error = E.game[g].error;
     E.game[g] = G;
     if (!E.par) E.nn_active[g] = 0;
@@ -1466,10 +1509,12 @@ __global__ void k_next_game(raz_engine_dev E, uint32_t first_game_id, const uint
 __global__ __launch_bounds__(64) void k_adopt_all(raz_engine_dev E) {
     const uint32_t g = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint32_t used = E.game[g].pool_used;
+    const uint32_t used = E.game[g].node_count;
     for (uint32_t i = blockIdx.y; i < used; i += gridDim.y) {
-        unsigned char* p = node_ptr(E, g, i);
-        const bool has_p = __ballot(node_P(p)[lane] != 0.0f) != 0ULL;
+        const uint32_t link = E.node_dir[(size_t)g * E.C + i];
+        unsigned char* p = node_ptr(E, g, link);
+        const int L = link_L(link);
+        const bool has_p = __ballot(lane < L && node_P(p, L)[lane] != 0.0f) != 0ULL;
         raz_node_hdr* h = node_hdr(p);
         if (lane == 0) {
             uint32_t t = h->tag & ~0xC0u;
@@ -1481,82 +1526,87 @@ __global__ __launch_bounds__(64) void k_adopt_all(raz_engine_dev E) {
 
 // ------------------------------------------------------------------ node pruning
 // The disc count only grows, so once the real game has D discs every node whose position has fewer
-// is unreachable (SURVEY.md §7 hard part 5).  k_gc compacts the pool of every game whose usage is at
-// least `threshold`: kept nodes slide down in index order (so relative order, and with it nothing
-// observable, changes), child / mirror / root / in-flight path indices are renumbered and the hash
-// table is rebuilt.  One 256-thread workgroup per game; launched between simulation steps.
+// is unreachable (SURVEY.md §7 hard part 5).  k_gc compacts the pool of every game whose node count is at
+// least `threshold`: kept nodes slide down in creation order (so relative order, and with it nothing
+// observable, changes), every link - child, mirror, root, in-flight paths and leaves - is renumbered and the
+// hash table is rebuilt.  Nodes are variable-size, so the walk goes through the game's node directory
+// (creation index -> link); a link is translated through its target's header: link -> header.index ->
+// remap[index] = the link after compaction.  One 256-thread workgroup per game; launched between simulation steps.
+__device__ __forceinline__ uint32_t gc_translate(const raz_engine_dev& E, uint32_t g, const uint32_t* remap, uint32_t link) {
+    return remap[node_hdr(node_ptr(E, g, link))->index];   // (the target still lies at its old place: nothing has moved yet)
+}
+
 __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold) {
     const uint32_t g = blockIdx.x;
     if (g >= E.B) return;
     raz_game& G = E.game[g];
-    const uint32_t used = G.pool_used;
-    if (G.status != 0 || used < threshold) return;
+    const uint32_t count = G.node_count;
+    if (G.status != 0 || count < threshold) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    __shared__ uint32_t s_cnt[256];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_cnt[256], s_size[256];
+    __shared__ uint32_t s_base_cnt, s_base_units;
     uint32_t* remap = E.gc_remap + (size_t)g * E.C;
+    uint32_t* dir = E.node_dir + (size_t)g * E.C;
     const int dmin = bb_popcount(G.root_black) + bb_popcount(G.root_white);
-    // pass 1: keep flags -> new indices (blocked exclusive scan, 256 nodes per round)
-    if (tid == 0) s_base = 0;
+    // pass 1: keep flags -> new indices and new offsets (blocked scans, 256 nodes per round)
+    if (tid == 0) {
+        s_base_cnt = 0;
+        s_base_units = 1;   // offset 0 is never a node
+    }
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < used; i0 += 256) {
+    for (uint32_t i0 = 0; i0 < count; i0 += 256) {
         const uint32_t i = i0 + tid;
-        uint32_t keep = 0;
-        if (i < used) {
-            const raz_node_hdr* h = node_hdr(node_ptr(E, g, i));
+        uint32_t keep = 0, units = 0, link = 0;
+        raz_node_hdr* h = nullptr;
+        if (i < count) {
+            link = dir[i];
+            h = node_hdr(node_ptr(E, g, link));
             keep = (bb_popcount(h->black) + bb_popcount(h->white)) >= dmin ? 1u : 0u;
+            units = keep ? node_units(link_L(link)) : 0u;
         }
         s_cnt[tid] = keep;
+        s_size[tid] = units;
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
-            const uint32_t v = tid >= off ? s_cnt[tid - off] : 0;
+        for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scans
+            const uint32_t v = tid >= off ? s_cnt[tid - off] : 0, u = tid >= off ? s_size[tid - off] : 0;
             __syncthreads();
             s_cnt[tid] += v;
+            s_size[tid] += u;
             __syncthreads();
         }
-        const uint32_t base = s_base;
-        if (i < used) remap[i] = keep ? base + s_cnt[tid] - 1 : RAZ_NO_NODE;
-        __syncthreads();
-        if (tid == 255) s_base = base + s_cnt[255];
-        __syncthreads();
-    }
-    const uint32_t kept = s_base;
-    // pass 2: slide kept nodes down, four per round (read all, barrier, write all: a destination
-    // never lies above its source, so later rounds' sources are untouched)
-    for (uint32_t i0 = 0; i0 < used; i0 += 4) {
-        const uint32_t i = i0 + wv;
-        const uint32_t dst = i < used ? remap[i] : RAZ_NO_NODE;
-        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-        const bool move = dst != RAZ_NO_NODE && dst != i;
-        if (move) {
-            const uint4* src = (const uint4*)node_ptr(E, g, i);
-            a = src[lane];
-            if (lane < 24) b = src[64 + lane];
+        const uint32_t bc = s_base_cnt, bu = s_base_units;
+        if (i < count) {
+            remap[i] = keep ? link_make(bu + s_size[tid] - units, link_L(link)) : RAZ_NO_NODE;
+            if (keep) h->gc_index = bc + s_cnt[tid] - 1;
         }
         __syncthreads();
-        if (move) {
-            uint4* d = (uint4*)node_ptr(E, g, dst);
-            d[lane] = a;
-            if (lane < 24) d[64 + lane] = b;
+        if (tid == 255) {
+            s_base_cnt = bc + s_cnt[255];
+            s_base_units = bu + s_size[255];
         }
         __syncthreads();
     }
-    // pass 3: renumber links inside the kept nodes; clear the table
-    for (uint32_t n = wv; n < kept; n += 4) {
-        unsigned char* p = node_ptr(E, g, n);
-        const uint32_t c = node_child(p)[lane];
-        if (c && !(c & 0x80000000u)) {
-            const uint32_t r = remap[c - 1];
-            node_child(p)[lane] = r == RAZ_NO_NODE ? 0u : r + 1;
+    const uint32_t kept = s_base_cnt, kept_units = s_base_units;
+    __threadfence_block();
+    // pass 2: renumber the links held by the kept nodes (targets are still at their old places)
+    for (uint32_t i = wv; i < count; i += 4) {
+        if (remap[i] == RAZ_NO_NODE) continue;
+        const uint32_t link = dir[i];
+        unsigned char* p = node_ptr(E, g, link);
+        const int L = link_L(link);
+        if (lane < L) {
+            const uint32_t c = node_child(p, L)[lane];
+            if (c && !(c & 0x80000000u)) {
+                const uint32_t r = gc_translate(E, g, remap, c);
+                node_child(p, L)[lane] = r == RAZ_NO_NODE ? 0u : r;
+            }
         }
         if (lane == 0) {
             raz_node_hdr* h = node_hdr(p);
             const uint32_t m = h->mirror;
-            if (m != RAZ_NO_NODE) h->mirror = remap[m];
+            if (m != RAZ_NO_NODE) h->mirror = gc_translate(E, g, remap, m);
         }
     }
-    raz_slot* tab = E.table + (size_t)g * E.H;
-    for (uint32_t sidx = tid; sidx < E.H; sidx += 256) tab[sidx].idx_tag = 0;
     // in-flight simulation state: of the game block (k_tree) or of every busy simulation slot (k_tree_par)
     const uint32_t nslots = E.par ? E.K : 1u;
     for (uint32_t j = 0; j < nslots; ++j) {
@@ -1567,39 +1617,79 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
             const uint32_t pn = E.path_node[pi * 64 + tid], pm = E.path_mirror[pi * 64 + tid];
             const int depth = (int)blk[GW(depth)];
             if (tid < depth) {
-                E.path_node[pi * 64 + tid] = remap[pn];
-                if (pm != RAZ_NO_NODE) E.path_mirror[pi * 64 + tid] = remap[pm];
+                E.path_node[pi * 64 + tid] = gc_translate(E, g, remap, pn);
+                if (pm != RAZ_NO_NODE) E.path_mirror[pi * 64 + tid] = gc_translate(E, g, remap, pm);
             }
         }
         if (tid == 0) {
             const uint32_t ln = blk[GW(leaf_node)], lm = blk[GW(leaf_mirror)], lk = blk[GW(leaf_kind)];
             if (lk == RAZ_LEAF_EXPAND || lk == RAZ_LEAF_SOLVED) {
-                if (ln != RAZ_NO_NODE) blk[GW(leaf_node)] = remap[ln];
-                if (lm != RAZ_NO_NODE) blk[GW(leaf_mirror)] = remap[lm];
+                if (ln != RAZ_NO_NODE) blk[GW(leaf_node)] = gc_translate(E, g, remap, ln);
+                if (lm != RAZ_NO_NODE) blk[GW(leaf_mirror)] = gc_translate(E, g, remap, lm);
                 blk[GW(leaf_slot)] = 0xfffffffeu;  // the slot found by select is gone: backup probes again
             }
-            if (E.par && blk[GW(sim_state)] == RAZ_SIM_WAIT_EXPAND) blk[GW(sim_parked)] = remap[blk[GW(sim_parked)]];
+            if (E.par && blk[GW(sim_state)] == RAZ_SIM_WAIT_EXPAND) blk[GW(sim_parked)] = gc_translate(E, g, remap, blk[GW(sim_parked)]);
         }
     }
     if (tid == 0) {
         const uint32_t rn = G.root_node;
-        if (rn != RAZ_NO_NODE) G.root_node = remap[rn];
-        G.pool_used = kept;
+        if (rn != RAZ_NO_NODE) G.root_node = gc_translate(E, g, remap, rn);
+    }
+    __syncthreads();
+    __threadfence_block();
+    // pass 3: slide the kept nodes down in creation order, four per round (read all, barrier, write all: a destination
+    // never lies above its source and the sources of later rounds lie above this round's, so nothing unread is overwritten)
+    for (uint32_t i0 = 0; i0 < count; i0 += 4) {
+        const uint32_t i = i0 + wv;
+        const uint32_t dst = i < count ? remap[i] : RAZ_NO_NODE;
+        const uint32_t src = i < count ? dir[i] : 0u;
+        const bool live = dst != RAZ_NO_NODE;
+        const uint32_t dwords = live ? 2u * node_units(link_L(src)) : 0u;   // <= 176
+        uint32_t a = 0, b = 0, c = 0;
+        if (live) {
+            const uint32_t* sp = (const uint32_t*)node_ptr(E, g, src);
+            if ((uint32_t)lane < dwords) a = sp[lane];
+            if ((uint32_t)lane + 64 < dwords) b = sp[lane + 64];
+            if ((uint32_t)lane + 128 < dwords) c = sp[lane + 128];
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t* dp = (uint32_t*)node_ptr(E, g, dst);
+            if ((uint32_t)lane < dwords) dp[lane] = a;
+            if ((uint32_t)lane + 64 < dwords) dp[lane + 64] = b;
+            if ((uint32_t)lane + 128 < dwords) dp[lane + 128] = c;
+        }
+        __syncthreads();
+        if (live && lane == 0) {   // the node now carries its new index; the directory entry of that index is free to take
+            raz_node_hdr* h = node_hdr(node_ptr(E, g, dst));
+            const uint32_t ni = h->gc_index;
+            h->index = ni;
+            dir[ni] = dst;
+        }
+        __syncthreads();
+    }
+    raz_slot* tab = E.table + (size_t)g * E.H;
+    for (uint32_t sidx = tid; sidx < E.H; sidx += 256) tab[sidx].idx_tag = 0;
+    if (tid == 0) {
+        G.pool_used = kept_units;
+        G.node_count = kept;
     }
     __syncthreads();
     __threadfence_block();
     // pass 4: rebuild the table (parallel insertion, one thread per kept node)
     const uint32_t mask = E.H - 1;
     for (uint32_t n = tid; n < kept; n += 256) {
-        const raz_node_hdr* h = node_hdr(node_ptr(E, g, n));
+        const uint32_t link = dir[n];
+        const raz_node_hdr* h = node_hdr(node_ptr(E, g, link));
         const raz_bb kb = h->black, kw = h->white;
         const uint32_t tagkey = h->tag & RAZ_SLOT_KEYMASK;
         uint32_t si = key_hash(kb, kw, tagkey) & mask;
-        const uint32_t val = (n << 8) | RAZ_SLOT_USED | tagkey;
+        const uint32_t val = RAZ_SLOT_USED | tagkey;
         for (;;) {
             if (atomicCAS(&tab[si].idx_tag, 0u, val) == 0u) {
                 tab[si].black = kb;
                 tab[si].white = kw;
+                tab[si].link = link;
                 break;
             }
             si = (si + 1) & mask;
@@ -1614,6 +1704,14 @@ inline size_t slots_of(const raz_engine_config& cfg) { return cfg.parallel_searc
 // k_tree_par drives the games when more than one simulation is in flight (or when reserved bit 3 asks for it)
 inline bool uses_slot_kernel(const raz_engine_config& cfg) { return slots_of(cfg) > 1 || (cfg.reserved & 8u); }
 
+// Bytes of one game's node pool: the caller's figure (rounded up to 8), or nodes_per_game average-size nodes plus room
+// for 64 nodes of the largest size (small pools: a burst of wide positions must not trip the byte limit first).
+inline unsigned long long pool_bytes_of(const raz_engine_config& cfg) {
+    const unsigned long long b = cfg.pool_bytes_per_game ? cfg.pool_bytes_per_game
+                                                         : (unsigned long long)cfg.nodes_per_game * RAZ_NODE_DEFAULT_BYTES + 64ULL * RAZ_NODE_MAX_BYTES;
+    return (b + 7ULL) & ~7ULL;
+}
+
 // Carve the workspace; with base == nullptr only the total size is computed.
 size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* E) {
     size_t off = 0;
@@ -1627,6 +1725,7 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     memset(&d, 0, sizeof d);
     d.cfg = cfg;
     d.B = (uint32_t)B; d.C = (uint32_t)C; d.H = (uint32_t)H; d.max_plies = (uint32_t)MP;
+    d.pool_bytes = pool_bytes_of(cfg);
     const size_t K = slots_of(cfg);
     d.K = (uint32_t)K;
     d.par = uses_slot_kernel(cfg) ? 1u : 0u;
@@ -1636,17 +1735,18 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.nn_active = take(BK);
     d.nn_own = (unsigned long long*)take(BK * 8); d.nn_enemy = (unsigned long long*)take(BK * 8);
     d.nn_policy = (float*)take(BK * 64 * 4); d.nn_value = (float*)take(BK * 4);
-    d.path_node = (uint32_t*)take(BK * 64 * 4); d.path_mirror = (uint32_t*)take(BK * 64 * 4); d.path_act = take(BK * 64);
+    d.path_node = (uint32_t*)take(BK * 64 * 4); d.path_mirror = (uint32_t*)take(BK * 64 * 4); d.path_act = (uint16_t*)take(BK * 64 * 2);
     d.table = (raz_slot*)take(B * H * sizeof(raz_slot));
-    d.nodes = take(B * C * RAZ_NODE_BYTES);
+    d.nodes = take(B * (size_t)d.pool_bytes);
+    d.node_dir = (uint32_t*)take(B * C * 4);
     d.rec = (raz_ply_header*)take(B * MP * sizeof(raz_ply_header));
     d.rec_n = (uint32_t*)take(B * MP * 64 * 4);
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
     d.M = cfg.solver_memo_slots;
     d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
     d.gc_remap = (uint32_t*)take(B * C * 4);
-    d.counters = (unsigned long long*)take(16 * 8);
-    d.node_out = take(RAZ_NODE_BYTES + 64);
+    d.counters = (unsigned long long*)take(32 * 8);
+    d.node_out = take(RAZ_NODE_OUT_BYTES + 64);
     d.prof = (unsigned long long*)take(B * 8 * 8);
     if (E) *E = d;
     return off;
@@ -1658,6 +1758,8 @@ int validate(const raz_engine_config* cfg) {
     if (cfg->table_slots < 2 * (size_t)cfg->nodes_per_game || (cfg->table_slots & (cfg->table_slots - 1)) || cfg->table_slots < RAZ_PROBE)
         return raz_fail(RAZ_EINVAL, "raz_engine: table_slots must be a power of two >= 2*nodes_per_game");
     if (cfg->max_plies < 64) return raz_fail(RAZ_EINVAL, "raz_engine: max_plies must be >= 64");
+    if (pool_bytes_of(*cfg) < 2 * RAZ_NODE_MAX_BYTES + 8 || pool_bytes_of(*cfg) > 8ULL * RAZ_LINK_MAX_UNITS)
+        return raz_fail(RAZ_EINVAL, "raz_engine: pool_bytes_per_game must be between 1416 bytes and 256 MB (a link holds a 25-bit offset in 8-byte units)");
     if (!(cfg->dirichlet_alpha > 0.0) || cfg->dirichlet_alpha > 1.0)
         return raz_fail(RAZ_EINVAL, "raz_engine: dirichlet_alpha must be in (0, 1] (all shipped configs use 0.5)");
     if (cfg->thinking_loop < 1) return raz_fail(RAZ_EINVAL, "raz_engine: thinking_loop must be >= 1");
@@ -1912,7 +2014,7 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_start: clear solver memo");
-    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 128, s), "raz_engine_start: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 256, s), "raz_engine_start: clear counters");
     if (d.par) {
         RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_start: clear simulation slots");
         RAZ_HIP_TRY(hipMemsetAsync(d.nn_active, 0, (size_t)d.B * d.K, s), "raz_engine_start: clear leaf flags");
@@ -1938,7 +2040,7 @@ extern "C" int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const
     RAZ_HIP_TRY(hipMemcpyAsync(e->d_sims, sims_per_move, (size_t)d.B * 4, hipMemcpyHostToDevice, s), "raz_engine_next_game: copy sims");
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_next_game: sync");  // host array may be transient
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_next_game: clear solver memo");
-    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 128, s), "raz_engine_next_game: clear counters");
+    RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 256, s), "raz_engine_next_game: clear counters");
     if (d.par) {
         RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_next_game: clear simulation slots");
         RAZ_HIP_TRY(hipMemsetAsync(d.nn_active, 0, (size_t)d.B * d.K, s), "raz_engine_next_game: clear leaf flags");
@@ -2039,9 +2141,9 @@ extern "C" int raz_engine_uses_graph(const raz_engine* e) { return e && e->graph
 
 extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
     if (!e || !out) return raz_fail(RAZ_EINVAL, "raz_engine_stats_sync: NULL argument");
-    unsigned long long c[8];
+    unsigned long long c[17];
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, e->dev);
-    RAZ_HIP_TRY(hipMemcpyAsync(c, e->dev.counters, 64, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_stats_sync: copy");
+    RAZ_HIP_TRY(hipMemcpyAsync(c, e->dev.counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_stats_sync: copy");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_stats_sync: sync");
     out->finished_games = c[0];
     out->total_sims = c[1];
@@ -2050,6 +2152,7 @@ extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_s
     out->selections = c[4];
     out->max_pool_used = c[5];
     out->idle_or_done = c[6];
+    out->max_pool_bytes = c[16];
     return RAZ_OK;
 }
 
@@ -2082,12 +2185,17 @@ __global__ __launch_bounds__(64) void k_read_node(raz_engine_dev E, uint32_t g, 
                                                   unsigned long long white, uint32_t np, uint32_t owner) {
     const int lane = threadIdx.x;
     const Found f = table_find(E, g, black, white, np | (owner << 2), lane);
-    uint32_t* flag = (uint32_t*)(E.node_out + RAZ_NODE_BYTES);
+    uint32_t* flag = (uint32_t*)(E.node_out + RAZ_NODE_OUT_BYTES);
     if (lane == 0) *flag = f.found ? 1u : 0u;
     if (!f.found) return;
-    const uint32_t* src = (const uint32_t*)node_ptr(E, g, f.node);
-    uint32_t* dst = (uint32_t*)E.node_out;
-    for (int i = lane; i < RAZ_NODE_BYTES / 4; i += 64) dst[i] = src[i];
+    unsigned char* p = node_ptr(E, g, f.node);
+    const int L = link_L(f.node);
+    const raz_bb legal = node_hdr(p)->legal;
+    const bool on = (legal >> lane) & 1ULL;
+    const int rk = rank_of(legal, lane);
+    ((double*)E.node_out)[lane] = on ? node_W(p, L)[rk] : 0.0;
+    ((uint32_t*)(E.node_out + 512))[lane] = on ? node_N(p, L)[rk] : 0u;
+    ((float*)(E.node_out + 768))[lane] = on ? node_P(p, L)[rk] : 0.0f;
 }
 }  // namespace
 
@@ -2112,10 +2220,12 @@ __global__ void k_stop_thinking(raz_engine_dev E, uint32_t g) {
 // (agent/player.py:47): every key that holds a prior counts as expanded for player index `pl`.
 __global__ __launch_bounds__(64) void k_adopt_tree(raz_engine_dev E, uint32_t g, uint32_t pl) {
     const int lane = threadIdx.x;
-    const uint32_t used = E.game[g].pool_used;
+    const uint32_t used = E.game[g].node_count;
     for (uint32_t i = blockIdx.x; i < used; i += gridDim.x) {
-        unsigned char* p = node_ptr(E, g, i);
-        const bool has_p = __ballot(node_P(p)[lane] != 0.0f) != 0ULL;
+        const uint32_t link = E.node_dir[(size_t)g * E.C + i];
+        unsigned char* p = node_ptr(E, g, link);
+        const int L = link_L(link);
+        const bool has_p = __ballot(lane < L && node_P(p, L)[lane] != 0.0f) != 0ULL;
         raz_node_hdr* h = node_hdr(p);
         if (lane == 0 && (has_p || ((h->tag >> 4) & 3u))) h->tag |= 1u << (4 + pl);
     }
@@ -2149,16 +2259,16 @@ extern "C" int raz_engine_read_node(raz_engine* e, uint32_t slot, uint64_t black
                        (unsigned long long)white, (uint32_t)next_player, (uint32_t)owner);
     int rc = raz_check_launch("raz_engine_read_node");
     if (rc != RAZ_OK) return rc;
-    unsigned char host[RAZ_NODE_BYTES + 64];
+    unsigned char host[RAZ_NODE_OUT_BYTES + 64];
     RAZ_HIP_TRY(hipMemcpyAsync(host, e->dev.node_out, sizeof(host), hipMemcpyDeviceToHost, s), "raz_engine_read_node: copy");
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_read_node: sync");
     uint32_t flag;
-    memcpy(&flag, host + RAZ_NODE_BYTES, 4);
+    memcpy(&flag, host + RAZ_NODE_OUT_BYTES, 4);
     *found = (int)flag;
     if (flag) {
-        if (w64) memcpy(w64, host + RAZ_NODE_W, 64 * sizeof(double));
-        if (n64) memcpy(n64, host + RAZ_NODE_N, 64 * sizeof(uint32_t));
-        if (p64) memcpy(p64, host + RAZ_NODE_P, 64 * sizeof(float));
+        if (w64) memcpy(w64, host, 64 * sizeof(double));
+        if (n64) memcpy(n64, host + 512, 64 * sizeof(uint32_t));
+        if (p64) memcpy(p64, host + 768, 64 * sizeof(float));
     } else {
         if (w64) memset(w64, 0, 64 * sizeof(double));
         if (n64) memset(n64, 0, 64 * sizeof(uint32_t));
@@ -2428,6 +2538,7 @@ __global__ __launch_bounds__(256) void k_harvest_apply(raz_engine_dev E, const u
     N.root_node = RAZ_NO_NODE;
     N.leaf_node = RAZ_NO_NODE;
     N.leaf_mirror = RAZ_NO_NODE;
+    N.pool_used = 1;
     if (what == 2) {
         const uint32_t k = plan[2 * g + 1], id = next_id + k;
         N.phase = RAZ_PHASE_NEW_MOVE;

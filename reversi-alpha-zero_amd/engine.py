@@ -13,7 +13,8 @@ import numpy as np
 from . import _native as N
 from ._native import lib, check
 
-NODE_POOL_BYTES_PER_NODE = 1408   # csrc/raz_engine.h RAZ_NODE_BYTES: what one tree node costs in a game's pool
+NODE_POOL_BYTES_PER_NODE = 232   # csrc/raz_engine.h RAZ_NODE_DEFAULT_BYTES: a game's default pool budget per node of nodes_per_game
+NODE_MAX_BYTES = 704             # RAZ_NODE_MAX_BYTES: 40 B header + 20 B x 33 legal moves
 
 PLY_HEADER = np.dtype([("own", "<u8"), ("enemy", "<u8"), ("n", "<f8"), ("q", "<f8"), ("action", "i1"),
                        ("player", "u1"), ("turn", "u1"), ("has_row", "u1"), ("sims", "<u4"),
@@ -88,7 +89,7 @@ class DeviceNet:
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
                        record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
-                       use_graph=False, force_slot_kernel=False):
+                       use_graph=False, force_slot_kernel=False, pool_bytes_per_game=0):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
     that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par)."""
@@ -116,15 +117,18 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (4 if use_graph else 0) | (8 if force_slot_kernel else 0)
         | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
-        solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par)
+        solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par,
+        pool_bytes_per_game=int(pool_bytes_per_game or 0))
     return c
 
 
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0):
-        """leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h
+                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0):
+        """nodes_per_game: most tree nodes a game's pool may hold; pool_bytes_per_game: its bytes (0 = nodes_per_game x 232 + 64 x 704:
+        nodes are compact - 40 B + 20 B per legal move, ~212 B on average - include/raz.h).
+        leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h
         raz_engine_set_leaf_cache): repeated positions are served from it, bit-identically.  None: no cache.
         leaf_cache_max_discs: cache only positions with at most that many discs (0 = all)."""
         import torch
@@ -145,7 +149,8 @@ class SelfPlayEngine:
             nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
                                       record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph,
-                                      force_slot_kernel=force_slot_kernel)
+                                      force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game)
+        self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
         self.slots = int(self.cfg.parallel_search_num) or 1   # simulation slots (leaf-exchange rows) per game
         # most nodes one step can add to a game's pool: k_tree completes <= inner_max (default 2) simulations,
         # each adding a leaf and its mirror; k_tree_par starts <= slots + inner_max simulations, wakes <= slots
@@ -260,7 +265,15 @@ class SelfPlayEngine:
             raise RuntimeError(f"engine error flags {st.error_flags:#x} (1 node pool full, 2 table full, "
                                f"4 records full, 8 path overflow): enlarge nodes_per_game/max_plies")
         return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves,
-                "selections": st.selections, "max_pool_used": st.max_pool_used, "idle_or_done": st.idle_or_done}
+                "selections": st.selections, "max_pool_used": st.max_pool_used, "idle_or_done": st.idle_or_done,
+                "max_pool_bytes": st.max_pool_bytes}
+
+    def pool_nearly_full(self, st, steps):
+        """True when the fullest running game's pool could overflow within `steps` more steps: a step adds at most
+        nodes_per_step nodes of at most 704 B to a game (a pool is full when EITHER its node count reaches nodes_per_game
+        or its bytes reach pool_bytes_per_game)."""
+        n = self.nodes_per_step * steps + 64
+        return st["max_pool_used"] + n > int(self.cfg.nodes_per_game) or st["max_pool_bytes"] + n * NODE_MAX_BYTES > self.pool_bytes
 
     def set_position(self, slot, black, white, player, sims, enable_resign=True, one_move=True):
         """Arm one move for `slot` on an arbitrary position, keeping the slot's tree (include/raz.h)."""
@@ -375,8 +388,8 @@ class SelfPlayEngine:
             self.step(chunk)
             steps += chunk
             st = self.stats()
-            if st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
-                self.gc(threshold=cap // 4)
+            if self.pool_nearly_full(st, chunk):
+                self.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
                 self.gc_runs += 1
             t1 = time.perf_counter()
             k = min(B, end - nxt)
@@ -415,8 +428,8 @@ class SelfPlayEngine:
             self.step(chunk)
             steps += chunk
             st = self.stats()
-            if allow_gc and st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
-                self.gc(threshold=cap // 4)
+            if allow_gc and self.pool_nearly_full(st, chunk):
+                self.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
                 self.gc_runs += 1
             if st["finished_games"] >= self.n_active:
                 st["steps"] = steps

@@ -78,8 +78,8 @@ class _Side:
         eng = self.engine
         st = eng.stats()   # raises on engine error flags
         cap = int(eng.cfg.nodes_per_game)
-        if st["max_pool_used"] + eng.nodes_per_step * 64 + 64 > cap:
-            eng.gc(threshold=cap // 4)
+        if eng.pool_nearly_full(st, 64):
+            eng.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
         return st["idle_or_done"] < eng.n_games
 
     def answers(self):

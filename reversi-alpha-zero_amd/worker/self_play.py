@@ -263,8 +263,9 @@ class BatchedSelfPlayWorker:
             if r > 1:   # the tree of a series is never pruned (its early positions are searched again): room for r games
                 nodes = r * whole
             else:
-                # 8192 games x 800 sims/move would need 1.1 TB for whole-game trees: size the pools for the HBM that is
-                # there (k_gc prunes the positions the real game has left behind; pools of ~16 x sims nodes suffice)
+                # whole-game trees for 8192 games x 800 sims/move would still be ~190 GB of compact nodes + 100 GB of tables:
+                # size the pools for the HBM that is there (k_gc prunes the positions the real game has left behind;
+                # pools of ~16 x sims nodes suffice)
                 cap = self._pool_nodes_that_fit(cache_log2=cache)
                 if cap is not None and cap < whole:
                     if cap < 12 * max_sims:
@@ -313,16 +314,18 @@ class BatchedSelfPlayWorker:
 
     def _pool_nodes_that_fit(self, fraction=0.7, cache_log2=None):
         """Tree nodes per game that fit in `fraction` of the device's free memory once the evaluation cache, the net scratch
-        and the outbox are taken out (node RAZ_NODE_POOL_BYTES_PER_NODE B of pool + up to 4 table slots of 32 B + a prune-map
-        word; include/raz.h raz_engine_workspace_bytes is the exact figure).  None when torch cannot tell."""
+        and the outbox are taken out.  Per node of nodes_per_game: 232 B of pool (compact nodes: 40 B + 20 B per legal move,
+        ~212 B on average) + up to 4 table slots of 32 B (table_slots is the next power of two >= 2 x nodes) + a directory
+        and a prune-map word; per game 64 x 704 B of pool slack (include/raz.h raz_engine_workspace_bytes is the exact
+        figure).  None when torch cannot tell."""
         try:
             import torch
             free, _ = torch.cuda.mem_get_info(torch.device(self.device))
         except Exception:
             return None
-        from ..engine import NODE_POOL_BYTES_PER_NODE
-        per_node = NODE_POOL_BYTES_PER_NODE + 2 * 32 * 2 + 4   # (table_slots is the next power of two >= 2 x nodes: up to 4 slots per node)
-        budget = int(free * fraction) - self._fixed_device_bytes(cache_log2)
+        from ..engine import NODE_MAX_BYTES, NODE_POOL_BYTES_PER_NODE
+        per_node = NODE_POOL_BYTES_PER_NODE + 4 * 32 + 4 + 4
+        budget = int(free * fraction) - self._fixed_device_bytes(cache_log2) - self.games_in_flight * 64 * NODE_MAX_BYTES
         return max(0, budget) // (self.games_in_flight * per_node)
 
     def play_batch(self, first_game_idx, n_games=None):

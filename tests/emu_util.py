@@ -40,7 +40,7 @@ class EmuEngine:
     """The subset of reversi_alpha_zero_amd.engine.SelfPlayEngine the parity tests use, on the emulated kernels."""
 
     def __init__(self, config, blob, n_games, seed=0, nodes_per_game=None, sims_hint=None, max_plies=72, record_root_w=True,
-                 inner_max=0, force_slot_kernel=False, **cfg_overrides):
+                 inner_max=0, force_slot_kernel=False, pool_bytes_per_game=0, **cfg_overrides):
         from reversi_alpha_zero_amd import _native as N
         from reversi_alpha_zero_amd.engine import engine_config_from
         self.lib = lib = load()
@@ -54,8 +54,10 @@ class EmuEngine:
             s = sims_hint or config.play.simulation_num_per_move
             share = bool(config.play.share_mtcs_info_in_self_play)
             nodes_per_game = (s * max(1, config.play.thinking_loop) * 62 + 128) * (2 if share else 1)
+        from reversi_alpha_zero_amd.engine import NODE_MAX_BYTES, NODE_POOL_BYTES_PER_NODE
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, None, record_root_w, False, True, 1, inner_max,
-                                      force_slot_kernel=force_slot_kernel)
+                                      force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game)
+        self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
         for k, v in cfg_overrides.items():
             setattr(self.cfg, k, v)
         self.slots = int(self.cfg.parallel_search_num) or 1
@@ -97,7 +99,11 @@ class EmuEngine:
         if st.error_flags:
             raise RuntimeError(f"engine error flags {st.error_flags:#x}")
         return {"finished_games": st.finished_games, "total_sims": st.total_sims, "nn_leaves": st.nn_leaves, "selections": st.selections,
-                "max_pool_used": st.max_pool_used, "idle_or_done": st.idle_or_done}
+                "max_pool_used": st.max_pool_used, "idle_or_done": st.idle_or_done, "max_pool_bytes": st.max_pool_bytes}
+
+    def pool_nearly_full(self, st, steps):
+        from reversi_alpha_zero_amd.engine import SelfPlayEngine
+        return SelfPlayEngine.pool_nearly_full(self, st, steps)
 
     def run(self, chunk=16, max_steps=200000, allow_gc=True):
         steps, cap, self.gc_runs = 0, int(self.cfg.nodes_per_game), 0
@@ -105,8 +111,8 @@ class EmuEngine:
             self.step(chunk)
             steps += chunk
             st = self.stats()
-            if allow_gc and st["max_pool_used"] + self.nodes_per_step * chunk + 64 > cap:
-                self.gc(cap // 4)
+            if allow_gc and self.pool_nearly_full(st, chunk):
+                self.gc(min(cap // 4, st["max_pool_used"] // 2))
                 self.gc_runs += 1
             if st["finished_games"] >= self.n_active:
                 st["steps"] = steps
@@ -138,6 +144,43 @@ class EmuEngine:
                                                           enable_resign.ctypes.data, fb.ctypes.data, fw.ctypes.data, None), "raz_engine_read_records")
         return dict(headers=hdr, root_n=root_n, root_w=root_w, n_plies=n_plies, status=status, resigned=resigned, game_id=game_id,
                     enable_resign=enable_resign, final_black=fb, final_white=fw)
+
+    # ---- continuous batching (raz_engine_harvest) on host arrays
+    def new_outbox(self, first_game_id, n_games):
+        mp = self.max_plies
+        return {"first": first_game_id, "n": n_games, "headers": np.zeros((n_games, mp, 48), dtype=np.uint8),
+                "root_n": np.zeros((n_games, mp, 64), dtype=np.int32), "summary": np.zeros((n_games, 32), dtype=np.uint8),
+                "done": np.zeros(n_games, dtype=np.uint8)}
+
+    def harvest(self, outbox, next_game_id, sims_per_move):
+        from reversi_alpha_zero_amd import _native as N
+        sims = np.ascontiguousarray(sims_per_move, dtype=np.uint32)
+        res = N.RazHarvestResult()
+        _check(self.lib, self.lib.raz_engine_harvest(self._h, next_game_id, sims.size, sims.ctypes.data if sims.size else None, None,
+                                                     outbox["first"], outbox["n"], outbox["headers"].ctypes.data, outbox["root_n"].ctypes.data,
+                                                     outbox["summary"].ctypes.data, outbox["done"].ctypes.data, ctypes.byref(res), None),
+               "raz_engine_harvest")
+        return res.harvested, res.restarted, res.skipped, res.playing
+
+    def play_continuous(self, first_game_id, total_games, sims, chunk=16):
+        B = self.n_games
+        n0 = min(B, total_games)
+        self.start(first_game_id, sims, n_active=n0)
+        outbox = self.new_outbox(first_game_id, total_games)
+        nxt, done, end, self.gc_runs = first_game_id + n0, 0, first_game_id + total_games, 0
+        cap = int(self.cfg.nodes_per_game)
+        while done < total_games:
+            self.step(chunk)
+            st = self.stats()
+            if self.pool_nearly_full(st, chunk):
+                self.gc(min(cap // 4, st["max_pool_used"] // 2))
+                self.gc_runs += 1
+            k = min(B, end - nxt)
+            h, r, skipped, _ = self.harvest(outbox, nxt, [sims] * k)
+            assert skipped == 0
+            nxt += r
+            done += h
+        return outbox
 
     def records(self, save_policy_of_tau_1=True, change_tau_turn=None):
         from reversi_alpha_zero_amd.engine import SelfPlayEngine

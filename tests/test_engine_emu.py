@@ -138,3 +138,30 @@ def test_emulated_series_on_a_carried_tree_and_position_api(golden, blob):
     fplies, _ = O.selfplay_game(ocfg, blob, 3, 201, done, stop_after_plies=1, start=start)
     assert np.array_equal(np.array(fplies[0]["root_n"]), n64.astype(np.float64))
     assert np.array_equal(np.array(fplies[0]["root_w"]).view(np.uint64), w64.view(np.uint64))
+
+
+def test_emulated_byte_limited_pool_and_continuous_batching(golden, blob):
+    """(1) A pool whose BYTES, not its node count, are the binding limit (compact nodes are variable-size: 40 B + 20 B per legal
+    move): pruning is triggered by raz_engine_stats.max_pool_bytes and nothing changes.  (2) raz_engine_harvest: 5 game ids
+    through 2 slots (a finished slot restarts on the next id with an empty pool) land in the outbox in id order == the
+    oracle's games."""
+    from reversi_alpha_zero_amd.engine import raw_from_packed
+    cfg = config_of(_variant(golden, "agz"))
+    ocfg = O.play_cfg_from_config(cfg)
+    eng = EmuEngine(cfg, blob, n_games=2, seed=9, sims_hint=12, nodes_per_game=4096, pool_bytes_per_game=40 * 1024)
+    eng.start(300, 12)
+    eng.run(chunk=8)
+    assert eng.gc_runs >= 2
+    for i, (plies, summ) in enumerate(eng.records(save_policy_of_tau_1=False)):
+        op, osum = O.selfplay_game(ocfg, blob, 9, 300 + i, 12)
+        _same(f"bytes/{i}", plies, summ, op, osum["winner"])
+    eng2 = EmuEngine(cfg, blob, n_games=2, seed=9, sims_hint=10, record_root_w=False)
+    outbox = eng2.play_continuous(600, 5, 10)
+    raw = raw_from_packed(outbox["headers"], outbox["root_n"], outbox["summary"])
+    assert list(raw["game_id"]) == [600, 601, 602, 603, 604] and outbox["done"].all()
+    for r in range(5):
+        op, osum = O.selfplay_game(ocfg, blob, 9, 600 + r, 10)
+        n = int(raw["n_plies"][r])
+        assert [int(a) for a in raw["headers"][r, :n]["action"]] == [p["action"] for p in op]
+        assert all([float(x) for x in raw["root_n"][r, i]] == p["root_n"] for i, p in enumerate(op))
+        assert (int(raw["status"][r]) & 0x0f) == osum["winner"]
