@@ -423,6 +423,9 @@ def headline_leg(args, dev, rank, world, cdev):
                      "achieved_over_f32_mfma_peak": ach / FP32_PEAK_TFLOPS},
         "kernels": {"k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms,
                                "algorithmic_bytes_per_launch": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / launches}},
+        "node_pools": {"nodes_per_game": int(eng.cfg.nodes_per_game), "bytes_per_game": int(eng.pool_bytes), "total_bytes": int(eng.pool_bytes) * args.games,
+                       "engine_workspace_bytes": int(eng.workspace_bytes),
+                       "layout": "compact nodes: 40 B header + 20 B per legal move (csrc/raz_engine.h)"},
         "bound_sims_per_s_per_gpu_at_f32_mfma_peak": FP32_PEAK_TFLOPS * 1e12 / (2.0 * macs),
         "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table_in_the_timed_region": served,
                         "note": "the steady-state batch comes from independent random playouts: only its slots in the first plies share positions; "
@@ -435,6 +438,21 @@ def headline_leg(args, dev, rank, world, cdev):
     k["achieved"] = k["algorithmic_bytes_per_launch"] / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None
     k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"
     k["frac"] = k["achieved"] / HBM_PEAK_GBS if k["achieved"] else None
+    k["note"] = "latency-bound (one wave per game, dependent round trips): the HBM fraction is nominal"
+    tpath = os.path.join(ROOT, "profiles", "r3_pmc", ("headline" if args.net == "ch5" else "config1") + "_traffic.json")
+    if os.path.exists(tpath):   # counter traffic of the same command (tools/run_profiles.sh): FETCH_SIZE / WRITE_SIZE passes
+        with open(tpath) as f:
+            kt = json.load(f).get("kernels", {}).get("k_tree")
+        if kt and k["algorithmic_bytes_per_launch"]:
+            raw = kt["fetch_bytes_raw"] + kt["write_bytes"]
+            k["traffic"] = raw
+            k["traffic_over_algorithmic"] = raw / k["algorithmic_bytes_per_launch"]
+            k["traffic_detail"] = {"fetch_bytes_raw": kt["fetch_bytes_raw"], "write_bytes": kt["write_bytes"],
+                                   "with_fetch_doubled": (2 * kt["fetch_bytes_raw"] + kt["write_bytes"]) / k["algorithmic_bytes_per_launch"],
+                                   "note": "FETCH_SIZE is calibrated (x2) for wide 16 B/lane reads only (MI355X_MICROARCH.md); the tree kernel reads 4-8 B per "
+                                           "lane, so the raw figure is the traffic and the doubled one an upper bound; measured on the profiled run's launches "
+                                           "(same command), algorithmic bytes from this run's selections and simulations",
+                                   "source": os.path.relpath(tpath, ROOT)}
     out["_ply_weights"] = weights
     del eng, net
     torch.cuda.empty_cache()
@@ -630,6 +648,55 @@ def cpu_baseline_reference(windows=(("ch5", 20.0), ("mini", 10.0))):
 # ------------------------------------------------------------------------------------------------------------
 # extra legs at N = 1
 # ------------------------------------------------------------------------------------------------------------
+def agz_config(sims):
+    """Play settings of config/alpha_go_zero.yml:5-18 over config.py:128-166 (unshared trees, c_puct 5, change_tau_turn 10,
+    resign from turn 20, solver off, thinking_loop 1; Dirichlet noise eps .25 / alpha .5), parallel_search_num = 1."""
+    play = types.SimpleNamespace(
+        simulation_num_per_move=sims, share_mtcs_info_in_self_play=False,
+        thinking_loop=1, required_visit_to_decide_action=400, start_rethinking_turn=8, c_puct=5,
+        noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3, parallel_search_num=1,
+        resign_threshold=-0.9, allowed_resign_turn=20, disable_resignation_rate=0.1,
+        use_solver_turn=0, use_solver_turn_in_simulation=0)
+    return types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=False))
+
+
+def config5_leg(args, dev, blob, weights, games=8192, sims=3200, steps=10):
+    """BASELINE configs[4] / SURVEY 8(d) "Config 5" on ONE GPU's share of it: 8192 concurrent games, alpha_go_zero.yml play
+    settings, the 256x10 net (the yml defines no deeper one), S = 3200 (the BASELINE's override), Dirichlet root noise on.
+    Node pools of 16 x S compact nodes per game, as the worker sizes them.  Same steady-state batch recipe as the headline,
+    fewer steps; the trees hold a few dozen simulations, so k_tree's share of a step is a lower bound of a long run's."""
+    import torch
+    from reversi_alpha_zero_amd.agent.model import macs_per_position
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    cfg = agz_config(sims)
+    net = DeviceNet(blob, dev, kernel=args.net_kernel)
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, nodes_per_game=16 * sims, parts=1,
+                         leaf_cache_log2=None if args.no_leaf_cache else 26, leaf_cache_max_discs=24)
+    eng.start(0, sims)
+    stagger(eng, games, sims, 4242, dev, weights)
+    eng.step(40)
+    st0 = eng.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tree_ms, net_ms = eng.step_timed(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    sims_done, leaves = st["total_sims"] - st0["total_sims"], st["nn_leaves"] - st0["nn_leaves"]
+    out = {"workload": f"BASELINE configs[4] on one GPU: {games} concurrent self-play games, alpha_go_zero.yml play settings (unshared trees, c_puct 5, "
+                       f"change_tau_turn 10), 256x10 net ({net.kernel_name}), {sims} sims/move, Dirichlet root noise on, thinking_loop=1, "
+                       f"parallel_search_num=1; steady-state ply mix, {steps} timed steps after 40 warm-up steps",
+           "value": sims_done / dt, "unit": "sims/s", "leaves_per_sec": leaves / dt, "ms_per_step": 1e3 * dt / steps,
+           "k_tree_avg_ms": tree_ms / steps, "net_forward_avg_ms": net_ms / steps,
+           "nodes_per_game": int(eng.cfg.nodes_per_game), "node_pool_bytes_per_game": int(eng.pool_bytes),
+           "node_pools_total_bytes": int(eng.pool_bytes) * games, "engine_workspace_bytes": int(eng.workspace_bytes),
+           "note": "round 2's 1408-byte nodes needed 590 GB for these pools; the compact nodes (40 B + 20 B per legal move) need "
+                   f"{int(eng.pool_bytes) * games / 1e9:.0f} GB"}
+    del eng, net
+    torch.cuda.empty_cache()
+    return out
+
+
 def config1_leg(dev, args, par=1):
     """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch)."""
     import numpy as np
@@ -902,6 +969,7 @@ def main():
         if world == 1 and not args.no_extra_legs:
             legs = ((("headline_on_exact_f32_kernels", lambda: exact_f32_leg(args, dev, blob, cfg, ply_weights)),)
                     if "f16x3" in out["dtype"] else ()) + (
+                    ("config5_8192x3200_agz", lambda: config5_leg(args, dev, blob, ply_weights)),
                     ("config1_4096x200_mini", lambda: config1_leg(dev, args, 1)[0]),
                     ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4)[0]),
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),

@@ -165,3 +165,24 @@ def test_emulated_byte_limited_pool_and_continuous_batching(golden, blob):
         assert [int(a) for a in raw["headers"][r, :n]["action"]] == [p["action"] for p in op]
         assert all([float(x) for x in raw["root_n"][r, i]] == p["root_n"] for i, p in enumerate(op))
         assert (int(raw["status"][r]) & 0x0f) == osum["winner"]
+
+
+def test_emulated_deep_search_first_plies(golden, blob):
+    """A search 600 simulations deep (deep paths, wide fan-out at the root, a pool that k_gc has to prune within the first plies)
+    == the oracle for the first three plies: the regime of BASELINE configs[4] (3200 sims/move; on the GPU: tests/test_config5_gpu.py)."""
+    cfg = config_of(_variant(golden, "agz"))
+    eng = EmuEngine(cfg, blob, n_games=1, seed=13, nodes_per_game=1500)
+    eng.start(77, 600)
+    cap, steps = 1500, 0
+    while int(eng.read_raw()["n_plies"][0]) < 3:
+        eng.step(64)
+        steps += 64
+        st = eng.stats()
+        if eng.pool_nearly_full(st, 64):
+            eng.gc(min(cap // 4, st["max_pool_used"] // 2))
+        assert steps < 4000
+    (plies, _), = eng.records(save_policy_of_tau_1=False)
+    oplies, _ = O.selfplay_game(O.play_cfg_from_config(cfg), blob, 13, 77, 600, stop_after_plies=3)
+    for i in range(3):
+        assert plies[i]["action"] == oplies[i]["action"] and plies[i]["root_n"] == oplies[i]["root_n"] and plies[i]["root_w"] == oplies[i]["root_w"], i
+    assert max(oplies[2]["root_n"]) > 100
