@@ -30,9 +30,16 @@ class OrcEnv(Structure):
 
 
 _lib = None
+_lock = __import__("threading").RLock()   # first use may come from several threads at once (tests, bench): build + bind exactly once
 
 
 def load():
+    global _lib
+    with _lock:
+        return _load_locked()
+
+
+def _load_locked():
     global _lib
     if _lib is None:
         build()
@@ -151,6 +158,11 @@ _ext_done = False
 
 def load_ext():
     """load() + signatures for the rng / net / mcts entry points."""
+    with _lock:
+        return _load_ext_locked()
+
+
+def _load_ext_locked():
     global _ext_done
     lib = load()
     if not _ext_done:

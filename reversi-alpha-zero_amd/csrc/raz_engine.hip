@@ -1138,6 +1138,36 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
     wave_sync();
 }
 
+// The path of the simulation in flight (lane d = level d).  Paths are short (2-6 levels; the mean is ~2.5), so only the
+// first 16 levels travel with the control block; the rest - and only the levels in use are ever stored - is fetched in the
+// rare case of a deeper path (one extra round trip).
+#ifndef RAZ_PATH_EAGER
+#define RAZ_PATH_EAGER 16   // (the wave-emulator build sets 2, so that its tiny games exercise the deep-path fetch all the time)
+#endif
+constexpr int kPathEager = RAZ_PATH_EAGER;
+__device__ __forceinline__ void path_load(const raz_engine_dev& E, Regs& R, size_t row, int lane, bool eager_only) {
+    const bool take = !eager_only || lane < kPathEager;
+    R.pnode = take ? E.path_node[row * 64 + lane] : 0u;
+    R.pmirror = take ? E.path_mirror[row * 64 + lane] : 0u;
+    R.pact = take ? (uint32_t)E.path_act[row * 64 + lane] : 0u;
+}
+__device__ __forceinline__ void path_load_rest(const raz_engine_dev& E, Regs& R, size_t row, int lane) {
+    const int depth = (int)G32(R, GW(depth));   // (of the block now in R.cw: the game's, or the simulation slot's just loaded)
+    if (depth > kPathEager && lane >= kPathEager) {
+        R.pnode = E.path_node[row * 64 + lane];
+        R.pmirror = E.path_mirror[row * 64 + lane];
+        R.pact = (uint32_t)E.path_act[row * 64 + lane];
+    }
+}
+__device__ __forceinline__ void path_store(const raz_engine_dev& E, const Regs& R, size_t row, int lane) {
+    const int depth = (int)G32(R, GW(depth));
+    if (lane < depth) {
+        E.path_node[row * 64 + lane] = R.pnode;
+        E.path_mirror[row * 64 + lane] = R.pmirror;
+        E.path_act[row * 64 + lane] = (uint16_t)R.pact;
+    }
+}
+
 // ------------------------------------------------------------------ the tree kernel
 // SOLVER = false compiles the end-game solver (and its LDS frames) out: the common case, and the
 // bench configuration.
@@ -1154,13 +1184,12 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
     uint32_t* gw = (uint32_t*)(E.game + g);
     Regs R;
     R.cw = gw[lane];
-    R.pnode = E.path_node[(size_t)g * 64 + lane];
-    R.pmirror = E.path_mirror[(size_t)g * 64 + lane];
-    R.pact = E.path_act[(size_t)g * 64 + lane];
+    path_load(E, R, (size_t)g, lane, true);
     R.pol_raw = E.nn_policy[(size_t)g * 64 + lane];
     R.val = E.nn_value[g];
     R.nn = 0u;
     R.path_dirty = 0u;
+    path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) return;  // nn_active is already 0
@@ -1200,11 +1229,7 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
     }
     // write the game back: one coalesced store (+ the path when a descent ran)
     gw[lane] = R.cw;
-    if (R.path_dirty) {
-        E.path_node[(size_t)g * 64 + lane] = R.pnode;
-        E.path_mirror[(size_t)g * 64 + lane] = R.pmirror;
-        E.path_act[(size_t)g * 64 + lane] = (uint16_t)R.pact;
-    }
+    if (R.path_dirty) path_store(E, R, (size_t)g, lane);
     if (lane == 0) E.nn_active[g] = (uint8_t)R.nn;
 }
 
@@ -1238,21 +1263,18 @@ struct Slots {
 __device__ __forceinline__ void slot_load(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t j, int lane, bool with_net) {
     const size_t gi = (size_t)g * E.K + j;
     const uint32_t v = E.sim[gi * 64 + lane];
-    R.pnode = E.path_node[gi * 64 + lane];
-    R.pmirror = E.path_mirror[gi * 64 + lane];
-    R.pact = E.path_act[gi * 64 + lane];
+    path_load(E, R, gi, lane, true);
     if (with_net) {
         R.pol_raw = E.nn_policy[gi * 64 + lane];
         R.val = E.nn_value[gi];
     }
     R.cw = ((kSimLanes >> lane) & 1ULL) ? v : R.cw;
+    path_load_rest(E, R, gi, lane);
 }
 __device__ __forceinline__ void slot_store(const raz_engine_dev& E, const Regs& R, uint32_t g, uint32_t j, int lane) {
     const size_t gi = (size_t)g * E.K + j;
     if ((kSimLanes >> lane) & 1ULL) E.sim[gi * 64 + lane] = R.cw;
-    E.path_node[gi * 64 + lane] = R.pnode;
-    E.path_mirror[gi * 64 + lane] = R.pmirror;
-    E.path_act[gi * 64 + lane] = (uint16_t)R.pact;
+    path_store(E, R, gi, lane);
 }
 // the slot of `mask` with the smallest order number (K <= 16: a scalar scan)
 __device__ __forceinline__ int pick_min_seq(uint32_t sq, unsigned long long mask) {
