@@ -15,6 +15,7 @@ from ._native import lib, check
 
 NODE_POOL_BYTES_PER_NODE = 232   # csrc/raz_engine.h RAZ_NODE_DEFAULT_BYTES: a game's default pool budget per node of nodes_per_game
 NODE_MAX_BYTES = 704             # RAZ_NODE_MAX_BYTES: 40 B header + 20 B x 33 legal moves
+WHOLE_GAME_BYTES_PER_NODE = 320  # byte budget per node of a pool sized for whole games (never pruned)
 
 PLY_HEADER = np.dtype([("own", "<u8"), ("enemy", "<u8"), ("n", "<f8"), ("q", "<f8"), ("action", "i1"),
                        ("player", "u1"), ("turn", "u1"), ("has_row", "u1"), ("sims", "<u4"),
@@ -147,6 +148,10 @@ class SelfPlayEngine:
             mirror = share if mirror_updates is None else bool(mirror_updates)
             # every simulation adds at most one node (two with mirror keys); ~62 searched plies
             nodes_per_game = (s * loops * 62 + 128) * (2 if mirror else 1)
+            if not pool_bytes_per_game:
+                # a pool that is never pruned must hold the whole game whatever its mobility: 320 B per node (14 legal moves
+                # on average; a game's average is ~8.5) instead of the 232 B default of pruned pools, capped at the link range
+                pool_bytes_per_game = min(nodes_per_game * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
                                       record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph,
                                       force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game)

@@ -272,9 +272,13 @@ class BatchedSelfPlayWorker:
                         raise RuntimeError(f"{self.games_in_flight} games in flight at {max_sims} sims/move leave {cap} tree nodes per "
                                            f"game in this GPU's free memory (< 12 x sims): lower games_in_flight")
                     nodes = cap
+            from ..engine import NODE_MAX_BYTES, WHOLE_GAME_BYTES_PER_NODE
+            pool_bytes = 0   # pruned pools: the default budget (232 B per node); k_gc is triggered by bytes as well as by count
+            if r > 1:        # never pruned: room for whole games whatever their mobility
+                pool_bytes = min(nodes * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=cache,
-                                          leaf_cache_max_discs=self.leaf_cache_max_discs)
+                                          leaf_cache_max_discs=self.leaf_cache_max_discs, pool_bytes_per_game=pool_bytes)
             self._engine_key = key
         self._engine.set_resign_threshold(self.config.play.resign_threshold)
         return self._engine

@@ -182,6 +182,17 @@ class EmuEngine:
             done += h
         return outbox
 
+    def attach_leaf_cache(self, log2_entries, max_discs=0):
+        need = self.lib.raz_leaf_cache_bytes(log2_entries, self.n_games * self.slots)
+        self._cache = np.zeros(need + 256, dtype=np.uint8)
+        base = (self._cache.ctypes.data + 255) // 256 * 256
+        _check(self.lib, self.lib.raz_engine_set_leaf_cache(self._h, base, need, log2_entries, max_discs, None), "raz_engine_set_leaf_cache")
+
+    def leaf_cache_stats(self):
+        out = (ctypes.c_uint64 * 4)()
+        _check(self.lib, self.lib.raz_engine_leaf_cache_stats(self._h, out, None), "raz_engine_leaf_cache_stats")
+        return {"hits": out[0], "in_batch_duplicates": out[1], "evaluated": out[2], "no_room": out[3]}
+
     def records(self, save_policy_of_tau_1=True, change_tau_turn=None):
         from reversi_alpha_zero_amd.engine import SelfPlayEngine
         return SelfPlayEngine.records(self, save_policy_of_tau_1, change_tau_turn)

@@ -186,3 +186,21 @@ def test_emulated_deep_search_first_plies(golden, blob):
     for i in range(3):
         assert plies[i]["action"] == oplies[i]["action"] and plies[i]["root_n"] == oplies[i]["root_n"] and plies[i]["root_w"] == oplies[i]["root_w"], i
     assert max(oplies[2]["root_n"]) > 100
+
+
+def test_emulated_leaf_cache_changes_nothing(golden, blob):
+    """raz_engine_set_leaf_cache: repeated positions served from the cross-game table (claim / resolve / fill kernels of
+    csrc/raz_leaf_cache.hip, here with a table small enough to run out of room) leave every record as it was."""
+    cfg = config_of(_variant(golden, "agz"))
+    out = []
+    for cache in (None, 6):
+        eng = EmuEngine(cfg, blob, n_games=4, seed=2, sims_hint=8)
+        if cache:
+            eng.attach_leaf_cache(10, 0)
+        eng.start(10, 8)
+        eng.run(chunk=32)
+        out.append(eng.records(save_policy_of_tau_1=False))
+        if cache:
+            st = eng.leaf_cache_stats()
+            assert st["hits"] + st["in_batch_duplicates"] > 0 and st["evaluated"] > 0
+    assert out[0] == out[1]
