@@ -214,8 +214,7 @@ def stagger(eng, n, sims, seed, dev, ply_weights=None):
     from bench_sweep import harvest_positions
     black, white, player, _ = harvest_positions(n, seed, dev, ply_weights)
     b, w, p = black.cpu().numpy(), white.cpu().numpy(), player.cpu().numpy()
-    for g in range(n):
-        eng.set_position(g, int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g]), sims, enable_resign=True, one_move=False)
+    eng.set_positions(0, black.contiguous(), white.contiguous(), player.contiguous(), sims, enable_resign=True, one_move=False)
     occ = np.unpackbits((b.view(np.uint64) | w.view(np.uint64)).view(np.uint8)).reshape(n, 64).sum(1)
     eng._staggered = (b, w, p)   # where every slot was put (the steady-state spot check starts the oracle there)
     return occ.astype(np.int64) - 4
@@ -439,11 +438,17 @@ def headline_leg(args, dev, rank, world, cdev):
     k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"
     k["frac"] = k["achieved"] / HBM_PEAK_GBS if k["achieved"] else None
     k["note"] = "latency-bound (one wave per game, dependent round trips): the HBM fraction is nominal"
-    tpath = os.path.join(ROOT, "profiles", "r3_pmc", ("headline" if args.net == "ch5" else "config1") + "_traffic.json")
+    # counter traffic of the tree kernel: profiles/r3_pmc/headline_ktree_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this
+    # command; "games_per_launch" says how many games the profiled launches covered - traffic per game is what is compared)
+    tpath = os.path.join(ROOT, "profiles", "r3_pmc", ("headline_ktree" if args.net == "ch5" else "config1") + "_traffic.json")
+    tgames = None
     if os.path.exists(tpath):   # counter traffic of the same command (tools/run_profiles.sh): FETCH_SIZE / WRITE_SIZE passes
         with open(tpath) as f:
-            kt = json.load(f).get("kernels", {}).get("k_tree")
+            tj = json.load(f)
+        kt, tgames = tj.get("kernels", {}).get("k_tree"), tj.get("games_per_launch")
         if kt and k["algorithmic_bytes_per_launch"]:
+            scale = (args.games / parts / tgames) if tgames else 1.0   # the profiled launches covered tgames games each
+            kt = dict(kt, fetch_bytes_raw=kt["fetch_bytes_raw"] * scale, write_bytes=kt["write_bytes"] * scale)
             raw = kt["fetch_bytes_raw"] + kt["write_bytes"]
             k["traffic"] = raw
             k["traffic_over_algorithmic"] = raw / k["algorithmic_bytes_per_launch"]

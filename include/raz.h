@@ -228,6 +228,11 @@ int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tree_ms, doub
  * raz_engine_read_records: the last recorded ply); 0: the game simply continues from that position. */
 int raz_engine_set_position(raz_engine* e, uint32_t slot, uint64_t black, uint64_t white, int player,
                             uint32_t sims, int enable_resign, int one_move, raz_stream_t stream);
+/* raz_engine_set_position for slots first_slot .. first_slot + n - 1 in one launch: (black, white, player to move) of slot
+ * first_slot + i in DEVICE arrays d_black[i], d_white[i], d_player[i] (players 1 / 2; the caller guarantees the positions are
+ * playable, as with the scalar call), the same sims / enable_resign / one_move for all.  Asynchronous on `stream`. */
+int raz_engine_set_positions(raz_engine* e, uint32_t first_slot, uint32_t n, const uint64_t* d_black, const uint64_t* d_white,
+                             const uint8_t* d_player, uint32_t sims, int enable_resign, int one_move, raz_stream_t stream);
 /* ReversiPlayer.stop_thinking (agent/player.py:163-164): the slot's running search ends at the next step
  * and the move is decided from the tree as it is. */
 int raz_engine_stop_thinking(raz_engine* e, uint32_t slot, raz_stream_t stream);

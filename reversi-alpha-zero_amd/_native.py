@@ -103,6 +103,7 @@ SIGNATURES.update({
     "raz_engine_step": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_step_timed": (c_int, [c_void_p, c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
     "raz_engine_set_position": (c_int, [c_void_p, c_uint32, c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, c_void_p]),
+    "raz_engine_set_positions": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_int, c_int, c_void_p]),
     "raz_engine_read_node": (c_int, [c_void_p, c_uint32, c_uint64, c_uint64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      POINTER(c_int), c_void_p]),
     "raz_engine_stop_thinking": (c_int, [c_void_p, c_uint32, c_void_p]),

@@ -2201,6 +2201,32 @@ __global__ void k_set_position(raz_engine_dev E, uint32_t g, unsigned long long 
     if (one_move) G.n_plies = 0;  // the facade reads each ply back right after it is decided
 }
 
+// The same for slots first_slot .. first_slot + n - 1 at once, positions in device arrays (one thread per slot).
+__global__ void k_set_positions(raz_engine_dev E, uint32_t first_slot, uint32_t n, const unsigned long long* black,
+                                const unsigned long long* white, const uint8_t* player, uint32_t sims, uint32_t enable_resign,
+                                uint32_t one_move) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = first_slot + i;
+    raz_game& G = E.game[g];
+    G.root_black = black[i];
+    G.root_white = white[i];
+    G.player = player[i];
+    G.status = 0;
+    G.phase = RAZ_PHASE_NEW_MOVE;
+    G.sims_per_move = sims;
+    G.sims_left = 0;
+    G.loops_done = 0;
+    G.move_sims = 0;
+    G.leaf_kind = RAZ_LEAF_NONE;
+    if (!E.par) E.nn_active[g] = 0;
+    G.par_stage = 0;
+    G.enable_resign = enable_resign;
+    G.one_move = one_move;
+    G.root_node = RAZ_NO_NODE;
+    if (one_move) G.n_plies = 0;
+}
+
 // var_n[key] / var_w[key] / var_p[key] of one slot: copy the node of (black, white, next_player)
 // owned by `owner` to node_out (found flag in the trailing word); never creates a node.
 __global__ __launch_bounds__(64) void k_read_node(raz_engine_dev E, uint32_t g, unsigned long long black,
@@ -2309,6 +2335,18 @@ extern "C" int raz_engine_set_position(raz_engine* e, uint32_t slot, uint64_t bl
                        (unsigned long long)black, (unsigned long long)white, (uint32_t)player, sims,
                        (uint32_t)(enable_resign != 0), (uint32_t)(one_move != 0));
     return raz_check_launch("raz_engine_set_position");
+}
+
+extern "C" int raz_engine_set_positions(raz_engine* e, uint32_t first_slot, uint32_t n, const uint64_t* d_black, const uint64_t* d_white,
+                                        const uint8_t* d_player, uint32_t sims, int enable_resign, int one_move, raz_stream_t stream) {
+    if (!e || !d_black || !d_white || !d_player) return raz_fail(RAZ_EINVAL, "raz_engine_set_positions: NULL argument");
+    if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_set_positions: call raz_engine_start first");
+    if ((size_t)first_slot + n > e->dev.B || sims == 0) return raz_fail(RAZ_EINVAL, "raz_engine_set_positions: bad slot range / sims");
+    if (n == 0) return RAZ_OK;
+    hipLaunchKernelGGL(k_set_positions, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dev, first_slot, n,
+                       (const unsigned long long*)d_black, (const unsigned long long*)d_white, d_player, sims,
+                       (uint32_t)(enable_resign != 0), (uint32_t)(one_move != 0));
+    return raz_check_launch("raz_engine_set_positions");
 }
 
 // Prune unreachable nodes (positions with fewer discs than the current real position) in every

@@ -287,6 +287,14 @@ class SelfPlayEngine:
             check(lib.raz_engine_set_position(self._h, slot, black, white, player, sims, int(enable_resign),
                                               int(one_move), _stream()), "raz_engine_set_position")
 
+    def set_positions(self, first_slot, black, white, player, sims, enable_resign=True, one_move=True):
+        """set_position for len(black) consecutive slots in one launch; black / white: int64 device tensors, player: uint8."""
+        import torch
+        assert black.is_contiguous() and white.is_contiguous() and player.is_contiguous() and player.dtype == torch.uint8
+        with torch.cuda.device(self.device):
+            check(lib.raz_engine_set_positions(self._h, first_slot, black.numel(), black.data_ptr(), white.data_ptr(), player.data_ptr(),
+                                               sims, int(enable_resign), int(one_move), _stream()), "raz_engine_set_positions")
+
     def stop_thinking(self, slot):
         import torch
         with torch.cuda.device(self.device):

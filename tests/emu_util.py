@@ -123,6 +123,11 @@ class EmuEngine:
     def set_position(self, slot, black, white, player, sims, enable_resign=True, one_move=True):
         _check(self.lib, self.lib.raz_engine_set_position(self._h, slot, black, white, player, sims, int(enable_resign), int(one_move), None), "raz_engine_set_position")
 
+    def set_positions(self, first_slot, black, white, player, sims, enable_resign=True, one_move=True):
+        b, w, p = (np.ascontiguousarray(black, dtype=np.uint64), np.ascontiguousarray(white, dtype=np.uint64), np.ascontiguousarray(player, dtype=np.uint8))
+        _check(self.lib, self.lib.raz_engine_set_positions(self._h, first_slot, b.size, b.ctypes.data, w.ctypes.data, p.ctypes.data, sims,
+                                                           int(enable_resign), int(one_move), None), "raz_engine_set_positions")
+
     def read_node(self, slot, black, white, next_player=1, owner=0):
         w, n, p = np.zeros(64), np.zeros(64, dtype=np.uint32), np.zeros(64, dtype=np.float32)
         found = ctypes.c_int(0)

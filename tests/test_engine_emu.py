@@ -129,7 +129,7 @@ def test_emulated_series_on_a_carried_tree_and_position_api(golden, blob):
     start = (int(oplies[20]["own"]), int(oplies[20]["enemy"]), 1) if oplies[20]["player"] == 1 else (int(oplies[20]["enemy"]), int(oplies[20]["own"]), 2)
     eng2 = EmuEngine(cfg, blob, n_games=2, seed=3, sims_hint=10)
     eng2.start(200, 10, n_active=0)
-    eng2.set_position(1, start[0], start[1], start[2], 10, enable_resign=True, one_move=False)
+    eng2.set_positions(1, [start[0]], [start[1]], [start[2]], 10, enable_resign=True, one_move=False)   # (the batched form of set_position)
     for _ in range(6):
         eng2.step(1)
     found, w64, n64, _ = eng2.read_node(1, int(oplies[20]["own"]), int(oplies[20]["enemy"]), 1, 0)

@@ -30,10 +30,10 @@ SETS=("" \
   "FETCH_SIZE" "WRITE_SIZE")
 for P in $PASSES; do
   if [ "$P" = "stats" ]; then
-    timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
+    timeout ${PROF_TIMEOUT:-700} rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH < /dev/null > "$OUT/stats.log" 2>&1
     echo "stats rc=$?"
   else
-    timeout 700 rocprofv3 --pmc ${SETS[$P]} --kernel-trace --output-format csv -d "$OUT/pmc$P" -- $BENCH < /dev/null > "$OUT/pmc$P.log" 2>&1
+    timeout ${PROF_TIMEOUT:-700} rocprofv3 --pmc ${SETS[$P]} --kernel-trace --output-format csv -d "$OUT/pmc$P" -- $BENCH < /dev/null > "$OUT/pmc$P.log" 2>&1
     echo "pmc$P rc=$?"
   fi
 done
