@@ -146,7 +146,7 @@ typedef struct {
     int32_t record_root_w;                    /* 1: also record root W per ply (parity tests) */
     double c_puct;                            /* :136 */
     double noise_eps;                         /* :137 */
-    double dirichlet_alpha;                   /* :138, must be in (0, 1] */
+    double dirichlet_alpha;                   /* :138, any alpha > 0 (0.5: Box-Muller pairs; < 1 / > 1: numpy's legacy gamma schemes) */
     double resign_threshold;                  /* :145 */
     double disable_resignation_rate;          /* :147 */
     uint32_t n_games;                         /* game slots in flight (B) */

@@ -24,6 +24,7 @@
  *   the device reproduces them bit for bit.  Accuracy ~1e-15 rel. (f64), ~2e-7 (f32): they are
  *   sampling/activation helpers, not libm replacements.
  */
+#include <math.h>
 #include <string.h>
 #include "orc.h"
 
@@ -156,15 +157,39 @@ float orc_det_tanhf(float x) {
 /* ---- root noise: Dirichlet([alpha]*k) as normalised Gamma(alpha,1) draws -------------------
  * Gamma(alpha) for alpha < 1 by the rejection scheme numpy's legacy generator uses for shape < 1
  * (numpy/random/src/legacy/legacy-distributions.c legacy_standard_gamma, an Ahrens-Dieter GS
- * variant); alpha == 1 is an exponential.  alpha > 1 is not needed by any shipped config
- * (config.py:138 dirichlet_alpha = 0.5) and returns -1. */
+ * variant); alpha == 1 is an exponential; alpha > 1 the Marsaglia-Tsang scheme the same function uses for shape > 1
+ * (no shipped config needs it - config.py:138 dirichlet_alpha = 0.5 - but lib/bitboard.py:162-171 takes any alpha). */
+double orc_det_cos2(double u);
+
 double orc_gamma_sample(double alpha, uint32_t seed, uint32_t game, uint32_t event, uint32_t sub) {
     double d[2];
     if (alpha == 1.0) {
         orc_rng_pair(seed, game, 2, event, sub, 0, d);
         return -orc_det_log(1.0 - d[0]);
     }
-    if (!(alpha > 0.0) || alpha > 1.0) return -1.0;
+    if (!(alpha > 0.0)) return -1.0;
+    if (alpha > 1.0) {
+        /* numpy's legacy_standard_gamma for shape > 1 (Marsaglia-Tsang), what np.random.dirichlet (lib/bitboard.py:164) runs
+         * per component: b = shape - 1/3, c = 1/sqrt(9b); X ~ N(0,1), V = (1 + cX)^3 > 0, U ~ U(0,1]; accept b V when
+         * U < 1 - 0.0331 X^4 or log U < X^2/2 + b (1 - V + log V).  raz-rng-v1: attempt t draws the normal from block
+         * (.., sub, 2t) (Box-Muller: |X| = sqrt(2 E cos^2 theta)), its sign and U from block (.., sub, 2t + 1). */
+        const double b = alpha - 0x1.5555555555555p-2, c = 1.0 / sqrt(9.0 * b);
+        for (uint32_t t = 0;; ++t) {
+            double e[2];
+            orc_rng_pair(seed, game, 2, event, sub, 2u * t, d);
+            orc_rng_pair(seed, game, 2, event, sub, 2u * t + 1u, e);
+            const double E = -orc_det_log(1.0 - d[0]);
+            const double z2 = 2.0 * (E * orc_det_cos2(d[1]));
+            const double az = sqrt(z2);
+            const double Z = e[0] < 0.5 ? -az : az;
+            double V = 1.0 + c * Z;
+            if (V <= 0.0) continue;
+            V = (V * V) * V;
+            const double U = 1.0 - e[1];
+            if (U < 1.0 - 0.0331 * (z2 * z2)) return b * V;
+            if (orc_det_log(U) < 0.5 * z2 + b * ((1.0 - V) + orc_det_log(V))) return b * V;
+        }
+    }
     for (uint32_t t = 0;; ++t) {
         orc_rng_pair(seed, game, 2, event, sub, t, d);
         double U = d[0], V = -orc_det_log(1.0 - d[1]);
@@ -202,7 +227,7 @@ double orc_det_cos2(double u) {
 /* The k Gamma(alpha,1) variates of one Dirichlet draw (raz-rng-v1 DIRICHLET).
  * alpha == 0.5 (config.py:138, every shipped config): Box-Muller pairs — block m gives
  * g[2m] = E cos^2(2 pi d1), g[2m+1] = E sin^2(2 pi d1) with E = -log(1 - d0) (Z^2/2 ~ Gamma(1/2)).
- * Other alpha in (0,1]: orc_gamma_sample (exponential / numpy-legacy rejection). */
+ * Other alpha: orc_gamma_sample (exponential / numpy-legacy rejection below 1 / Marsaglia-Tsang above 1). */
 void orc_dirichlet_gammas(double alpha, int k, uint32_t seed, uint32_t game, uint32_t event, double* g) {
     if (alpha == 0.5) {
         for (int m = 0; 2 * m < k; ++m) {

@@ -206,18 +206,38 @@ RAZ_HD void raz_gamma_half_pair(uint32_t seed, uint32_t game, uint32_t event, ui
     g1 = E * (1.0 - c2);
 }
 
-// One attempt `t` of the Gamma(alpha, 1) sampler for 0 < alpha <= 1, alpha != 0.5 (0.5 uses the pair
-// construction above): alpha == 1 is an exponential (always accepted); alpha < 1
-// is the rejection scheme of numpy's legacy_standard_gamma for shape < 1.  Attempt t of sample `sub`
-// of draw `event` uses the Philox block (seed, game, DIRICHLET, event, sub, t), so attempts can be
-// evaluated in any order or in parallel; the sample is the accepted attempt with the smallest t.
+// One attempt `t` of the Gamma(alpha, 1) sampler for alpha != 0.5 (0.5 uses the pair construction above): alpha == 1 is
+// an exponential (always accepted); alpha < 1 is the rejection scheme of numpy's legacy_standard_gamma for shape < 1;
+// alpha > 1 its Marsaglia-Tsang scheme for shape > 1 (np.random.dirichlet -> legacy_standard_gamma, the sampler behind
+// lib/bitboard.py:162-171).  Attempt t of sample `sub` of draw `event` uses the Philox block (seed, game, DIRICHLET, event,
+// sub, t) - for alpha > 1 the two blocks (.., 2t) and (.., 2t + 1): a standard normal from the first (Box-Muller: |Z| =
+// sqrt(2 E cos^2 theta)), its sign and the acceptance uniform from the second - so attempts can be evaluated in any order
+// or in parallel; the sample is the accepted attempt with the smallest t.
 RAZ_HD bool raz_gamma_attempt(double alpha, uint32_t seed, uint32_t game, uint32_t event, uint32_t sub,
                               uint32_t t, double& X) {
     double d0, d1;
-    raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, sub, t, d0, d1);
+    raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, sub, alpha > 1.0 ? 2u * t : t, d0, d1);
     if (alpha == 1.0) {
         X = -raz_det_log(1.0 - d0);
         return true;
+    }
+    if (alpha > 1.0) {
+        double e0, e1;
+        raz_rng_pair(seed, game, RAZ_RNG_DIRICHLET, event, sub, 2u * t + 1u, e0, e1);
+        const double E = -raz_det_log(1.0 - d0);
+        const double z2 = 2.0 * (E * raz_det_cos2(d1));   // Z^2, Z ~ N(0, 1)
+        const double az = sqrt(z2);
+        const double Z = e0 < 0.5 ? -az : az;
+        const double b = alpha - 0x1.5555555555555p-2;    // alpha - 1/3
+        const double c = 1.0 / sqrt(9.0 * b);
+        double V = 1.0 + c * Z;
+        X = 0.0;
+        if (V <= 0.0) return false;
+        V = (V * V) * V;
+        X = b * V;
+        const double U = 1.0 - e1;                        // uniform on (0, 1]
+        if (U < 1.0 - 0.0331 * (z2 * z2)) return true;
+        return raz_det_log(U) < 0.5 * z2 + b * ((1.0 - V) + raz_det_log(V));
     }
     const double inv = 1.0 / alpha;
     const double U = d0, V = -raz_det_log(1.0 - d1);

@@ -1782,8 +1782,8 @@ int validate(const raz_engine_config* cfg) {
     if (cfg->max_plies < 64) return raz_fail(RAZ_EINVAL, "raz_engine: max_plies must be >= 64");
     if (pool_bytes_of(*cfg) < 2 * RAZ_NODE_MAX_BYTES + 8 || pool_bytes_of(*cfg) > 8ULL * RAZ_LINK_MAX_UNITS)
         return raz_fail(RAZ_EINVAL, "raz_engine: pool_bytes_per_game must be between 1416 bytes and 256 MB (a link holds a 25-bit offset in 8-byte units)");
-    if (!(cfg->dirichlet_alpha > 0.0) || cfg->dirichlet_alpha > 1.0)
-        return raz_fail(RAZ_EINVAL, "raz_engine: dirichlet_alpha must be in (0, 1] (all shipped configs use 0.5)");
+    if (!(cfg->dirichlet_alpha > 0.0) || !(cfg->dirichlet_alpha < 1e6))
+        return raz_fail(RAZ_EINVAL, "raz_engine: dirichlet_alpha must be a positive finite number (all shipped configs use 0.5)");
     if (cfg->thinking_loop < 1) return raz_fail(RAZ_EINVAL, "raz_engine: thinking_loop must be >= 1");
     if (cfg->parallel_search_num > 16)
         return raz_fail(RAZ_EINVAL, "raz_engine: parallel_search_num must be <= 16 (prediction_queue_size, config.py:141: the reference's queue would block beyond it)");

@@ -204,3 +204,18 @@ def test_emulated_leaf_cache_changes_nothing(golden, blob):
             st = eng.leaf_cache_stats()
             assert st["hits"] + st["in_batch_duplicates"] > 0 and st["evaluated"] > 0
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("alpha", [1.3, 4.0])
+def test_emulated_dirichlet_alpha_above_one(golden, blob, alpha):
+    """lib/bitboard.py:162-171 takes any alpha: above 1 numpy's legacy gamma sampler is Marsaglia-Tsang, restated on
+    counter-based draws in csrc/raz_detmath.h (attempts evaluated in parallel across lanes) and oracle/orc_rng.c."""
+    cfg = config_of(_variant(golden, "mini_shared"))
+    cfg.play.dirichlet_alpha, cfg.play.noise_eps, cfg.play.thinking_loop = alpha, 0.4, 1
+    eng = EmuEngine(cfg, blob, n_games=2, seed=19, sims_hint=10)
+    eng.start(810, 10)
+    eng.run(chunk=32)
+    ocfg = O.play_cfg_from_config(cfg)
+    for i, (plies, summ) in enumerate(eng.records(save_policy_of_tau_1=True)):
+        op, osum = O.selfplay_game(ocfg, blob, 19, 810 + i, 10)
+        _same(f"alpha{alpha}/{i}", plies, summ, op, osum["winner"])

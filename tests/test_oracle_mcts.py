@@ -188,6 +188,34 @@ def test_live_reference_game_matches_oracle(blob):
     assert summ["winner"] == ref["winner"]
 
 
+def test_gamma_sampler_above_one_has_the_gamma_distribution():
+    """raz-rng-v1's Gamma(alpha > 1) (numpy's legacy Marsaglia-Tsang scheme on counter-based draws, oracle/orc_rng.c): a
+    Kolmogorov-Smirnov test against scipy's Gamma(alpha) over 20 000 samples per alpha, and Dirichlet components that sum to 1."""
+    from scipy import stats
+    lib = O.load_ext()
+    for alpha in (1.01, 1.7, 3.0, 12.5):
+        xs = np.array([lib.orc_gamma_sample(alpha, 11, 5, ev, ev % 7) for ev in range(20000)])
+        assert xs.min() > 0.0
+        assert stats.kstest(xs, "gamma", args=(alpha,)).pvalue > 1e-3, alpha
+    out = (ctypes.c_double * 64)()
+    lib.orc_dirichlet_noise_of_mask(0x0000001818000000 | 0x81, 2.5, 1, 2, 3, ctypes.byref(out))
+    v = np.array(out[:])
+    assert abs(v.sum() - 1.0) < 1e-12 and (v > 0).sum() == 6
+
+
+@pytest.mark.needs_reference
+def test_reference_game_at_dirichlet_alpha_above_one_matches_oracle(blob):
+    """The unmodified reference with dirichlet_alpha = 2.0 (np.random.dirichlet served by the raz-rng-v1 stream) == the oracle."""
+    import ref_harness as rh
+    import ref_selfplay as rs
+    cfg = rh.load_config("alpha_go_zero.yml", {"play": {"parallel_search_num": 1, "noise_eps": 0.5, "dirichlet_alpha": 2.0}})
+    ref = rs.run_reference_game(cfg, blob, seed=31, game_id=77, sims_per_move=12)
+    plies, summ = O.selfplay_game(O.play_cfg_from_config(cfg), blob, 31, 77, 12)
+    assert [p["action"] for p in plies] == [p["action"] for p in ref["plies"]]
+    for a, b in zip(plies, ref["plies"]):
+        assert a["root_n"] == b["root_n"] and a["root_w"] == b["root_w"]
+
+
 @pytest.mark.needs_reference
 def test_game_taken_up_at_a_position_matches_the_reference(blob):
     """orc_selfplay_game_from (bench.py's check of its steady-state batch): the reference worker whose env is put on a
