@@ -23,6 +23,7 @@ def load():
             raise RuntimeError("wave-emulator build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
         from reversi_alpha_zero_amd import _native as N
         lib = ctypes.CDLL(EMU_LIB)
+        lib.raz_last_error.restype = ctypes.c_char_p
         for name, (res, args) in N.SIGNATURES.items():
             fn = getattr(lib, name, None)
             if fn is not None:

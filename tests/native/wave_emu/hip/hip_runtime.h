@@ -33,6 +33,11 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint4 { unsigned x, y, z, w; };
+struct ulonglong2 { unsigned long long x, y; };
+struct uchar2 { unsigned char x, y; };
+struct char2 { signed char x, y; };
+static inline char2 make_char2(signed char x, signed char y) { char2 r = {x, y}; return r; }
+static inline uchar2 make_uchar2(unsigned char x, unsigned char y) { uchar2 r = {x, y}; return r; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 
 namespace wave_emu {
@@ -113,6 +118,8 @@ static inline T emu_shfl(T v, int src, int line) {
     return r;
 }
 #define __shfl(v, src) emu_shfl((v), (src), __LINE__)
+#define __any(p) (wave_emu::ballot((p) != 0, "__any", __LINE__) != 0ULL)
+static inline int __ffs(int x) { return __builtin_ffs(x); }
 #define __syncthreads() wave_emu::block_barrier(__LINE__)
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
