@@ -47,6 +47,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 // rendezvous of the calling lane's wave: publish v, wait for every live lane of the wave, return the value lane `src` published
 uint64_t exchange(uint64_t v, int src, const char* what, int line);
 uint64_t ballot(bool pred, const char* what, int line);
+// publish v, wait for the wave, copy what all 64 lanes published into out[64] (the matrix-core emulation)
+void gather(uint64_t v, uint64_t* out, const char* what, int line);
 void wave_barrier(const char* what, int line);
 void block_barrier(int line);
 unsigned long long clock64();
@@ -118,6 +120,7 @@ static inline T emu_shfl(T v, int src, int line) {
     return r;
 }
 #define __shfl(v, src) emu_shfl((v), (src), __LINE__)
+#define __shfl_xor(v, mask) emu_shfl((v), emu_lane() ^ (mask), __LINE__)
 #define __any(p) (wave_emu::ballot((p) != 0, "__any", __LINE__) != 0ULL)
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 #define __syncthreads() wave_emu::block_barrier(__LINE__)
@@ -164,3 +167,46 @@ static inline int emu_dpp_src(int lane, int ctrl) {
     ((int)(uint32_t)wave_emu::exchange((uint32_t)(src), emu_dpp_src(emu_lane(), (ctrl)), "dpp", __LINE__))
 // v_writelane_b32 (bound through the LLVM intrinsic in the product source): src and lane are wave-uniform
 static inline uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t old) { return (uint32_t)emu_lane() == (lane & 63u) ? src : old; }
+
+// ---- pieces only the net kernels need (tests/native/wave_emu Makefile target libraz_emu_net.so, compiled with clang++ for the
+// kernels' ext_vector_type vectors).  Dynamic LDS (`extern __shared__ float smem[]`) is rewritten by the Makefile into a static
+// 160 KB array of the same name before compilation.
+#define RAZ_EMU_LDS_FLOATS 40960
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+#define __builtin_amdgcn_wave_barrier() wave_emu::wave_barrier("wave_barrier", __LINE__)
+static inline float emu_lo_f(uint64_t x) { uint32_t u = (uint32_t)x; float f; memcpy(&f, &u, 4); return f; }
+static inline float emu_hi_f(uint64_t x) { uint32_t u = (uint32_t)(x >> 32); float f; memcpy(&f, &u, 4); return f; }
+static inline uint64_t emu_pack_ff(float a, float b) { uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4); return ((uint64_t)y << 32) | x; }
+// v_mfma_f32_16x16x4_f32: D[16x16] = A[16x4] B[4x16] + C.  Lane l holds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16] and, in
+// vector element r, C/D[i = 4 (l / 16) + r][j = l % 16].  One output = one k-ordered fmaf chain (tools/probe_numerics.hip).
+template <class V4>
+static inline V4 emu_mfma_f32_16x16x4(float a, float b, V4 c, int line) {
+    uint64_t all[64];
+    wave_emu::gather(emu_pack_ff(a, b), all, "mfma_f32_16x16x4", line);
+    const int l = emu_lane(), j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(emu_lo_f(all[i + 16 * k]), emu_hi_f(all[j + 16 * k]), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4((a), (b), (c), __LINE__)
+// v_mfma_f32_32x32x2_f32: D[32x32] = A[32x2] B[2x32] + C.  Lane l holds A[i = l % 32][k = l / 32], B[k = l / 32][j = l % 32] and, in
+// vector element v (0..15), C/D[i = 8 (v / 4) + 4 (l / 32) + v % 4][j = l % 32].
+template <class V16>
+static inline V16 emu_mfma_f32_32x32x2(float a, float b, V16 c, int line) {
+    uint64_t all[64];
+    wave_emu::gather(emu_pack_ff(a, b), all, "mfma_f32_32x32x2", line);
+    const int l = emu_lane(), j = l & 31;
+    for (int v = 0; v < 16; ++v) {
+        const int i = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3);
+        float acc = c[v];
+        for (int k = 0; k < 2; ++k) acc = fmaf(emu_lo_f(all[i + 32 * k]), emu_hi_f(all[j + 32 * k]), acc);
+        c[v] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2((a), (b), (c), __LINE__)

@@ -132,6 +132,16 @@ uint64_t ballot(bool pred, const char* what, int line) {
     return m;
 }
 
+void gather(uint64_t v, uint64_t* out, const char* what, int line) {
+    Fiber* f = running;
+    const int k = (int)(f->ops & 1u);
+    f->pub[k] = v;
+    ++f->ops;
+    arrive(waves[f->wave], what, line);
+    const int base = f->wave * 64;
+    for (int i = 0; i < 64; ++i) out[i] = base + i < n_fibers ? fibers[base + i].pub[k] : 0;
+}
+
 void wave_barrier(const char* what, int line) { arrive(waves[running->wave], what, line); }
 void block_barrier(int line) { arrive(block, "__syncthreads", line); }
 unsigned long long clock64() { return ++ticks; }

@@ -1,0 +1,93 @@
+"""CPU: the exact-f32 NET kernels (raznet-forward-v1) on EMULATED matrix cores against the CPU oracle, bit for bit:
+k_net_mfma (v_mfma_f32_16x16x4_f32, narrow nets), k_net_wave (VALU + LDS, any shape), k_conv0_wide / k_conv3x3_wide / k_heads_wide
+(v_mfma_f32_32x32x2_f32, F >= 128) - csrc/raz_net.hip, raz_net_mfma.hip, raz_net_wide.hip compiled for the host against the wave
+emulator (tests/native/wave_emu: fibers for lanes, a matrix-core instruction = an all-gather of the operands + the k-ordered
+fmaf chains of its documented lane layout).  The GPU tests (tests/test_engine_gpu.py) are the tests of record; this is the loop in
+which a net kernel's indexing can be developed without a GPU - the emulation is self-validating: a wrong operand layout or
+accumulation order does not reproduce the oracle.  The split-f16 trunk (f16 matrix cores, LDS-DMA) is not emulated."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import ROOT
+
+EMU_DIR = os.path.join(ROOT, "tests", "native", "wave_emu")
+LIB = os.path.join(ROOT, "tests", "native", "libraz_emu_net.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    r = subprocess.run(["make", "-C", EMU_DIR, "../libraz_emu_net.so"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    from reversi_alpha_zero_amd import _native as N
+    lib = ctypes.CDLL(LIB)
+    lib.raz_last_error.restype = ctypes.c_char_p
+    for name in ("raz_net_weight_bytes", "raz_net_scratch_bytes", "raz_net_load", "raz_net_forward"):
+        getattr(lib, name).restype, getattr(lib, name).argtypes = N.SIGNATURES[name]
+    return lib
+
+
+def _forward(lib, blob, own, enemy, reserved=0, active=None):
+    from reversi_alpha_zero_amd import _native as N
+    _, _, F, R, V = struct.unpack_from("<5i", blob, 0)
+    w = np.zeros(lib.raz_net_weight_bytes(F, R, V), dtype=np.uint8)
+    net = N.RazNet()
+    net.reserved = reserved
+    assert lib.raz_net_load(ctypes.byref(net), blob, len(blob), w.ctypes.data, w.size, None) == 0, lib.raz_last_error()
+    n = len(own)
+    need = lib.raz_net_scratch_bytes(F, V, n)
+    scratch = np.zeros(max(need, 8), dtype=np.uint8)
+    pol, val = np.full((n, 64), 7.0, np.float32), np.full(n, 7.0, np.float32)
+    rc = lib.raz_net_forward(ctypes.byref(net), own.ctypes.data, enemy.ctypes.data, active.ctypes.data if active is not None else None,
+                             pol.ctypes.data, val.ctypes.data, n, scratch.ctypes.data if need else None, need, None)
+    assert rc == 0, lib.raz_last_error()
+    return pol, val
+
+
+def _oracle(blob, own, enemy):
+    o = O.load_ext()
+    pol, val = np.zeros((len(own), 64), np.float32), np.zeros(len(own), np.float32)
+    for i in range(len(own)):
+        v = np.zeros(1, np.float32)
+        assert o.orc_net_forward(blob, len(blob), int(own[i]), int(enemy[i]), pol[i].ctypes.data, v.ctypes.data) == 0
+        val[i] = v[0]
+    return pol, val
+
+
+def _positions(n, seed):
+    rng = np.random.default_rng(seed)
+    own = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    return own, rng.integers(0, 2**64, size=n, dtype=np.uint64) & ~own
+
+
+@pytest.mark.parametrize("shape,reserved", [((16, 1, 16), 0), ((16, 2, 48), 0), ((32, 1, 32), 0), ((16, 1, 16), 1), ((48, 1, 20), 0), ((16, 1, 16), 3)])
+def test_emulated_narrow_net_kernels_equal_oracle(lib, shape, reserved):
+    """k_net_mfma (reserved 0, F in {16, 32}: 16x16x4 matrix-core tiles; R = 1 with the weights hoisted into registers, R = 2 without),
+    k_net_wave (reserved 1, and any shape the matrix-core kernel does not take: F = 48), k_net_mfma16_wg (reserved 3: eight-wave
+    workgroups sharing the dense weights in LDS) == the oracle's C net, with an active mask (skipped rows stay untouched)."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    blob = ReversiNet(*shape).keras_init_(3).randomize_bn_(4).to_blob()
+    n = 11
+    own, enemy = _positions(n, 5)
+    active = (np.arange(n) % 4 != 2).astype(np.uint8)
+    pol, val = _forward(lib, blob, own, enemy, reserved, active)
+    rp, rv = _oracle(blob, own, enemy)
+    on = active.astype(bool)
+    assert np.array_equal(pol[on].view(np.uint32), rp[on].view(np.uint32)) and np.array_equal(val[on].view(np.uint32), rv[on].view(np.uint32))
+    assert (pol[~on] == 7.0).all() and (val[~on] == 7.0).all()
+
+
+def test_emulated_wide_net_kernels_equal_oracle(lib):
+    """k_conv0_wide + k_conv3x3_wide (implicit GEMM on 32x32x2 matrix-core tiles, 4-wave workgroups, chunk-major K order) +
+    k_heads_wide on a 128-filter net == the oracle, bit for bit, on a batch that is not a multiple of the 4 positions per workgroup."""
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    blob = ReversiNet(128, 1, 32).keras_init_(6).randomize_bn_(7).to_blob()
+    own, enemy = _positions(6, 8)
+    pol, val = _forward(lib, blob, own, enemy, 0)
+    rp, rv = _oracle(blob, own, enemy)
+    assert np.array_equal(pol.view(np.uint32), rp.view(np.uint32)) and np.array_equal(val.view(np.uint32), rv.view(np.uint32))
