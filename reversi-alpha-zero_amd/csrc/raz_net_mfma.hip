@@ -101,21 +101,34 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const f
             }
         } else {
             const float* base = in + kk * PS + pidx(i);  // M tile mt adds 24 floats (two board rows)
-            // k order of raznet-forward-v1: 16-channel chunks, then tap, then channel within the chunk
+            // k order of raznet-forward-v1: 16-channel chunks, then tap, then channel within the chunk.
+            // Software-pipelined DEPTH k-steps deep: the A operands of k-step s + DEPTH are requested before the MFMAs of k-step s, so
+            // an LDS round trip has DEPTH x 4 x 32 matrix-core cycles to land (same MFMAs in the same order: bit-identical).
+            auto koff = [](int s) {
+                const int c = s / 36, t = (s / 4) % 9, q = s % 4;
+                return (c * 16 + q * 4) * PS + (t / 3 - 1) * 12 + (t % 3 - 1);
+            };
+            constexpr int DEPTH = 2;   // k-steps of A operands in flight ahead of the one being multiplied
+            float aq[DEPTH + 1][4];
 #pragma unroll
-            for (int c = 0; c < CIN / 16; ++c) {
+            for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int mt = 0; mt < 4; ++mt) aq[d][mt] = base[koff(d < KS ? d : KS - 1) + mt * 24];
+            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int s = (c * 9 + t) * 4 + q;
-                        const int off = (c * 16 + q * 4) * PS + (t / 3 - 1) * 12 + (t % 3 - 1);
+            for (int s = 0; s < KS; ++s) {
+                if (s + DEPTH < KS) {
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const float a = base[off + mt * 24];
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[s], acc[mt], 0, 0, 0);
-                        }
-                    }
+                    for (int mt = 0; mt < 4; ++mt) aq[DEPTH][mt] = base[koff(s + DEPTH) + mt * 24];
+                }
+                // keep the requests above where they are: the matrix-core instructions below must not be hoisted over them
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[0][mt], wreg[s], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) aq[d][mt] = aq[d + 1][mt];
                 }
             }
         }
