@@ -317,7 +317,9 @@ int launch(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy,
         hipError_t e = hipFuncSetAttribute((const void*)k_net_mfma<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
     }
-    const unsigned maxgrid = 2048;  // LDS-limited residency: 16 (F=16) / 8 workgroups per CU
+    unsigned maxgrid = 2048;  // LDS-limited residency: 16 (F=16) / 8 workgroups per CU
+    if (const char* g = getenv("RAZ_NET_MAXGRID"))   // tests only: fewer workgroups, so that each one loops over several positions
+        if (atoi(g) > 0) maxgrid = (unsigned)atoi(g);
     const unsigned grid = (unsigned)(n < maxgrid ? n : maxgrid);
     if (prof)
         hipLaunchKernelGGL((k_net_mfma<F, true>), dim3(grid), dim3(64), shm, s, W, R, V, own, enemy, active, policy,
