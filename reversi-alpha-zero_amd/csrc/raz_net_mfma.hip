@@ -47,30 +47,23 @@ __device__ __forceinline__ void load_wregs(const float* __restrict__ Wl, int nt,
     for (int s = 0; s < KS; ++s) wreg[s] = Wl[((size_t)nt * KS + s) * 64 + lane];
 }
 
-// One 3x3 conv layer over the zero-haloed planes `in` (CIN channels; for FIRST the two input bit
-// planes) -> `out` (F channels).  SKIP: out is also the residual input (updated in place).
-// PRE: the layer's B operands are already in registers (`pre`, F == 16 only).
-// For F == 16 (one channel tile) `in` and `out` may be the SAME buffer: a single wave performs every
-// read of the layer (the MFMA operands) before the epilogue stores, and the residual input is the
-// lane's own D fragment of the previous block (`frag`, kept in registers), so one LDS buffer per
-// position is enough (16 workgroups per CU instead of 8).
-// INPLACE (k_net_mfma16_wg, F == 16): `in` and `out` are the same buffer (see above), the residual is
-// added from `frag`, a block output is kept in `frag` (keep_frag), and the closing synchronisation is
-// wave-local (the workgroup's other waves work on their own positions).
-// MT < 4 (k_net_mfma16_split): the wave computes only MT of the four 16-square M tiles, the ones that start at
-// `in` / `out` (the caller passes both advanced by 24 floats per skipped tile); the other waves of the
-// workgroup compute the rest of the same position, and the closing barrier is the workgroup's.
+// LDS hand-over inside ONE wave (a head computed by a single wave of k_net_mfma16_split)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int F, int CIN, bool FIRST, bool SKIP, bool PRE, bool INPLACE = false, int MT = 4>
+// One 3x3 conv layer over the zero-haloed planes `in` (CIN channels; for FIRST the two input bit
+// planes) -> `out` (F channels).  SKIP: out is also the residual input (updated in place).
+// PRE: the layer's B operands are already in registers (`pre`, F == 16 only).
+// MT < 4 (k_net_mfma16_split): the wave computes only MT of the four 16-square M tiles, the ones that start at
+// `in` / `out` (the caller passes both advanced by 24 floats per skipped tile); the other waves of the
+// workgroup compute the rest of the same position, and the closing barrier is the workgroup's.
+template <int F, int CIN, bool FIRST, bool SKIP, bool PRE, int MT = 4>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const float* __restrict__ bias,
                                            const float* in, float* out, int lane,
-                                           const float (&pre)[LayerK<F, CIN, FIRST>::KS], float preb,
-                                           f32x4 (&frag)[4], bool keep_frag) {
+                                           const float (&pre)[LayerK<F, CIN, FIRST>::KS], float preb) {
     constexpr int KS = LayerK<F, CIN, FIRST>::KS;
     const int i = lane & 15, kk = lane >> 4;
     for (int nt = 0; nt < F / 16; ++nt) {
@@ -141,20 +134,13 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const f
         for (int mt = 0; mt < MT; ++mt) {
             f32x4* dst = (f32x4*)(obase + mt * 24);
             f32x4 v = acc[mt];
-            if (SKIP) {
-                const f32x4 sk = INPLACE ? frag[mt] : *dst;
-                v = v + sk;
-            }
+            if (SKIP) v = v + *dst;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
             *dst = v;
-            if (INPLACE && keep_frag) frag[mt] = v;
         }
     }
-    if (INPLACE)
-        wave_lds_sync();
-    else
-        __syncthreads();
+    __syncthreads();
 }
 
 // PROF: lane 0 records s_memtime ticks at phase boundaries into prof[pos][8] (debug launches only:
@@ -220,27 +206,24 @@ __global__ __launch_bounds__(64, F == 16 ? 2 : 1) void k_net_mfma(const float* _
         bufT[PS + pidx(lane)] = (float)((be >> lane) & 1ULL);
         __syncthreads();
         RAZ_NET_TICK(1);
-        f32x4 frag[4];  // the lane's D fragment of the last block output (residual input), F == 16
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) frag[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (HOIST && pre) {
             if constexpr (HOIST) {
-                conv_layer<F, 2, true, false, true>(nullptr, nullptr, bufT, bufA, lane, w0, pb0, frag, true);
+                conv_layer<F, 2, true, false, true>(nullptr, nullptr, bufT, bufA, lane, w0, pb0);
                 RAZ_NET_TICK(2);
-                conv_layer<F, F, false, false, true>(nullptr, nullptr, bufA, bufT, lane, w1, pb1, frag, false);
-                conv_layer<F, F, false, true, true>(nullptr, nullptr, bufT, bufA, lane, w2, pb2, frag, true);
+                conv_layer<F, F, false, false, true>(nullptr, nullptr, bufA, bufT, lane, w1, pb1);
+                conv_layer<F, F, false, true, true>(nullptr, nullptr, bufT, bufA, lane, w2, pb2);
             }
         } else {
             float dummyK[LayerK<F, F, false>::KS];
             conv_layer<F, 2, true, false, false>(W + mfma_layer_off(F, R, V, 0), W + conv_off(F, 0) + (size_t)F * 9 * 2, bufT,
-                                                 bufA, lane, dummy5, 0.f, frag, true);
+                                                 bufA, lane, dummy5, 0.f);
             RAZ_NET_TICK(2);
             for (int r = 0; r < R; ++r) {
                 const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
                 conv_layer<F, F, false, false, false>(W + mfma_layer_off(F, R, V, l1), W + conv_off(F, l1) + (size_t)F * 9 * F,
-                                                      bufA, bufT, lane, dummyK, 0.f, frag, false);
+                                                      bufA, bufT, lane, dummyK, 0.f);
                 conv_layer<F, F, false, true, false>(W + mfma_layer_off(F, R, V, l2), W + conv_off(F, l2) + (size_t)F * 9 * F,
-                                                     bufT, bufA, lane, dummyK, 0.f, frag, true);
+                                                     bufT, bufA, lane, dummyK, 0.f);
             }
         }
         RAZ_NET_TICK(3);
@@ -334,169 +317,6 @@ int launch(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy,
 }
 
 
-// ------------------------------------------------------------------ bulk variant (F == 16, n >= 4096)
-// k_net_mfma spends a third of a position (9 k of 27 k cycles) in the two dense heads: lane = output,
-// one dependent fmaf chain whose 128 + 64 weights per lane come from L2 in batches of 32 - every
-// position re-reads the same 36 KB.  Here a workgroup is EIGHT waves (one position each at a time,
-// 2 waves per SIMD as before) that share ONE copy of the dense weights in LDS (32 KB policy + 64 V
-// value), staged once per workgroup; a chain step is then a conflict-free ds_read_b32 (lanes read
-// consecutive floats) instead of an L2 round trip.  The room comes from running the F == 16 trunk in
-// place in a single plane buffer per wave (conv_layer<.., INPLACE>: one wave performs every operand
-// read of a layer before the epilogue stores; the residual input stays in the lane's D fragment).
-// Same arithmetic, same order: bit-identical to k_net_mfma / k_net_wave / the oracle.
-// MEASURED, NOT ADOPTED (kept selectable: raz_net.reserved = 3, DeviceNet(kernel="mfma_wg"), and tested
-// for bit-equality): stand-alone it gains 5 % at 16 384 positions (127.6 vs 133.7 us) and nothing at
-// 4096 - with two waves per SIMD the heads of one wave already hide behind the other's MFMA phase, and
-// what caps the trunk at ~54 % of the f32 MFMA peak is LDS operand traffic (four ds_read_b32 per four
-// MFMAs per wave, now plus the B operand) - and inside the engine it is slower (parallel_search_num 4:
-// 75.4 vs 85.7 M sims/s): an eight-wave workgroup holds its CU's LDS until its last wave is done, which
-// delays the other slices' kernels.  raz_net_forward therefore never picks it by itself.
-constexpr int kWgWaves = 8;
-
-// WLDS: the B operands of all conv layers are staged in LDS too ((5 + 72 R) x 256 B: R <= 2); otherwise each
-// layer's operands come from L2.  (Keeping them in 77 registers across positions, as k_net_mfma does for
-// R == 1, leaves no room for the residual fragment at 2 waves per SIMD.)
-template <bool WLDS>
-__global__ __launch_bounds__(64 * kWgWaves, 1) void k_net_mfma16_wg(const float* __restrict__ W, int R, int V,
-                                                                   const raz_bb* __restrict__ own,
-                                                                   const raz_bb* __restrict__ enemy,
-                                                                   const uint8_t* __restrict__ active,
-                                                                   float* __restrict__ policy, float* __restrict__ value, int n) {
-    constexpr int F = 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* H = W + heads_off(F, R);
-    const float* pol_w = H;
-    const float* pol_b = pol_w + 2 * F;
-    const float* pfc_w = pol_b + 2;
-    const float* pfc_b = pfc_w + 128 * 64;
-    const float* val_w = pfc_b + 64;
-    const float* val_b = val_w + F;
-    const float* v1_w = val_b + 1;
-    const float* v1_b = v1_w + 64 * V;
-    const float* v2_w = v1_b + V;
-    const float* v2_b = v2_w + V;
-    float* pw = smem;                 // [128][64] policy dense weights
-    float* vw = smem + 128 * 64;      // [64][V]   value dense weights
-    float* cw = vw + ((64 * V + 3) & ~3);   // conv B operands, all layers (WLDS)
-    const int conv_floats_lds = WLDS ? (5 + 72 * R) * 64 : 0;
-    const int wave_floats = F * PS + 192 + ((V + 3) & ~3);
-    float* buf = cw + conv_floats_lds + wave * wave_floats;
-    float* head = buf + F * PS;       // ph[128] vh[64] h1[V]
-    for (int j = tid; j < 128 * 64; j += 64 * kWgWaves) pw[j] = pfc_w[j];
-    for (int j = tid; j < 64 * V; j += 64 * kWgWaves) vw[j] = v1_w[j];
-    if (WLDS) {
-        const float* src = W + mfma_layer_off(F, R, V, 0);
-        for (int j = tid; j < conv_floats_lds; j += 64 * kWgWaves) cw[j] = src[j];
-    }
-    {  // halos must read as 0; interiors are overwritten for every position
-        f32x4* z = (f32x4*)buf;
-        for (int j = lane; j < F * PS / 4; j += 64) z[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();  // the only workgroup barrier: the shared weights are in place
-    float* ph = head;
-    float* vh = head + 128;
-    float* h1 = head + 192;
-    const float dummy5[5] = {0, 0, 0, 0, 0};
-    const size_t l0 = mfma_layer_off(F, R, V, 0);
-    for (int pos = blockIdx.x * kWgWaves + wave; pos < n; pos += gridDim.x * kWgWaves) {
-        if (active && !active[pos]) continue;
-        const raz_bb bo = own[pos], be = enemy[pos];
-        buf[pidx(lane)] = (float)((bo >> lane) & 1ULL);       // the two input bit planes: planes 0/1
-        buf[PS + pidx(lane)] = (float)((be >> lane) & 1ULL);
-        wave_lds_sync();
-        f32x4 frag[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) frag[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {
-            float dummyK[LayerK<F, F, false>::KS];
-            const float* wl = WLDS ? (const float*)cw : W + l0;
-            conv_layer<F, 2, true, false, false, true>(wl, W + conv_off(F, 0) + (size_t)F * 9 * 2, buf, buf, lane, dummy5, 0.f,
-                                                       frag, true);
-            for (int r = 0; r < R; ++r) {
-                const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-                const float* w1 = WLDS ? (const float*)cw + (mfma_layer_off(F, R, V, l1) - l0) : W + mfma_layer_off(F, R, V, l1);
-                const float* w2 = WLDS ? (const float*)cw + (mfma_layer_off(F, R, V, l2) - l0) : W + mfma_layer_off(F, R, V, l2);
-                conv_layer<F, F, false, false, false, true>(w1, W + conv_off(F, l1) + (size_t)F * 9 * F, buf, buf, lane, dummyK, 0.f,
-                                                            frag, false);
-                conv_layer<F, F, false, true, false, true>(w2, W + conv_off(F, l2) + (size_t)F * 9 * F, buf, buf, lane, dummyK, 0.f,
-                                                           frag, true);
-            }
-        }
-        {
-            const float* a = buf + pidx(lane);
-            float p0 = pol_b[0], p1 = pol_b[1], v0 = val_b[0];
-#pragma unroll 8
-            for (int ic = 0; ic < F; ++ic) {
-                const float xv = a[ic * PS];
-                p0 = fmaf(xv, pol_w[ic], p0);
-                p1 = fmaf(xv, pol_w[F + ic], p1);
-                v0 = fmaf(xv, val_w[ic], v0);
-            }
-            ph[lane] = p0 > 0.0f ? p0 : 0.0f;
-            ph[64 + lane] = p1 > 0.0f ? p1 : 0.0f;
-            vh[lane] = v0 > 0.0f ? v0 : 0.0f;
-        }
-        wave_lds_sync();
-        // policy dense 128 -> 64, lane = output: one chain, operands from LDS
-        float logit = pfc_b[lane];
-#pragma unroll 16
-        for (int j = 0; j < 128; ++j) logit = fmaf(ph[j], pw[j * 64 + lane], logit);
-        float m = logit;
-        m = fmaxf(m, dppf<0xB1>(m));
-        m = fmaxf(m, dppf<0x4E>(m));
-        m = fmaxf(m, dppf<0x141>(m));
-        m = fmaxf(m, dppf<0x140>(m));
-        m = fmaxf(fmaxf(lanef(m, 0), lanef(m, 16)), fmaxf(lanef(m, 32), lanef(m, 48)));
-        const float e = raz_det_expf(logit - m);
-        float sum = e;
-        sum = sum + dppf<0xB1>(sum);
-        sum = sum + dppf<0x4E>(sum);
-        sum = sum + dppf<0x141>(sum);
-        sum = sum + dppf<0x140>(sum);
-        sum = (lanef(sum, 0) + lanef(sum, 16)) + (lanef(sum, 32) + lanef(sum, 48));
-        policy[(size_t)pos * 64 + lane] = e / sum;
-        for (int o0 = 0; o0 < V; o0 += 64) {
-            const int o = o0 + lane;
-            if (o < V) {
-                float acc = v1_b[o];
-#pragma unroll 16
-                for (int j = 0; j < 64; ++j) acc = fmaf(vh[j], vw[j * V + o], acc);
-                h1[o] = acc > 0.0f ? acc : 0.0f;
-            }
-        }
-        wave_lds_sync();
-        float acc = v2_b[0];
-        for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
-        if (lane == 0) value[pos] = raz_det_tanhf(acc);
-        wave_lds_sync();  // the next position overwrites the planes / head
-    }
-}
-
-inline size_t wg_shm_bytes(int R, int V, bool wlds) {
-    return ((size_t)128 * 64 + ((64 * (size_t)V + 3) & ~(size_t)3) + (wlds ? (size_t)(5 + 72 * R) * 64 : 0) +
-            kWgWaves * ((size_t)16 * PS + 192 + ((V + 3) & ~3))) * sizeof(float);
-}
-inline bool wg_usable(int F, int R, int V) { return F == 16 && wg_shm_bytes(R, V, false) <= 160 * 1024; }
-
-int launch_wg(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy, const uint8_t* active, float* policy,
-              float* value, size_t n, hipStream_t s) {
-    const bool wlds = wg_shm_bytes(R, V, true) <= 160 * 1024;
-    const size_t shm = wg_shm_bytes(R, V, wlds);
-    const void* fn = wlds ? (const void*)k_net_mfma16_wg<true> : (const void*)k_net_mfma16_wg<false>;
-    {   // (per call: the limit is per function and nets of different R / V share the two instantiations)
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute (wg)");
-    }
-    const size_t wgs = (n + kWgWaves - 1) / kWgWaves;
-    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);  // one workgroup per CU (LDS), 2 waves per SIMD
-    if (wlds)
-        hipLaunchKernelGGL(k_net_mfma16_wg<true>, dim3(grid), dim3(64 * kWgWaves), shm, s, W, R, V, own, enemy, active, policy, value, (int)n);
-    else
-        hipLaunchKernelGGL(k_net_mfma16_wg<false>, dim3(grid), dim3(64 * kWgWaves), shm, s, W, R, V, own, enemy, active, policy, value, (int)n);
-    return raz_check_launch("raz_net_forward (mfma, shared dense weights)");
-}
-
 // ------------------------------------------------------------------ latency variant (F == 16, small launches)
 // Inside the engine a launch is one slice of the batch (configs[1]: 1365 positions): fewer positions than the
 // 2048 waves the chip holds, so k_net_mfma's time there is the serial latency of ONE position on ONE wave
@@ -547,7 +367,6 @@ __global__ __launch_bounds__(64 * WPP, 3) void k_net_mfma16_split(const float* _
         pb2 = (W + conv_off(F, 2) + (size_t)F * 9 * F)[lane & 15];
     }
     const float dummy5[5] = {0, 0, 0, 0, 0};
-    f32x4 frag[4];  // (unused: the residual comes from LDS)
     const int toff = wave * MT * 24;  // this wave's first M tile, as an offset into a plane (two board rows per tile)
     for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
         if (active && !active[pos]) continue;
@@ -558,19 +377,19 @@ __global__ __launch_bounds__(64 * WPP, 3) void k_net_mfma16_split(const float* _
         }
         __syncthreads();
         if constexpr (PRE) {
-            conv_layer<F, 2, true, false, true, false, MT>(nullptr, nullptr, bufT + toff, bufA + toff, lane, w0, pb0, frag, false);
-            conv_layer<F, F, false, false, true, false, MT>(nullptr, nullptr, bufA + toff, bufT + toff, lane, w1, pb1, frag, false);
-            conv_layer<F, F, false, true, true, false, MT>(nullptr, nullptr, bufT + toff, bufA + toff, lane, w2, pb2, frag, false);
+            conv_layer<F, 2, true, false, true, MT>(nullptr, nullptr, bufT + toff, bufA + toff, lane, w0, pb0);
+            conv_layer<F, F, false, false, true, MT>(nullptr, nullptr, bufA + toff, bufT + toff, lane, w1, pb1);
+            conv_layer<F, F, false, true, true, MT>(nullptr, nullptr, bufT + toff, bufA + toff, lane, w2, pb2);
         } else {
             float dummyK[LayerK<F, F, false>::KS];
-            conv_layer<F, 2, true, false, false, false, MT>(W + mfma_layer_off(F, R, V, 0), W + conv_off(F, 0) + (size_t)F * 9 * 2,
-                                                            bufT + toff, bufA + toff, lane, dummy5, 0.f, frag, false);
+            conv_layer<F, 2, true, false, false, MT>(W + mfma_layer_off(F, R, V, 0), W + conv_off(F, 0) + (size_t)F * 9 * 2,
+                                                            bufT + toff, bufA + toff, lane, dummy5, 0.f);
             for (int r = 0; r < R; ++r) {
                 const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-                conv_layer<F, F, false, false, false, false, MT>(W + mfma_layer_off(F, R, V, l1), W + conv_off(F, l1) + (size_t)F * 9 * F,
-                                                                 bufA + toff, bufT + toff, lane, dummyK, 0.f, frag, false);
-                conv_layer<F, F, false, true, false, false, MT>(W + mfma_layer_off(F, R, V, l2), W + conv_off(F, l2) + (size_t)F * 9 * F,
-                                                                bufT + toff, bufA + toff, lane, dummyK, 0.f, frag, false);
+                conv_layer<F, F, false, false, false, MT>(W + mfma_layer_off(F, R, V, l1), W + conv_off(F, l1) + (size_t)F * 9 * F,
+                                                                 bufA + toff, bufT + toff, lane, dummyK, 0.f);
+                conv_layer<F, F, false, true, false, MT>(W + mfma_layer_off(F, R, V, l2), W + conv_off(F, l2) + (size_t)F * 9 * F,
+                                                                bufT + toff, bufA + toff, lane, dummyK, 0.f);
             }
         }
         // (the last layer's barrier has passed: bufA holds the trunk output of all 64 squares)
@@ -659,16 +478,13 @@ int launch_split(const float* W, int R, int V, const raz_bb* own, const raz_bb* 
 
 bool raz_net_mfma_supported(int F, int V) { return (F == 16 || F == 32 || F == 64) && V <= 1024; }
 
-// variant: 0 = by batch size, 2 = one single-wave workgroup per position, 3 = eight-wave workgroups
-// sharing the dense weights in LDS (F == 16 only), 5 / 6 = one position per workgroup of two / four waves
+// variant: 0 / 2 = one single-wave workgroup per position, 5 / 6 = one position per workgroup of two / four waves
 // (F == 16 only: the latency variant for launches smaller than the chip)
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
                          unsigned long long* prof, int variant) {
     const raz_bb* o = (const raz_bb*)own;
     const raz_bb* e = (const raz_bb*)enemy;
-    if (variant == 3 && !wg_usable(F, R, V)) return raz_fail(RAZ_EINVAL, "raz_net_forward_mfma: the shared-weights variant needs F == 16");
-    if (!prof && variant == 3) return launch_wg(W, R, V, o, e, active, policy, value, n, s);
     if ((variant == 5 || variant == 6) && (F != 16 || V > 1024))
         return raz_fail(RAZ_EINVAL, "raz_net_forward_mfma: the split variant needs F == 16");
     if (!prof && variant == 5) return launch_split<2>(W, R, V, o, e, active, policy, value, n, s);

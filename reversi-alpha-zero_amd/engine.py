@@ -35,9 +35,9 @@ class DeviceNet:
         """kernel: None / "f32" = the exact-f32 kernels chosen by shape (raznet-forward-v1, bit-identical to the CPU oracle);
         "f16x3" = raznet-forward-v2 for filters % 128 == 0: the 3x3 trunk on the f16 matrix cores with split operands, within
         1e-5 of the fp32 graph (include/raz.h raz_net_range_check); "auto" = "f16x3" where supported, else "f32".
-        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position; "mfma_wg" = eight-wave
-        workgroups sharing the dense weights in LDS (F == 16); "mfma_split2" / "mfma_split4" = one position per workgroup of two /
-        four waves (F == 16: the latency variant for launches smaller than the chip, csrc/raz_net_mfma.hip k_net_mfma16_split)."""
+        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position; "mfma_split2" / "mfma_split4" =
+        one position per workgroup of two / four waves (F == 16: the latency variant for launches smaller than the chip,
+        csrc/raz_net_mfma.hip k_net_mfma16_split)."""
         import torch
         import struct
         magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -52,7 +52,7 @@ class DeviceNet:
         if kernel == "auto":
             kernel = "f16x3" if (F >= 128 and F % 128 == 0) else "f32"
         self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk"}.get(kernel, kernel)
-        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "mfma_wg": 3, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6}[kernel]
+        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")

@@ -43,10 +43,10 @@ def test_net_mfma_kernel_equals_valu_kernel(shape):
 
 
 @pytest.mark.parametrize("shape", [(16, 1, 16), (16, 2, 48), (16, 3, 16)])
-def test_net_shared_weights_kernel_equals_other_kernels(shape):
-    """k_net_mfma16_wg (eight-wave workgroups, dense and conv weights shared in LDS, trunk in place; an
-    opt-in variant, see its header) == k_net_mfma (one wave per position) == k_net_wave (VALU), bit for bit,
-    on a ragged batch with an active mask; R = 3 takes the variant whose conv operands stay in L2."""
+def test_net_split_kernels_equal_other_kernels(shape):
+    """k_net_mfma16_split (one position on a workgroup of two / four waves, the two heads side by side; an opt-in latency
+    variant, see its header) == k_net_mfma (one wave per position) == k_net_wave (VALU), bit for bit, on a ragged batch
+    with an active mask; R != 1 takes the form whose conv operands are fetched per layer."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
     from reversi_alpha_zero_amd.engine import DeviceNet
     blob = ReversiNet(*shape).keras_init_(2).randomize_bn_(3).to_blob()
@@ -55,13 +55,13 @@ def test_net_shared_weights_kernel_equals_other_kernels(shape):
     o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
     act = torch.from_numpy((np.random.default_rng(8).random(n) < 0.8).astype(np.uint8)).to(DEV)
     outs = []
-    for kernel in ("mfma_wg", None, "mfma_wave", "valu"):
+    for kernel in ("mfma_split2", "mfma_split4", None, "mfma_wave", "valu"):
         p, v = DeviceNet(blob, DEV, kernel=kernel).predict_bitboards(o, e, active=act)
         outs.append((p.view(torch.int32), v.view(torch.int32)))
     for p, v in outs[1:]:
         assert torch.equal(outs[0][0], p) and torch.equal(outs[0][1], v)
     assert bool((outs[0][0][act == 0] == 0).all()) and bool((outs[0][0][act == 1] != 0).any())
-    p_all, v_all = DeviceNet(blob, DEV, kernel="mfma_wg").predict_bitboards(o[:9], e[:9])   # a batch smaller than one workgroup
+    p_all, v_all = DeviceNet(blob, DEV, kernel="mfma_split4").predict_bitboards(o[:9], e[:9])   # a handful of positions
     p_ref, v_ref = DeviceNet(blob, DEV, kernel="valu").predict_bitboards(o[:9], e[:9])
     assert torch.equal(p_all.view(torch.int32), p_ref.view(torch.int32)) and torch.equal(v_all.view(torch.int32), v_ref.view(torch.int32))
 
