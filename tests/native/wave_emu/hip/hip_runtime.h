@@ -49,6 +49,7 @@ uint64_t exchange(uint64_t v, int src, const char* what, int line);
 uint64_t ballot(bool pred, const char* what, int line);
 // publish v, wait for the wave, copy what all 64 lanes published into out[64] (the matrix-core emulation)
 void gather(uint64_t v, uint64_t* out, const char* what, int line);
+void gather32(const uint64_t v[4], uint64_t (*out)[4], const char* what, int line);   // the same with 32 bytes per lane
 void wave_barrier(const char* what, int line);
 void block_barrier(int line);
 unsigned long long clock64();
@@ -129,6 +130,7 @@ static inline void __threadfence_block() {}
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 #define __ATOMIC_EMU_SCOPE 0
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
@@ -169,9 +171,10 @@ static inline int emu_dpp_src(int lane, int ctrl) {
 static inline uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t old) { return (uint32_t)emu_lane() == (lane & 63u) ? src : old; }
 
 // ---- pieces only the net kernels need (tests/native/wave_emu Makefile target libraz_emu_net.so, compiled with clang++ for the
-// kernels' ext_vector_type vectors).  Dynamic LDS (`extern __shared__ float smem[]`) is rewritten by the Makefile into a static
-// 160 KB array of the same name before compilation.
+// kernels' ext_vector_type vectors).  Dynamic LDS (`extern __shared__ float smem[]` / `unsigned char lds[]`) is rewritten by the
+// Makefile into a static 160 KB array of the same name before compilation.
 #define RAZ_EMU_LDS_FLOATS 40960
+#define RAZ_EMU_LDS_BYTES 163840
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
@@ -211,3 +214,42 @@ static inline V16 emu_mfma_f32_32x32x2(float a, float b, V16 c, int line) {
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2((a), (b), (c), __LINE__)
+
+// ---- the split-f16 trunk (csrc/raz_net_f16x3.hip): f16 matrix cores and LDS-DMA ------------------------------------------------
+#if defined(__clang__)
+// v_mfma_f32_32x32x16_f16: D[32x32] = A[32x16] B[16x32] + C.  Lane l holds the 8 halfs A[i = l % 32][k = 8 (l / 32) + 0..7] and
+// B[k = 8 (l / 32) + 0..7][j = l % 32]; C/D as for 32x32x2 (element v: i = 8 (v / 4) + 4 (l / 32) + v % 4, j = l % 32).
+// The products of halfs are exact in f32; the ORDER in which the matrix core adds the 16 of them to the accumulator is not
+// documented - here: k ascending, one f32 addition each.  Results on this path are compared at a tolerance (and bit for bit only
+// between kernels that issue the same matrix instructions in the same order per accumulator).
+template <class H8, class V16>
+static inline V16 emu_mfma_f32_32x32x16_f16(H8 a, H8 b, V16 c, int line) {
+    uint64_t mine[4], all[64][4];
+    memcpy(&mine[0], &a, 16);
+    memcpy(&mine[2], &b, 16);
+    wave_emu::gather32(mine, all, "mfma_f32_32x32x16_f16", line);
+    const int l = emu_lane(), j = l & 31;
+    float bk[16];
+    for (int g = 0; g < 2; ++g) {
+        _Float16 h[8];
+        memcpy(h, &all[j + 32 * g][2], 16);
+        for (int e = 0; e < 8; ++e) bk[8 * g + e] = (float)h[e];
+    }
+    for (int v = 0; v < 16; ++v) {
+        const int i = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3);
+        float acc = c[v];
+        for (int g = 0; g < 2; ++g) {
+            _Float16 h[8];
+            memcpy(h, &all[i + 32 * g][0], 16);
+            for (int e = 0; e < 8; ++e) acc = acc + (float)h[e] * bk[8 * g + e];
+        }
+        c[v] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_f16((a), (b), (c), __LINE__)
+// global_load_lds (LDS-DMA), 16 bytes per lane: the LDS address is the wave-uniform base + lane * 16, the global address is per lane.
+// Synchronous here (the kernels' waits and barriers are not what this emulation checks).
+#define __builtin_amdgcn_global_load_lds(gptr, lptr, size, off, aux) \
+    memcpy((unsigned char*)(lptr) + (off) + emu_lane() * (size), (const void*)(gptr), (size))
+#endif

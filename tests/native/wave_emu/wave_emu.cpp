@@ -33,6 +33,7 @@ struct Fiber {
     int wave;
     uint32_t ops;          // cross-lane operations completed (parity selects the publish buffer)
     uint64_t pub[2];
+    uint64_t wide[2][4];   // 32-byte payloads (two 8-half matrix operands), double-buffered like pub
     const char* wait_what;
     int wait_line;
 };
@@ -140,6 +141,19 @@ void gather(uint64_t v, uint64_t* out, const char* what, int line) {
     arrive(waves[f->wave], what, line);
     const int base = f->wave * 64;
     for (int i = 0; i < 64; ++i) out[i] = base + i < n_fibers ? fibers[base + i].pub[k] : 0;
+}
+
+void gather32(const uint64_t v[4], uint64_t (*out)[4], const char* what, int line) {
+    Fiber* f = running;
+    const int k = (int)(f->ops & 1u);
+    memcpy(f->wide[k], v, 32);
+    ++f->ops;
+    arrive(waves[f->wave], what, line);
+    const int base = f->wave * 64;
+    for (int i = 0; i < 64; ++i) {
+        if (base + i < n_fibers) memcpy(out[i], fibers[base + i].wide[k], 32);
+        else memset(out[i], 0, 32);
+    }
 }
 
 void wave_barrier(const char* what, int line) { arrive(waves[running->wave], what, line); }
