@@ -702,8 +702,9 @@ def config5_leg(args, dev, blob, weights, games=8192, sims=3200, steps=10):
     return out
 
 
-def config1_leg(dev, args, par=1):
-    """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch)."""
+def config1_leg(dev, args, par=1, fused=False):
+    """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch).
+    fused: tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip, opt-in)."""
     import numpy as np
     import torch
     from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
@@ -713,7 +714,7 @@ def config1_leg(dev, args, par=1):
     F, R, V = NETS["mini"]
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     net = DeviceNet(blob, dev)
-    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims)
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, fused=fused)
     eng.start(0, sims)
     eng.step(50)
     eng.stats()
@@ -739,19 +740,24 @@ def config1_leg(dev, args, par=1):
     dt = time.perf_counter() - t0
     lps = 3
     macs = macs_per_position(F, R, V)
-    leaves_per_launch = st["nn_leaves"] / (steps * lps)
-    net_avg = net_ms / (timed * lps)
-    ach = 2.0 * macs * leaves_per_launch / (net_avg * 1e-3) / 1e12
     out = {"workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
-                       f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)",
+                       f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)"
+                       + ("; tree and net in ONE kernel (k_tree_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else ""),
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
-           "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims,
-           "leaf_slot_occupancy": st["nn_leaves"] / (steps * games * max(par, 1)),
-           "roofline": {"bound": "mfma", "kernel": "k_net_mfma", "avg_kernel_ms": net_avg, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                        "note": "3 slices on 3 streams overlap, so the per-launch duration is stretched by co-residency"},
-           "k_tree_avg_ms": tree_ms / (timed * lps)}
+           "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims}
+    if fused:
+        out["k_tree_net_ms_per_simulation_step"] = tree_ms / timed
+        out["matrix_core_tflops_inside_the_fused_kernel"] = 2.0 * macs * st["nn_leaves"] / dt / 1e12
+    else:
+        leaves_per_launch = st["nn_leaves"] / (steps * lps)
+        net_avg = net_ms / (timed * lps)
+        ach = 2.0 * macs * leaves_per_launch / (net_avg * 1e-3) / 1e12
+        out["leaf_slot_occupancy"] = st["nn_leaves"] / (steps * games * max(par, 1))
+        out["roofline"] = {"bound": "mfma", "kernel": "k_net_mfma", "avg_kernel_ms": net_avg, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                           "note": "3 slices on 3 streams overlap, so the per-launch duration is stretched by co-residency"}
+        out["k_tree_avg_ms"] = tree_ms / (timed * lps)
     if par == 1 and not args.no_spotcheck:
         slots = [int(x) for x in np.linspace(0, games - 1, 8).astype(int)]
         t1 = time.perf_counter()
@@ -859,6 +865,32 @@ def cpu_baseline_port(cfg, blob, sims, threads, stop_after_plies=0, what=""):
 
 
 # ------------------------------------------------------------------------------------------------------------
+def fused_leg_child(args):
+    """configs[1] on the fused tree + net kernel (k_tree_net), in a process of its own: the kernel is opt-in and younger than the rest
+    of the engine, and nothing it does may cost the parent its line.  Prints one JSON document."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(0)
+    import __graft_entry__ as g
+    g.build()
+    out, _, _ = config1_leg(torch.device("cuda", 0), args, 1, fused=True)
+    print(json.dumps(out))
+    return 0
+
+
+def fused_leg(timeout=420.0):
+    """Runs fused_leg_child in a child process and returns its document, or what went wrong."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-leg-only"], capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the child process did not finish within {timeout:.0f} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    return json.loads(lines[-1])
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` (N > 1) started without a launcher: become N ranks."""
     import socket
@@ -895,7 +927,10 @@ def main():
     ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
     ap.add_argument("--whole-slots", type=int, default=1024, help="slots of the whole-game leg")
     ap.add_argument("--whole-ids", type=int, default=1536, help="game ids the whole-game leg plays to the end")
+    ap.add_argument("--fused-leg-only", action="store_true", help="(child mode of the default run) configs[1] on the fused tree + net kernel only")
     args = ap.parse_args()
+    if args.fused_leg_only:
+        return fused_leg_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -988,6 +1023,10 @@ def main():
                     raise
                 except Exception as ex:   # never lose the main line over an extra leg
                     out[key] = {"error": repr(ex)}
+            # last, in a process of its own: the same configs[1] batch on the opt-in fused tree + net kernel
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["config1_4096x200_mini_fused_tree_net_kernel"] = fused_leg()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

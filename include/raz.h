@@ -155,9 +155,11 @@ typedef struct {
     uint32_t max_plies;                       /* record capacity per game (>= 64) */
     uint32_t seed;
     uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream; bit 3: drive even
-                                                 parallel_search_num <= 1 with the slot kernel (tests); bits 8-11: slices/streams
-                                                 (0 = 3); bits 12-15: max simulations per game per tree launch (0 = 2; slot
-                                                 kernel: simulations STARTED per launch beyond parallel_search_num) */
+                                                 parallel_search_num <= 1 with the slot kernel (tests); bit 4: 16-filter nets,
+                                                 parallel_search_num <= 1: tree and net in ONE kernel, the game's wave evaluates
+                                                 its own leaves (csrc/raz_engine.hip k_tree_net; same results); bits 8-11:
+                                                 slices/streams (0 = 3); bits 12-15: max simulations per game per tree launch
+                                                 (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num) */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
                                                  (agent/player.py:100-103,150-161; lib/alt/reversi_solver_cython.pyx) */
     int32_t use_solver_turn_in_simulation;    /* config.py:155: 0 = off, else >= 46: win/loss solve inside simulations

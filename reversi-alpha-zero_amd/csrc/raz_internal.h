@@ -15,3 +15,7 @@ int raz_check_launch(const char* where);
         hipError_t _e = (expr);                               \
         if (_e != hipSuccess) return raz_fail_hip(_e, where); \
     } while (0)
+
+// raz_engine_fused.hip: `n_steps` simulation steps of the whole batch with k_tree_net (tree + narrow net in one kernel)
+struct raz_engine_dev;
+int raz_launch_tree_net(const raz_engine_dev& d, bool solver, uint32_t n_steps, const float* W, int R, int V, hipStream_t s);

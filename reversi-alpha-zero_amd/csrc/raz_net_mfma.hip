@@ -20,128 +20,9 @@
 #include "raz_detmath.h"
 #include "raz_internal.h"
 #include "raz_net_layout.h"
+#include "raz_net_wave.h"   // plane layout, conv_layer, the in-wave forward
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int PS = 136;  // padded plane stride in floats (136 % 32 == 8 keeps bank overlap at 4 of 32)
-
-__device__ __forceinline__ int pidx(int sq) { return ((sq >> 3) + 1) * 12 + (sq & 7) + 4; }
-
-template <int CTRL>
-__device__ __forceinline__ float dppf(float v) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float lanef(float v, int l) {
-    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
-}
-
-template <int F, int CIN, bool FIRST>
-struct LayerK {
-    static constexpr int KS = FIRST ? 5 : 9 * CIN / 4;
-};
-
-template <int KS>
-__device__ __forceinline__ void load_wregs(const float* __restrict__ Wl, int nt, int lane, float (&wreg)[KS]) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) wreg[s] = Wl[((size_t)nt * KS + s) * 64 + lane];
-}
-
-// LDS hand-over inside ONE wave (a head computed by a single wave of k_net_mfma16_split)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// One 3x3 conv layer over the zero-haloed planes `in` (CIN channels; for FIRST the two input bit
-// planes) -> `out` (F channels).  SKIP: out is also the residual input (updated in place).
-// PRE: the layer's B operands are already in registers (`pre`, F == 16 only).
-// MT < 4 (k_net_mfma16_split): the wave computes only MT of the four 16-square M tiles, the ones that start at
-// `in` / `out` (the caller passes both advanced by 24 floats per skipped tile); the other waves of the
-// workgroup compute the rest of the same position, and the closing barrier is the workgroup's.
-template <int F, int CIN, bool FIRST, bool SKIP, bool PRE, int MT = 4>
-__device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const float* __restrict__ bias,
-                                           const float* in, float* out, int lane,
-                                           const float (&pre)[LayerK<F, CIN, FIRST>::KS], float preb) {
-    constexpr int KS = LayerK<F, CIN, FIRST>::KS;
-    const int i = lane & 15, kk = lane >> 4;
-    for (int nt = 0; nt < F / 16; ++nt) {
-        float wreg[KS];
-        float b;
-        if (PRE) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) wreg[s] = pre[s];
-            b = preb;
-        } else {
-            load_wregs<KS>(Wl, nt, lane, wreg);
-            b = bias[nt * 16 + i];
-        }
-        f32x4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){b, b, b, b};
-        if (FIRST) {
-            // k = tap*2 + plane: k-step s holds taps 2s (lanes 0..31) and 2s+1 (lanes 32..63); the
-            // padded k = 18, 19 carry zero weights, so any in-bounds address will do for them
-            const float* base = in + (kk & 1) * PS + pidx(i);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int ta = 2 * s, tb = 2 * s + 1 > 8 ? 8 : 2 * s + 1;
-                const int offa = (ta / 3 - 1) * 12 + (ta % 3 - 1), offb = (tb / 3 - 1) * 12 + (tb % 3 - 1);
-                const int off = (kk < 2) ? offa : offb;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float a = base[off + mt * 24];
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[s], acc[mt], 0, 0, 0);
-                }
-            }
-        } else {
-            const float* base = in + kk * PS + pidx(i);  // M tile mt adds 24 floats (two board rows)
-            // k order of raznet-forward-v1: 16-channel chunks, then tap, then channel within the chunk.
-            // Software-pipelined DEPTH k-steps deep: the A operands of k-step s + DEPTH are requested before the MFMAs of k-step s, so
-            // an LDS round trip has DEPTH x 4 x 32 matrix-core cycles to land (same MFMAs in the same order: bit-identical).
-            auto koff = [](int s) {
-                const int c = s / 36, t = (s / 4) % 9, q = s % 4;
-                return (c * 16 + q * 4) * PS + (t / 3 - 1) * 12 + (t % 3 - 1);
-            };
-            constexpr int DEPTH = 2;   // k-steps of A operands in flight ahead of the one being multiplied
-            float aq[DEPTH + 1][MT];
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) aq[d][mt] = base[koff(d < KS ? d : KS - 1) + mt * 24];
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s + DEPTH < KS) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) aq[DEPTH][mt] = base[koff(s + DEPTH) + mt * 24];
-                }
-                // keep the requests above where they are: the matrix-core instructions below must not be hoisted over them
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[0][mt], wreg[s], acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) aq[d][mt] = aq[d + 1][mt];
-                }
-            }
-        }
-        // D fragment: channel nt*16 + i, squares mt*16 + kk*4 + r (r = 0..3): one row segment
-        float* obase = out + (nt * 16 + i) * PS + ((kk >> 1) + 1) * 12 + (kk & 1) * 4 + 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4* dst = (f32x4*)(obase + mt * 24);
-            f32x4 v = acc[mt];
-            if (SKIP) v = v + *dst;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
-            *dst = v;
-        }
-    }
-    __syncthreads();
-}
 
 // PROF: lane 0 records s_memtime ticks at phase boundaries into prof[pos][8] (debug launches only:
 // RAZ_NET_PROF=1 + a scratch buffer).

@@ -91,7 +91,7 @@ class DeviceNet:
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
                        record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
-                       use_graph=False, force_slot_kernel=False, pool_bytes_per_game=0):
+                       use_graph=False, force_slot_kernel=False, pool_bytes_per_game=0, fused=False):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
     that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par)."""
@@ -117,7 +117,7 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
         reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (4 if use_graph else 0) | (8 if force_slot_kernel else 0)
-        | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
+        | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
         solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par,
         pool_bytes_per_game=int(pool_bytes_per_game or 0))
@@ -127,8 +127,10 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0):
-        """nodes_per_game: most tree nodes a game's pool may hold; pool_bytes_per_game: its bytes (0 = nodes_per_game x 232 + 64 x 704:
+                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False):
+        """fused: 16-filter nets with parallel_search_num 1 - tree and net in ONE kernel, every game's wave evaluating its own leaves
+        (csrc/raz_engine_fused.hip; same results, opt-in).
+        nodes_per_game: most tree nodes a game's pool may hold; pool_bytes_per_game: its bytes (0 = nodes_per_game x 232 + 64 x 704:
         nodes are compact - 40 B + 20 B per legal move, ~212 B on average - include/raz.h).
         leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h
         raz_engine_set_leaf_cache): repeated positions are served from it, bit-identically.  None: no cache.
@@ -155,7 +157,8 @@ class SelfPlayEngine:
                 pool_bytes_per_game = min(nodes_per_game * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
                                       record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph,
-                                      force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game)
+                                      force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused)
+        self.fused = bool(fused)
         self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
         self.slots = int(self.cfg.parallel_search_num) or 1   # simulation slots (leaf-exchange rows) per game
         # most nodes one step can add to a game's pool: k_tree completes <= inner_max (default 2) simulations,

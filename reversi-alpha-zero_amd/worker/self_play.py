@@ -189,7 +189,7 @@ class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
     def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None,
-                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24):
+                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24, fused_tree_net=False):
         """games_in_flight: game slots resident on the device.  block_games (per rank; default = games_in_flight): the
         number of consecutive game ids a rank plays between two gathers.  With block_games > games_in_flight the slots are
         refilled as games finish (continuous batching, SelfPlayEngine.play_continuous); the files do not depend on either
@@ -205,6 +205,9 @@ class BatchedSelfPlayWorker:
         # whose forward is what a step costs; none for narrow nets (two extra launches per step cost more than they save)
         self.leaf_cache_log2 = leaf_cache_log2
         self.leaf_cache_max_discs = leaf_cache_max_discs
+        # 16-filter nets with parallel_search_num 1: tree and net in ONE kernel, the game's wave evaluating its own leaves
+        # (csrc/raz_engine_fused.hip; same files; opt-in)
+        self.fused_tree_net = bool(fused_tree_net)
         self.seed = seed
         self.device = device
         self.rank, self.world = rank, world
@@ -276,9 +279,10 @@ class BatchedSelfPlayWorker:
             pool_bytes = 0   # pruned pools: the default budget (232 B per node); k_gc is triggered by bytes as well as by count
             if r > 1:        # never pruned: room for whole games whatever their mobility
                 pool_bytes = min(nodes * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
+            fused = (self.fused_tree_net and self._net.filters == 16 and int(getattr(p, "parallel_search_num", 1) or 1) <= 1)
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
-                                          sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=cache,
-                                          leaf_cache_max_discs=self.leaf_cache_max_discs, pool_bytes_per_game=pool_bytes)
+                                          sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=None if fused else cache,
+                                          leaf_cache_max_discs=self.leaf_cache_max_discs, pool_bytes_per_game=pool_bytes, fused=fused)
             self._engine_key = key
         self._engine.set_resign_threshold(self.config.play.resign_threshold)
         return self._engine

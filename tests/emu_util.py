@@ -12,24 +12,27 @@ from conftest import ROOT
 
 EMU_DIR = os.path.join(ROOT, "tests", "native", "wave_emu")
 EMU_LIB = os.path.join(ROOT, "tests", "native", "libraz_emu.so")
-_lib = None
+EMU_FULL_LIB = os.path.join(ROOT, "tests", "native", "libraz_emu_full.so")
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is None:
-        r = subprocess.run(["make", "-C", EMU_DIR], capture_output=True, text=True)
+def load(full=False):
+    """full=False: the tree kernels, leaves evaluated by the oracle's C net (libraz_emu.so, seconds to build).  full=True: the
+    whole product incl. the real net kernels on emulated matrix cores (libraz_emu_full.so, a minute to build): what the fused
+    tree + net kernel needs."""
+    if full not in _libs:
+        r = subprocess.run(["make", "-C", EMU_DIR] + (["../libraz_emu_full.so"] if full else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("wave-emulator build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
         from reversi_alpha_zero_amd import _native as N
-        lib = ctypes.CDLL(EMU_LIB)
+        lib = ctypes.CDLL(EMU_FULL_LIB if full else EMU_LIB)
         lib.raz_last_error.restype = ctypes.c_char_p
         for name, (res, args) in N.SIGNATURES.items():
             fn = getattr(lib, name, None)
             if fn is not None:
                 fn.restype, fn.argtypes = res, args
-        _lib = lib
-    return _lib
+        _libs[full] = lib
+    return _libs[full]
 
 
 def _check(lib, rc, what):
@@ -41,10 +44,11 @@ class EmuEngine:
     """The subset of reversi_alpha_zero_amd.engine.SelfPlayEngine the parity tests use, on the emulated kernels."""
 
     def __init__(self, config, blob, n_games, seed=0, nodes_per_game=None, sims_hint=None, max_plies=72, record_root_w=True,
-                 inner_max=0, force_slot_kernel=False, pool_bytes_per_game=0, **cfg_overrides):
+                 inner_max=0, force_slot_kernel=False, pool_bytes_per_game=0, fused=False, full_lib=False, **cfg_overrides):
+        """fused: the tree + net kernel (raz_engine_config.reserved bit 4); it, and full_lib, run on the whole-product library."""
         from reversi_alpha_zero_amd import _native as N
         from reversi_alpha_zero_amd.engine import engine_config_from
-        self.lib = lib = load()
+        self.lib = lib = load(full=bool(fused or full_lib))
         self.n_games, self.max_plies, self.record_root_w = n_games, max_plies, record_root_w
         import struct
         _, _, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -57,7 +61,7 @@ class EmuEngine:
             nodes_per_game = (s * max(1, config.play.thinking_loop) * 62 + 128) * (2 if share else 1)
         from reversi_alpha_zero_amd.engine import NODE_MAX_BYTES, NODE_POOL_BYTES_PER_NODE
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, None, record_root_w, False, True, 1, inner_max,
-                                      force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game)
+                                      force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused)
         self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
         for k, v in cfg_overrides.items():
             setattr(self.cfg, k, v)
@@ -69,7 +73,10 @@ class EmuEngine:
         self._ws = np.zeros(nbytes + 256, dtype=np.uint8)
         base = (self._ws.ctypes.data + 255) // 256 * 256
         self._h = ctypes.c_void_p()
-        _check(lib, lib.raz_engine_create(ctypes.byref(self.cfg), ctypes.byref(self.net), base, nbytes, None, 0, ctypes.byref(self._h)), "raz_engine_create")
+        need = lib.raz_net_scratch_bytes(F, V, n_games * self.slots)
+        self._scratch = np.zeros(max(need, 8), dtype=np.uint8)
+        _check(lib, lib.raz_engine_create(ctypes.byref(self.cfg), ctypes.byref(self.net), base, nbytes, self._scratch.ctypes.data if need else None, need,
+                                          ctypes.byref(self._h)), "raz_engine_create")
         self.nodes_per_step = 2 * (inner_max or 2) if (self.slots == 1 and not force_slot_kernel) else 3 * self.slots + (inner_max or 2)
 
     def __del__(self):
