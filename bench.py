@@ -28,7 +28,8 @@ sampled slots of the TIMED steady-state batch, root N / W bit for bit against th
 outputs), a WHOLE-GAME leg on the headline settings (1024 slots, continuous batching over 1536 game ids, ~4 min: games/hour
 and sims/s measured on complete games, two complete games == the oracle), `cpu_baseline` = the reference's own pure-Python
 self-play timed in this run on this box's host cores (oracle/_ref, tools/ref_python_baseline.py), BASELINE configs[1]
-(4096 games x mini net x 200 sims/move, whole games, with its own spot check) and the bitboard-sweep HBM leg.
+(4096 games x mini net x 200 sims/move, whole games, with its own spot check) and the bitboard-sweep HBM leg.  Last, in a child
+process with a timeout (`--fused-leg-only`): the same configs[1] batch on the opt-in fused tree + net kernel (csrc/raz_engine_fused.hip).
 At N > 1: the record gather over RCCL is timed and its payload verified (per-rank checksums), and a small whole-game batch is
 played sharded AND on rank 0 alone: the gathered records must be byte-identical (SURVEY 8(d) Config 4's acceptance).
 """

@@ -42,3 +42,10 @@ extern "C" int raz_net_range_check(const raz_net*, int* overflowed, raz_stream_t
     if (overflowed) *overflowed = 0;
     return RAZ_OK;
 }
+// the fused tree + net kernel evaluates leaves on the (emulated) matrix cores: it is part of the whole-product build
+// (libraz_emu_full.so, tests/test_engine_fused_emu.py), not of this one
+struct raz_engine_dev;
+int raz_fail(int code, const char* msg);
+int raz_launch_tree_net(const raz_engine_dev&, bool, uint32_t, const float*, int, int, hipStream_t) {
+    return raz_fail(RAZ_EINVAL, "wave emulator (tree-only build): the fused tree + net kernel needs libraz_emu_full.so");
+}
