@@ -207,12 +207,12 @@ __device__ __forceinline__ void raz_net16_forward_in_wave(const float* __restric
     wave_lds_sync();
     float logit = pfc_b[lane];
 #pragma unroll 1
-    for (int j0 = 0; j0 < 128; j0 += 16) {  // 16 loads in flight, then their 16 chained fmas (register budget: see above)
-        float wv[16];
+    for (int j0 = 0; j0 < 128; j0 += 32) {  // 32 loads in flight, then their 32 chained fmas
+        float wv[32];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wv[j] = pfc_w[(j0 + j) * 64 + lane];
+        for (int j = 0; j < 32; ++j) wv[j] = pfc_w[(j0 + j) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) logit = fmaf(ph[j0 + j], wv[j], logit);
+        for (int j = 0; j < 32; ++j) logit = fmaf(ph[j0 + j], wv[j], logit);
     }
     float m = logit;
     m = fmaxf(m, dppf<0xB1>(m));
@@ -233,12 +233,12 @@ __device__ __forceinline__ void raz_net16_forward_in_wave(const float* __restric
         if (o < V) {
             float acc = v1_b[o];
 #pragma unroll 1
-            for (int j0 = 0; j0 < 64; j0 += 16) {
-                float wv[16];
+            for (int j0 = 0; j0 < 64; j0 += 32) {
+                float wv[32];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) wv[j] = v1_w[(j0 + j) * V + o];
+                for (int j = 0; j < 32; ++j) wv[j] = v1_w[(j0 + j) * V + o];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc = fmaf(vh[j0 + j], wv[j], acc);
+                for (int j = 0; j < 32; ++j) acc = fmaf(vh[j0 + j], wv[j], acc);
             }
             h1[o] = acc > 0.0f ? acc : 0.0f;
         }
