@@ -30,6 +30,7 @@
 //   epilogue  = * 1/S, + bias, (+ skip), relu, split into (hi, lo), 8-byte stores that tile 512-byte runs
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "raz_bitboard.h"
@@ -193,6 +194,172 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
             }
         }
     if (over) atomicOr(flag, 1u);   // an activation beyond the f16 range: the caller must fall back to the f32 kernel
+}
+
+// EXPERIMENTAL VARIANT of the kernel above (selected per launch by the environment variable RAZ_F16X3_PIPE, measurements only):
+// the same stages, the same matrix instructions in the same order per accumulator - bit-identical output - with the operand
+// traffic scheduled by hand instead of by the compiler.  A stage is 12 units (tap tt, M tile m) of 6 matrix instructions; the
+// LDS reads of unit u + 2 (the M tile's weight pair, and with m == 0 the tap's four activation operands) are requested BEFORE
+// the matrix instructions of unit u, so that a read has two units (384 matrix-core cycles) to land whatever the LDS queue looks
+// like; the stage barrier moves two units up the instruction stream accordingly (it precedes the first read of the next
+// stage, i.e. unit 10 of the current one), and the activation operands of the three taps of a stage live in their own
+// registers (228 VGPRs).  Everything else - staging, addresses, epilogue - is the kernel above.
+__global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3_pipe(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
+                                                               const float* __restrict__ inv_scale_ptr, const unsigned char* in,
+                                                               unsigned char* out, const unsigned char* skip,
+                                                               const uint8_t* __restrict__ active, int n, int F, unsigned* __restrict__ flag,
+                                                               const uint32_t* __restrict__ n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
+    const int noct = F / OCT, nchunks = F / 16;
+    const int b = blockIdx.x;
+    const int ot = (b >> 3) % noct;
+    const int pg = (b / (8 * noct)) * 8 + (b & 7);
+    const int p0 = pg * NWAVE, pos = p0 + wv;
+    if (p0 >= n) return;
+    const bool live = pos < n && (!active || active[pos]);
+    const size_t pos_bytes = (size_t)F * 256;
+    const unsigned char* in_pos = in + (size_t)(pos < n ? pos : n - 1) * pos_bytes;
+    if (tid < 160) {
+        const int im = tid / 80, k = tid % 80;
+        ((f32x4*)(lds + LDS_ACT + im * ACT_IMG + Z_OFF))[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int kg = lane >> 5;
+    uint32_t boff[2][9];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int sq = nt * 32 + (lane & 31), y = sq >> 3, x = sq & 7;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+            const int s2 = sq + (t / 3 - 1) * 8 + (t % 3 - 1);
+            boff[nt][t] = ok ? (uint32_t)(wv * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(Z_OFF + (s2 & 15) * 16);
+        }
+    }
+    const uint32_t aoff = (uint32_t)(kg * 4096 + (lane & 31) * 16);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE + lane * 16;
+    const unsigned char* asrc = in_pos + lane * 16;
+    const int nstages = nchunks * 3;
+    auto issue = [&](int st) {   // stage st = (chunk st / 3, tap group st % 3), as in the kernel above
+        const int c = st / 3;
+        const unsigned char* src = wsrc + (size_t)st * W_STAGE;
+        unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) GLDS16(src + (wv * 3 + i) * 1024, dst + (wv * 3 + i) * 1024);
+        if (st % 3 == 0) {
+            const unsigned char* a = asrc + (size_t)c * ACT_POS;
+            unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + wv * ACT_POS;
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) GLDS16(a + pl * 1024, ad + pl * 1024);
+        }
+    };
+    h8 ah[3], al[3];          // weight pairs of three units in flight (ring: unit u lives in slot u % 3; 12 units per stage)
+    h8 bh[3][2], bl[3][2];    // activation operands of the stage's three taps (slot = tap in stage)
+    // the reads of unit u of stage st (TG = st % 3 is a compile-time constant at every call site)
+#define RAZ_FETCH(st_, TG, u_)                                                                         \
+    do {                                                                                               \
+        constexpr int tt_ = (u_) / 4, m_ = (u_) % 4, t_ = (TG) * 3 + tt_;                              \
+        const uint32_t wb_ = (uint32_t)(LDS_W + ((st_) & 1) * W_STAGE) + aoff + tt_ * 8192 + m_ * 512; \
+        ah[(u_) % 3] = *(const h8*)(lds + wb_);                                                        \
+        al[(u_) % 3] = *(const h8*)(lds + wb_ + 2048);                                                 \
+        if (m_ == 0) {                                                                                 \
+            const uint32_t ab_ = (uint32_t)(LDS_ACT + (((st_) / 3) & 1) * ACT_IMG);                    \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                         \
+                bh[tt_][nt] = *(const h8*)(lds + ab_ + boff[nt][t_]);                                  \
+                bl[tt_][nt] = *(const h8*)(lds + ab_ + boff[nt][t_] + 1024);                           \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+#define RAZ_UNIT(u_)                                                                                                   \
+    do {                                                                                                               \
+        constexpr int tt_ = (u_) / 4, m_ = (u_) % 4;                                                                   \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                             \
+            acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[(u_) % 3], bh[tt_][nt], acc[m_][nt], 0, 0, 0);     \
+            acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u_) % 3], bl[tt_][nt], acc[m_][nt], 0, 0, 0);     \
+            acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u_) % 3], bh[tt_][nt], acc[m_][nt], 0, 0, 0);     \
+        }                                                                                                              \
+    } while (0)
+    // one stage: before the matrix instructions of unit u the reads of unit u + 2 are requested; with u == 10 that is the next
+    // stage's first unit, so the stage barrier (and the DMA of the stage after next, into the buffer everybody has just finished
+    // reading) comes first
+#define RAZ_STEP(st_, TG, u_)                                                                     \
+    do {                                                                                          \
+        if ((u_) == 10 && (st_) + 1 < nstages) {                                                  \
+            __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): this wave's reads of the buffer have RETURNED before any DMA may refill it */ \
+            __syncthreads();                                                                      \
+            if ((st_) + 2 < nstages) issue((st_) + 2);                                            \
+        }                                                                                         \
+        if ((u_) < 10)                                                                            \
+            RAZ_FETCH(st_, TG, ((u_) + 2) % 12);                                                  \
+        else if ((st_) + 1 < nstages)                                                             \
+            RAZ_FETCH((st_) + 1, ((TG) + 1) % 3, ((u_) + 2) % 12);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        RAZ_UNIT(u_);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#define RAZ_STAGE(st_, TG)                                                                                                          \
+    RAZ_STEP(st_, TG, 0); RAZ_STEP(st_, TG, 1); RAZ_STEP(st_, TG, 2); RAZ_STEP(st_, TG, 3); RAZ_STEP(st_, TG, 4); RAZ_STEP(st_, TG, 5); \
+    RAZ_STEP(st_, TG, 6); RAZ_STEP(st_, TG, 7); RAZ_STEP(st_, TG, 8); RAZ_STEP(st_, TG, 9); RAZ_STEP(st_, TG, 10); RAZ_STEP(st_, TG, 11)
+    issue(0);
+    __syncthreads();
+    if (nstages > 1) issue(1);
+    RAZ_FETCH(0, 0, 0);
+    RAZ_FETCH(0, 0, 1);
+    for (int c = 0; c < nchunks; ++c) {
+        const int st0 = c * 3;
+        RAZ_STAGE(st0, 0);
+        RAZ_STAGE(st0 + 1, 1);
+        RAZ_STAGE(st0 + 2, 2);
+    }
+#undef RAZ_STAGE
+#undef RAZ_STEP
+#undef RAZ_UNIT
+#undef RAZ_FETCH
+    if (!live) return;
+    const float inv_scale = *inv_scale_ptr;
+    unsigned char* out_pos = out + (size_t)pos * pos_bytes;
+    const unsigned char* skip_pos = skip ? skip + (size_t)pos * pos_bytes : nullptr;
+    bool over = false;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oc8 = ot * OCT + m * 32 + q * 8;
+            const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
+            const size_t unit = (size_t)(oc8 >> 4) * ACT_POS + (size_t)((oc8 >> 3) & 1) * 2048;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const size_t o = unit + (size_t)(nt * 32 + (lane & 31)) * 16 + kg * 8;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[m][nt][q * 4 + j] * inv_scale + bv[j];
+                if (skip_pos) {
+                    const h4 sh = *(const h4*)(skip_pos + o), sl = *(const h4*)(skip_pos + o + 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] + ((float)sh[j] + (float)sl[j]);
+                }
+                h4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = v[j] > 0.0f ? v[j] : 0.0f;
+                    over |= !(r < 60000.0f);
+                    hi[j] = (_Float16)r;
+                    lo[j] = (_Float16)(r - (float)hi[j]);
+                }
+                *(h4*)(out_pos + o) = hi;
+                *(h4*)(out_pos + o + 1024) = lo;
+            }
+        }
+    if (over) atomicOr(flag, 1u);
 }
 
 // Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.  The work per
@@ -372,19 +539,21 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
         attr_set = true;
     }
+    const auto conv = getenv("RAZ_F16X3_PIPE") ? k_conv3x3_f16x3_pipe : k_conv3x3_f16x3;   // measurements only (see the variant's header)
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
     for (int r = 0; r < R; ++r) {
         const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
+        hipLaunchKernelGGL(conv, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
                            scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, list ? nullptr : active, (int)n, F, flag, n_ptr);
-        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
+        hipLaunchKernelGGL(conv, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
                            scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr);
     }

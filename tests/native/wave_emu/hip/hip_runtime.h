@@ -178,6 +178,7 @@ static inline uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t 
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 #define __builtin_amdgcn_wave_barrier() wave_emu::wave_barrier("wave_barrier", __LINE__)
 static inline float emu_lo_f(uint64_t x) { uint32_t u = (uint32_t)x; float f; memcpy(&f, &u, 4); return f; }
 static inline float emu_hi_f(uint64_t x) { uint32_t u = (uint32_t)(x >> 32); float f; memcpy(&f, &u, 4); return f; }
