@@ -880,16 +880,20 @@ def fused_leg_child(args):
     return 0
 
 
-def fused_leg(timeout=420.0):
-    """Runs fused_leg_child in a child process and returns its document, or what went wrong."""
+def child_leg(argv, timeout):
+    """Runs a leg in a child process and returns the JSON document it prints, or what went wrong."""
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-leg-only"], capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout)
     except subprocess.TimeoutExpired:
         return {"error": f"the child process did not finish within {timeout:.0f} s"}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
     return json.loads(lines[-1])
+
+
+def fused_leg(timeout=420.0):
+    return child_leg([os.path.abspath(__file__), "--fused-leg-only"], timeout)
 
 
 def respawn_under_torchrun(args):
@@ -1028,6 +1032,9 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["config1_4096x200_mini_fused_tree_net_kernel"] = fused_leg()
+            # and the one-process A/B of the headline conv kernel's hand-scheduled variant (k_conv3x3_f16x3_pipe: bit equality on
+            # the device + ms per 8192-position forward of both) - a measurement for the next round, not part of the line's figures
+            out["headline_conv_kernel_hand_scheduled_variant_ab"] = child_leg([os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")], 240.0)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
