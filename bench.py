@@ -29,7 +29,8 @@ outputs), a WHOLE-GAME leg on the headline settings (1024 slots, continuous batc
 and sims/s measured on complete games, two complete games == the oracle), `cpu_baseline` = the reference's own pure-Python
 self-play timed in this run on this box's host cores (oracle/_ref, tools/ref_python_baseline.py), BASELINE configs[1]
 (4096 games x mini net x 200 sims/move, whole games, with its own spot check) and the bitboard-sweep HBM leg.  Last, in a child
-process with a timeout (`--fused-leg-only`): the same configs[1] batch on the opt-in fused tree + net kernel (csrc/raz_engine_fused.hip).
+processes with timeouts (`--config1-variant`): the same configs[1] batch on the opt-in fused tree + net kernel (csrc/raz_engine_fused.hip) and with the
+two-waves-per-position variant of the narrow-net kernel, then the A/B of the headline conv kernel's hand-scheduled variant.
 At N > 1: the record gather over RCCL is timed and its payload verified (per-rank checksums), and a small whole-game batch is
 played sharded AND on rank 0 alone: the gathered records must be byte-identical (SURVEY 8(d) Config 4's acceptance).
 """
@@ -703,9 +704,10 @@ def config5_leg(args, dev, blob, weights, games=8192, sims=3200, steps=10):
     return out
 
 
-def config1_leg(dev, args, par=1, fused=False):
+def config1_leg(dev, args, par=1, fused=False, net_kernel=None):
     """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch).
-    fused: tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip, opt-in)."""
+    fused: tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip, opt-in).
+    net_kernel: a test variant of the narrow-net kernel for the engine's launches ("mfma_split2": one position on two waves)."""
     import numpy as np
     import torch
     from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
@@ -714,7 +716,7 @@ def config1_leg(dev, args, par=1, fused=False):
     cfg = mini_config(sims, par)
     F, R, V = NETS["mini"]
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
-    net = DeviceNet(blob, dev)
+    net = DeviceNet(blob, dev, kernel=net_kernel)
     eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, fused=fused)
     eng.start(0, sims)
     eng.step(50)
@@ -743,7 +745,8 @@ def config1_leg(dev, args, par=1, fused=False):
     macs = macs_per_position(F, R, V)
     out = {"workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
                        f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)"
-                       + ("; tree and net in ONE kernel (k_tree_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else ""),
+                       + ("; tree and net in ONE kernel (k_tree_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else "")
+                       + (f"; narrow-net kernel variant {net_kernel}" if net_kernel else ""),
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
            "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims}
@@ -866,16 +869,17 @@ def cpu_baseline_port(cfg, blob, sims, threads, stop_after_plies=0, what=""):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def fused_leg_child(args):
-    """configs[1] on the fused tree + net kernel (k_tree_net), in a process of its own: the kernel is opt-in and younger than the rest
-    of the engine, and nothing it does may cost the parent its line.  Prints one JSON document."""
+def config1_variant_child(args):
+    """configs[1] on the fused tree + net kernel (k_tree_net) or with a narrow-net kernel variant, in a process of its own: these are
+    opt-in and younger than the rest of the engine, and nothing they do may cost the parent its line.  Prints one JSON document."""
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(0)
     import __graft_entry__ as g
     g.build()
-    out, _, _ = config1_leg(torch.device("cuda", 0), args, 1, fused=True)
+    v = args.config1_variant
+    out, _, _ = config1_leg(torch.device("cuda", 0), args, 1, fused=(v == "fused"), net_kernel=(None if v == "fused" else v))
     print(json.dumps(out))
     return 0
 
@@ -892,8 +896,8 @@ def child_leg(argv, timeout):
     return json.loads(lines[-1])
 
 
-def fused_leg(timeout=420.0):
-    return child_leg([os.path.abspath(__file__), "--fused-leg-only"], timeout)
+def config1_variant_leg(variant, timeout=420.0):
+    return child_leg([os.path.abspath(__file__), "--config1-variant", variant], timeout)
 
 
 def respawn_under_torchrun(args):
@@ -932,10 +936,12 @@ def main():
     ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
     ap.add_argument("--whole-slots", type=int, default=1024, help="slots of the whole-game leg")
     ap.add_argument("--whole-ids", type=int, default=1536, help="game ids the whole-game leg plays to the end")
-    ap.add_argument("--fused-leg-only", action="store_true", help="(child mode of the default run) configs[1] on the fused tree + net kernel only")
+    ap.add_argument("--config1-variant", default=None, choices=["fused", "mfma_split2", "mfma_split4"],
+                    help="(child mode of the default run) ONLY the configs[1] whole-game batch, on the fused tree + net kernel or with a "
+                         "variant of the narrow-net kernel")
     args = ap.parse_args()
-    if args.fused_leg_only:
-        return fused_leg_child(args)
+    if args.config1_variant:
+        return config1_variant_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1031,7 +1037,8 @@ def main():
             # last, in a process of its own: the same configs[1] batch on the opt-in fused tree + net kernel
             gc.collect()
             torch.cuda.empty_cache()
-            out["config1_4096x200_mini_fused_tree_net_kernel"] = fused_leg()
+            out["config1_4096x200_mini_fused_tree_net_kernel"] = config1_variant_leg("fused")
+            out["config1_4096x200_mini_net_kernel_mfma_split2"] = config1_variant_leg("mfma_split2", 240.0)
             # and the one-process A/B of the headline conv kernel's hand-scheduled variant (k_conv3x3_f16x3_pipe: bit equality on
             # the device + ms per 8192-position forward of both) - a measurement for the next round, not part of the line's figures
             out["headline_conv_kernel_hand_scheduled_variant_ab"] = child_leg([os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")], 240.0)
