@@ -29,8 +29,8 @@ outputs), a WHOLE-GAME leg on the headline settings (1024 slots, continuous batc
 and sims/s measured on complete games, two complete games == the oracle), `cpu_baseline` = the reference's own pure-Python
 self-play timed in this run on this box's host cores (oracle/_ref, tools/ref_python_baseline.py), BASELINE configs[1]
 (4096 games x mini net x 200 sims/move, whole games, with its own spot check) and the bitboard-sweep HBM leg.  Last, in a child
-processes with timeouts (`--config1-variant`): the same configs[1] batch on the opt-in fused tree + net kernel (csrc/raz_engine_fused.hip) and with the
-two-waves-per-position variant of the narrow-net kernel, then the A/B of the headline conv kernel's hand-scheduled variant.
+processes with timeouts (`--config1-variant`): the same configs[1] batch on the opt-in fused tree + net kernel (csrc/raz_engine_fused.hip; `--config1-variant mfma_split2` runs it
+with the two-waves-per-position net kernel instead), then the A/B of the headline conv kernel's hand-scheduled variant.
 At N > 1: the record gather over RCCL is timed and its payload verified (per-rank checksums), and a small whole-game batch is
 played sharded AND on rank 0 alone: the gathered records must be byte-identical (SURVEY 8(d) Config 4's acceptance).
 """
@@ -1038,7 +1038,6 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["config1_4096x200_mini_fused_tree_net_kernel"] = config1_variant_leg("fused")
-            out["config1_4096x200_mini_net_kernel_mfma_split2"] = config1_variant_leg("mfma_split2", 240.0)
             # and the one-process A/B of the headline conv kernel's hand-scheduled variant (k_conv3x3_f16x3_pipe: bit equality on
             # the device + ms per 8192-position forward of both) - a measurement for the next round, not part of the line's figures
             out["headline_conv_kernel_hand_scheduled_variant_ab"] = child_leg([os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")], 240.0)
