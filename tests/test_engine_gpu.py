@@ -42,30 +42,6 @@ def test_net_mfma_kernel_equals_valu_kernel(shape):
     assert torch.equal(va.view(torch.int32), vb.view(torch.int32))
 
 
-@pytest.mark.parametrize("shape", [(16, 1, 16), (16, 2, 48), (16, 3, 16)])
-def test_net_split_kernels_equal_other_kernels(shape):
-    """k_net_mfma16_split (one position on a workgroup of two / four waves, the two heads side by side; an opt-in latency
-    variant, see its header) == k_net_mfma (one wave per position) == k_net_wave (VALU), bit for bit, on a ragged batch
-    with an active mask; R != 1 takes the form whose conv operands are fetched per layer."""
-    from reversi_alpha_zero_amd.agent.model import ReversiNet
-    from reversi_alpha_zero_amd.engine import DeviceNet
-    blob = ReversiNet(*shape).keras_init_(2).randomize_bn_(3).to_blob()
-    n = 4101
-    own, enemy = _positions(n, 7)
-    o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
-    act = torch.from_numpy((np.random.default_rng(8).random(n) < 0.8).astype(np.uint8)).to(DEV)
-    outs = []
-    for kernel in ("mfma_split2", "mfma_split4", None, "mfma_wave", "valu"):
-        p, v = DeviceNet(blob, DEV, kernel=kernel).predict_bitboards(o, e, active=act)
-        outs.append((p.view(torch.int32), v.view(torch.int32)))
-    for p, v in outs[1:]:
-        assert torch.equal(outs[0][0], p) and torch.equal(outs[0][1], v)
-    assert bool((outs[0][0][act == 0] == 0).all()) and bool((outs[0][0][act == 1] != 0).any())
-    p_all, v_all = DeviceNet(blob, DEV, kernel="mfma_split4").predict_bitboards(o[:9], e[:9])   # a handful of positions
-    p_ref, v_ref = DeviceNet(blob, DEV, kernel="valu").predict_bitboards(o[:9], e[:9])
-    assert torch.equal(p_all.view(torch.int32), p_ref.view(torch.int32)) and torch.equal(v_all.view(torch.int32), v_ref.view(torch.int32))
-
-
 @pytest.mark.parametrize("shape,n", [((128, 1, 64), 37), ((256, 2, 256), 21)])
 def test_net_wide_kernel_equals_valu_kernel(shape, n):
     """k_conv3x3_wide (implicit GEMM on v_mfma_f32_32x32x2) == k_net_wave (VALU) bit for bit, ragged n."""
