@@ -196,19 +196,26 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
     if (over) atomicOr(flag, 1u);   // an activation beyond the f16 range: the caller must fall back to the f32 kernel
 }
 
-// EXPERIMENTAL VARIANT of the kernel above (selected per launch by the environment variable RAZ_F16X3_PIPE, measurements only):
-// the same stages, the same matrix instructions in the same order per accumulator - bit-identical output - with the operand
-// traffic scheduled by hand instead of by the compiler.  A stage is 12 units (tap tt, M tile m) of 6 matrix instructions; the
-// LDS reads of unit u + 2 (the M tile's weight pair, and with m == 0 the tap's four activation operands) are requested BEFORE
-// the matrix instructions of unit u, so that a read has two units (384 matrix-core cycles) to land whatever the LDS queue looks
-// like; the stage barrier moves two units up the instruction stream accordingly (it precedes the first read of the next
-// stage, i.e. unit 10 of the current one), and the activation operands of the three taps of a stage live in their own
-// registers (228 VGPRs).  Everything else - staging, addresses, epilogue - is the kernel above.
-__global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3_pipe(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
+// EXPERIMENTAL VARIANTS of the kernel above (selected per launch by the environment variable RAZ_F16X3_PIPE = 1 / 2, measurements
+// only): the same stages, the same matrix instructions in the same order per accumulator - bit-identical output - with the
+// operand traffic scheduled by hand instead of by the compiler.  A stage is 12 units (tap tt, M tile m); the LDS reads of unit
+// u + 2 (the M tile's weight pair, and with m == 0 the tap's activation operands) are requested BEFORE the matrix instructions of
+// unit u, so that a read has two units to land whatever the LDS queue looks like; the stage barrier moves two units up the
+// instruction stream accordingly (it precedes the first read of the next stage, i.e. unit 10 of the current one), and the
+// activation operands of the three taps of a stage live in their own registers.
+//   PPW = 1 (RAZ_F16X3_PIPE=1): the tiling above - 8 waves, one position each, 2 waves per SIMD, 245 VGPRs.
+//   PPW = 2 (RAZ_F16X3_PIPE=2): 4 waves per workgroup, TWO positions each = 128 output channels x 128 squares per wave (256
+//            accumulator registers, one wave per SIMD): a weight pair read from LDS feeds 12 matrix instructions instead of 6 -
+//            0.33 LDS reads per matrix instruction instead of 0.5 - as the large GEMM tilings do.
+// Everything else - staging, addresses, epilogue - is the kernel above.
+template <int PPW>
+__global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_pipe(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
                                                                const float* __restrict__ inv_scale_ptr, const unsigned char* in,
                                                                unsigned char* out, const unsigned char* skip,
                                                                const uint8_t* __restrict__ active, int n, int F, unsigned* __restrict__ flag,
                                                                const uint32_t* __restrict__ n_ptr) {
+    constexpr int NT = 2 * PPW;           // 32-square N tiles per wave
+    constexpr int WAVES = NWAVE / PPW;    // waves per workgroup (NWAVE positions per workgroup either way)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
@@ -216,54 +223,57 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3_pipe(const unsigned ch
     const int b = blockIdx.x;
     const int ot = (b >> 3) % noct;
     const int pg = (b / (8 * noct)) * 8 + (b & 7);
-    const int p0 = pg * NWAVE, pos = p0 + wv;
+    const int p0 = pg * NWAVE, pos0 = p0 + wv * PPW;   // this wave's first position
     if (p0 >= n) return;
-    const bool live = pos < n && (!active || active[pos]);
     const size_t pos_bytes = (size_t)F * 256;
-    const unsigned char* in_pos = in + (size_t)(pos < n ? pos : n - 1) * pos_bytes;
     if (tid < 160) {
         const int im = tid / 80, k = tid % 80;
         ((f32x4*)(lds + LDS_ACT + im * ACT_IMG + Z_OFF))[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int kg = lane >> 5;
-    uint32_t boff[2][9];
+    uint32_t boff[NT][9];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int sq = nt * 32 + (lane & 31), y = sq >> 3, x = sq & 7;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int sq = (nt & 1) * 32 + (lane & 31), y = sq >> 3, x = sq & 7;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
             const int s2 = sq + (t / 3 - 1) * 8 + (t % 3 - 1);
-            boff[nt][t] = ok ? (uint32_t)(wv * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(Z_OFF + (s2 & 15) * 16);
+            boff[nt][t] = ok ? (uint32_t)((wv * PPW + (nt >> 1)) * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(Z_OFF + (s2 & 15) * 16);
         }
     }
     const uint32_t aoff = (uint32_t)(kg * 4096 + (lane & 31) * 16);
-    f32x16 acc[4][2];
+    f32x16 acc[4][NT];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
     const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE + lane * 16;
-    const unsigned char* asrc = in_pos + lane * 16;
+    const unsigned char* asrc[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) asrc[pp] = in + (size_t)(pos0 + pp < n ? pos0 + pp : n - 1) * pos_bytes + lane * 16;
     const int nstages = nchunks * 3;
-    auto issue = [&](int st) {   // stage st = (chunk st / 3, tap group st % 3), as in the kernel above
+    auto issue = [&](int st) {   // stage st = (chunk st / 3, tap group st % 3), as in the kernel above: 24 weight pieces + the positions' planes
         const int c = st / 3;
         const unsigned char* src = wsrc + (size_t)st * W_STAGE;
         unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) GLDS16(src + (wv * 3 + i) * 1024, dst + (wv * 3 + i) * 1024);
+        for (int i = 0; i < 24 / WAVES; ++i) GLDS16(src + (wv * (24 / WAVES) + i) * 1024, dst + (wv * (24 / WAVES) + i) * 1024);
         if (st % 3 == 0) {
-            const unsigned char* a = asrc + (size_t)c * ACT_POS;
-            unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + wv * ACT_POS;
 #pragma unroll
-            for (int pl = 0; pl < 4; ++pl) GLDS16(a + pl * 1024, ad + pl * 1024);
+            for (int pp = 0; pp < PPW; ++pp) {
+                const unsigned char* a = asrc[pp] + (size_t)c * ACT_POS;
+                unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + (wv * PPW + pp) * ACT_POS;
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) GLDS16(a + pl * 1024, ad + pl * 1024);
+            }
         }
     };
-    h8 ah[3], al[3];          // weight pairs of three units in flight (ring: unit u lives in slot u % 3; 12 units per stage)
-    h8 bh[3][2], bl[3][2];    // activation operands of the stage's three taps (slot = tap in stage)
+    h8 ah[3], al[3];            // weight pairs of three units in flight (ring: unit u lives in slot u % 3; 12 units per stage)
+    h8 bh[3][NT], bl[3][NT];    // activation operands of the stage's three taps (slot = tap in stage)
     // the reads of unit u of stage st (TG = st % 3 is a compile-time constant at every call site)
 #define RAZ_FETCH(st_, TG, u_)                                                                         \
     do {                                                                                               \
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3_pipe(const unsigned ch
         al[(u_) % 3] = *(const h8*)(lds + wb_ + 2048);                                                 \
         if (m_ == 0) {                                                                                 \
             const uint32_t ab_ = (uint32_t)(LDS_ACT + (((st_) / 3) & 1) * ACT_IMG);                    \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                         \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                        \
                 bh[tt_][nt] = *(const h8*)(lds + ab_ + boff[nt][t_]);                                  \
                 bl[tt_][nt] = *(const h8*)(lds + ab_ + boff[nt][t_] + 1024);                           \
             }                                                                                          \
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3_pipe(const unsigned ch
 #define RAZ_UNIT(u_)                                                                                                   \
     do {                                                                                                               \
         constexpr int tt_ = (u_) / 4, m_ = (u_) % 4;                                                                   \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                            \
             acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[(u_) % 3], bh[tt_][nt], acc[m_][nt], 0, 0, 0);     \
             acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u_) % 3], bl[tt_][nt], acc[m_][nt], 0, 0, 0);     \
             acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u_) % 3], bh[tt_][nt], acc[m_][nt], 0, 0, 0);     \
@@ -324,41 +334,46 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3_pipe(const unsigned ch
 #undef RAZ_STEP
 #undef RAZ_UNIT
 #undef RAZ_FETCH
-    if (!live) return;
     const float inv_scale = *inv_scale_ptr;
-    unsigned char* out_pos = out + (size_t)pos * pos_bytes;
-    const unsigned char* skip_pos = skip ? skip + (size_t)pos * pos_bytes : nullptr;
     bool over = false;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int pos = pos0 + pp;
+        if (!(pos < n && (!active || active[pos]))) continue;
+        unsigned char* out_pos = out + (size_t)pos * pos_bytes;
+        const unsigned char* skip_pos = skip ? skip + (size_t)pos * pos_bytes : nullptr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int oc8 = ot * OCT + m * 32 + q * 8;
-            const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
-            const size_t unit = (size_t)(oc8 >> 4) * ACT_POS + (size_t)((oc8 >> 3) & 1) * 2048;
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const size_t o = unit + (size_t)(nt * 32 + (lane & 31)) * 16 + kg * 8;
-                float v[4];
+            for (int q = 0; q < 4; ++q) {
+                const int oc8 = ot * OCT + m * 32 + q * 8;
+                const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
+                const size_t unit = (size_t)(oc8 >> 4) * ACT_POS + (size_t)((oc8 >> 3) & 1) * 2048;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[m][nt][q * 4 + j] * inv_scale + bv[j];
-                if (skip_pos) {
-                    const h4 sh = *(const h4*)(skip_pos + o), sl = *(const h4*)(skip_pos + o + 1024);
+                for (int h = 0; h < 2; ++h) {
+                    const int nt = pp * 2 + h;
+                    const size_t o = unit + (size_t)(h * 32 + (lane & 31)) * 16 + kg * 8;
+                    float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] + ((float)sh[j] + (float)sl[j]);
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][nt][q * 4 + j] * inv_scale + bv[j];
+                    if (skip_pos) {
+                        const h4 sh = *(const h4*)(skip_pos + o), sl = *(const h4*)(skip_pos + o + 1024);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] + ((float)sh[j] + (float)sl[j]);
+                    }
+                    h4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float r = v[j] > 0.0f ? v[j] : 0.0f;
+                        over |= !(r < 60000.0f);
+                        hi[j] = (_Float16)r;
+                        lo[j] = (_Float16)(r - (float)hi[j]);
+                    }
+                    *(h4*)(out_pos + o) = hi;
+                    *(h4*)(out_pos + o + 1024) = lo;
                 }
-                h4 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float r = v[j] > 0.0f ? v[j] : 0.0f;
-                    over |= !(r < 60000.0f);
-                    hi[j] = (_Float16)r;
-                    lo[j] = (_Float16)(r - (float)hi[j]);
-                }
-                *(h4*)(out_pos + o) = hi;
-                *(h4*)(out_pos + o + 1024) = lo;
             }
-        }
+    }
     if (over) atomicOr(flag, 1u);
 }
 
@@ -539,21 +554,25 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
         attr_set = true;
     }
-    const auto conv = getenv("RAZ_F16X3_PIPE") ? k_conv3x3_f16x3_pipe : k_conv3x3_f16x3;   // measurements only (see the variant's header)
+    const char* pipe = getenv("RAZ_F16X3_PIPE");   // measurements only (see the variants' header)
+    const int variant = pipe ? atoi(pipe) : 0;
+    const auto conv = variant == 2 ? k_conv3x3_f16x3_pipe<2> : variant == 1 ? k_conv3x3_f16x3_pipe<1> : k_conv3x3_f16x3;
+    const unsigned conv_threads = variant == 2 ? NWAVE * 64 / 2 : NWAVE * 64;
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
     for (int r = 0; r < R; ++r) {
         const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-        hipLaunchKernelGGL(conv, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
+        hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
                            scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, list ? nullptr : active, (int)n, F, flag, n_ptr);
-        hipLaunchKernelGGL(conv, dim3(grid), dim3(NWAVE * 64), LDS_BYTES, s,
+        hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
                            scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr);
     }

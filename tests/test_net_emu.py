@@ -116,18 +116,21 @@ def test_emulated_split_f16_trunk_is_within_tolerance_of_the_oracle(lib, shape, 
     assert (pol[~on] == 7.0).all() and (val[~on] == 7.0).all()
 
 
-def test_emulated_hand_scheduled_split_f16_variant_is_bit_identical(lib, monkeypatch):
-    """k_conv3x3_f16x3_pipe (RAZ_F16X3_PIPE: operand reads requested two units ahead, the stage barrier moved up accordingly - a
-    scheduling experiment for the headline kernel) issues the same matrix instructions in the same order per accumulator as
-    k_conv3x3_f16x3: identical bits on the emulated matrix cores (as on real ones), ragged groups and an active mask included."""
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_emulated_hand_scheduled_split_f16_variants_are_bit_identical(lib, monkeypatch, variant):
+    """k_conv3x3_f16x3_pipe (RAZ_F16X3_PIPE = 1: operand reads requested two units ahead, the stage barrier moved up accordingly; = 2:
+    the same with 4 waves of two positions each, 128 x 128 outputs per wave - scheduling experiments for the headline kernel) issue the
+    same matrix instructions in the same order per accumulator as k_conv3x3_f16x3: identical bits on the emulated matrix cores (as
+    on real ones), ragged groups (an odd position count: a wave with one of its two positions beyond the batch) and an active mask
+    included."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
     blob = ReversiNet(128, 2, 32).keras_init_(8).randomize_bn_(9).to_blob()
-    n = 10
+    n = 11
     own, enemy = _positions(n, 6)
     active = (np.arange(n) % 4 != 1).astype(np.uint8)
     monkeypatch.delenv("RAZ_F16X3_PIPE", raising=False)
     p0, v0 = _forward(lib, blob, own, enemy, 4, active)
-    monkeypatch.setenv("RAZ_F16X3_PIPE", "1")
+    monkeypatch.setenv("RAZ_F16X3_PIPE", variant)
     p1, v1 = _forward(lib, blob, own, enemy, 4, active)
     assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
     rp, rv = _oracle(blob, own, enemy)

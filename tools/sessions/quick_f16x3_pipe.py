@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the headline conv kernel's hand-scheduled variant (k_conv3x3_f16x3_pipe, RAZ_F16X3_PIPE - read per launch) in ONE process:
-outputs of a 256x10 forward over 8192 positions must equal the default kernel's bit for bit; ms per forward (median / best of
-`iters`) for both.  Prints one JSON line."""
+"""A/B of the headline conv kernel's hand-scheduled variants (k_conv3x3_f16x3_pipe<1> / <2>, RAZ_F16X3_PIPE = 1 / 2 - read per launch)
+in ONE process: outputs of a 256x10 forward over 8192 positions must equal the default kernel's bit for bit; ms per forward
+(median / best of `iters`, two rounds) for all three.  Prints one JSON line."""
 import json
 import os
 import statistics
@@ -25,10 +25,11 @@ def main(n=8192, iters=12):
     enemy = rng.integers(0, 2**64, size=n, dtype=np.uint64) & ~own
     o, e = torch.from_numpy(own.view(np.int64)).to(dev), torch.from_numpy(enemy.view(np.int64)).to(dev)
     out, res = {}, {}
-    for mode in ("default", "pipe", "default", "pipe"):
+    names = {"0": "default", "1": "pipe_8_waves_x_1_position", "2": "pipe_4_waves_x_2_positions"}
+    for mode in ("0", "1", "2", "0", "1", "2"):
         os.environ.pop("RAZ_F16X3_PIPE", None)
-        if mode == "pipe":
-            os.environ["RAZ_F16X3_PIPE"] = "1"
+        if mode != "0":
+            os.environ["RAZ_F16X3_PIPE"] = mode
         p, v = net.predict_bitboards(o, e)
         torch.cuda.synchronize()
         res[mode] = (p.clone(), v.clone())
@@ -39,10 +40,10 @@ def main(n=8192, iters=12):
             ev[i + 1].record()
         torch.cuda.synchronize()
         ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(iters)]
-        out.setdefault(f"{mode}_ms_per_forward", []).append([round(statistics.median(ms), 3), round(min(ms), 3)])
+        out.setdefault(names[mode] + "_ms_per_forward", []).append([round(statistics.median(ms), 3), round(min(ms), 3)])
     os.environ.pop("RAZ_F16X3_PIPE", None)
-    out["bit_equal"] = bool(torch.equal(res["default"][0].view(torch.int32), res["pipe"][0].view(torch.int32))
-                            and torch.equal(res["default"][1].view(torch.int32), res["pipe"][1].view(torch.int32)))
+    same = lambda a, b: bool(torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)))
+    out["bit_equal"] = {names[m]: same(res["0"], res[m]) for m in ("1", "2")}
     out["range_ok"] = bool(net.range_ok())
     print(json.dumps(out))
 
