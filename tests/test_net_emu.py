@@ -99,11 +99,11 @@ def test_emulated_wide_net_kernels_equal_oracle(lib):
     assert np.array_equal(pol.view(np.uint32), rp.view(np.uint32)) and np.array_equal(val.view(np.uint32), rv.view(np.uint32))
 
 
-@pytest.mark.parametrize("shape,n", [((128, 1, 32), 11), ((256, 1, 16), 9)])
+@pytest.mark.parametrize("shape,n", [((128, 1, 32), 11), ((256, 1, 16), 3)])
 def test_emulated_split_f16_trunk_is_within_tolerance_of_the_oracle(lib, shape, n):
     """raznet-forward-v2 (reserved 4): k_conv0_split + k_conv3x3_f16x3 (8-wave workgroups = 8 positions x 128 output channels, 48-stage
     LDS-DMA pipeline, three f16 matrix instructions per product) + k_heads_split within 1e-5 of the oracle's f32 net (the tolerance
-    include/raz.h states for this path), on a ragged batch (a second, partly filled position group; F = 256: two output-channel
+    include/raz.h states for this path), on a ragged batch (F = 128: a second, partly filled position group; F = 256: two output-channel
     tiles per group) with an active mask; skipped rows stay untouched and the range flag stays clear."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
     blob = ReversiNet(*shape).keras_init_(6).randomize_bn_(7).to_blob()
@@ -116,23 +116,23 @@ def test_emulated_split_f16_trunk_is_within_tolerance_of_the_oracle(lib, shape, 
     assert (pol[~on] == 7.0).all() and (val[~on] == 7.0).all()
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-def test_emulated_hand_scheduled_split_f16_variants_are_bit_identical(lib, monkeypatch, variant):
+def test_emulated_hand_scheduled_split_f16_variants_are_bit_identical(lib, monkeypatch):
     """k_conv3x3_f16x3_pipe (RAZ_F16X3_PIPE = 1: operand reads requested two units ahead, the stage barrier moved up accordingly; = 2:
     the same with 4 waves of two positions each, 128 x 128 outputs per wave - scheduling experiments for the headline kernel) issue the
     same matrix instructions in the same order per accumulator as k_conv3x3_f16x3: identical bits on the emulated matrix cores (as
     on real ones), ragged groups (an odd position count: a wave with one of its two positions beyond the batch) and an active mask
     included."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
-    blob = ReversiNet(128, 2, 32).keras_init_(8).randomize_bn_(9).to_blob()
+    blob = ReversiNet(128, 1, 32).keras_init_(8).randomize_bn_(9).to_blob()
     n = 11
     own, enemy = _positions(n, 6)
     active = (np.arange(n) % 4 != 1).astype(np.uint8)
     monkeypatch.delenv("RAZ_F16X3_PIPE", raising=False)
     p0, v0 = _forward(lib, blob, own, enemy, 4, active)
-    monkeypatch.setenv("RAZ_F16X3_PIPE", variant)
-    p1, v1 = _forward(lib, blob, own, enemy, 4, active)
-    assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
     rp, rv = _oracle(blob, own, enemy)
     on = active.astype(bool)
-    assert np.abs(p1[on] - rp[on]).max() <= 1e-5 and np.abs(v1[on] - rv[on]).max() <= 1e-5
+    assert np.abs(p0[on] - rp[on]).max() <= 1e-5 and np.abs(v0[on] - rv[on]).max() <= 1e-5
+    for variant in ("1", "2"):
+        monkeypatch.setenv("RAZ_F16X3_PIPE", variant)
+        p1, v1 = _forward(lib, blob, own, enemy, 4, active)
+        assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32)), variant
