@@ -745,7 +745,7 @@ def config1_leg(dev, args, par=1, fused=False, net_kernel=None):
     macs = macs_per_position(F, R, V)
     out = {"workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
                        f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)"
-                       + ("; tree and net in ONE kernel (k_tree_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else "")
+                       + ("; tree and net in ONE kernel (k_tree_net / k_tree_par_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else "")
                        + (f"; narrow-net kernel variant {net_kernel}" if net_kernel else ""),
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
@@ -879,7 +879,8 @@ def config1_variant_child(args):
     import __graft_entry__ as g
     g.build()
     v = args.config1_variant
-    out, _, _ = config1_leg(torch.device("cuda", 0), args, 1, fused=(v == "fused"), net_kernel=(None if v == "fused" else v))
+    fused = v.startswith("fused")
+    out, _, _ = config1_leg(torch.device("cuda", 0), args, 4 if v == "fused_par4" else 1, fused=fused, net_kernel=(None if fused else v))
     print(json.dumps(out))
     return 0
 
@@ -936,7 +937,7 @@ def main():
     ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
     ap.add_argument("--whole-slots", type=int, default=1024, help="slots of the whole-game leg")
     ap.add_argument("--whole-ids", type=int, default=1536, help="game ids the whole-game leg plays to the end")
-    ap.add_argument("--config1-variant", default=None, choices=["fused", "mfma_split2", "mfma_split4"],
+    ap.add_argument("--config1-variant", default=None, choices=["fused", "fused_par4", "mfma_split2", "mfma_split4"],
                     help="(child mode of the default run) ONLY the configs[1] whole-game batch, on the fused tree + net kernel or with a "
                          "variant of the narrow-net kernel")
     args = ap.parse_args()
@@ -1038,6 +1039,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["config1_4096x200_mini_fused_tree_net_kernel"] = config1_variant_leg("fused")
+            out["config1_mini_yml_parallel_search_num_4_fused_tree_net_kernel"] = config1_variant_leg("fused_par4", 300.0)
             # and the one-process A/B of the headline conv kernel's hand-scheduled variant (k_conv3x3_f16x3_pipe: bit equality on
             # the device + ms per 8192-position forward of both) - a measurement for the next round, not part of the line's figures
             out["headline_conv_kernel_hand_scheduled_variant_ab"] = child_leg([os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")], 240.0)

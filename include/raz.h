@@ -155,9 +155,9 @@ typedef struct {
     uint32_t max_plies;                       /* record capacity per game (>= 64) */
     uint32_t seed;
     uint32_t reserved;                        /* bit 0: in-kernel phase profile; bit 1: single stream; bit 3: drive even
-                                                 parallel_search_num <= 1 with the slot kernel (tests); bit 4: 16-filter nets,
-                                                 parallel_search_num <= 1: tree and net in ONE kernel, the game's wave evaluates
-                                                 its own leaves (csrc/raz_engine.hip k_tree_net; same results); bits 8-11:
+                                                 parallel_search_num <= 1 with the slot kernel (tests); bit 4: 16-filter nets: tree and net in
+                                                 ONE kernel, the game's wave evaluates its own leaves (csrc/raz_engine_fused.hip
+                                                 k_tree_net / k_tree_par_net; same results); bits 8-11:
                                                  slices/streams (0 = 3); bits 12-15: max simulations per game per tree launch
                                                  (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num) */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root

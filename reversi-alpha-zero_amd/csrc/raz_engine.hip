@@ -115,48 +115,6 @@ __global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint
 // out of its per-launch budget (games whose simulations all end on finished positions would otherwise
 // be the launch's stragglers) continues at the next launch WITHOUT an intervening B, so the result
 // does not depend on the budget.
-#define LB(f) (1ULL << GW(f))
-constexpr unsigned long long kSimLanes =
-    LB(leaf_b) | (LB(leaf_b) << 1) | LB(leaf_w) | (LB(leaf_w) << 1) | LB(leaf_legal) | (LB(leaf_legal) << 1) |
-    LB(leaf_kind) | LB(leaf_sym) | LB(leaf_np) | LB(depth) | LB(leaf_action) | LB(leaf_node) | LB(leaf_slot) |
-    LB(leaf_tag) | LB(leaf_mirror) | LB(leaf_term_v);
-#undef LB
-
-struct Slots {
-    uint32_t st, sq, pk;  // lane j = slot j: RAZ_SIM_*, order number, node slept on
-};
-
-__device__ __forceinline__ void slot_load(const raz_engine_dev& E, Regs& R, uint32_t g, uint32_t j, int lane, bool with_net) {
-    const size_t gi = (size_t)g * E.K + j;
-    const uint32_t v = E.sim[gi * 64 + lane];
-    path_load(E, R, gi, lane, true);
-    if (with_net) {
-        R.pol_raw = E.nn_policy[gi * 64 + lane];
-        R.val = E.nn_value[gi];
-    }
-    R.cw = ((kSimLanes >> lane) & 1ULL) ? v : R.cw;
-    path_load_rest(E, R, gi, lane);
-}
-__device__ __forceinline__ void slot_store(const raz_engine_dev& E, const Regs& R, uint32_t g, uint32_t j, int lane) {
-    const size_t gi = (size_t)g * E.K + j;
-    if ((kSimLanes >> lane) & 1ULL) E.sim[gi * 64 + lane] = R.cw;
-    path_store(E, R, gi, lane);
-}
-// the slot of `mask` with the smallest order number (K <= 16: a scalar scan)
-__device__ __forceinline__ int pick_min_seq(uint32_t sq, unsigned long long mask) {
-    int best = -1;
-    uint32_t bs = 0;
-    for (unsigned long long m = mask; m; m &= m - 1) {
-        const int j = __ffsll((long long)m) - 1;
-        const uint32_t q = lane_u32(sq, j);
-        if (best < 0 || q < bs) {
-            bs = q;
-            best = j;
-        }
-    }
-    return best;
-}
-
 // The kernel is ONE loop with a single call site each for the controller, the descent and the return
 // path (the three large inlined bodies): duplicating them per phase doubled the code to 66 KB, more
 // than the instruction cache two CUs share.  Each iteration picks the next operation of the round -
@@ -853,9 +811,9 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     e->graph_off = (cfg->reserved & 4u) == 0;   // reserved bit 2: replay captured hipGraphs (measured slower on ROCm 7.2: off by default)
     e->fused = (cfg->reserved & 16u) != 0;      // reserved bit 4: tree + narrow net in one kernel (k_tree_net)
     if (e->fused) {
-        if (net->filters != 16 || net->value_fc > 1024 || e->dev.par) {
+        if (net->filters != 16 || net->value_fc > 1024) {
             delete e;
-            return raz_fail(RAZ_EINVAL, "raz_engine_create: the fused tree + net kernel (reserved bit 4) needs a 16-filter net and parallel_search_num <= 1");
+            return raz_fail(RAZ_EINVAL, "raz_engine_create: the fused tree + net kernels (reserved bit 4) need a 16-filter net");
         }
         e->graph_off = true;
         parts = 1;

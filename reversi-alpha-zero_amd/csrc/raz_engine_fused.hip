@@ -88,6 +88,170 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+// The same for parallel_search_num > 1: k_tree_par's round (B: the queued leaves' simulations return, C: the free slots are
+// refilled, D: sleepers are polled, C': refill) followed by the evaluation of the round's queued leaves by the game's own wave, one
+// after the other, `iters` times per launch.  One iteration is exactly one launch of k_tree_par + the net batch of the classic
+// pipeline - including a fill that ran out of its per-launch budget and goes on after the evaluation without a B in between - so
+// the raz-sched-v1 schedule, and with it every record, is unchanged.  The slot states stay in registers across iterations; the
+// leaves' positions and answers still travel through the leaf-exchange rows (written and read by this wave only).
+template <bool SOLVER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree_par_net(raz_engine_dev E, uint32_t g0, uint32_t count,
+                                                                                              uint32_t iters, const float* __restrict__ net_w,
+                                                                                              int net_R, int net_V) {
+    if (blockIdx.x >= count) return;
+    __shared__ float lds64[64];
+    __shared__ SolverLDS slds_store;
+    extern __shared__ __attribute__((aligned(16))) float netbuf[];
+    SolverLDS* slds_p = SOLVER ? &slds_store : nullptr;
+    const uint32_t g = g0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    if (g >= E.B) return;
+    const uint32_t K = E.K;
+    const unsigned long long kmask = (1ULL << K) - 1ULL;  // K <= 16
+    uint32_t* gw = (uint32_t*)(E.game + g);
+    Regs R;
+    R.cw = gw[lane];
+    R.pnode = R.pmirror = R.pact = 0u;
+    R.pol_raw = 0.0f;
+    R.val = 0.0f;
+    R.nn = 0u;
+    R.path_dirty = 0u;
+    Slots T;
+    T.st = T.sq = T.pk = 0u;
+    uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
+    if (lane < (int)K) {
+        T.st = myblk[GW(sim_state)];
+        T.sq = myblk[GW(sim_seq)];
+        T.pk = myblk[GW(sim_parked)];
+    }
+    {
+        const uint32_t phase = G32(R, GW(phase));
+        if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) {
+            if (lane < (int)K) E.nn_active[(size_t)g * K + lane] = 0;
+            return;
+        }
+    }
+    raz_net16_zero_planes(netbuf, lane);
+    constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D never outlives an iteration
+    uint32_t stage = G32(R, GW(par_stage));
+    for (uint32_t it = 0; it < iters; ++it) {
+        {
+            const uint32_t phase = G32(R, GW(phase));
+            if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) break;
+        }
+        uint32_t nnmask = 0u;
+        int budget = (int)K + (((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax);
+        unsigned long long dmask = 0ULL;  // sleepers still to poll in D
+        for (;;) {
+            if (G32(R, GW(error))) break;
+            // ---- the next operation of the round
+            int j = -1;
+            bool resume = false, wake = false;
+            if (stage == kStageB) {
+                const unsigned long long m = __ballot(T.st == RAZ_SIM_WAIT_NET) & kmask;
+                if (!m) {
+                    stage = kStageC;
+                    continue;
+                }
+                j = pick_min_seq(T.sq, m);
+                resume = true;
+            } else if (stage == kStageD) {
+                if (!dmask) {
+                    stage = kStageC2;
+                    continue;
+                }
+                j = pick_min_seq(T.sq, dmask);
+                dmask &= ~(1ULL << j);
+                wake = true;
+            } else {  // C / C': the per-move controller, then a new simulation into a free slot
+                for (int guard = 0; guard < 8; ++guard) {
+                    const uint32_t phase = G32(R, GW(phase));
+                    if (phase == RAZ_PHASE_NEW_MOVE) {
+                        begin_move<SOLVER>(E, R, g, lane, slds_p);
+                        continue;
+                    }
+                    if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {  // every simulation has returned
+                        decide_move(E, R, g, lane);
+                        continue;
+                    }
+                    break;
+                }
+                const unsigned long long busy = __ballot(T.st != RAZ_SIM_FREE) & kmask;
+                const int inflight = __popcll(busy);
+                const int to_start = (int32_t)G32(R, GW(sims_left)) - inflight;
+                if (G32(R, GW(phase)) != RAZ_PHASE_SEARCH || G32(R, GW(error)) || inflight >= (int)K || to_start <= 0) {
+                    if (stage == kStageC2) {
+                        stage = kStageB;  // the round is complete: the next iteration starts with B
+                        break;
+                    }
+                    const uint32_t pl = G32(R, GW(player)) - 1;
+                    const bool sl = lane < (int)K && T.st == RAZ_SIM_WAIT_EXPAND;
+                    uint32_t tg = 0u;
+                    if (sl) tg = node_hdr(node_ptr(E, g, T.pk))->tag;
+                    dmask = __ballot(sl && !((tg >> (6 + pl)) & 1u)) & kmask;
+                    stage = kStageD;
+                    continue;
+                }
+                if (budget <= 0) break;  // the fill goes on at the next iteration, without a B in between
+                --budget;
+                j = __ffsll((long long)(~busy & kmask)) - 1;
+            }
+            // ---- at most one slot load, one descent, one return
+            bool back = resume;
+            if (resume || wake) slot_load(E, R, g, (uint32_t)j, lane, resume);
+            if (!resume) {
+                select_leaf<SOLVER, true>(E, R, g, lane, slds_p, g * K + (uint32_t)j,
+                                          wake ? lane_u32(T.pk, j) : G32(R, GW(root_node)), wake ? (int)G32(R, GW(depth)) : 0, wake);
+                const uint32_t kind = G32(R, GW(leaf_kind));
+                if (kind == RAZ_LEAF_TERMINAL || kind == RAZ_LEAF_SOLVED) {
+                    back = true;
+                } else if (kind == RAZ_LEAF_EXPAND || kind == RAZ_LEAF_PARKED) {
+                    if (kind == RAZ_LEAF_EXPAND || !wake) {  // a sleeper that goes back to sleep keeps its place
+                        const uint32_t seq = G32(R, GW(par_seq_next));
+                        S32(R, GW(par_seq_next), seq + 1);
+                        T.sq = writelane_r(T.sq, seq, j, lane);
+                    }
+                    if (kind == RAZ_LEAF_EXPAND) {
+                        T.st = writelane_r(T.st, RAZ_SIM_WAIT_NET, j, lane);
+                        nnmask |= 1u << j;
+                    } else {
+                        T.st = writelane_r(T.st, RAZ_SIM_WAIT_EXPAND, j, lane);
+                        T.pk = writelane_r(T.pk, G32(R, GW(sim_parked)), j, lane);
+                    }
+                    slot_store(E, R, g, (uint32_t)j, lane);
+                    S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
+                }
+            }
+            if (back) {
+                backup_leaf<true>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+                T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
+            }
+        }
+        if (stage == kStageD) stage = kStageC2;   // (what the classic kernel stores at the end of a launch)
+        // ---- the net batch of this iteration: the leaves queued above, evaluated by this wave (their answers go where the net
+        // kernel would have put them; the B phase of the next iteration picks them up with slot_load)
+        wave_sync();
+        for (uint32_t m = nnmask; m; m &= m - 1) {
+            const uint32_t jj = (uint32_t)__ffs((int)m) - 1u;
+            const size_t gi = (size_t)g * K + jj;
+            const raz_bb own = uni((raz_bb)E.nn_own[gi]), enemy = uni((raz_bb)E.nn_enemy[gi]);
+            float pol, val;
+            raz_net16_forward_in_wave(net_w, net_R, net_V, own, enemy, netbuf, lane, pol, val);
+            E.nn_policy[gi * 64 + lane] = pol;
+            if (lane == 0) E.nn_value[gi] = val;
+        }
+        wave_sync();
+    }
+    S32(R, GW(par_stage), stage);
+    gw[lane] = R.cw;
+    if (lane < (int)K) {
+        myblk[GW(sim_state)] = T.st;
+        myblk[GW(sim_seq)] = T.sq;
+        myblk[GW(sim_parked)] = T.pk;
+        E.nn_active[(size_t)g * K + lane] = 0;
+    }
+}
+
 }  // namespace
 
 // `n_steps` simulation steps of the whole batch in ceil(n_steps / 32) launches on stream s (raz_engine_step, reserved bit 4)
@@ -97,7 +261,11 @@ int raz_launch_tree_net(const raz_engine_dev& d, bool solver, uint32_t n_steps, 
     int rc = RAZ_OK;
     while (n_steps && rc == RAZ_OK) {
         const uint32_t it = n_steps < kFusedIters ? n_steps : kFusedIters;
-        if (solver)
+        if (d.par && solver)
+            hipLaunchKernelGGL(k_tree_par_net<true>, dim3(d.B), dim3(64), shm, s, d, 0u, d.B, it, W, R, V);
+        else if (d.par)
+            hipLaunchKernelGGL(k_tree_par_net<false>, dim3(d.B), dim3(64), shm, s, d, 0u, d.B, it, W, R, V);
+        else if (solver)
             hipLaunchKernelGGL(k_tree_net<true>, dim3(d.B), dim3(64), shm, s, d, 0u, d.B, it, W, R, V);
         else
             hipLaunchKernelGGL(k_tree_net<false>, dim3(d.B), dim3(64), shm, s, d, 0u, d.B, it, W, R, V);

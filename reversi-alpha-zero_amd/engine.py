@@ -128,8 +128,8 @@ class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
                  use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False):
-        """fused: 16-filter nets with parallel_search_num 1 - tree and net in ONE kernel, every game's wave evaluating its own leaves
-        (csrc/raz_engine_fused.hip; same results, opt-in).
+        """fused: 16-filter nets - tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip:
+        k_tree_net, k_tree_par_net for parallel_search_num > 1; same results, opt-in).
         nodes_per_game: most tree nodes a game's pool may hold; pool_bytes_per_game: its bytes (0 = nodes_per_game x 232 + 64 x 704:
         nodes are compact - 40 B + 20 B per legal move, ~212 B on average - include/raz.h).
         leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h

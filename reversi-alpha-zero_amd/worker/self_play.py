@@ -205,7 +205,7 @@ class BatchedSelfPlayWorker:
         # whose forward is what a step costs; none for narrow nets (two extra launches per step cost more than they save)
         self.leaf_cache_log2 = leaf_cache_log2
         self.leaf_cache_max_discs = leaf_cache_max_discs
-        # 16-filter nets with parallel_search_num 1: tree and net in ONE kernel, the game's wave evaluating its own leaves
+        # 16-filter nets: tree and net in ONE kernel, the game's wave evaluating its own leaves
         # (csrc/raz_engine_fused.hip; same files; opt-in)
         self.fused_tree_net = bool(fused_tree_net)
         self.seed = seed
@@ -279,7 +279,7 @@ class BatchedSelfPlayWorker:
             pool_bytes = 0   # pruned pools: the default budget (232 B per node); k_gc is triggered by bytes as well as by count
             if r > 1:        # never pruned: room for whole games whatever their mobility
                 pool_bytes = min(nodes * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
-            fused = (self.fused_tree_net and self._net.filters == 16 and int(getattr(p, "parallel_search_num", 1) or 1) <= 1)
+            fused = self.fused_tree_net and self._net.filters == 16
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=None if fused else cache,
                                           leaf_cache_max_discs=self.leaf_cache_max_discs, pool_bytes_per_game=pool_bytes, fused=fused)

@@ -54,15 +54,32 @@ def test_fused_batch_equals_oracle_with_pruning_and_partial_launches(golden, blo
 
 
 def test_fused_kernel_is_refused_where_it_does_not_apply(golden, blob):
-    """parallel_search_num > 1 and nets that are not 16 filters wide: raz_engine_create says so instead of running something else."""
-    import types
+    """Nets that are not 16 filters wide: raz_engine_create says so instead of running something else."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
     cfg = config_of(_variant(golden, "mini_shared"))
-    par = types.SimpleNamespace(play=types.SimpleNamespace(**dict(vars(cfg.play), parallel_search_num=4)), play_data=cfg.play_data)
-    with pytest.raises(RuntimeError, match="fused"):
-        EmuEngine(par, blob, n_games=1, sims_hint=8, fused=True)
     with pytest.raises(RuntimeError, match="fused"):
         EmuEngine(cfg, ReversiNet(32, 1, 16).keras_init_(0).to_blob(), n_games=1, sims_hint=8, fused=True)
+
+
+@pytest.mark.parametrize("k,pool", [(4, None), (3, 400)])
+def test_fused_slot_kernel_equals_oracle(blob, k, pool):
+    """k_tree_par_net: parallel_search_num simulations in flight per game on the raz-sched-v1 rounds, every round's queued leaves
+    evaluated by the game's own wave before the next round; with and without pruning."""
+    from oracle_util import load_par_golden
+    par = load_par_golden()
+    g0 = next(g for g in par["games"] if g["resolved_play"]["share_mtcs_info_in_self_play"])
+    cfg = config_of(g0)
+    cfg.play.parallel_search_num = k
+    cfg.play.use_solver_turn = cfg.play.use_solver_turn_in_simulation = 0
+    cfg.play.thinking_loop = 1
+    eng = EmuEngine(cfg, blob, n_games=2, seed=7, sims_hint=14, nodes_per_game=pool, fused=True)
+    eng.start(40, 14)
+    eng.run(chunk=8 if pool else 32)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=k)
+    for i in range(2):
+        plies, summ = O.selfplay_game(ocfg, blob, 7, 40 + i, 14)
+        _same(f"fused/par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
 def test_fused_solver_game_equals_oracle(golden, blob):

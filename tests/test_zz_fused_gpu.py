@@ -36,8 +36,10 @@ from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
 gold = load_mcts_golden()
 blob = golden_net_blob(gold["net"])
 out = {{}}
-for variant, solver in (("mini_shared", False), ("agz", False), ("mini_solver_noresign", True)):
+for variant, solver, par in (("mini_shared", False, 1), ("agz", False, 1), ("mini_solver_noresign", True, 1), ("mini_shared", False, 4)):
     cfg = config_of(next(g for g in gold["games"] if g["variant"] == variant))
+    if par > 1:     # k_tree_par_net: simulation slots on the raz-sched-v1 rounds
+        cfg.play.parallel_search_num, cfg.play.thinking_loop = par, 1
     n, sims = (96, 14) if not solver else (8, 10)
     recs = []
     for fused in (False, True):
@@ -47,7 +49,7 @@ for variant, solver in (("mini_shared", False), ("agz", False), ("mini_solver_no
         recs.append(eng.records(save_policy_of_tau_1=True))
         del eng
     assert recs[0] == recs[1], variant + ": fused records differ from the classic pipeline's"
-    ocfg = O.play_cfg_from_config(cfg)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=par) if par > 1 else O.play_cfg_from_config(cfg)
     for i in (0, n - 1):
         plies, summ = O.selfplay_game(ocfg, blob, 5, 1000 + i, sims)
         got_plies, got_sum = recs[1][i]
