@@ -897,10 +897,6 @@ def child_leg(argv, timeout):
     return json.loads(lines[-1])
 
 
-def config1_variant_leg(variant, timeout=420.0):
-    return child_leg([os.path.abspath(__file__), "--config1-variant", variant], timeout)
-
-
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` (N > 1) started without a launcher: become N ranks."""
     import socket
@@ -1035,14 +1031,19 @@ def main():
                     raise
                 except Exception as ex:   # never lose the main line over an extra leg
                     out[key] = {"error": repr(ex)}
-            # last, in a process of its own: the same configs[1] batch on the opt-in fused tree + net kernel
+            # last, in processes of their own (a timeout each; after the first one that does not come back the rest is skipped, so
+            # that a wedged device costs the line 150 s at most): the configs[1] batches on the opt-in fused tree + net kernels, and
+            # the one-process A/B of the headline conv kernel's hand-scheduled variants (bit equality on the device + ms per
+            # 8192-position forward) - measurements for the next round, not part of the line's figures
             gc.collect()
             torch.cuda.empty_cache()
-            out["config1_4096x200_mini_fused_tree_net_kernel"] = config1_variant_leg("fused")
-            out["config1_mini_yml_parallel_search_num_4_fused_tree_net_kernel"] = config1_variant_leg("fused_par4", 300.0)
-            # and the one-process A/B of the headline conv kernel's hand-scheduled variant (k_conv3x3_f16x3_pipe: bit equality on
-            # the device + ms per 8192-position forward of both) - a measurement for the next round, not part of the line's figures
-            out["headline_conv_kernel_hand_scheduled_variant_ab"] = child_leg([os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")], 240.0)
+            children = (("config1_4096x200_mini_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused"]),
+                        ("config1_mini_yml_parallel_search_num_4_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused_par4"]),
+                        ("headline_conv_kernel_hand_scheduled_variant_ab", [os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")]))
+            stuck = False
+            for key, argv in children:
+                out[key] = {"error": "skipped: an earlier child process did not come back"} if stuck else child_leg(argv, 150.0)
+                stuck = stuck or "did not finish" in str(out[key].get("error", ""))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
