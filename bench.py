@@ -886,14 +886,21 @@ def config1_variant_child(args):
 
 
 def child_leg(argv, timeout):
-    """Runs a leg in a child process and returns the JSON document it prints, or what went wrong."""
+    """Runs a leg in a child process and returns the JSON document it prints, or what went wrong.  A child that neither finishes
+    nor dies when killed (stuck in the driver) is abandoned, not waited for."""
+    p = subprocess.Popen([sys.executable] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        r = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout)
+        so, se = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
+        p.kill()
+        try:
+            p.communicate(timeout=15)
+        except subprocess.TimeoutExpired:
+            pass
         return {"error": f"the child process did not finish within {timeout:.0f} s"}
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"child exit code {p.returncode}", "stderr_tail": se[-600:]}
     return json.loads(lines[-1])
 
 
