@@ -62,10 +62,18 @@ print("FUSED_OK")
 
 @pytest.mark.xfail(reason="first hardware run of the opt-in fused kernel (validated on the wave emulator only so far)", strict=False)
 def test_fused_kernel_equals_the_classic_pipeline_and_the_oracle_on_the_device():
-    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, PYTHONPATH=ROOT))
-    assert r.returncode == 0 and "FUSED_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
-
+    p = subprocess.Popen([sys.executable, "-c", _CHILD.format(root=ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=dict(os.environ, PYTHONPATH=ROOT))
+    try:
+        so, se = p.communicate(timeout=420)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        try:
+            p.communicate(timeout=15)
+        except subprocess.TimeoutExpired:
+            pass    # stuck in the driver: abandoned, not waited for
+        pytest.fail("the child process did not finish within 420 s")
+    assert p.returncode == 0 and "FUSED_OK" in so, (p.returncode, so[-1500:], se[-3000:])
 
 def _positions(n, seed):
     rng = np.random.default_rng(seed)
