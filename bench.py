@@ -290,7 +290,8 @@ def headline_leg(args, dev, rank, world, cdev):
     # (tools/whole_games_config3.py)
     cache_log2 = None if (args.no_leaf_cache or args.net != "ch5") else 26
     eng = SelfPlayEngine(cfg, net, n_games=args.games, seed=0, sims_hint=args.sims,
-                         nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=parts, leaf_cache_log2=cache_log2, leaf_cache_max_discs=24)
+                         nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=parts, leaf_cache_log2=cache_log2, leaf_cache_max_discs=24,
+                         fused=bool(args.fused and args.net == "mini"))
     first_id = rank * args.games
     out = {}
 
@@ -386,7 +387,7 @@ def headline_leg(args, dev, rank, world, cdev):
     launches = args.steps * parts
     leaves_per_launch = (leaves / world - served) / launches   # rows the net evaluated on this rank (the cache serves the rest)
     net_avg_ms, tree_avg_ms = net_ms / launches, tree_ms / launches
-    ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12
+    ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12 if net_avg_ms else 0.0   # (--fused: no separate net kernel to time)
     traffic, traffic_src = conv_traffic() if args.net == "ch5" else (None, None)
     v2 = "f16x3" in (net.kernel_name or "")
     net_kernel = {"ch5": ("one net forward = k_conv0_split + 20 x k_conv3x3_f16x3 (implicit GEMM on the f16 matrix cores, split operands: "
@@ -935,6 +936,7 @@ def main():
     ap.add_argument("--opening", action="store_true", help="time the first steps from the opening instead of the steady state")
     ap.add_argument("--no-spotcheck", action="store_true")
     ap.add_argument("--no-leaf-cache", action="store_true", help="headline engine without the cross-game evaluation cache")
+    ap.add_argument("--fused", action="store_true", help="--net mini only: the headline leg on the fused tree + net kernel (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only (whole-game, configs[1], par-4 and sweep legs skipped)")
     ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
