@@ -7,7 +7,7 @@
 // in registers, raz_net16_forward_in_wave (raz_net_wave.h: matrix-core trunk in one LDS plane buffer of this wave, heads as
 // k_net_mfma) returns the policy row and the value into the registers backup_leaf reads, and the loop goes on with the next
 // simulation - `iters` of them per launch, the control block and the path staying in registers throughout.  No leaf exchange, no
-// second kernel, no slices; one launch per `iters` simulation steps of the whole batch.  4 waves per SIMD (128 VGPRs, 10 KB of
+// second kernel, no slices; one launch per `iters` simulation steps of the whole batch.  4 waves per SIMD (128 VGPRs, 9.7 KB of
 // LDS per wave): 4096 games are resident at once.  Every game performs exactly the operations it performs under k_tree +
 // k_net_mfma, in the same order: results are bit-identical (tests/test_engine_fused_emu.py on the wave emulator,
 // tests/test_engine_gpu.py).  Opt-in (raz_engine_config.reserved bit 4) for parallel_search_num == 1 without the evaluation
@@ -24,10 +24,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                                                           uint32_t iters, const float* __restrict__ net_w,
                                                                                           int net_R, int net_V) {
     if (blockIdx.x >= count) return;
-    __shared__ float lds64[64];
-    __shared__ SolverLDS slds_store;
+    // LDS of the wave: the net's plane buffer, then ONE scratch area shared in time by the net's heads (during a forward), the
+    // reduction scratch of backup_leaf and the solver's frames (between forwards; both are initialised by their users on every
+    // call) - 9.7 KB in all, so that 16 waves fit a CU's 160 KB whatever the allocation granule
     extern __shared__ __attribute__((aligned(16))) float netbuf[];
-    SolverLDS* slds_p = SOLVER ? &slds_store : nullptr;
+    float* lds64 = netbuf + 16 * PS;
+    SolverLDS* slds_p = SOLVER ? (SolverLDS*)(netbuf + 16 * PS + 64) : nullptr;
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
@@ -99,10 +101,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                                                               uint32_t iters, const float* __restrict__ net_w,
                                                                                               int net_R, int net_V) {
     if (blockIdx.x >= count) return;
-    __shared__ float lds64[64];
-    __shared__ SolverLDS slds_store;
+    // LDS of the wave: the net's plane buffer, then ONE scratch area shared in time by the net's heads (during a forward), the
+    // reduction scratch of backup_leaf and the solver's frames (between forwards; both are initialised by their users on every
+    // call) - 9.7 KB in all, so that 16 waves fit a CU's 160 KB whatever the allocation granule
     extern __shared__ __attribute__((aligned(16))) float netbuf[];
-    SolverLDS* slds_p = SOLVER ? &slds_store : nullptr;
+    float* lds64 = netbuf + 16 * PS;
+    SolverLDS* slds_p = SOLVER ? (SolverLDS*)(netbuf + 16 * PS + 64) : nullptr;
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // `n_steps` simulation steps of the whole batch in ceil(n_steps / 32) launches on stream s (raz_engine_step, reserved bit 4)
 int raz_launch_tree_net(const raz_engine_dev& d, bool solver, uint32_t n_steps, const float* W, int R, int V, hipStream_t s) {
     constexpr uint32_t kFusedIters = 32;
-    const size_t shm = (size_t)raz_net16_lds_floats(V) * sizeof(float);
+    const int head = 192 + V > 64 + (int)(sizeof(SolverLDS) / sizeof(float)) ? 192 + V : 64 + (int)(sizeof(SolverLDS) / sizeof(float));
+    const size_t shm = ((size_t)16 * PS + head) * sizeof(float);
     int rc = RAZ_OK;
     while (n_steps && rc == RAZ_OK) {
         const uint32_t it = n_steps < kFusedIters ? n_steps : kFusedIters;
