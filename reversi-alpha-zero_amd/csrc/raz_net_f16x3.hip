@@ -203,12 +203,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
 // unit u, so that a read has two units to land whatever the LDS queue looks like; the stage barrier moves two units up the
 // instruction stream accordingly (it precedes the first read of the next stage, i.e. unit 10 of the current one), and the
 // activation operands of the three taps of a stage live in their own registers.
+//   PERSIST (RAZ_F16X3_PIPE = 3 / 4 = the two tilings below, persistent): one workgroup per CU walks its tiles (blockIdx.x,
+//            + gridDim.x, ...) instead of one workgroup per tile; the first stage of the NEXT tile is requested right after the
+//            barrier that admits the current tile's last stage, so it lands under that stage and the epilogue's stores (a
+//            workgroup's start-up - launch, first DMA round trip - is otherwise exposed 8 times per CU and layer).
 //   PPW = 1 (RAZ_F16X3_PIPE=1): the tiling above - 8 waves, one position each, 2 waves per SIMD, 245 VGPRs.
 //   PPW = 2 (RAZ_F16X3_PIPE=2): 4 waves per workgroup, TWO positions each = 128 output channels x 128 squares per wave (256
 //            accumulator registers, one wave per SIMD): a weight pair read from LDS feeds 12 matrix instructions instead of 6 -
 //            0.33 LDS reads per matrix instruction instead of 0.5 - as the large GEMM tilings do.
 // Everything else - staging, addresses, epilogue - is the kernel above.
-template <int PPW>
+template <int PPW, bool PERSIST>
 __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_pipe(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
                                                                const float* __restrict__ inv_scale_ptr, const unsigned char* in,
                                                                unsigned char* out, const unsigned char* skip,
@@ -220,12 +224,11 @@ __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_p
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
     const int noct = F / OCT, nchunks = F / 16;
-    const int b = blockIdx.x;
-    const int ot = (b >> 3) % noct;
-    const int pg = (b / (8 * noct)) * 8 + (b & 7);
-    const int p0 = pg * NWAVE, pos0 = p0 + wv * PPW;   // this wave's first position
-    if (p0 >= n) return;
     const size_t pos_bytes = (size_t)F * 256;
+    // a tile = (output-channel tile ot, position group pg), numbered as the blocks of the kernel above are; PERSIST: the workgroup
+    // walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (their position groups ascend, so the first one beyond the batch ends the walk)
+    const int ntiles = PERSIST ? (int)((((unsigned)((n + NWAVE - 1) / NWAVE) + 7) / 8) * 8 * (unsigned)noct) : (int)blockIdx.x + 1;
+    const int tstride = PERSIST ? (int)gridDim.x : 1;
     if (tid < 160) {
         const int im = tid / 80, k = tid % 80;
         ((f32x4*)(lds + LDS_ACT + im * ACT_IMG + Z_OFF))[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -245,32 +248,38 @@ __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_p
     }
     const uint32_t aoff = (uint32_t)(kg * 4096 + (lane & 31) * 16);
     f32x16 acc[4][NT];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
-    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE + lane * 16;
-    const unsigned char* asrc[PPW];
-#pragma unroll
-    for (int pp = 0; pp < PPW; ++pp) asrc[pp] = in + (size_t)(pos0 + pp < n ? pos0 + pp : n - 1) * pos_bytes + lane * 16;
     const int nstages = nchunks * 3;
-    auto issue = [&](int st) {   // stage st = (chunk st / 3, tap group st % 3), as in the kernel above: 24 weight pieces + the positions' planes
+    // stage st = (chunk st / 3, tap group st % 3), as in the kernel above: 24 weight pieces + the positions' planes
+    auto issue_from = [&](const unsigned char* wsrc_, const unsigned char* const* asrc_, int st) {
         const int c = st / 3;
-        const unsigned char* src = wsrc + (size_t)st * W_STAGE;
+        const unsigned char* src = wsrc_ + (size_t)st * W_STAGE;
         unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
 #pragma unroll
         for (int i = 0; i < 24 / WAVES; ++i) GLDS16(src + (wv * (24 / WAVES) + i) * 1024, dst + (wv * (24 / WAVES) + i) * 1024);
         if (st % 3 == 0) {
 #pragma unroll
             for (int pp = 0; pp < PPW; ++pp) {
-                const unsigned char* a = asrc[pp] + (size_t)c * ACT_POS;
+                const unsigned char* a = asrc_[pp] + (size_t)c * ACT_POS;
                 unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + (wv * PPW + pp) * ACT_POS;
 #pragma unroll
                 for (int pl = 0; pl < 4; ++pl) GLDS16(a + pl * 1024, ad + pl * 1024);
             }
         }
+    };
+    auto tile_sources = [&](int t, const unsigned char*& wsrc_, const unsigned char** asrc_) {
+        const int ot_ = (t >> 3) % noct, pos0_ = ((t / (8 * noct)) * 8 + (t & 7)) * NWAVE + wv * PPW;
+        wsrc_ = Wl + (size_t)ot_ * nchunks * 3 * W_STAGE + lane * 16;
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) asrc_[pp] = in + (size_t)(pos0_ + pp < n ? pos0_ + pp : n - 1) * pos_bytes + lane * 16;
+    };
+    const unsigned char* wsrc = nullptr;
+    const unsigned char* asrc[PPW];
+    auto issue = [&](int st) { issue_from(wsrc, asrc, st); };
+    auto issue_next_tile = [&](int t) {   // the first stage of tile t (once per tile: its addresses are not kept)
+        const unsigned char* w2;
+        const unsigned char* a2[PPW];
+        tile_sources(t, w2, a2);
+        issue_from(w2, a2, 0);
     };
     h8 ah[3], al[3];            // weight pairs of three units in flight (ring: unit u lives in slot u % 3; 12 units per stage)
     h8 bh[3][NT], bl[3][NT];    // activation operands of the stage's three taps (slot = tap in stage)
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_p
             __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): this wave's reads of the buffer have RETURNED before any DMA may refill it */ \
             __syncthreads();                                                                      \
             if ((st_) + 2 < nstages) issue((st_) + 2);                                            \
+            else if (PERSIST && have_next) issue_next_tile(tile + tstride); /* lands under this tile's last stage and epilogue */ \
         }                                                                                         \
         if ((u_) < 10)                                                                            \
             RAZ_FETCH(st_, TG, ((u_) + 2) % 12);                                                  \
@@ -319,8 +329,21 @@ __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_p
 #define RAZ_STAGE(st_, TG)                                                                                                          \
     RAZ_STEP(st_, TG, 0); RAZ_STEP(st_, TG, 1); RAZ_STEP(st_, TG, 2); RAZ_STEP(st_, TG, 3); RAZ_STEP(st_, TG, 4); RAZ_STEP(st_, TG, 5); \
     RAZ_STEP(st_, TG, 6); RAZ_STEP(st_, TG, 7); RAZ_STEP(st_, TG, 8); RAZ_STEP(st_, TG, 9); RAZ_STEP(st_, TG, 10); RAZ_STEP(st_, TG, 11)
-    issue(0);
-    __syncthreads();
+    bool over = false, prefetched = false;
+    for (int tile = blockIdx.x; tile < ntiles; tile += tstride) {
+    const int ot = (tile >> 3) % noct;
+    const int p0 = ((tile / (8 * noct)) * 8 + (tile & 7)) * NWAVE, pos0 = p0 + wv * PPW;   // this wave's first position
+    if (p0 >= n) break;
+    const bool have_next = PERSIST && tile + tstride < ntiles && ((((tile + tstride) / (8 * noct)) * 8 + ((tile + tstride) & 7)) * NWAVE < n);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+    tile_sources(tile, wsrc, asrc);
+    if (!prefetched) issue(0);
+    __syncthreads();   // stage 0 has landed; everybody has finished the previous tile's reads
     if (nstages > 1) issue(1);
     RAZ_FETCH(0, 0, 0);
     RAZ_FETCH(0, 0, 1);
@@ -330,12 +353,8 @@ __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_p
         RAZ_STAGE(st0 + 1, 1);
         RAZ_STAGE(st0 + 2, 2);
     }
-#undef RAZ_STAGE
-#undef RAZ_STEP
-#undef RAZ_UNIT
-#undef RAZ_FETCH
+    prefetched = have_next;
     const float inv_scale = *inv_scale_ptr;
-    bool over = false;
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
         const int pos = pos0 + pp;
@@ -374,8 +393,13 @@ __global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_p
                 }
             }
     }
+    }   // tiles
     if (over) atomicOr(flag, 1u);
 }
+#undef RAZ_STAGE
+#undef RAZ_STEP
+#undef RAZ_UNIT
+#undef RAZ_FETCH
 
 // Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.  The work per
 // position is tiny and latency-bound (scalar weight loads), so a position's 16-channel chunks are spread over the 4 waves
@@ -554,19 +578,25 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
         attr_set = true;
     }
     const char* pipe = getenv("RAZ_F16X3_PIPE");   // measurements only (see the variants' header)
     const int variant = pipe ? atoi(pipe) : 0;
-    const auto conv = variant == 2 ? k_conv3x3_f16x3_pipe<2> : variant == 1 ? k_conv3x3_f16x3_pipe<1> : k_conv3x3_f16x3;
-    const unsigned conv_threads = variant == 2 ? NWAVE * 64 / 2 : NWAVE * 64;
+    const auto conv = variant == 4 ? k_conv3x3_f16x3_pipe<2, true> : variant == 3 ? k_conv3x3_f16x3_pipe<1, true>
+                      : variant == 2 ? k_conv3x3_f16x3_pipe<2, false> : variant == 1 ? k_conv3x3_f16x3_pipe<1, false> : k_conv3x3_f16x3;
+    const unsigned conv_threads = (variant == 2 || variant == 4) ? NWAVE * 64 / 2 : NWAVE * 64;
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
-    const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
+    const unsigned tiles = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
+    unsigned grid = (variant == 3 || variant == 4) && tiles > 256 ? 256 : tiles;   // persistent variants: one workgroup per CU walks the tiles
+    if (const char* g = getenv("RAZ_F16X3_GRID"))   // tests only: fewer workgroups, so that each one walks several tiles
+        if ((variant == 3 || variant == 4) && atoi(g) > 0 && (unsigned)atoi(g) < grid) grid = (unsigned)atoi(g);
     for (int r = 0; r < R; ++r) {
         const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
         hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
