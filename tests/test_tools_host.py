@@ -58,3 +58,28 @@ def test_bench_reports_no_traffic_without_both_passes(tmp_path, monkeypatch):
     assert bench.conv_traffic() == (None, None)
     json.dump({"net_forward_hbm_bytes_per_launch": 2.5e10, "fetch_pass_present": True, "write_pass_present": True}, open(d / "headline_config3_traffic.json", "w"))
     assert bench.conv_traffic()[0] == 2.5e10
+
+
+def test_pmc_summary_tells_the_fused_kernels_from_the_classic_ones():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary as P
+    name = "void (anonymous namespace)::{}<false>(raz_engine_dev, unsigned int, unsigned int)"
+    assert P.short(name.format("k_tree")) == "k_tree" and P.short(name.format("k_tree_par")) == "k_tree_par"
+    assert P.short(name.format("k_tree_net")) == "k_tree_net" and P.short(name.format("k_tree_par_net")) == "k_tree_par_net"
+    assert P.short("void (anonymous namespace)::k_conv3x3_f16x3_pipe<2, true>(...)") == "k_conv3x3_f16x3_pipe"
+    assert P.short("(anonymous namespace)::k_conv3x3_f16x3(unsigned char const*, ...)") == "k_conv3x3_f16x3"
+
+
+def test_bench_child_legs_never_cost_the_parent_its_line():
+    """bench.child_leg: the document a child prints, or what went wrong - a child that crashes, prints nothing, or hangs (killed after
+    the timeout) yields an error entry, not an exception and not a hung parent."""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    assert bench.child_leg(["-c", "print('noise'); print('{\"value\": 3}')"], 30.0) == {"value": 3}
+    assert "exit code 7" in bench.child_leg(["-c", "import sys; sys.exit(7)"], 30.0)["error"]
+    assert "exit code" in bench.child_leg(["-c", "import os; os.abort()"], 30.0)["error"]
+    assert "error" in bench.child_leg(["-c", "print('no json here')"], 30.0)
+    t0 = time.time()
+    assert "did not finish" in bench.child_leg(["-c", "import time; time.sleep(60)"], 1.0)["error"]
+    assert time.time() - t0 < 20
