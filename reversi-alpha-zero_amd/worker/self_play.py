@@ -860,8 +860,9 @@ def try_reload_model(config, model):
         return False
 
 
-def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None):
-    """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU."""
+def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None, fused_tree_net=False):
+    """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU.  fused_tree_net: see
+    BatchedSelfPlayWorker (16-filter nets: tree and net in one kernel; opt-in)."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -887,6 +888,7 @@ def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0,
             return model.model.to_blob() if try_reload_model(config, model) else None
     B = games_in_flight or 4096
     w = BatchedSelfPlayWorker(config, net_blob, B, seed=seed, device=f"cuda:{local}", rank=rank, world=world,
-                              block_games=block_games or 4 * B)   # continuous batching: 4 games per slot between two gathers
+                              block_games=block_games or 4 * B,   # continuous batching: 4 games per slot between two gathers
+                              fused_tree_net=fused_tree_net)
     w.run(total_games, reload_model=reload_model)
     return w
