@@ -575,20 +575,17 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     unsigned char* bufT = bufA + (size_t)n * F * 256;
     unsigned* flag = raz_net_f16x3_flag(W, F, R, V);
     const float* scales = W + f16x3_scale_off(F, R, V);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3_f16x3_pipe<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
-        attr_set = true;
-    }
     const char* pipe = getenv("RAZ_F16X3_PIPE");   // measurements only (see the variants' header)
     const int variant = pipe ? atoi(pipe) : 0;
     const auto conv = variant == 4 ? k_conv3x3_f16x3_pipe<2, true> : variant == 3 ? k_conv3x3_f16x3_pipe<1, true>
                       : variant == 2 ? k_conv3x3_f16x3_pipe<2, false> : variant == 1 ? k_conv3x3_f16x3_pipe<1, false> : k_conv3x3_f16x3;
+    static bool attr_set[5] = {false, false, false, false, false};   // per kernel: a variant can never cost the default path anything
+    const int vi = variant >= 1 && variant <= 4 ? variant : 0;
+    if (!attr_set[vi]) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
+        attr_set[vi] = true;
+    }
     const unsigned conv_threads = (variant == 2 || variant == 4) ? NWAVE * 64 / 2 : NWAVE * 64;
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
