@@ -1047,8 +1047,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             children = (("config1_4096x200_mini_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused"]),
-                        ("config1_mini_yml_parallel_search_num_4_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused_par4"]),
-                        ("headline_conv_kernel_hand_scheduled_variant_ab", [os.path.join(ROOT, "tools", "sessions", "quick_f16x3_pipe.py")]))
+                        ("config1_mini_yml_parallel_search_num_4_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused_par4"]))
             stuck = False
             for key, argv in children:
                 out[key] = {"error": "skipped: an earlier child process did not come back"} if stuck else child_leg(argv, 150.0)

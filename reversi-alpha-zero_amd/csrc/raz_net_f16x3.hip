@@ -55,6 +55,47 @@ constexpr int LDS_ACT = 2 * W_STAGE;             // two activation images (doubl
 constexpr int LDS_BYTES = LDS_ACT + 2 * ACT_IMG; // 117,248 B: one workgroup of 8 waves per CU
 constexpr int Z_OFF = NWAVE * ACT_POS;           // the zero rows inside an image (at Z_OFF and Z_OFF + 1024)
 
+// Timeline instrumentation of the conv kernel, compiled in ONLY by tools/probe_conv.hip (which includes this file with
+// RAZ_F16X3_STAMPS defined): per wave 8 words - s_memtime at entry [0], when stage 0 has landed [1], at the end of the K loop [2],
+// after the last store was issued [3] and after the stores have drained [4]; the cycles spent inside the 48 stage barriers [5];
+// HW_ID [6] (which CU / SIMD ran the wave); s_memrealtime at entry [7].  The product build has none of it.
+#ifdef RAZ_F16X3_STAMPS
+#define RAZ_STAMP_PARAM , unsigned long long* __restrict__ stamps
+#define RAZ_STAMP_ARG , (unsigned long long*)nullptr
+#define RAZ_STAMP_BEGIN                                                                                           \
+    unsigned long long st_t[8];                                                                                   \
+    st_t[0] = __builtin_amdgcn_s_memtime();                                                                       \
+    st_t[7] = __builtin_amdgcn_s_memrealtime();                                                                   \
+    st_t[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
+    st_t[5] = 0;                                                                                                  \
+    st_t[1] = st_t[2] = st_t[3] = st_t[4] = 0;                                                                    \
+    unsigned long long st_b = 0
+#define RAZ_STAMP_BARRIER_IN st_b = __builtin_amdgcn_s_memtime()
+#define RAZ_STAMP_BARRIER_OUT(st_)                                    \
+    do {                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        st_t[5] += t_ - st_b;                                         \
+        if ((st_) == 0) st_t[1] = t_;                                 \
+    } while (0)
+#define RAZ_STAMP_AT(i_) st_t[i_] = __builtin_amdgcn_s_memtime()
+#define RAZ_STAMP_END                                                                                    \
+    do {                                                                                                 \
+        st_t[3] = __builtin_amdgcn_s_memtime();                                                          \
+        __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) */                                               \
+        st_t[4] = __builtin_amdgcn_s_memtime();                                                          \
+        if (lane == 0 && stamps)                                                                         \
+            for (int i_ = 0; i_ < 8; ++i_) stamps[((size_t)blockIdx.x * NWAVE + wv) * 8 + i_] = st_t[i_]; \
+    } while (0)
+#else
+#define RAZ_STAMP_PARAM
+#define RAZ_STAMP_ARG
+#define RAZ_STAMP_BEGIN
+#define RAZ_STAMP_BARRIER_IN
+#define RAZ_STAMP_BARRIER_OUT(st_)
+#define RAZ_STAMP_AT(i_)
+#define RAZ_STAMP_END
+#endif
+
 #define GLDS16(gptr, lptr)                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                     \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
@@ -66,9 +107,10 @@ constexpr int Z_OFF = NWAVE * ACT_POS;           // the zero rows inside an imag
 __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
                                                           const float* __restrict__ inv_scale_ptr, const unsigned char* in, unsigned char* out,
                                                           const unsigned char* skip, const uint8_t* __restrict__ active, int n, int F,
-                                                          unsigned* __restrict__ flag, const uint32_t* __restrict__ n_ptr) {
+                                                          unsigned* __restrict__ flag, const uint32_t* __restrict__ n_ptr RAZ_STAMP_PARAM) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    RAZ_STAMP_BEGIN;
     if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;   // rows 0..n-1 of a compacted batch (raz_leaf_cache.hip): the count lives on the device
     const int noct = F / OCT, nchunks = F / 16;
     // blocks b and b + 8 run on the same XCD (round-robin dispatch): give them the oc tiles of the SAME positions, so the
@@ -130,7 +172,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
 #pragma unroll
         for (int tg = 0; tg < 3; ++tg) {
             const int st = c * 3 + tg;
+            RAZ_STAMP_BARRIER_IN;
             __syncthreads();   // stage st has landed (every wave drained its DMA before arriving); stage st-1's reads are done
+            RAZ_STAMP_BARRIER_OUT(st);
             if (tg < 2) issue(c, tg + 1);
             else if (c + 1 < nchunks) issue(c + 1, 0);
             const uint32_t wbase = (uint32_t)(LDS_W + (st & 1) * W_STAGE) + aoff;
@@ -157,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
             }
         }
     }
+    RAZ_STAMP_AT(2);
     if (!live) return;
     const float inv_scale = *inv_scale_ptr;
     // epilogue.  D layout: column = lane & 31 = square, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = channel in the 32-tile
@@ -194,212 +239,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
             }
         }
     if (over) atomicOr(flag, 1u);   // an activation beyond the f16 range: the caller must fall back to the f32 kernel
+    RAZ_STAMP_END;
 }
-
-// EXPERIMENTAL VARIANTS of the kernel above (selected per launch by the environment variable RAZ_F16X3_PIPE = 1 / 2, measurements
-// only): the same stages, the same matrix instructions in the same order per accumulator - bit-identical output - with the
-// operand traffic scheduled by hand instead of by the compiler.  A stage is 12 units (tap tt, M tile m); the LDS reads of unit
-// u + 2 (the M tile's weight pair, and with m == 0 the tap's activation operands) are requested BEFORE the matrix instructions of
-// unit u, so that a read has two units to land whatever the LDS queue looks like; the stage barrier moves two units up the
-// instruction stream accordingly (it precedes the first read of the next stage, i.e. unit 10 of the current one), and the
-// activation operands of the three taps of a stage live in their own registers.
-//   PERSIST (RAZ_F16X3_PIPE = 3 / 4 = the two tilings below, persistent): one workgroup per CU walks its tiles (blockIdx.x,
-//            + gridDim.x, ...) instead of one workgroup per tile; the first stage of the NEXT tile is requested right after the
-//            barrier that admits the current tile's last stage, so it lands under that stage and the epilogue's stores (a
-//            workgroup's start-up - launch, first DMA round trip - is otherwise exposed 8 times per CU and layer).
-//   PPW = 1 (RAZ_F16X3_PIPE=1): the tiling above - 8 waves, one position each, 2 waves per SIMD, 245 VGPRs.
-//   PPW = 2 (RAZ_F16X3_PIPE=2): 4 waves per workgroup, TWO positions each = 128 output channels x 128 squares per wave (256
-//            accumulator registers, one wave per SIMD): a weight pair read from LDS feeds 12 matrix instructions instead of 6 -
-//            0.33 LDS reads per matrix instruction instead of 0.5 - as the large GEMM tilings do.
-// Everything else - staging, addresses, epilogue - is the kernel above.
-template <int PPW, bool PERSIST>
-__global__ __launch_bounds__(512 / PPW, PPW == 1 ? 2 : 1) void k_conv3x3_f16x3_pipe(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
-                                                               const float* __restrict__ inv_scale_ptr, const unsigned char* in,
-                                                               unsigned char* out, const unsigned char* skip,
-                                                               const uint8_t* __restrict__ active, int n, int F, unsigned* __restrict__ flag,
-                                                               const uint32_t* __restrict__ n_ptr) {
-    constexpr int NT = 2 * PPW;           // 32-square N tiles per wave
-    constexpr int WAVES = NWAVE / PPW;    // waves per workgroup (NWAVE positions per workgroup either way)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
-    const int noct = F / OCT, nchunks = F / 16;
-    const size_t pos_bytes = (size_t)F * 256;
-    // a tile = (output-channel tile ot, position group pg), numbered as the blocks of the kernel above are; PERSIST: the workgroup
-    // walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (their position groups ascend, so the first one beyond the batch ends the walk)
-    const int ntiles = PERSIST ? (int)((((unsigned)((n + NWAVE - 1) / NWAVE) + 7) / 8) * 8 * (unsigned)noct) : (int)blockIdx.x + 1;
-    const int tstride = PERSIST ? (int)gridDim.x : 1;
-    if (tid < 160) {
-        const int im = tid / 80, k = tid % 80;
-        ((f32x4*)(lds + LDS_ACT + im * ACT_IMG + Z_OFF))[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const int kg = lane >> 5;
-    uint32_t boff[NT][9];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int sq = (nt & 1) * 32 + (lane & 31), y = sq >> 3, x = sq & 7;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            const int s2 = sq + (t / 3 - 1) * 8 + (t % 3 - 1);
-            boff[nt][t] = ok ? (uint32_t)((wv * PPW + (nt >> 1)) * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(Z_OFF + (s2 & 15) * 16);
-        }
-    }
-    const uint32_t aoff = (uint32_t)(kg * 4096 + (lane & 31) * 16);
-    f32x16 acc[4][NT];
-    const int nstages = nchunks * 3;
-    // stage st = (chunk st / 3, tap group st % 3), as in the kernel above: 24 weight pieces + the positions' planes
-    auto issue_from = [&](const unsigned char* wsrc_, const unsigned char* const* asrc_, int st) {
-        const int c = st / 3;
-        const unsigned char* src = wsrc_ + (size_t)st * W_STAGE;
-        unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
-#pragma unroll
-        for (int i = 0; i < 24 / WAVES; ++i) GLDS16(src + (wv * (24 / WAVES) + i) * 1024, dst + (wv * (24 / WAVES) + i) * 1024);
-        if (st % 3 == 0) {
-#pragma unroll
-            for (int pp = 0; pp < PPW; ++pp) {
-                const unsigned char* a = asrc_[pp] + (size_t)c * ACT_POS;
-                unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + (wv * PPW + pp) * ACT_POS;
-#pragma unroll
-                for (int pl = 0; pl < 4; ++pl) GLDS16(a + pl * 1024, ad + pl * 1024);
-            }
-        }
-    };
-    auto tile_sources = [&](int t, const unsigned char*& wsrc_, const unsigned char** asrc_) {
-        const int ot_ = (t >> 3) % noct, pos0_ = ((t / (8 * noct)) * 8 + (t & 7)) * NWAVE + wv * PPW;
-        wsrc_ = Wl + (size_t)ot_ * nchunks * 3 * W_STAGE + lane * 16;
-#pragma unroll
-        for (int pp = 0; pp < PPW; ++pp) asrc_[pp] = in + (size_t)(pos0_ + pp < n ? pos0_ + pp : n - 1) * pos_bytes + lane * 16;
-    };
-    const unsigned char* wsrc = nullptr;
-    const unsigned char* asrc[PPW];
-    auto issue = [&](int st) { issue_from(wsrc, asrc, st); };
-    auto issue_next_tile = [&](int t) {   // the first stage of tile t (once per tile: its addresses are not kept)
-        const unsigned char* w2;
-        const unsigned char* a2[PPW];
-        tile_sources(t, w2, a2);
-        issue_from(w2, a2, 0);
-    };
-    h8 ah[3], al[3];            // weight pairs of three units in flight (ring: unit u lives in slot u % 3; 12 units per stage)
-    h8 bh[3][NT], bl[3][NT];    // activation operands of the stage's three taps (slot = tap in stage)
-    // the reads of unit u of stage st (TG = st % 3 is a compile-time constant at every call site)
-#define RAZ_FETCH(st_, TG, u_)                                                                         \
-    do {                                                                                               \
-        constexpr int tt_ = (u_) / 4, m_ = (u_) % 4, t_ = (TG) * 3 + tt_;                              \
-        const uint32_t wb_ = (uint32_t)(LDS_W + ((st_) & 1) * W_STAGE) + aoff + tt_ * 8192 + m_ * 512; \
-        ah[(u_) % 3] = *(const h8*)(lds + wb_);                                                        \
-        al[(u_) % 3] = *(const h8*)(lds + wb_ + 2048);                                                 \
-        if (m_ == 0) {                                                                                 \
-            const uint32_t ab_ = (uint32_t)(LDS_ACT + (((st_) / 3) & 1) * ACT_IMG);                    \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                        \
-                bh[tt_][nt] = *(const h8*)(lds + ab_ + boff[nt][t_]);                                  \
-                bl[tt_][nt] = *(const h8*)(lds + ab_ + boff[nt][t_] + 1024);                           \
-            }                                                                                          \
-        }                                                                                              \
-    } while (0)
-#define RAZ_UNIT(u_)                                                                                                   \
-    do {                                                                                                               \
-        constexpr int tt_ = (u_) / 4, m_ = (u_) % 4;                                                                   \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                            \
-            acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[(u_) % 3], bh[tt_][nt], acc[m_][nt], 0, 0, 0);     \
-            acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u_) % 3], bl[tt_][nt], acc[m_][nt], 0, 0, 0);     \
-            acc[m_][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(u_) % 3], bh[tt_][nt], acc[m_][nt], 0, 0, 0);     \
-        }                                                                                                              \
-    } while (0)
-    // one stage: before the matrix instructions of unit u the reads of unit u + 2 are requested; with u == 10 that is the next
-    // stage's first unit, so the stage barrier (and the DMA of the stage after next, into the buffer everybody has just finished
-    // reading) comes first
-#define RAZ_STEP(st_, TG, u_)                                                                     \
-    do {                                                                                          \
-        if ((u_) == 10 && (st_) + 1 < nstages) {                                                  \
-            __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): this wave's reads of the buffer have RETURNED before any DMA may refill it */ \
-            __syncthreads();                                                                      \
-            if ((st_) + 2 < nstages) issue((st_) + 2);                                            \
-            else if (PERSIST && have_next) issue_next_tile(tile + tstride); /* lands under this tile's last stage and epilogue */ \
-        }                                                                                         \
-        if ((u_) < 10)                                                                            \
-            RAZ_FETCH(st_, TG, ((u_) + 2) % 12);                                                  \
-        else if ((st_) + 1 < nstages)                                                             \
-            RAZ_FETCH((st_) + 1, ((TG) + 1) % 3, ((u_) + 2) % 12);                                \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        RAZ_UNIT(u_);                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    } while (0)
-#define RAZ_STAGE(st_, TG)                                                                                                          \
-    RAZ_STEP(st_, TG, 0); RAZ_STEP(st_, TG, 1); RAZ_STEP(st_, TG, 2); RAZ_STEP(st_, TG, 3); RAZ_STEP(st_, TG, 4); RAZ_STEP(st_, TG, 5); \
-    RAZ_STEP(st_, TG, 6); RAZ_STEP(st_, TG, 7); RAZ_STEP(st_, TG, 8); RAZ_STEP(st_, TG, 9); RAZ_STEP(st_, TG, 10); RAZ_STEP(st_, TG, 11)
-    bool over = false, prefetched = false;
-    for (int tile = blockIdx.x; tile < ntiles; tile += tstride) {
-    const int ot = (tile >> 3) % noct;
-    const int p0 = ((tile / (8 * noct)) * 8 + (tile & 7)) * NWAVE, pos0 = p0 + wv * PPW;   // this wave's first position
-    if (p0 >= n) break;
-    const bool have_next = PERSIST && tile + tstride < ntiles && ((((tile + tstride) / (8 * noct)) * 8 + ((tile + tstride) & 7)) * NWAVE < n);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
-    tile_sources(tile, wsrc, asrc);
-    if (!prefetched) issue(0);
-    __syncthreads();   // stage 0 has landed; everybody has finished the previous tile's reads
-    if (nstages > 1) issue(1);
-    RAZ_FETCH(0, 0, 0);
-    RAZ_FETCH(0, 0, 1);
-    for (int c = 0; c < nchunks; ++c) {
-        const int st0 = c * 3;
-        RAZ_STAGE(st0, 0);
-        RAZ_STAGE(st0 + 1, 1);
-        RAZ_STAGE(st0 + 2, 2);
-    }
-    prefetched = have_next;
-    const float inv_scale = *inv_scale_ptr;
-#pragma unroll
-    for (int pp = 0; pp < PPW; ++pp) {
-        const int pos = pos0 + pp;
-        if (!(pos < n && (!active || active[pos]))) continue;
-        unsigned char* out_pos = out + (size_t)pos * pos_bytes;
-        const unsigned char* skip_pos = skip ? skip + (size_t)pos * pos_bytes : nullptr;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int oc8 = ot * OCT + m * 32 + q * 8;
-                const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
-                const size_t unit = (size_t)(oc8 >> 4) * ACT_POS + (size_t)((oc8 >> 3) & 1) * 2048;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int nt = pp * 2 + h;
-                    const size_t o = unit + (size_t)(h * 32 + (lane & 31)) * 16 + kg * 8;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[m][nt][q * 4 + j] * inv_scale + bv[j];
-                    if (skip_pos) {
-                        const h4 sh = *(const h4*)(skip_pos + o), sl = *(const h4*)(skip_pos + o + 1024);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = v[j] + ((float)sh[j] + (float)sl[j]);
-                    }
-                    h4 hi, lo;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float r = v[j] > 0.0f ? v[j] : 0.0f;
-                        over |= !(r < 60000.0f);
-                        hi[j] = (_Float16)r;
-                        lo[j] = (_Float16)(r - (float)hi[j]);
-                    }
-                    *(h4*)(out_pos + o) = hi;
-                    *(h4*)(out_pos + o + 1024) = lo;
-                }
-            }
-    }
-    }   // tiles
-    if (over) atomicOr(flag, 1u);
-}
-#undef RAZ_STAGE
-#undef RAZ_STEP
-#undef RAZ_UNIT
-#undef RAZ_FETCH
 
 // Layer 0: 2 bit planes -> F channels, exact f32 chains as in k_conv0_wide, written in the split layout.  The work per
 // position is tiny and latency-bound (scalar weight loads), so a position's 16-channel chunks are spread over the 4 waves
@@ -559,6 +400,14 @@ void raz_net_build_f16x3(const float* src, float* dst, int F, int R, int V) {
     }
 }
 
+// The heads over a trunk output in the plain split layout (shared with raznet-forward-v3, raz_net_wino.hip).
+int raz_net_heads_split(const float* W, int F, int R, int V, const unsigned char* trunk, const uint8_t* active, float* policy, float* value,
+                        size_t n, hipStream_t s, const uint32_t* list, const uint32_t* n_ptr) {
+    hipLaunchKernelGGL(k_heads_split, dim3((unsigned)n), dim3(64), (192 + (size_t)V) * sizeof(float), s, W + heads_off(F, R), trunk, active,
+                       policy, value, (int)n, F, V, list, n_ptr);
+    return raz_check_launch("raz_net_forward (split heads)");
+}
+
 size_t raz_net_f16x3_scratch_bytes(int F, size_t n) { return (size_t)2 * n * F * 256; }
 
 // The sticky range flag lives in the device weight image, after the per-layer scales (raz_net_layout.h leaves 64 floats there).
@@ -575,35 +424,30 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     unsigned char* bufT = bufA + (size_t)n * F * 256;
     unsigned* flag = raz_net_f16x3_flag(W, F, R, V);
     const float* scales = W + f16x3_scale_off(F, R, V);
-    const char* pipe = getenv("RAZ_F16X3_PIPE");   // measurements only (see the variants' header)
-    const int variant = pipe ? atoi(pipe) : 0;
-    const auto conv = variant == 4 ? k_conv3x3_f16x3_pipe<2, true> : variant == 3 ? k_conv3x3_f16x3_pipe<1, true>
-                      : variant == 2 ? k_conv3x3_f16x3_pipe<2, false> : variant == 1 ? k_conv3x3_f16x3_pipe<1, false> : k_conv3x3_f16x3;
-    static bool attr_set[5] = {false, false, false, false, false};   // per kernel: a variant can never cost the default path anything
-    const int vi = variant >= 1 && variant <= 4 ? variant : 0;
-    if (!attr_set[vi]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return raz_fail_hip(e, "raz_net_forward: hipFuncSetAttribute");
-        attr_set[vi] = true;
+    const auto conv = k_conv3x3_f16x3;
+    {   // the kernel's LDS image exceeds the default dynamic limit: raise it once per device
+        static unsigned long long attr_devices = 0;   // bit d = done on device d (one process drives one device; a second one still gets its call)
+        int dev = 0;
+        RAZ_HIP_TRY(hipGetDevice(&dev), "raz_net_forward: hipGetDevice");
+        if (dev >= 64 || !(attr_devices >> dev & 1)) {
+            RAZ_HIP_TRY(hipFuncSetAttribute((const void*)conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "raz_net_forward: hipFuncSetAttribute");
+            if (dev < 64) attr_devices |= 1ull << dev;
+        }
     }
-    const unsigned conv_threads = (variant == 2 || variant == 4) ? NWAVE * 64 / 2 : NWAVE * 64;
+    const unsigned conv_threads = NWAVE * 64;
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
     const unsigned tiles = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
-    unsigned grid = (variant == 3 || variant == 4) && tiles > 256 ? 256 : tiles;   // persistent variants: one workgroup per CU walks the tiles
-    if (const char* g = getenv("RAZ_F16X3_GRID"))   // tests only: fewer workgroups, so that each one walks several tiles
-        if ((variant == 3 || variant == 4) && atoi(g) > 0 && (unsigned)atoi(g) < grid) grid = (unsigned)atoi(g);
+    const unsigned grid = tiles;
     for (int r = 0; r < R; ++r) {
         const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
         hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
-                           scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, list ? nullptr : active, (int)n, F, flag, n_ptr);
+                           scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, list ? nullptr : active, (int)n, F, flag, n_ptr RAZ_STAMP_ARG);
         hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
-                           scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr);
+                           scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr RAZ_STAMP_ARG);
     }
-    hipLaunchKernelGGL(k_heads_split, dim3((unsigned)n), dim3(64), (192 + (size_t)V) * sizeof(float), s,
-                       W + heads_off(F, R), (const unsigned char*)bufA, active, policy, value, (int)n, F, V, list, n_ptr);
-    return raz_check_launch("raz_net_forward (f16x3)");
+    return raz_net_heads_split(W, F, R, V, bufA, active, policy, value, n, s, list, n_ptr);
 }

@@ -51,8 +51,9 @@ class DeviceNet:
         kernel = "valu" if force_valu_kernel else kernel
         if kernel == "auto":
             kernel = "f16x3" if (F >= 128 and F % 128 == 0) else "f32"
-        self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk"}.get(kernel, kernel)
-        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6}[kernel]
+        self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk",
+                            "wino": "Winograd F(2,3) x split-operand f16 MFMA trunk"}.get(kernel, kernel)
+        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6, "wino": 7}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")
@@ -99,6 +100,13 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
     par = int(getattr(p, "parallel_search_num", 1) or 1)
     if not 1 <= par <= 16:
         raise ValueError("parallel_search_num must be 1..16 (prediction_queue_size, config.py:141)")
+    # agent/player.py:411: temperature = min(exp(1 - (turn / policy_decay_turn) ** policy_decay_power), 1) is 1 - i.e. inert - for every
+    # turn <= policy_decay_turn when the power is >= 0 (config.py:150 "not used": 60, 3).  Anything else would change the search's
+    # priors; the engine does not implement it and says so instead of ignoring the value.
+    pdt, pdp = getattr(p, "policy_decay_turn", 60), getattr(p, "policy_decay_power", 3)
+    if pdt is not None and pdp is not None and (float(pdt) < 60 or float(pdp) < 0):
+        raise ValueError(f"policy_decay_turn={pdt} / policy_decay_power={pdp} would decay the policy inside a game (agent/player.py:411); "
+                         "only the inert setting (turn >= 60, power >= 0) is supported")
     ust = int(getattr(p, "use_solver_turn", 0) or 0)
     usts = int(getattr(p, "use_solver_turn_in_simulation", 0) or 0)
     share = bool(p.share_mtcs_info_in_self_play)
@@ -154,7 +162,16 @@ class SelfPlayEngine:
             if not pool_bytes_per_game:
                 # a pool that is never pruned must hold the whole game whatever its mobility: 320 B per node (14 legal moves
                 # on average; a game's average is ~8.5) instead of the 232 B default of pruned pools, capped at the link range
-                pool_bytes_per_game = min(nodes_per_game * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
+                want = nodes_per_game * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES
+                pool_bytes_per_game = min(want, 255 << 20)
+                if pool_bytes_per_game < want:
+                    # the link range (25-bit offsets in 8-byte units) caps a pool at 256 MB: keep the node count consistent with the
+                    # bytes that are there, so that the directory / table are sized for what can exist and an overflow shows up as
+                    # "pool full" at the count the constructor states, not deep into a run
+                    nodes_per_game = (pool_bytes_per_game - 64 * NODE_MAX_BYTES) // WHOLE_GAME_BYTES_PER_NODE
+                    import warnings
+                    warnings.warn(f"never-pruned node pool capped at 255 MB per game: {nodes_per_game} nodes instead of the {want // WHOLE_GAME_BYTES_PER_NODE} "
+                                  "a whole game at this simulations x thinking_loop could create", RuntimeWarning)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
                                       record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph,
                                       force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused)

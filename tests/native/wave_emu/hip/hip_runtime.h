@@ -162,11 +162,17 @@ static inline int emu_dpp_src(int lane, int ctrl) {
         case 0x4E: return (lane & ~3) | ((lane & 3) ^ 2);          // quad_perm [2,3,0,1]
         case 0x141: return (lane & ~7) | (7 - (lane & 7));         // row_half_mirror
         case 0x140: return (lane & ~15) | (15 - (lane & 15));      // row_mirror
+        case 0x111: return (lane & 15) >= 1 ? lane - 1 : -1;       // row_shr:1 (lane i <- lane i - 1; the row's first lane: bound_ctrl -> 0)
+        case 0x101: return (lane & 15) <= 14 ? lane + 1 : -1;      // row_shl:1 (lane i <- lane i + 1; the row's last lane: bound_ctrl -> 0)
         default: fprintf(stderr, "wave_emu: DPP control %#x not modelled\n", ctrl); abort();
     }
 }
-#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) \
-    ((int)(uint32_t)wave_emu::exchange((uint32_t)(src), emu_dpp_src(emu_lane(), (ctrl)), "dpp", __LINE__))
+static inline int emu_update_dpp(int old, int src, int ctrl, bool bc, int line) {
+    const int from = emu_dpp_src(emu_lane(), ctrl);   // -1: the source lane lies outside the row
+    const int got = (int)(uint32_t)wave_emu::exchange((uint32_t)src, from < 0 ? emu_lane() : from, "dpp", line);
+    return from < 0 ? (bc ? 0 : old) : got;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) emu_update_dpp((int)(old), (int)(src), (ctrl), (bc), __LINE__)
 // v_writelane_b32 (bound through the LLVM intrinsic in the product source): src and lane are wave-uniform
 static inline uint32_t raz_llvm_writelane(uint32_t src, uint32_t lane, uint32_t old) { return (uint32_t)emu_lane() == (lane & 63u) ? src : old; }
 

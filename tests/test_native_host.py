@@ -118,6 +118,16 @@ def test_engine_workspace_scales_with_parallel_search_num():
                                                  play_data=cfg.play_data), n_games=64, seed=0, nodes_per_game=256)
     c.parallel_search_num = 17
     assert N.lib.raz_engine_workspace_bytes(ctypes.byref(c)) == 0 and b"parallel_search_num" in N.lib.raz_last_error()
+    # policy_decay_turn / policy_decay_power (agent/player.py:411): inert at the shipped 60 / 3 and at anything that keeps
+    # min(exp(1 - (turn / T) ** p), 1) == 1 for turn <= 60; a value that would decay the priors is refused, not ignored
+    play.parallel_search_num = 1
+    for turn, power, ok in ((60, 3, True), (80, 1, True), (60, 0, True), (30, 3, False), (59, 3, False), (60, -1, False)):
+        play.policy_decay_turn, play.policy_decay_power = turn, power
+        if ok:
+            engine_config_from(cfg, n_games=64, seed=0, nodes_per_game=256)
+        else:
+            with pytest.raises(ValueError, match="policy_decay"):
+                engine_config_from(cfg, n_games=64, seed=0, nodes_per_game=256)
 
 
 def test_valu_shaped_bitboard_ops_equal_the_reference_shaped_ones(tmp_path):

@@ -66,7 +66,6 @@ def test_pmc_summary_tells_the_fused_kernels_from_the_classic_ones():
     name = "void (anonymous namespace)::{}<false>(raz_engine_dev, unsigned int, unsigned int)"
     assert P.short(name.format("k_tree")) == "k_tree" and P.short(name.format("k_tree_par")) == "k_tree_par"
     assert P.short(name.format("k_tree_net")) == "k_tree_net" and P.short(name.format("k_tree_par_net")) == "k_tree_par_net"
-    assert P.short("void (anonymous namespace)::k_conv3x3_f16x3_pipe<2, true>(...)") == "k_conv3x3_f16x3_pipe"
     assert P.short("(anonymous namespace)::k_conv3x3_f16x3(unsigned char const*, ...)") == "k_conv3x3_f16x3"
 
 
