@@ -20,7 +20,7 @@ int raz_check_launch(const char* where);
 struct raz_engine_dev;
 int raz_launch_tree_net(const raz_engine_dev& d, bool solver, uint32_t n_steps, const float* W, int R, int V, hipStream_t s);
 
-// raz_net_f16x3.hip, shared with raz_net_wino.hip: the sticky range flag of the split-f16 paths and their exact-f32 heads
+// raz_net_f16x3.hip: the sticky range flag of the split-f16 path and its exact-f32 heads
 unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V);
 int raz_net_heads_split(const float* W, int F, int R, int V, const unsigned char* trunk, const uint8_t* active, float* policy, float* value,
                         size_t n, hipStream_t s, const uint32_t* list, const uint32_t* n_ptr);

@@ -33,11 +33,6 @@ int raz_net_forward_wide(const float* W, int F, int R, int V, const uint64_t* ow
 void raz_net_build_f16x3(const float* src, float* dst, int F, int R, int V);
 size_t raz_net_f16x3_scratch_bytes(int F, size_t n);
 unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V);
-void raz_net_build_wino(const float* src, float* dst, int F, int R, int V);
-size_t raz_net_wino_scratch_bytes(int F, size_t n);
-int raz_net_forward_wino(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy, const uint8_t* active,
-                         float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes, hipStream_t s,
-                         const uint32_t* list, const uint32_t* n_ptr);
 int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                           const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
                           hipStream_t s, const uint32_t* list, const uint32_t* n_ptr);
@@ -216,8 +211,7 @@ extern "C" size_t raz_net_scratch_bytes(int filters, int value_fc, size_t n) {
     if (raz_net_mfma_supported(filters, value_fc) || use_lds(filters, value_fc)) return 0;
     if (wide_supported(filters)) {  // the larger of the two paths (reserved==1 forces the VALU kernel)
         const size_t a = raz_net_wide_scratch_bytes(filters, n), b = n * 3 * (size_t)filters * 64 * sizeof(float);
-        const size_t c = f16x3_supported(filters) ? raz_net_wino_scratch_bytes(filters, n) : 0;   // raznet-forward-v3: V, V, P
-        return a > b ? (a > c ? a : c) : (b > c ? b : c);
+        return a > b ? a : b;
     }
     return n * 3 * (size_t)filters * 64 * sizeof(float);
 }
@@ -292,10 +286,7 @@ extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, v
             lsrc += (size_t)F * F * 9 + F;
         }
     }
-    if (f16x3_supported(F)) {
-        raz_net_build_f16x3((const float*)((const char*)blob + 32), dst.data(), F, R, V);  // region 4 (+ a cleared range flag)
-        raz_net_build_wino((const float*)((const char*)blob + 32), dst.data(), F, R, V);   // region 5
-    }
+    if (f16x3_supported(F)) raz_net_build_f16x3((const float*)((const char*)blob + 32), dst.data(), F, R, V);  // region 4 (+ a cleared range flag)
     RAZ_HIP_TRY(hipMemcpyAsync(d_weights, dst.data(), need, hipMemcpyHostToDevice, (hipStream_t)stream),
                 "raz_net_load: hipMemcpyAsync");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_load: sync");  // dst is a local
@@ -328,9 +319,6 @@ extern "C" int raz_net_range_check(const raz_net* net, int* overflowed, raz_stre
 int raz_net_forward_compact(const raz_net* net, const uint64_t* own, const uint64_t* enemy, const uint8_t* active, float* policy,
                             float* value, size_t n, void* scratch, size_t scratch_bytes, hipStream_t stream, const uint32_t* list,
                             const uint32_t* n_ptr) {
-    if (n && net && f16x3_supported(net->filters) && net->reserved == 7)
-        return raz_net_forward_wino((const float*)net->d_weights, net->filters, net->res_layers, net->value_fc, own, enemy, active,
-                                    policy, value, n, scratch, scratch_bytes, stream, list, n_ptr);
     if (n && net && f16x3_supported(net->filters) && net->reserved == 4)
         return raz_net_forward_f16x3((const float*)net->d_weights, net->filters, net->res_layers, net->value_fc, own, enemy, active,
                                      policy, value, n, scratch, scratch_bytes, stream, list, n_ptr);
@@ -359,12 +347,7 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     if (f16x3_supported(F) && net->reserved == 4)
         return raz_net_forward_f16x3((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy, value, n,
                                      scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr);
-    // reserved 7: raznet-forward-v3 - v2's split operands under Winograd F(2,3) along the rows (raz_net_wino.hip): 1.5x fewer matrix
-    // instructions, the same 1e-5 contract
-    if (f16x3_supported(F) && net->reserved == 7)
-        return raz_net_forward_wino((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy, value, n,
-                                    scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr);
-    if (net->reserved == 4 || net->reserved == 7) return raz_fail(RAZ_EINVAL, "raz_net_forward: the split-f16 kernels need filters % 128 == 0");
+    if (net->reserved == 4) return raz_fail(RAZ_EINVAL, "raz_net_forward: the f16x3 kernel needs filters % 128 == 0");
     if (wide_supported(F) && net->reserved != 1)
         return raz_net_forward_wide((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
                                     value, n, scratch, scratch_bytes, (hipStream_t)stream);

@@ -400,7 +400,7 @@ void raz_net_build_f16x3(const float* src, float* dst, int F, int R, int V) {
     }
 }
 
-// The heads over a trunk output in the plain split layout (shared with raznet-forward-v3, raz_net_wino.hip).
+// The heads over a trunk output in the split layout.
 int raz_net_heads_split(const float* W, int F, int R, int V, const unsigned char* trunk, const uint8_t* active, float* policy, float* value,
                         size_t n, hipStream_t s, const uint32_t* list, const uint32_t* n_ptr) {
     hipLaunchKernelGGL(k_heads_split, dim3((unsigned)n), dim3(64), (192 + (size_t)V) * sizeof(float), s, W + heads_off(F, R), trunk, active,

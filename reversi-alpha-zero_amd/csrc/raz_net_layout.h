@@ -44,17 +44,7 @@ RAZ_HD_LAYOUT bool f16x3_supported(int F) { return F >= 128 && F % 128 == 0; }
 RAZ_HD_LAYOUT size_t f16x3_off(int F, int R, int V) { return (wide_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F) + 63) / 64 * 64; }
 RAZ_HD_LAYOUT size_t f16x3_layer_off(int F, int R, int V, int l) { return f16x3_off(F, R, V) + (size_t)(l - 1) * wide_layer_floats(F); }  // l >= 1
 RAZ_HD_LAYOUT size_t f16x3_scale_off(int F, int R, int V) { return f16x3_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F); }
-// Region 5 ("wino" layout, used by k_conv3x3_wino, raznet-forward-v3, F % 128 == 0): the Winograd F(2,3) filter transform along x of
-//   every conv layer l >= 1 - U_a[oc][ic][dy], a = 0..3: g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2 of the filter row dy, formed in
-//   double - as pairs of halfs like region 4, scaled per layer by a power of two S_l (max |U| * S_l in [2^14, 2^15)).  Per layer:
-//   [oc tile of 128][16-channel chunk][dy 3][point a 4][k group of 8 channels 2][hi, lo][oc in tile 128][8 halfs]: one (oc tile,
-//   chunk, dy) stage of the kernel is 32,768 contiguous bytes in its LDS image order.  Then 2R floats: 1 / S_l per layer.
-//   The range flag of region 4 is shared.
-RAZ_HD_LAYOUT size_t wino_layer_floats(int F) { return (size_t)F * F * 12; }
-RAZ_HD_LAYOUT size_t wino_off(int F, int R, int V) { return (f16x3_scale_off(F, R, V) + (size_t)2 * R + 64 + 63) / 64 * 64; }
-RAZ_HD_LAYOUT size_t wino_layer_off(int F, int R, int V, int l) { return wino_off(F, R, V) + (size_t)(l - 1) * wino_layer_floats(F); }  // l >= 1
-RAZ_HD_LAYOUT size_t wino_scale_off(int F, int R, int V) { return wino_off(F, R, V) + (size_t)2 * R * wino_layer_floats(F); }
 RAZ_HD_LAYOUT size_t total_floats(int F, int R, int V) {
-    if (f16x3_supported(F)) return wino_scale_off(F, R, V) + (size_t)2 * R + 64;
+    if (f16x3_supported(F)) return f16x3_scale_off(F, R, V) + (size_t)2 * R + 64;
     return wide_supported(F) ? wide_off(F, R, V) + (size_t)2 * R * wide_layer_floats(F) : mfma_layer_off(F, R, V, 2 * R + 1);
 }

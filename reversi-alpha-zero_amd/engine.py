@@ -51,9 +51,8 @@ class DeviceNet:
         kernel = "valu" if force_valu_kernel else kernel
         if kernel == "auto":
             kernel = "f16x3" if (F >= 128 and F % 128 == 0) else "f32"
-        self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk",
-                            "wino": "Winograd F(2,3) x split-operand f16 MFMA trunk"}.get(kernel, kernel)
-        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6, "wino": 7}[kernel]
+        self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk"}.get(kernel, kernel)
+        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")

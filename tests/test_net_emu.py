@@ -114,23 +114,3 @@ def test_emulated_split_f16_trunk_is_within_tolerance_of_the_oracle(lib, shape, 
     on = active.astype(bool)
     assert np.abs(pol[on] - rp[on]).max() <= 1e-5 and np.abs(val[on] - rv[on]).max() <= 1e-5
     assert (pol[~on] == 7.0).all() and (val[~on] == 7.0).all()
-
-
-@pytest.mark.parametrize("shape,n", [((128, 1, 32), 11), ((256, 1, 16), 6), ((128, 2, 32), 5)])
-def test_emulated_winograd_split_f16_trunk_is_within_tolerance_of_the_oracle(lib, shape, n):
-    """raznet-forward-v3 (reserved 7, csrc/raz_net_wino.hip): k_conv0_wino + k_conv3x3_wino (Winograd F(2,3) along the rows on split f16
-    operands: 8-wave workgroups = 4 positions x 128 output channels, the point pairs of a wave pair swapped through LDS, the next
-    layer's input transform formed in the epilogue across lanes) + k_heads_split within 1e-5 of the oracle's f32 net, on ragged
-    batches (position groups of 4 partly filled; F = 256: two output-channel tiles; R = 2: the transformed output of a block's
-    second convolution feeding the next block) with an active mask; skipped rows stay untouched, the range flag stays clear."""
-    from reversi_alpha_zero_amd.agent.model import ReversiNet
-    blob = ReversiNet(*shape).keras_init_(6).randomize_bn_(7).to_blob()
-    own, enemy = _positions(n, 5)
-    active = (np.arange(n) % 5 != 3).astype(np.uint8)
-    pol, val = _forward(lib, blob, own, enemy, 7, active)
-    rp, rv = _oracle(blob, own, enemy)
-    on = active.astype(bool)
-    assert np.abs(pol[on] - rp[on]).max() <= 1e-5 and np.abs(val[on] - rv[on]).max() <= 1e-5, (np.abs(pol[on] - rp[on]).max(), np.abs(val[on] - rv[on]).max())
-    assert (pol[~on] == 7.0).all() and (val[~on] == 7.0).all()
-    p2, v2 = _forward(lib, blob, own, enemy, 4, active)      # and next to raznet-forward-v2: the same arithmetic family
-    assert np.abs(pol[on] - p2[on]).max() <= 1e-5 and np.abs(val[on] - v2[on]).max() <= 1e-5

@@ -1,5 +1,13 @@
-// raz_net_wino.hip — forward pass of WIDE policy/value nets (F % 128 == 0) with the 3x3 convolutions of the trunk as
-// Winograd F(2,3) ALONG THE ROWS on the f16 matrix cores with split operands: "raznet-forward-v3".
+// raz_net_wino.hip — EXPERIMENT, not part of libraz.so (round 4; built only by tools/probe_conv.hip -DPROBE_WINO).  Forward pass of
+// WIDE policy/value nets (F % 128 == 0) with the 3x3 convolutions of the trunk as Winograd F(2,3) ALONG THE ROWS on the f16 matrix
+// cores with split operands.  RESULT: correct (emulator: <= 1e-5 of the oracle's f32 net on three shapes; hardware: a layer == its
+// double-precision restatement to 7e-8, a whole 256x10 forward closer to the f64 graph than raznet-forward-v2: policy 2.6e-6 vs
+// 5.6e-6), 1.5x fewer matrix instructions - and NOT faster: 1.25 ms per layer at 8192 positions against v2's 1.23-1.29 ms
+// (profiles/r4/conv_wino_*.jsonl).  The accumulators a CU can hold (8 waves x 128 registers) cap a workgroup at 4 positions x 128
+// output channels x 4 points, at which the layer moves 8.6 GB from L2 / HBM into the CUs instead of v2's 4.0 GB (the transformed
+// weights are 4/3 the bytes and are re-read per 4 positions instead of 8; the transformed activations are twice the bytes): on zero
+// operands it runs at ~8.8 TB/s of CU-side traffic, 50 % matrix-pipe busy, and on random operands both kernels sit at the same
+// power-limited time.  Kept for the record and for tools/probe_wino (check / time); DESIGN.md 4.4.
 //
 // Why: the split-operand kernel of raznet-forward-v2 (raz_net_f16x3.hip) is limited by POWER, not by its schedule - on zero
 // operands the same instruction stream runs 1.27-1.33x faster (2.4 GHz instead of the 1.75-1.9 GHz the chip holds under random
@@ -26,14 +34,19 @@
 //
 // k_conv3x3_wino, GEMM view per point a: D_a[oc, col] += U_a[oc, k] * V_a[k, col], k = (chunk, dy, channel in chunk).
 //   workgroup = 8 waves = 128 output channels x 4 positions;
-//   wave      = 2 positions x 64 output channels x 2 of the 4 points = 2 x 2 x 2 MFMA tiles (128 accumulator registers);
+//   wave      = 4 positions x 32 output channels x 2 of the 4 points = 2 x 4 MFMA tiles (128 accumulator registers);
 //               waves w and w ^ 4 hold the two point pairs of the same outputs and swap half of their tiles through LDS at the end,
-//               so that each finishes 32 channels with all four M_a in registers
-//   K loop    = 16 chunks x 3 rows (dy) = 48 stages; a stage's weights (32 KiB: 4 points x 16 channels x 128 oc x {hi, lo}) and,
-//               once per chunk, the 4 positions' transformed activations (32 KiB) arrive by LDS-DMA in a double buffer while the
-//               previous stage's 24 matrix instructions per wave run: one barrier per stage
-//   rows      = the dy shift is +-4 columns of the 32-column plane; off-board rows read a zero block of the image (per-lane
-//               addresses precomputed, no predicates, bank-conflict free like v2's taps)
+//               so that each finishes 2 positions x 32 channels with all four M_a in registers
+//   weights   = NOT staged in LDS: a wave's A operands (its 32 channels x its 2 points x {hi, lo} = 4 KiB per (chunk, dy) stage) are
+//               private to it, so they go straight from L2 into registers (4 global_load_dwordx4 of 1 KiB per stage, the layout is
+//               the operand order), requested TWO stages ahead.  The first version staged them through LDS one stage ahead with a
+//               barrier per stage: a staging round trip (3,100 cycles measured) is twice a stage's matrix time (1,536), so the
+//               kernel waited on every stage and was no faster than v2 (profiles/r4/conv_wino_v0_*.jsonl)
+//   K loop    = 16 chunks x 3 rows (dy); a chunk's transformed activations of the 4 positions (32 KiB) arrive by LDS-DMA in a ring
+//               of three images, requested two chunks ahead: ONE barrier per chunk (72 matrix instructions per wave), raw s_barrier
+//               with explicit waits - __syncthreads() would drain the weight loads in flight
+//   rows      = the dy shift is +-4 columns of the 32-column plane; off-board rows read the zero block behind the position's planes
+//               (per-lane addresses precomputed, no predicates, bank-conflict free like v2's taps)
 //   epilogue  = output transform, * 1/S, + bias, (+ skip), relu, then BOTH forms of the result: P (plain, if the layer feeds a
 //               skip connection or the heads) and V for the next layer (the neighbouring tiles' border columns come from the
 //               adjacent lanes by DPP), each split into (hi, lo), 8-byte stores
@@ -42,10 +55,16 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "raz_bitboard.h"
-#include "raz_detmath.h"
-#include "raz_internal.h"
-#include "raz_net_layout.h"
+#include "../../reversi-alpha-zero_amd/csrc/raz_bitboard.h"
+#include "../../reversi-alpha-zero_amd/csrc/raz_detmath.h"
+#include "../../reversi-alpha-zero_amd/csrc/raz_internal.h"
+#include "../../reversi-alpha-zero_amd/csrc/raz_net_layout.h"
+
+// region-5 offsets of the experiment's weight image (the product's raz_net_layout.h ends with region 4)
+RAZ_HD_LAYOUT size_t wino_layer_floats(int F) { return (size_t)F * F * 12; }
+RAZ_HD_LAYOUT size_t wino_off(int F, int R, int V) { return (f16x3_scale_off(F, R, V) + (size_t)2 * R + 64 + 63) / 64 * 64; }
+RAZ_HD_LAYOUT size_t wino_layer_off(int F, int R, int V, int l) { return wino_off(F, R, V) + (size_t)(l - 1) * wino_layer_floats(F); }  // l >= 1
+RAZ_HD_LAYOUT size_t wino_scale_off(int F, int R, int V) { return wino_off(F, R, V) + (size_t)2 * R * wino_layer_floats(F); }
 
 namespace {
 
@@ -57,14 +76,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int OCT = 128;                          // output channels per workgroup
 constexpr int NPOS = 4;                           // positions per workgroup
 constexpr int NWAVE = 8;
-constexpr int W_STAGE = 4 * 2 * 2 * OCT * 16;     // 32,768 B: [point 4][k-group 2][hi/lo][oc 128][16 B]
+constexpr int W_STAGE = 4 * 4 * 2 * 2 * 32 * 16;  // 32,768 B: [oc quarter 4][point 4][hi/lo][k-group 2][oc 32][16 B]
 constexpr int V_POS = 16 * 512;                   // 8,192 B: [plane 16][col 32][16 B] - one (position, chunk)
-constexpr int Z_OFF = NPOS * V_POS;               // the zero block of an image
-constexpr int Z_BYTES = 3072;                     // off-board reads land at Z_OFF + slot * 16 + {0, 512, 2048, 2560}
-constexpr int V_IMG = Z_OFF + Z_BYTES;            // 35,840 B
-constexpr int LDS_W = 0;                          // two weight stages (double buffer)
-constexpr int LDS_ACT = 2 * W_STAGE;              // two activation images (double buffer)
-constexpr int LDS_BYTES = LDS_ACT + 2 * V_IMG;    // 137,216 B: one workgroup of 8 waves per CU
+constexpr int Z_BYTES = 3072;                     // zero block behind a position's planes: off-board reads land at 8192 + slot * 16 + {0, 512, 2048, 2560}
+constexpr int L_POS = V_POS + Z_BYTES;            // 11,264 B per position in LDS
+constexpr int V_IMG = NPOS * L_POS;               // 45,056 B: one chunk's image
+constexpr int NRING = 3;                          // images in flight: the chunk being read + two requested
+constexpr int LDS_BYTES = NRING * V_IMG;          // 135,168 B: one workgroup of 8 waves per CU
 constexpr int X_WAVE = 16384;                     // epilogue exchange: 64 accumulator registers per wave, 8 x 16 KiB <= LDS_BYTES
 constexpr int P_CHUNK = 4 * 64 * 16;              // plain layout: 4,096 B per (position, chunk)
 
@@ -78,6 +96,51 @@ __device__ inline float dpp_from_lower_lane(float v) {   // lane i <- lane i - 1
 __device__ inline float dpp_from_upper_lane(float v) {   // lane i <- lane i + 1 within its row of 16 lanes, 0 at the row's last lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
+
+// The K loop's memory traffic is issued and awaited BY HAND (inline assembly): the compiler's own wait insertion (a) drains every
+// load in flight at __syncthreads() (its release fence), (b) makes any LDS read wait for every LDS-DMA in flight (it cannot tell
+// the ring slots apart) and (c) falls back to vmcnt(0) around the loop's back edge - each of which turns a two-stage prefetch into
+// none.  Vector loads return in order, so "at most N operations outstanding" means everything older than the N newest has landed:
+//   load_weights4   four 1 KiB global_load_dwordx4 (a wave's A operands of one stage) into registers
+//   stage_acts4     four 1 KiB LDS-DMA pieces of an activation image
+//   wait_loads<N>   s_waitcnt vmcnt(N), tied to the registers it makes valid (the compiler may not move their uses above it)
+//   wg_barrier<N>   s_waitcnt vmcnt(N) lgkmcnt(0) + s_barrier
+// On the wave emulator (tests/native/wave_emu, synchronous copies) they are plain C++.
+#ifdef RAZ_WAVE_EMU
+__device__ inline void load_weights4(f32x4 (&w)[4], const unsigned char* p) {
+    for (int i = 0; i < 4; ++i) w[i] = *(const f32x4*)(p + i * 1024);
+}
+__device__ inline void stage_acts4(const unsigned char* g, unsigned char* l) {
+    for (int i = 0; i < 4; ++i) GLDS16(g + i * 1024, l + i * 1024);
+}
+template <int N> __device__ inline void wait_loads(f32x4 (&)[4]) {}
+template <int N> __device__ inline void wg_barrier() { __syncthreads(); }
+#else
+__device__ inline void load_weights4(f32x4 (&w)[4], const unsigned char* p) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:3072"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(p) : "memory");
+}
+__device__ inline void stage_acts4(const unsigned char* g, unsigned char* l) {   // g: per-lane source (+ lane * 16), l: wave-uniform LDS destination
+    const uint32_t la = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)l;
+    // the instruction's immediate offset advances BOTH addresses (global and LDS): one M0 for the four pieces
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:3072"
+                 :: "v"(g), "s"(la) : "memory", "m0");
+}
+template <int N> __device__ inline void wait_loads(f32x4 (&w)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
+}
+template <int N> __device__ inline void wg_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+#endif
 
 // inV: transformed activations of the layer input.  outV / outP: the result in transformed / plain form (either may be null).
 // skipP: plain activations added before the relu (null: none).  Wl: this layer's region-5 weights.
@@ -97,105 +160,100 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(const unsigned char* __
     const int pg = (b / (8 * noct)) * 8 + (b & 7);
     const int p0 = pg * NPOS;
     if (p0 >= n) return;
-    const int pp = wv & 1, oh = (wv >> 1) & 1, pq = wv >> 2;   // position pair, 64-channel half, point pair of this wave
+    const int ocq = wv & 3, pq = wv >> 2;   // 32-channel quarter and point pair of this wave
     const size_t posV = (size_t)F * 512, posP = (size_t)F * 256;
-    if (tid < 2 * (Z_BYTES / 16)) {   // the zero blocks of both images
-        const int im = tid / (Z_BYTES / 16), k = tid % (Z_BYTES / 16);
-        ((f32x4*)(lds + LDS_ACT + im * V_IMG + Z_OFF))[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    // per-lane LDS byte offsets (inside an activation image) of the B operand: [position of the pair][dy], for this wave's first
-    // point and the hi plane; + 2048 for its second point, + 512 for the lo plane
-    const int kg = lane >> 5, col = lane & 31;
-    uint32_t boff[2][3];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = (col >> 2) + dy - 1, c2 = col + (dy - 1) * 4;
-            boff[q][dy] = (yy >= 0 && yy < 8) ? (uint32_t)((pp * 2 + q) * V_POS + pq * 4096 + kg * 1024 + c2 * 16)
-                                              : (uint32_t)(Z_OFF + (c2 & 15) * 16);
+    {   // the zero blocks of the three images: 12 x 3,072 B
+        for (int k = tid; k < NRING * NPOS * (Z_BYTES / 16); k += NWAVE * 64) {
+            const int blk = k / (Z_BYTES / 16), u = k % (Z_BYTES / 16);
+            ((f32x4*)(lds + (blk / NPOS) * V_IMG + (blk % NPOS) * L_POS + V_POS))[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    // A operand inside a weight stage: + a' * 8192 + hl * 2048 + m * 512
-    const uint32_t aoff = (uint32_t)(pq * 16384 + kg * 4096 + (oh * 64 + (lane & 31)) * 16);
-    f32x16 acc[2][2][2];   // [point of the pair][m tile][position of the pair]
+    }
+    // per-lane LDS byte offsets (inside an image) of the B operand for the three rows dy: position 0 of the group, this wave's first
+    // point, the hi plane; + q * L_POS for position q, + 2048 for the second point, + 512 for the lo plane
+    const int kg = lane >> 5, col = lane & 31;
+    uint32_t boff[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = (col >> 2) + dy - 1, c2 = col + (dy - 1) * 4;
+        boff[dy] = (yy >= 0 && yy < 8) ? (uint32_t)(pq * 4096 + kg * 1024 + c2 * 16) : (uint32_t)(V_POS + (c2 & 15) * 16);
+    }
+    f32x16 acc[2][4];   // [point of the pair][position of the group]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][m][q][r] = 0.f;
-    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE + lane * 16;
+            for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
+    // this wave's A operands of stage st: 4 KiB at wsrc + st * W_STAGE: [point of the pair][hi, lo][lane][16 B]
+    const unsigned char* wsrc = Wl + (size_t)ot * nchunks * 3 * W_STAGE + (size_t)(ocq * 4 + pq * 2) * 2048 + lane * 16;
     // the activation pieces this wave moves: position wv >> 1 of the group, half wv & 1 of its 8 KiB
     const int lpos = p0 + (wv >> 1);
     const unsigned char* asrc = inV + (size_t)(lpos < n ? lpos : n - 1) * posV + (wv & 1) * 4096 + lane * 16;
-    auto issue = [&](int c, int dy) {
-        const int st = c * 3 + dy;
-        const unsigned char* src = wsrc + (size_t)st * W_STAGE;
-        unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(src + (wv * 4 + i) * 1024, dst + (wv * 4 + i) * 1024);
-        if (dy == 0) {
-            const unsigned char* a = asrc + (size_t)c * V_POS;
-            unsigned char* ad = lds + LDS_ACT + (c & 1) * V_IMG + (wv >> 1) * V_POS + (wv & 1) * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) GLDS16(a + i * 1024, ad + i * 1024);
-        }
+    auto issue_acts = [&](int c, int slot) {
+        stage_acts4(asrc + (size_t)c * V_POS, lds + slot * V_IMG + (wv >> 1) * L_POS + (wv & 1) * 4096);
     };
-    issue(0, 0);
+    f32x4 wreg[3][4];   // [stage % 3][point of the pair * 2 + {hi, lo}]: the weights of three stages, two of them in flight
+    const int nstages = nchunks * 3;
+    // Requests past the end are clamped to the last chunk / stage instead of skipped (a duplicate into a free slot): the order and
+    // number of operations in flight is the same in every iteration, which is what the hand-placed waits count on.  In program order:
+    //   DMA(0) DMA(1) W(0) W(1) | per chunk c: [barrier] DMA(c+2) W(3c+2) <stage 3c> W(3c+3) <stage 3c+1> W(3c+4) <stage 3c+2>
+    // (4 operations each).  Needed at the barrier of chunk c: DMA(c) - younger ones outstanding: DMA(c+1) W(3c) W(3c+1) = 12;
+    // at stage 3c: W(3c) - younger: W(3c+1) DMA(c+2) W(3c+2) = 12; at 3c+1: W(3c+1) - younger: DMA(c+2) W(3c+2) W(3c+3) = 12; at 3c+2: W(3c+2) -
+    // younger: W(3c+3) W(3c+4) = 8.
+    issue_acts(0, 0);
+    issue_acts(nchunks > 1 ? 1 : 0, 1);
+    load_weights4(wreg[0], wsrc);
+    load_weights4(wreg[1], wsrc + (size_t)(nstages > 1 ? 1 : 0) * W_STAGE);
     for (int c = 0; c < nchunks; ++c) {
-        const uint32_t abase = (uint32_t)(LDS_ACT + (c & 1) * V_IMG);
+        wg_barrier<12>();   // chunk c's image has landed for everybody, and everybody is done reading chunk c - 1's: its slot takes chunk c + 2
+        issue_acts(c + 2 < nchunks ? c + 2 : nchunks - 1, (c + 2) % NRING);   // (past the end: a duplicate into the free slot)
+        const uint32_t abase = (uint32_t)((c % NRING) * V_IMG);
+        // a chunk = 24 units (dy, point a, position q) of three matrix instructions; the B operands of unit u + 1 are requested before
+        // the matrix instructions of unit u
+        h8 bh[2], bl[2];
+        bh[0] = *(const h8*)(lds + abase + boff[0]);
+        bl[0] = *(const h8*)(lds + abase + boff[0] + 512);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int st = c * 3 + dy;
-            __syncthreads();   // stage st has landed (every wave drained its DMA before arriving); stage st-1's reads are done
-            if (dy < 2) issue(c, dy + 1);
-            else if (c + 1 < nchunks) issue(c + 1, 0);
-            const uint32_t wbase = (uint32_t)(LDS_W + (st & 1) * W_STAGE) + aoff;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                h8 bh[2], bl[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    bh[q] = *(const h8*)(lds + abase + boff[q][dy] + a * 2048);
-                    bl[q] = *(const h8*)(lds + abase + boff[q][dy] + a * 2048 + 512);
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const h8 ah = *(const h8*)(lds + wbase + a * 8192 + m * 512);
-                    const h8 al = *(const h8*)(lds + wbase + a * 8192 + m * 512 + 2048);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        acc[a][m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q], acc[a][m][q], 0, 0, 0);
-                        acc[a][m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q], acc[a][m][q], 0, 0, 0);
-                        acc[a][m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q], acc[a][m][q], 0, 0, 0);
-                    }
-                }
+        for (int u = 0; u < 24; ++u) {
+            const int dy = u / 8, a = (u % 8) / 4, q = u % 4;
+            if (u % 8 == 0) {
+                const int st2 = c * 3 + dy + 2;
+                load_weights4(wreg[(dy + 2) % 3], wsrc + (size_t)(st2 < nstages ? st2 : nstages - 1) * W_STAGE);
+                if (dy == 2) wait_loads<8>(wreg[dy]);
+                else wait_loads<12>(wreg[dy]);
             }
+            if (u + 1 < 24) {
+                const int dy1 = (u + 1) / 8, a1 = ((u + 1) % 8) / 4, q1 = (u + 1) % 4;
+                bh[(u + 1) & 1] = *(const h8*)(lds + abase + boff[dy1] + q1 * L_POS + a1 * 2048);
+                bl[(u + 1) & 1] = *(const h8*)(lds + abase + boff[dy1] + q1 * L_POS + a1 * 2048 + 512);
+            }
+            const h8 ah = __builtin_bit_cast(h8, wreg[dy][a * 2]), al = __builtin_bit_cast(h8, wreg[dy][a * 2 + 1]);
+            acc[a][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u & 1], acc[a][q], 0, 0, 0);
+            acc[a][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u & 1], acc[a][q], 0, 0, 0);
+            acc[a][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u & 1], acc[a][q], 0, 0, 0);
         }
     }
-    // ---- epilogue.  The point pairs swap tiles: wave pq = 0 finishes m tile 0 (needs the partner's M2, M3 of it), wave pq = 1 m tile 1
-    // (needs M0, M1).  Each writes the 64 registers of the tile it gives away: [tile = a' * 2 + q][register group g of 4][lane][16 B].
-    __syncthreads();   // every wave is done with the staging buffers
+    // ---- epilogue.  The point pairs swap tiles: wave pq = 0 finishes positions 0, 1 of the group (needs the partner's M2, M3 of them),
+    // wave pq = 1 positions 2, 3 (needs M0, M1).  Each writes the 64 registers it gives away: [tile = a' * 2 + position][register group g of 4][lane][16 B].
+    wg_barrier<0>();   // every wave is done with the images, and nothing of its own is in flight any more
     unsigned char* xmine = lds + wv * X_WAVE + lane * 16;
     const unsigned char* xpartner = lds + (wv ^ 4) * X_WAVE + lane * 16;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x16& give = pq == 0 ? acc[a][1][q] : acc[a][0][q];
-                *(f32x4*)(xmine + ((a * 2 + q) * 4 + g) * 1024) = (f32x4){give[g * 4], give[g * 4 + 1], give[g * 4 + 2], give[g * 4 + 3]};
+                const f32x16& give = pq == 0 ? acc[a][2 + qq] : acc[a][qq];
+                *(f32x4*)(xmine + ((a * 2 + qq) * 4 + g) * 1024) = (f32x4){give[g * 4], give[g * 4 + 1], give[g * 4 + 2], give[g * 4 + 3]};
             }
     __syncthreads();
     const float inv_scale = *inv_scale_ptr;
     const int t_in_row = col & 3;
     bool over = false;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pos = p0 + pp * 2 + q;
+    for (int qq = 0; qq < 2; ++qq) {
+        const int pos = p0 + pq * 2 + qq;
         if (!(pos < n && (!active || active[pos]))) continue;   // wave-uniform
         unsigned char* oV = outV ? outV + (size_t)pos * posV : nullptr;
         unsigned char* oP = outP ? outP + (size_t)pos * posP : nullptr;
@@ -203,16 +261,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(const unsigned char* __
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): register group g = channels 8 g + 4 kg + 0..3 of the tile
-            const f32x4 r0 = *(const f32x4*)(xpartner + ((0 * 2 + q) * 4 + g) * 1024);
-            const f32x4 r1 = *(const f32x4*)(xpartner + ((1 * 2 + q) * 4 + g) * 1024);
-            const int oc8 = ot * OCT + oh * 64 + pq * 32 + g * 8;   // this lane pair's 8-channel group; this lane holds 4 of them
+            const f32x4 r0 = *(const f32x4*)(xpartner + ((0 * 2 + qq) * 4 + g) * 1024);
+            const f32x4 r1 = *(const f32x4*)(xpartner + ((1 * 2 + qq) * 4 + g) * 1024);
+            const int oc8 = ot * OCT + ocq * 32 + g * 8;   // this lane pair's 8-channel group; this lane holds 4 of them
             const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
             float e[4], o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float m0, m1, m2, m3;
-                if (pq == 0) { m0 = acc[0][0][q][g * 4 + j]; m1 = acc[1][0][q][g * 4 + j]; m2 = r0[j]; m3 = r1[j]; }
-                else { m0 = r0[j]; m1 = r1[j]; m2 = acc[0][1][q][g * 4 + j]; m3 = acc[1][1][q][g * 4 + j]; }
+                if (pq == 0) { m0 = acc[0][qq][g * 4 + j]; m1 = acc[1][qq][g * 4 + j]; m2 = r0[j]; m3 = r1[j]; }
+                else { m0 = r0[j]; m1 = r1[j]; m2 = acc[0][2 + qq][g * 4 + j]; m3 = acc[1][2 + qq][g * 4 + j]; }
                 e[j] = ((m0 + m1) + m2) * inv_scale + bv[j];
                 o[j] = ((m1 - m2) - m3) * inv_scale + bv[j];
             }
@@ -385,9 +443,11 @@ void raz_net_build_wino(const float* src, float* dst, int F, int R, int V) {
                                     const int oc = ot * 128 + o, ic = c * 16 + kg * 8 + j;
                                     const float v = U[(((size_t)a * F + oc) * F + ic) * 3 + dy] * S;   // exact: S is a power of two
                                     const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-                                    const size_t base = stage * (W_STAGE / 2) + ((size_t)(a * 2 + kg) * 2) * 128 * 8;
-                                    w[base + (size_t)o * 8 + j] = hi;
-                                    w[base + 128 * 8 + (size_t)o * 8 + j] = lo;
+                                    // [oc quarter][point][hi, lo][k-group][oc in quarter][8 halfs]: (quarter, point, hi/lo) = one 1 KiB load of a wave
+                                    const size_t unit = ((size_t)(o >> 5) * 4 + a) * 2;
+                                    const size_t base = stage * (W_STAGE / 2) + (size_t)(kg * 32 + (o & 31)) * 8 + j;
+                                    w[base + (unit + 0) * 512] = hi;
+                                    w[base + (unit + 1) * 512] = lo;
                                 }
                 }
         lsrc += (size_t)F * F * 9 + F;

@@ -8,10 +8,10 @@
 //            barrier wait inside the loop, epilogue, store drain), the gap a CU shows between two consecutive workgroups, the
 //            shader clock (s_memtime ticks per s_memrealtime tick at 100 MHz)
 // Build (cross-compiles without a GPU):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probe_conv.hip -o tools/probe_conv
-// -DPROBE_WINO builds tools/probe_wino instead: the same `time` / `pmc` experiments on k_conv3x3_wino (raznet-forward-v3,
-// csrc/raz_net_wino.hip: 4 positions x 128 output channels per workgroup, transformed activations in and out).
+// -DPROBE_WINO builds tools/probe_wino instead: the same `time` / `pmc` experiments on k_conv3x3_wino (the Winograd experiment,
+// tools/experiments/raz_net_wino.hip: 4 positions x 128 output channels per workgroup, transformed activations in and out).
 #ifdef PROBE_WINO
-#include "../reversi-alpha-zero_amd/csrc/raz_net_wino.hip"
+#include "experiments/raz_net_wino.hip"
 unsigned* raz_net_f16x3_flag(const float*, int, int, int) { return nullptr; }
 int raz_net_heads_split(const float*, int, int, int, const unsigned char*, const uint8_t*, float*, float*, size_t, hipStream_t, const uint32_t*, const uint32_t*) { return 0; }
 #define IN_BYTES_PER_F 512
@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
     {
         std::vector<_Float16> h;
         // weights: uniform in +-2^15 after scaling; activations: post-ReLU, half of them zero (the value statistics set the switching activity)
-        fill_split(h, wl_bytes / 16, 128, [] { return (urand() * 2.f - 1.f) * 32000.f; });
+        fill_split(h, wl_bytes / 16, W_TAPS == 12 ? 64 : 128, [] { return (urand() * 2.f - 1.f) * 32000.f; });
         CK(hipMemcpy(dW, h.data(), wl_bytes, hipMemcpyHostToDevice));
         CK(hipMemset(dWz, 0, wl_bytes));
 #ifdef PROBE_WINO
@@ -148,6 +148,74 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+#ifdef PROBE_WINO
+    if (all || !strcmp(mode, "check")) {
+        // one launch against a double-precision restatement of the layer as a function of the SAME operand images (the split halves
+        // summed): data movement, the ring, the tile swap and both output forms, for a few positions x all 256 channels
+        const int n = 8190;   // a ragged last group
+        std::vector<_Float16> hW(wl_bytes / 2), hV((size_t)nmax * pos_bytes / 2);
+        CK(hipMemcpy(hW.data(), dW, wl_bytes, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hV.data(), dA, (size_t)nmax * pos_bytes, hipMemcpyDeviceToHost));
+        CK(hipMemset(dB, 0xff, (size_t)nmax * pos_bytes));
+        CK(hipMemset(dP, 0xff, (size_t)nmax * F * 256));
+        launch(dW, dA, n, nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<_Float16> oV((size_t)nmax * pos_bytes / 2), oP((size_t)nmax * F * 128);
+        CK(hipMemcpy(oV.data(), dB, oV.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(oP.data(), dP, oP.size() * 2, hipMemcpyDeviceToHost));
+        float hsc;
+        CK(hipMemcpy(&hsc, dscale, 4, hipMemcpyDeviceToHost));
+        auto U = [&](int a, int oc, int ic, int dy) {
+            const size_t o = (((((size_t)(oc >> 7) * 16 + (ic >> 4)) * 3 + dy) * 4 + ((oc >> 5) & 3)) * 4 + a) * 2 * 512 + (size_t)(((ic >> 3) & 1) * 32 + (oc & 31)) * 8 + (ic & 7);
+            return (double)(float)hW[o] + (double)(float)hW[o + 512];
+        };
+        auto Vin = [&](int pos, int a, int ic, int col) {
+            const size_t o = (size_t)pos * F * 256 + (size_t)(ic >> 4) * 4096 + (size_t)((a * 4 + ((ic >> 3) & 1) * 2) * 32 + col) * 8 + (ic & 7);
+            return (double)(float)hV[o] + (double)(float)hV[o + 256];
+        };
+        double worst_p = 0, worst_v = 0, biggest = 0;
+        size_t untouched = 0;
+        const int probe_pos[] = {0, 1, 2, 3, 4093, 8189};
+        for (int pos : probe_pos) {
+            std::vector<double> e(F * 32), o(F * 32);
+            for (int oc = 0; oc < F; ++oc)
+                for (int col = 0; col < 32; ++col) {
+                    double M[4] = {0, 0, 0, 0};
+                    for (int a = 0; a < 4; ++a)
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int yy = (col >> 2) + dy - 1;
+                            if (yy < 0 || yy > 7) continue;
+                            for (int ic = 0; ic < F; ++ic) M[a] += U(a, oc, ic, dy) * Vin(pos, a, ic, yy * 4 + (col & 3));
+                        }
+                    const double ev = (M[0] + M[1] + M[2]) * hsc + 0.01, ov = (M[1] - M[2] - M[3]) * hsc + 0.01;
+                    e[oc * 32 + col] = ev > 0 ? ev : 0;
+                    o[oc * 32 + col] = ov > 0 ? ov : 0;
+                    biggest = std::max(biggest, std::max(e[oc * 32 + col], o[oc * 32 + col]));
+                }
+            for (int oc = 0; oc < F; ++oc)
+                for (int col = 0; col < 32; ++col) {
+                    const size_t po = (size_t)pos * F * 128 + (size_t)(oc >> 4) * 2048 + (size_t)(((oc >> 3) & 1) * 2 * 64 + 2 * col) * 8 + (oc & 7);
+                    const double ge = (double)(float)oP[po] + (double)(float)oP[po + 512], go = (double)(float)oP[po + 8] + (double)(float)oP[po + 8 + 512];
+                    worst_p = std::max(worst_p, std::max(fabs(ge - e[oc * 32 + col]), fabs(go - o[oc * 32 + col])));
+                    const int t = col & 3;
+                    const double L = t ? o[oc * 32 + col - 1] : 0.0, R = t < 3 ? e[oc * 32 + col + 1] : 0.0, E = e[oc * 32 + col], O = o[oc * 32 + col];
+                    const double want[4] = {L - O, E + O, O - E, E - R};
+                    for (int a = 0; a < 4; ++a) {
+                        const size_t vo = (size_t)pos * F * 256 + (size_t)(oc >> 4) * 4096 + (size_t)((a * 4 + ((oc >> 3) & 1) * 2) * 32 + col) * 8 + (oc & 7);
+                        const double gv = (double)(float)oV[vo] + (double)(float)oV[vo + 256];
+                        if (gv != gv) ++untouched;
+                        worst_v = std::max(worst_v, fabs(gv - want[a]));
+                    }
+                }
+        }
+        // rows beyond n must stay untouched (0xffff halfs = NaN)
+        const float beyond = (float)oP[(size_t)8191 * F * 128 + 5];
+        printf("{\"experiment\": \"check\", \"positions_checked\": 6, \"largest_output\": %.4f, \"max_abs_err_plain\": %.3e, \"max_abs_err_transformed\": %.3e, "
+               "\"nan_outputs\": %zu, \"row_beyond_n_untouched\": %s, \"ok\": %s}\n", biggest, worst_p, worst_v, untouched, beyond != beyond ? "true" : "false",
+               (worst_p < 1e-4 * std::max(1.0, biggest) && worst_v < 2e-4 * std::max(1.0, biggest) && !untouched && beyond != beyond) ? "true" : "false");
+        fflush(stdout);
+    }
+#endif
     if (!strcmp(mode, "pmc")) {   // the launches a counter pass looks at: 8192 positions, random operands (argv[3] = positions)
         const int n = argc > 3 ? atoi(argv[3]) : 8192;
         const float r = timeit(dW, dA, n);
