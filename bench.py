@@ -942,7 +942,7 @@ def main():
     ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
     ap.add_argument("--whole-slots", type=int, default=1024, help="slots of the whole-game leg")
     ap.add_argument("--whole-ids", type=int, default=1536, help="game ids the whole-game leg plays to the end")
-    ap.add_argument("--config1-variant", default=None, choices=["fused", "fused_par4", "mfma_split2", "mfma_split4"],
+    ap.add_argument("--config1-variant", default=None, choices=["fused", "fused_par4", "classic", "classic_par4"],
                     help="(child mode of the default run) ONLY the configs[1] whole-game batch, on the fused tree + net kernel or with a "
                          "variant of the narrow-net kernel")
     args = ap.parse_args()

@@ -115,7 +115,7 @@ int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* ene
 /* raz_net.reserved selects the forward kernels: 0 = the exact-f32 kernels chosen by shape ("raznet-forward-v1": every output
  * one k-ordered fmaf chain, bit-identical to the CPU oracle); 4 (filters % 128 == 0) = "raznet-forward-v2": the 3x3 trunk on
  * the f16 matrix cores with every f32 operand split into two halfs (csrc/raz_net_f16x3.hip: 3 f16 MFMAs per product, f32
- * accumulation, within 1e-5 of the fp32 graph, 16/3 of the f32-MFMA rate); 1, 2, 5, 6: test variants of v1 (same bits).  v2's split activations must
+ * accumulation, within 1e-5 of the fp32 graph, 16/3 of the f32-MFMA rate); 1, 2: test variants of v1 (same bits).  v2's split activations must
  * stay inside the f16 range; *overflowed = 1 reports that some activation since raz_net_load did not (sticky): run the net
  * with reserved = 0 then.  Synchronises `stream`. */
 int raz_net_range_check(const raz_net* net, int* overflowed, raz_stream_t stream);
@@ -211,12 +211,8 @@ int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const uint32_t* 
  * net batch over the gathered leaves).  Asynchronous w.r.t. the host; all work is ordered after
  * prior work on `stream` and before later work on it.  With n_games >= 256 the batch is stepped as
  * 3 slices on `stream` and two internal streams so that one slice's net kernel overlaps the
- * other slices' tree kernels.  With raz_engine_config.reserved bit 2 set, runs of 16 steps are
- * replayed from a hipGraph captured on first use (one host call per 16 x slices x 2 launches);
- * measured 6 % slower than direct launches on ROCm 7.2 / MI355X, hence opt-in. */
+ * other slices' tree kernels. */
 int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream);
-/* 1 when raz_engine_step replays a captured hipGraph, 0 when it launches kernel by kernel. */
-int raz_engine_uses_graph(const raz_engine* e);
 /* Same as raz_engine_step, with HIP events recorded around every kernel launch on the stream it runs
  * on: the summed durations (ms) of the tree-kernel launches and of the net-kernel launches are
  * ADDED to *tree_ms / *net_ms (with n_games >= 256 a step is 2 launches of each kernel, one per

@@ -108,7 +108,6 @@ SIGNATURES.update({
                                      POINTER(c_int), c_void_p]),
     "raz_engine_stop_thinking": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_adopt_tree": (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
-    "raz_engine_uses_graph": (c_int, [c_void_p]),
     "raz_engine_gc": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_set_parts": (c_int, [c_void_p, c_int]),
     "raz_engine_stats_sync": (c_int, [c_void_p, POINTER(RazEngineStats), c_void_p]),

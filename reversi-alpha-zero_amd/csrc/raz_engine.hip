@@ -673,21 +673,10 @@ struct raz_engine {
     int parts;
     hipStream_t aux[kMaxParts];
     hipEvent_t ev_fork, ev_join[kMaxParts];
-    // kGraphSteps simulation steps (parts x 2 kernels each, fork/join included) captured once as a
-    // hipGraph and replayed: one host call per kGraphSteps * parts * 2 launches.
-    hipGraphExec_t graph_exec;
-    hipStream_t graph_stream;   // the caller stream the graph was captured on
-    int graph_parts;
-    bool graph_off;             // cfg.reserved bit 2 not set, or capture failed once
     bool fused;                 // cfg.reserved bit 4: k_tree_net drives the games (tree + narrow net in one kernel)
 };
 
 namespace {
-
-void drop_graph(raz_engine* e) {
-    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
-    e->graph_exec = nullptr;
-}
 
 struct Half {
     uint32_t g0, count;
@@ -805,17 +794,12 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     if (parts > kMaxParts) parts = kMaxParts;
     if (cfg->n_games < 256 || (cfg->reserved & 2u)) parts = 1;
     e->parts = parts;
-    e->graph_exec = nullptr;
-    e->graph_stream = nullptr;
-    e->graph_parts = 0;
-    e->graph_off = (cfg->reserved & 4u) == 0;   // reserved bit 2: replay captured hipGraphs (measured slower on ROCm 7.2: off by default)
     e->fused = (cfg->reserved & 16u) != 0;      // reserved bit 4: tree + narrow net in one kernel (k_tree_net)
     if (e->fused) {
         if (net->filters != 16 || net->value_fc > 1024) {
             delete e;
             return raz_fail(RAZ_EINVAL, "raz_engine_create: the fused tree + net kernels (reserved bit 4) need a 16-filter net");
         }
-        e->graph_off = true;
         parts = 1;
         e->parts = 1;
     }
@@ -852,7 +836,6 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
         if (err == hipSuccess && !e->ev_join[h]) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
     }
     if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_set_parts");
-    if (parts != e->parts) drop_graph(e);
     e->parts = parts;
     return RAZ_OK;
 }
@@ -864,7 +847,6 @@ extern "C" void raz_engine_destroy(raz_engine* e) {
         if (e->ev_join[h]) hipEventDestroy(e->ev_join[h]);
     }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     delete e;
 }
 
@@ -917,8 +899,6 @@ extern "C" int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const
 }
 
 namespace {
-constexpr uint32_t kGraphSteps = 16;
-
 int launch_steps_direct(raz_engine* e, uint32_t n_steps, hipStream_t s) {
     if (e->fused) return launch_fused_steps(e, n_steps, s);
     int rc = fork_aux(e, s);
@@ -928,81 +908,15 @@ int launch_steps_direct(raz_engine* e, uint32_t n_steps, hipStream_t s) {
     const int rj = join_aux(e, s);
     return rc != RAZ_OK ? rc : rj;
 }
-
-// Capture kGraphSteps steps on (s, aux streams).  On any failure the engine keeps launching directly.
-bool ensure_graph(raz_engine* e, hipStream_t s) {
-    if (e->graph_off) return false;
-    if (e->cache.tags) return false;   // the cache's step stamp is a host-side kernel argument: a replayed graph would freeze it
-    if (e->graph_exec && e->graph_stream == s && e->graph_parts == e->parts) return true;
-    drop_graph(e);
-    hipGraph_t g = nullptr;
-    hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (eb != hipSuccess) {
-        (void)hipGetLastError();
-        raz_fail_hip(eb, "raz_engine_step: hipStreamBeginCapture (falling back to direct launches)");
-        e->graph_off = true;
-        return false;
-    }
-    const int rc = launch_steps_direct(e, kGraphSteps, s);
-    const hipError_t ec = hipStreamEndCapture(s, &g);
-    if (rc != RAZ_OK || ec != hipSuccess || !g) {
-        (void)hipGetLastError();
-        if (ec != hipSuccess) raz_fail_hip(ec, "raz_engine_step: hipStreamEndCapture (falling back to direct launches)");
-        if (g) hipGraphDestroy(g);
-        e->graph_off = true;
-        return false;
-    }
-    const hipError_t ei = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
-    if (ei != hipSuccess) {
-        (void)hipGetLastError();
-        raz_fail_hip(ei, "raz_engine_step: hipGraphInstantiate (falling back to direct launches)");
-        e->graph_exec = nullptr;
-        e->graph_off = true;
-        return false;
-    }
-    e->graph_stream = s;
-    e->graph_parts = e->parts;
-    return true;
-}
 }  // namespace
 
+// (A hipGraph replay of 16 steps x slices x 2 kernels was measured 6 % slower than these direct launches on ROCm 7.2 / MI355X in
+// rounds 1-3 and removed in round 4: DESIGN.md section 4, "tried".)
 extern "C" int raz_engine_step(raz_engine* e, uint32_t n_steps, raz_stream_t stream) {
     if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_step: NULL engine");
     if (!e->started) return raz_fail(RAZ_ESTATE, "raz_engine_step: call raz_engine_start first");
-    hipStream_t s = (hipStream_t)stream;
-    if (n_steps < kGraphSteps || e->graph_off) return launch_steps_direct(e, n_steps, s);
-    // The legacy default stream cannot be captured: run on an internal stream ordered after / before it.
-    hipStream_t run = s;
-    if (s == nullptr) {
-        if (!e->aux[0]) {
-            hipError_t err = raz_pool_stream(0, &e->aux[0]);
-            if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming);
-            if (err == hipSuccess && !e->ev_fork) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-            if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step: internal stream");
-        }
-        run = e->aux[0];
-        RAZ_HIP_TRY(hipEventRecord(e->ev_join[0], s), "raz_engine_step: order after the caller stream");
-        RAZ_HIP_TRY(hipStreamWaitEvent(run, e->ev_join[0], 0), "raz_engine_step: order after the caller stream");
-    }
-    int rc = RAZ_OK;
-    if (ensure_graph(e, run)) {
-        while (n_steps >= kGraphSteps) {
-            hipError_t err = hipGraphLaunch(e->graph_exec, run);
-            if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step: hipGraphLaunch");
-            n_steps -= kGraphSteps;
-        }
-    }
-    if (n_steps) rc = launch_steps_direct(e, n_steps, run);
-    if (run != s) {
-        RAZ_HIP_TRY(hipEventRecord(e->ev_join[0], run), "raz_engine_step: order before the caller stream");
-        RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_join[0], 0), "raz_engine_step: order before the caller stream");
-    }
-    return rc;
+    return launch_steps_direct(e, n_steps, (hipStream_t)stream);
 }
-
-// 1 when raz_engine_step replays a captured hipGraph, 0 when it launches kernel by kernel.
-extern "C" int raz_engine_uses_graph(const raz_engine* e) { return e && e->graph_exec ? 1 : 0; }
 
 extern "C" int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream) {
     if (!e || !out) return raz_fail(RAZ_EINVAL, "raz_engine_stats_sync: NULL argument");
@@ -1523,7 +1437,6 @@ extern "C" int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t by
                                          raz_stream_t stream) {
     if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_leaf_cache: NULL engine");
     if (e->fused && d_cache) return raz_fail(RAZ_EINVAL, "raz_engine_set_leaf_cache: the fused tree + net kernel evaluates leaves in place (no leaf exchange to cache)");
-    drop_graph(e);   // a captured graph holds the old launch sequence
     if (!d_cache) {
         memset(&e->cache, 0, sizeof e->cache);
         return RAZ_OK;
@@ -1556,7 +1469,6 @@ extern "C" int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold,
     if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_resign_threshold: NULL engine");
     e->dev.cfg.has_resign_threshold = has_threshold ? 1 : 0;
     e->dev.cfg.resign_threshold = threshold;
-    drop_graph(e);   // a captured graph holds the old parameter block
     return RAZ_OK;
 }
 

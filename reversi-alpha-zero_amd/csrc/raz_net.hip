@@ -38,7 +38,7 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
                           hipStream_t s, const uint32_t* list, const uint32_t* n_ptr);
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
-                         unsigned long long* prof, int variant);
+                         unsigned long long* prof);
 
 namespace {
 
@@ -332,15 +332,14 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     if (!net || !net->d_weights || !own || !enemy || !policy || !value)
         return raz_fail(RAZ_EINVAL, "raz_net_forward: NULL argument");
     const int F = net->filters, V = net->value_fc;
-    // reserved (tests): 1 forces the VALU kernel, 2 the one-wave-per-position MFMA kernel, 5 / 6 its two- / four-waves-per-position
-    // latency variant
+    // reserved (tests): 1 forces the VALU kernel, 2 the one-wave-per-position MFMA kernel
     if (raz_net_mfma_supported(F, V) && net->reserved != 1)
     {
         // debug: RAZ_NET_PROF=1 and a caller scratch of >= n*64 bytes -> per-position phase ticks
         unsigned long long* prof = nullptr;
         if (scratch && scratch_bytes >= n * 64 && getenv("RAZ_NET_PROF")) prof = (unsigned long long*)scratch;
         return raz_net_forward_mfma((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
-                                    value, n, (hipStream_t)stream, prof, net->reserved == 5 || net->reserved == 6 ? net->reserved : 0);
+                                    value, n, (hipStream_t)stream, prof);
     }
     // reserved 4: raznet-forward-v2 - the trunk on the f16 matrix cores with split operands (raz_net_f16x3.hip), within 1e-5
     // of the fp32 graph but not bit-identical to the exact-f32 kernels (0 / 5: raznet-forward-v1)

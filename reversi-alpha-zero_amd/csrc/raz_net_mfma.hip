@@ -197,179 +197,15 @@ int launch(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy,
     return raz_check_launch("raz_net_forward (mfma)");
 }
 
-
-// ------------------------------------------------------------------ latency variant (F == 16, small launches)
-// Inside the engine a launch is one slice of the batch (configs[1]: 1365 positions): fewer positions than the
-// 2048 waves the chip holds, so k_net_mfma's time there is the serial latency of ONE position on ONE wave
-// (25 k cycles: 14 k trunk + 11 k heads), not throughput.  Here a position is spread over a workgroup of
-// WPP = 2 or 4 waves: each wave computes 4 / WPP of the four 16-square M tiles of every conv layer (the MFMAs
-// of a position then run on WPP matrix pipes at once; the layers are separated by workgroup barriers because
-// a 3x3 tap reads the neighbouring waves' squares), and the two heads run side by side - wave 0 the policy
-// head (its two 1x1 planes, the 128-long dense chains, softmax), wave 1 the value head.  Every output element
-// is computed by the same operations in the same order as in k_net_mfma: bit-identical.
-template <int WPP, bool PRE>
-__global__ __launch_bounds__(64 * WPP, 3) void k_net_mfma16_split(const float* __restrict__ W, int R, int V,
-                                                                       const raz_bb* __restrict__ own,
-                                                                       const raz_bb* __restrict__ enemy,
-                                                                       const uint8_t* __restrict__ active,
-                                                                       float* __restrict__ policy, float* __restrict__ value, int n) {
-    constexpr int F = 16, MT = 4 / WPP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* bufA = smem;
-    float* bufT = smem + F * PS;
-    float* head = smem + 2 * F * PS;  // ph[128] vh[64] h1[V]
-    {
-        f32x4* z = (f32x4*)smem;
-        for (int j = tid; j < 2 * F * PS / 4; j += 64 * WPP) z[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    const float* H = W + heads_off(F, R);
-    const float* pol_w = H;
-    const float* pol_b = pol_w + 2 * F;
-    const float* pfc_w = pol_b + 2;
-    const float* pfc_b = pfc_w + 128 * 64;
-    const float* val_w = pfc_b + 64;
-    const float* val_b = val_w + F;
-    const float* v1_w = val_b + 1;
-    const float* v1_b = v1_w + 64 * V;
-    const float* v2_w = v1_b + V;
-    const float* v2_b = v2_w + V;
-    float* ph = head;
-    float* vh = head + 128;
-    float* h1 = head + 192;
-    float w0[5], w1[PRE ? 36 : 1], w2[PRE ? 36 : 1], pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;
-    if (PRE) {
-        load_wregs<5>(W + mfma_layer_off(F, R, V, 0), 0, lane, w0);
-        load_wregs<PRE ? 36 : 1>(W + mfma_layer_off(F, R, V, 1), 0, lane, w1);
-        load_wregs<PRE ? 36 : 1>(W + mfma_layer_off(F, R, V, 2), 0, lane, w2);
-        pb0 = (W + conv_off(F, 0) + (size_t)F * 9 * 2)[lane & 15];
-        pb1 = (W + conv_off(F, 1) + (size_t)F * 9 * F)[lane & 15];
-        pb2 = (W + conv_off(F, 2) + (size_t)F * 9 * F)[lane & 15];
-    }
-    const float dummy5[5] = {0, 0, 0, 0, 0};
-    const int toff = wave * MT * 24;  // this wave's first M tile, as an offset into a plane (two board rows per tile)
-    for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
-        if (active && !active[pos]) continue;
-        if (wave == 0) {
-            const raz_bb bo = own[pos], be = enemy[pos];
-            bufT[pidx(lane)] = (float)((bo >> lane) & 1ULL);
-            bufT[PS + pidx(lane)] = (float)((be >> lane) & 1ULL);
-        }
-        __syncthreads();
-        if constexpr (PRE) {
-            conv_layer<F, 2, true, false, true, MT>(nullptr, nullptr, bufT + toff, bufA + toff, lane, w0, pb0);
-            conv_layer<F, F, false, false, true, MT>(nullptr, nullptr, bufA + toff, bufT + toff, lane, w1, pb1);
-            conv_layer<F, F, false, true, true, MT>(nullptr, nullptr, bufT + toff, bufA + toff, lane, w2, pb2);
-        } else {
-            float dummyK[LayerK<F, F, false>::KS];
-            conv_layer<F, 2, true, false, false, MT>(W + mfma_layer_off(F, R, V, 0), W + conv_off(F, 0) + (size_t)F * 9 * 2,
-                                                            bufT + toff, bufA + toff, lane, dummy5, 0.f);
-            for (int r = 0; r < R; ++r) {
-                const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
-                conv_layer<F, F, false, false, false, MT>(W + mfma_layer_off(F, R, V, l1), W + conv_off(F, l1) + (size_t)F * 9 * F,
-                                                                 bufA + toff, bufT + toff, lane, dummyK, 0.f);
-                conv_layer<F, F, false, true, false, MT>(W + mfma_layer_off(F, R, V, l2), W + conv_off(F, l2) + (size_t)F * 9 * F,
-                                                                bufT + toff, bufA + toff, lane, dummyK, 0.f);
-            }
-        }
-        // (the last layer's barrier has passed: bufA holds the trunk output of all 64 squares)
-        if (wave == 0) {
-            const float* a = bufA + pidx(lane);
-            float p0 = pol_b[0], p1 = pol_b[1];
-#pragma unroll 8
-            for (int ic = 0; ic < F; ++ic) {
-                const float xv = a[ic * PS];
-                p0 = fmaf(xv, pol_w[ic], p0);
-                p1 = fmaf(xv, pol_w[F + ic], p1);
-            }
-            ph[lane] = p0 > 0.0f ? p0 : 0.0f;
-            ph[64 + lane] = p1 > 0.0f ? p1 : 0.0f;
-            wave_lds_sync();
-            float logit = pfc_b[lane];
-#pragma unroll 1
-            for (int j0 = 0; j0 < 128; j0 += 32) {
-                float wv[32];
-#pragma unroll
-                for (int j = 0; j < 32; ++j) wv[j] = pfc_w[(j0 + j) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 32; ++j) logit = fmaf(ph[j0 + j], wv[j], logit);
-            }
-            float m = logit;
-            m = fmaxf(m, dppf<0xB1>(m));
-            m = fmaxf(m, dppf<0x4E>(m));
-            m = fmaxf(m, dppf<0x141>(m));
-            m = fmaxf(m, dppf<0x140>(m));
-            m = fmaxf(fmaxf(lanef(m, 0), lanef(m, 16)), fmaxf(lanef(m, 32), lanef(m, 48)));
-            const float e = raz_det_expf(logit - m);
-            float sum = e;
-            sum = sum + dppf<0xB1>(sum);
-            sum = sum + dppf<0x4E>(sum);
-            sum = sum + dppf<0x141>(sum);
-            sum = sum + dppf<0x140>(sum);
-            sum = (lanef(sum, 0) + lanef(sum, 16)) + (lanef(sum, 32) + lanef(sum, 48));
-            policy[(size_t)pos * 64 + lane] = e / sum;
-        } else if (wave == 1) {
-            const float* a = bufA + pidx(lane);
-            float v0 = val_b[0];
-#pragma unroll 8
-            for (int ic = 0; ic < F; ++ic) v0 = fmaf(a[ic * PS], val_w[ic], v0);
-            vh[lane] = v0 > 0.0f ? v0 : 0.0f;
-            wave_lds_sync();
-            for (int o0 = 0; o0 < V; o0 += 64) {
-                const int o = o0 + lane;
-                if (o < V) {
-                    float acc = v1_b[o];
-#pragma unroll 1
-                    for (int j0 = 0; j0 < 64; j0 += 32) {
-                        float wv[32];
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) wv[j] = v1_w[(j0 + j) * V + o];
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) acc = fmaf(vh[j0 + j], wv[j], acc);
-                    }
-                    h1[o] = acc > 0.0f ? acc : 0.0f;
-                }
-            }
-            wave_lds_sync();
-            float acc = v2_b[0];
-            for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
-            if (lane == 0) value[pos] = raz_det_tanhf(acc);
-        }
-        __syncthreads();  // the next position overwrites bufT / head
-    }
-}
-
-template <int WPP>
-int launch_split(const float* W, int R, int V, const raz_bb* own, const raz_bb* enemy, const uint8_t* active, float* policy,
-                 float* value, size_t n, hipStream_t s) {
-    const size_t shm = ((size_t)2 * 16 * PS + 192 + V) * sizeof(float);
-    unsigned maxgrid = 3072 / WPP;  // resident workgroups: 3 waves per SIMD (at most 168 VGPRs each) = 12 per CU
-    if (const char* g = getenv("RAZ_NET_MAXGRID"))   // tests only (see launch<>)
-        if (atoi(g) > 0) maxgrid = (unsigned)atoi(g);
-    const unsigned grid = (unsigned)(n < maxgrid ? n : maxgrid);
-    if (R == 1)
-        hipLaunchKernelGGL((k_net_mfma16_split<WPP, true>), dim3(grid), dim3(64 * WPP), shm, s, W, R, V, own, enemy, active, policy, value, (int)n);
-    else
-        hipLaunchKernelGGL((k_net_mfma16_split<WPP, false>), dim3(grid), dim3(64 * WPP), shm, s, W, R, V, own, enemy, active, policy, value, (int)n);
-    return raz_check_launch("raz_net_forward (mfma, position split over waves)");
-}
-
 }  // namespace
 
 bool raz_net_mfma_supported(int F, int V) { return (F == 16 || F == 32 || F == 64) && V <= 1024; }
 
-// variant: 0 / 2 = one single-wave workgroup per position, 5 / 6 = one position per workgroup of two / four waves
-// (F == 16 only: the latency variant for launches smaller than the chip)
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
-                         unsigned long long* prof, int variant) {
+                         unsigned long long* prof) {
     const raz_bb* o = (const raz_bb*)own;
     const raz_bb* e = (const raz_bb*)enemy;
-    if ((variant == 5 || variant == 6) && (F != 16 || V > 1024))
-        return raz_fail(RAZ_EINVAL, "raz_net_forward_mfma: the split variant needs F == 16");
-    if (!prof && variant == 5) return launch_split<2>(W, R, V, o, e, active, policy, value, n, s);
-    if (!prof && variant == 6) return launch_split<4>(W, R, V, o, e, active, policy, value, n, s);
     switch (F) {
         case 16: return launch<16>(W, R, V, o, e, active, policy, value, n, s, prof);
         case 32: return launch<32>(W, R, V, o, e, active, policy, value, n, s, nullptr);

@@ -34,7 +34,7 @@ __device__ __forceinline__ void load_wregs(const float* __restrict__ Wl, int nt,
     for (int s = 0; s < KS; ++s) wreg[s] = Wl[((size_t)nt * KS + s) * 64 + lane];
 }
 
-// LDS hand-over inside ONE wave (a head computed by a single wave of k_net_mfma16_split)
+// LDS hand-over inside ONE wave (single-wave workgroups)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -48,9 +48,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // operand read of the layer before its epilogue stores; the residual input is the lane's own D fragment of the previous block
 // (`frag`, kept in registers; keep_frag: this layer's output becomes the next residual), and the closing synchronisation is
 // wave-local.
-// MT < 4 (k_net_mfma16_split): the wave computes only MT of the four 16-square M tiles, the ones that start at
-// `in` / `out` (the caller passes both advanced by 24 floats per skipped tile); the other waves of the
-// workgroup compute the rest of the same position, and the closing barrier is the workgroup's.
+// MT: the 16-square M tiles the wave computes, starting at `in` / `out` (4 = the whole board; the product uses nothing else).
 template <int F, int CIN, bool FIRST, bool SKIP, bool PRE, int MT = 4, bool INPLACE = false>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ Wl, const float* __restrict__ bias,
                                            const float* in, float* out, int lane,

@@ -35,9 +35,7 @@ class DeviceNet:
         """kernel: None / "f32" = the exact-f32 kernels chosen by shape (raznet-forward-v1, bit-identical to the CPU oracle);
         "f16x3" = raznet-forward-v2 for filters % 128 == 0: the 3x3 trunk on the f16 matrix cores with split operands, within
         1e-5 of the fp32 graph (include/raz.h raz_net_range_check); "auto" = "f16x3" where supported, else "f32".
-        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position; "mfma_split2" / "mfma_split4" =
-        one position per workgroup of two / four waves (F == 16: the latency variant for launches smaller than the chip,
-        csrc/raz_net_mfma.hip k_net_mfma16_split)."""
+        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position."""
         import torch
         import struct
         magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -52,7 +50,7 @@ class DeviceNet:
         if kernel == "auto":
             kernel = "f16x3" if (F >= 128 and F % 128 == 0) else "f32"
         self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk"}.get(kernel, kernel)
-        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "mfma_split2": 5, "mfma_split4": 6}[kernel]
+        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")
@@ -91,7 +89,7 @@ class DeviceNet:
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
                        record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
-                       use_graph=False, force_slot_kernel=False, pool_bytes_per_game=0, fused=False):
+                       force_slot_kernel=False, pool_bytes_per_game=0, fused=False):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
     that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par)."""
@@ -123,7 +121,7 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         resign_threshold=float(p.resign_threshold if p.resign_threshold is not None else 0.0),
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
-        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (4 if use_graph else 0) | (8 if force_slot_kernel else 0)
+        reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (8 if force_slot_kernel else 0)
         | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
         solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par,
@@ -134,9 +132,10 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 use_graph=False, force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False):
+                 force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False):
         """fused: 16-filter nets - tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip:
-        k_tree_net, k_tree_par_net for parallel_search_num > 1; same results, opt-in).
+        k_tree_net, k_tree_par_net for parallel_search_num > 1; the same results bit for bit, +40 % on BASELINE configs[1]; what
+        BatchedSelfPlayWorker selects for 16-filter nets).  No evaluation cache in that form.
         nodes_per_game: most tree nodes a game's pool may hold; pool_bytes_per_game: its bytes (0 = nodes_per_game x 232 + 64 x 704:
         nodes are compact - 40 B + 20 B per legal move, ~212 B on average - include/raz.h).
         leaf_cache_log2: attach a cross-game evaluation cache of 2**leaf_cache_log2 entries (320 B each; include/raz.h
@@ -172,7 +171,7 @@ class SelfPlayEngine:
                     warnings.warn(f"never-pruned node pool capped at 255 MB per game: {nodes_per_game} nodes instead of the {want // WHOLE_GAME_BYTES_PER_NODE} "
                                   "a whole game at this simulations x thinking_loop could create", RuntimeWarning)
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
-                                      record_root_w, phase_profile, single_stream, parts, inner_max, use_graph=use_graph,
+                                      record_root_w, phase_profile, single_stream, parts, inner_max,
                                       force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused)
         self.fused = bool(fused)
         self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
@@ -252,9 +251,6 @@ class SelfPlayEngine:
         import torch
         with torch.cuda.device(self.device):
             check(lib.raz_engine_step(self._h, n, _stream()), "raz_engine_step")
-
-    def uses_graph(self):
-        return bool(lib.raz_engine_uses_graph(self._h))
 
     def set_parts(self, parts):
         import torch

@@ -189,7 +189,7 @@ class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
     def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None,
-                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24, fused_tree_net=False):
+                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24, fused_tree_net="auto"):
         """games_in_flight: game slots resident on the device.  block_games (per rank; default = games_in_flight): the
         number of consecutive game ids a rank plays between two gathers.  With block_games > games_in_flight the slots are
         refilled as games finish (continuous batching, SelfPlayEngine.play_continuous); the files do not depend on either
@@ -205,9 +205,9 @@ class BatchedSelfPlayWorker:
         # whose forward is what a step costs; none for narrow nets (two extra launches per step cost more than they save)
         self.leaf_cache_log2 = leaf_cache_log2
         self.leaf_cache_max_discs = leaf_cache_max_discs
-        # 16-filter nets: tree and net in ONE kernel, the game's wave evaluating its own leaves
-        # (csrc/raz_engine_fused.hip; same files; opt-in)
-        self.fused_tree_net = bool(fused_tree_net)
+        # 16-filter nets: tree and net in ONE kernel, the game's wave evaluating its own leaves (csrc/raz_engine_fused.hip; the same
+        # files bit for bit, +40 % on BASELINE configs[1]).  "auto" = wherever it applies; False = the two-kernel pipeline
+        self.fused_tree_net = fused_tree_net if fused_tree_net in ("auto", True, False) else bool(fused_tree_net)
         self.seed = seed
         self.device = device
         self.rank, self.world = rank, world
@@ -278,8 +278,19 @@ class BatchedSelfPlayWorker:
             from ..engine import NODE_MAX_BYTES, WHOLE_GAME_BYTES_PER_NODE
             pool_bytes = 0   # pruned pools: the default budget (232 B per node); k_gc is triggered by bytes as well as by count
             if r > 1:        # never pruned: room for whole games whatever their mobility
-                pool_bytes = min(nodes * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES, 255 << 20)
-            fused = self.fused_tree_net and self._net.filters == 16
+                want = nodes * WHOLE_GAME_BYTES_PER_NODE + 64 * NODE_MAX_BYTES
+                pool_bytes = min(want, 255 << 20)
+                if pool_bytes < want:   # the link range caps a pool at 256 MB: size the node count (directory, table) for the bytes that exist
+                    nodes = (pool_bytes - 64 * NODE_MAX_BYTES) // WHOLE_GAME_BYTES_PER_NODE
+                    logger.warning(f"series of {r} games at {max_sims} sims/move x thinking_loop {p.thinking_loop}: the never-pruned node pool is "
+                                   f"capped at 255 MB per game ({nodes} nodes instead of {r * whole}); a series that outgrows it fails with 'pool full'")
+                free = self._free_bytes()
+                if free is not None and self.games_in_flight * (pool_bytes + nodes * (4 * 32 + 8)) > free:   # pools + table slots + directory
+                    raise RuntimeError(f"{self.games_in_flight} games in flight with never-pruned trees of {r} games at {max_sims} sims/move need "
+                                       f"{self.games_in_flight * pool_bytes / 2**30:.0f} GiB of node pools; {free / 2**30:.0f} GiB are free: lower games_in_flight")
+            # 16-filter nets: tree and net in one kernel unless told otherwise ("auto"; the evaluation cache is for wide nets only)
+            fused = (self._net.filters == 16 and self._net.value_fc <= 1024 and self._net.c.reserved == 0
+                     and (self.fused_tree_net is True or (self.fused_tree_net == "auto" and not cache)))
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=None if fused else cache,
                                           leaf_cache_max_discs=self.leaf_cache_max_discs, pool_bytes_per_game=pool_bytes, fused=fused)
@@ -319,6 +330,14 @@ class BatchedSelfPlayWorker:
         if self.block_games > self.games_in_flight:
             total += self.block_games * (72 * (48 + 256) + 33)
         return total
+
+    def _free_bytes(self):
+        """Free device memory, or None when torch cannot tell (CPU-side tests with a stub engine)."""
+        try:
+            import torch
+            return torch.cuda.mem_get_info(torch.device(self.device))[0]
+        except Exception:
+            return None
 
     def _pool_nodes_that_fit(self, fraction=0.7, cache_log2=None):
         """Tree nodes per game that fit in `fraction` of the device's free memory once the evaluation cache, the net scratch
@@ -860,7 +879,7 @@ def try_reload_model(config, model):
         return False
 
 
-def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None, fused_tree_net=False):
+def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None, fused_tree_net="auto"):
     """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU.  fused_tree_net: see
     BatchedSelfPlayWorker (16-filter nets: tree and net in one kernel; opt-in)."""
     import torch

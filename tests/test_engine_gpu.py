@@ -321,25 +321,6 @@ def test_engine_batch_vs_oracle_many_games(golden, blob, variant):
     assert st["total_sims"] == sum(sum(p["sims"] for p in r[0]) for r in recs)
 
 
-def test_engine_hipgraph_replay_equals_direct_launches(golden, blob):
-    """raz_engine_config.reserved bit 2: runs of 16 steps replayed from a captured hipGraph (opt-in: measured slower than
-    direct launches on ROCm 7.2) play the same games as kernel-by-kernel launches, on 3 slices / 3 streams."""
-    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
-    g0 = next(g for g in golden["games"] if g["variant"] == "mini_shared")
-    cfg = config_of(g0)
-    dnet = DeviceNet(blob, DEV)
-    out = []
-    for graph in (False, True):
-        eng = SelfPlayEngine(cfg, dnet, n_games=300, seed=9, sims_hint=10, use_graph=graph)
-        eng.start(first_game_id=0, sims_per_move=10)
-        eng.run(chunk=64)
-        assert eng.uses_graph() == graph
-        out.append(eng.read_raw())
-    for k in ("n_plies", "status", "final_black", "final_white", "root_n"):
-        assert np.array_equal(out[0][k], out[1][k]), k
-    assert np.array_equal(out[0]["headers"]["action"], out[1]["headers"]["action"])
-
-
 def test_engine_mirror_off_equals_mirror_on_unshared(golden, blob):
     """share=False: skipping the colour-mirrored writes changes nothing (they are dead)."""
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine

@@ -68,11 +68,10 @@ def _positions(n, seed):
 
 
 @pytest.mark.parametrize("shape,reserved", [((16, 1, 16), 0), ((16, 2, 48), 0), ((32, 1, 32), 0), ((16, 1, 16), 1), ((48, 1, 20), 0),
-                                            ((16, 1, 64), 0), ((16, 1, 80), 0), ((16, 1, 16), 5), ((16, 1, 16), 6), ((16, 2, 48), 5), ((16, 2, 80), 6)])
+                                            ((16, 1, 64), 0), ((16, 1, 80), 0)])
 def test_emulated_narrow_net_kernels_equal_oracle(lib, shape, reserved, monkeypatch):
     """k_net_mfma (reserved 0, F in {16, 32}: 16x16x4 matrix-core tiles; R = 1 with the weights hoisted into registers, R = 2 without),
-    k_net_wave (reserved 1, and any shape the matrix-core kernel does not take: F = 48), k_net_mfma16_split (reserved 5 / 6: one position on two / four waves, the heads side by
-    side on two of them) == the oracle's C net, with an active mask (skipped rows stay untouched).
+    k_net_wave (reserved 1, and any shape the matrix-core kernel does not take: F = 48) == the oracle's C net, with an active mask (skipped rows stay untouched).
     The grid is capped at 3 workgroups so that every workgroup loops over several positions (the registers that stay resident
     across positions, the prefetched dense-head operands: value widths 16..64 take that path, 80 the plain one)."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--net", default="ch5", choices=["mini", "ch5"])
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--kernel", default=None, choices=["valu", "mfma_wave", "mfma_split2", "mfma_split4", "f32", "f16x3", "auto"],
+    ap.add_argument("--kernel", default=None, choices=["valu", "mfma_wave", "f32", "f16x3", "auto"],
                     help="force a kernel variant (default: the exact-f32 kernel chosen by shape and n)")
     args = ap.parse_args()
     import numpy as np

@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-SHORT = ["k_tree_par_net", "k_tree_net", "k_tree_par", "k_tree", "k_net_mfma16_split", "k_net_mfma", "k_conv3x3_wide", "k_heads_wide", "k_conv0_wide", "k_conv3x3_f16x3", "k_conv0_split",
+SHORT = ["k_tree_par_net", "k_tree_net", "k_tree_par", "k_tree", "k_net_mfma", "k_conv3x3_wide", "k_heads_wide", "k_conv0_wide", "k_conv3x3_f16x3", "k_conv0_split",
          "k_heads_split", "k_stats", "k_start", "k_gc", "k_step", "k_legal_moves", "k_leaf_claim", "k_leaf_resolve", "k_leaf_fill"]
 TRAFFIC = ("FETCH_SIZE", "WRITE_SIZE")
 
