@@ -23,16 +23,20 @@ long run holds at any instant; --tree-warm + W warm-up steps are run on that sta
 search trees that already hold a few dozen simulations.  metric = MCTS simulations/sec = start_search_my_move invocations / wall time, NN included,
 inputs resident in HBM, whole job over all GPUs.  games/hour is extrapolated from it (labelled).
 
-The same line carries, at N = 1: the parity spot checks (8 sampled games of the 8192-game batch from the opening AND 8
-sampled slots of the TIMED steady-state batch, root N / W bit for bit against the CPU oracle fed with the device net's
-outputs), a WHOLE-GAME leg on the headline settings (1024 slots, continuous batching over 1536 game ids, ~4 min: games/hour
-and sims/s measured on complete games, two complete games == the oracle), `cpu_baseline` = the reference's own pure-Python
-self-play timed in this run on this box's host cores (oracle/_ref, tools/ref_python_baseline.py), BASELINE configs[1]
-(4096 games x mini net x 200 sims/move, whole games, with its own spot check) and the bitboard-sweep HBM leg.  Last, in a child
-processes with timeouts (`--config1-variant`): the same configs[1] batch on the opt-in fused tree + net kernel (csrc/raz_engine_fused.hip; `--config1-variant mfma_split2` runs it
-with the two-waves-per-position net kernel instead), then the A/B of the headline conv kernel's hand-scheduled variant.
-At N > 1: the record gather over RCCL is timed and its payload verified (per-rank checksums), and a small whole-game batch is
-played sharded AND on rank 0 alone: the gathered records must be byte-identical (SURVEY 8(d) Config 4's acceptance).
+ONE line of at most 8 KB is printed (compact_line: the contract keys, `roofline`, `cpu_baseline`, one short object per leg with
+its value and its parity result); the full document with every leg's detail goes to bench_full.json (gpurun_out/ when present).
+At N = 1 the run also holds: the parity spot checks (8 sampled games of the 8192-game batch from the opening AND 8 sampled slots
+of the TIMED steady-state batch, root N / W bit for bit against the CPU oracle fed with the device net's outputs);
+`whole_games_measured` = the headline configuration (all 8192 slots) PLAYED for a fixed 120 s window with continuous batching -
+sims/s, games finished per hour, two games that finished inside the window == the oracle; `cpu_baseline` = the reference's own
+pure-Python self-play timed in this run on this box's host cores (oracle/_ref, tools/ref_python_baseline.py); the headline on
+the exact-f32 kernels; `ch5_yml_as_shipped` = the same batch with NO declared override (thinking_loop 10, parallel_search_num 8,
+solver from turn 50) and the solver's measured share of a step; BASELINE configs[4] on one GPU; BASELINE configs[1] (4096 games x
+mini net x 200 sims/move, whole games, spot-checked) on the fused tree + net kernel the worker runs for 16-filter nets, at
+parallel_search_num 1 and mini.yml's 4, and on the two-kernel pipeline beside it; continuous batching; the bitboard-sweep HBM leg.
+At N > 1 (and at N = 1 under RAZ_BENCH_NCCL_WORLD1=1, an RCCL group of one rank): the record gather is timed and its payload
+verified (per-rank checksums), and a small whole-game batch is played sharded AND on rank 0 alone: the gathered records must be
+byte-identical (SURVEY 8(d) Config 4's acceptance).
 """
 import argparse
 import json
@@ -273,7 +277,7 @@ def sweep_traffic():
         return json.load(f)
 
 
-def headline_leg(args, dev, rank, world, cdev):
+def headline_leg(args, dev, rank, world, cdev, group=False):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -323,12 +327,12 @@ def headline_leg(args, dev, rank, world, cdev):
     st0 = eng.stats()
     c0 = eng.leaf_cache_stats()
     torch.cuda.synchronize()
-    if world > 1:
+    if group:
         dist.barrier()
     t0 = time.perf_counter()
     tree_ms, net_ms = eng.step_timed(args.steps)   # HIP events around every launch, on the launching stream
     torch.cuda.synchronize()
-    if world > 1:
+    if group:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
@@ -337,7 +341,7 @@ def headline_leg(args, dev, rank, world, cdev):
     served = float((c1["hits"] - c0["hits"]) + (c1["in_batch_duplicates"] - c0["in_batch_duplicates"]))
     tot = torch.tensor([d["total_sims"], d["nn_leaves"], d["selections"], elapsed, float(st["finished_games"])],
                        dtype=torch.float64, device=cdev)
-    if world > 1:
+    if group:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -347,7 +351,7 @@ def headline_leg(args, dev, rank, world, cdev):
     # (3) the single collective of the path: records -> rank 0, from HBM, cut to the games' plies
     t1 = time.perf_counter()
     gather = {"collective": "none (1 GPU)", "bytes": 0}
-    if world > 1:
+    if group:
         import numpy as np
         from reversi_alpha_zero_amd.worker.self_play import gather_packed
         last = {}
@@ -413,7 +417,10 @@ def headline_leg(args, dev, rank, world, cdev):
         "games_per_hour_note": f"EXTRAPOLATED (the whole-game leg did not run): sims/s / ({args.sims} sims/move x {MEAN_SEARCHED_PLIES} searched plies/game)",
         "total_sims": total_sims, "nn_leaves": leaves, "leaf_slot_occupancy": leaves / world / (args.steps * args.games),
         "mean_selections_per_sim": selections / max(total_sims, 1.0),
-        "roofline": {"bound": "mfma", "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
+        "roofline": {"bound": "mfma", "kernel_name": ("k_conv3x3_f16x3" if v2 else "k_conv3x3_wide") if args.net == "ch5" else "k_net_mfma",
+                     "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
+                     "power_limited": ("the conv kernel runs 1.27-1.34x faster on zero operands (same instruction stream; 1.88 GHz under random operands by "
+                                       "GRBM_GUI_ACTIVE, 77 % matrix-pipe busy): profiles/r4/conv_f16x3_probe_session1.jsonl, profiles/r4_pmc/") if v2 else None,
                      "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                      # activations are 4 B per element in both kernel families: per conv layer one read + one write of
@@ -503,13 +510,14 @@ def exact_f32_leg(args, dev, blob, cfg, weights, steps=8):
 # ------------------------------------------------------------------------------------------------------------
 # whole games on the headline settings (driver-timed: measured, not extrapolated)
 # ------------------------------------------------------------------------------------------------------------
-def whole_games_leg(args, dev, blob, cfg, slots=1024, ids=1536):
-    """COMPLETE games of the headline search (256x10 net on the split-f16 trunk, 800 sims/move, ch5.yml play settings,
-    thinking_loop 1, solver off, parallel_search_num 1) at a reduced number of slots so that it fits the bench's time budget:
-    `slots` resident games, continuous batching over `ids` game ids (a finished slot restarts on the next id at once),
-    node pools of 16 x sims pruned by k_gc, the evaluation cache attached as the worker attaches it.  games/hour and sims/s
-    are MEASURED on complete games, including the ramp-down of the last games; the steady window (first refill .. last
-    refill) is reported beside it.  Returns (result dict, records of the sampled ids for the complete-game check)."""
+def steady_window_leg(args, dev, blob, cfg, weights, slots=8192, seconds=120.0, chunk=32):
+    """The headline CONFIGURATION over a fixed wall-clock window instead of 20 steps: `slots` (8192) resident games on the headline
+    settings (256x10 net on the split-f16 trunk, 800 sims/move, ch5.yml play settings, thinking_loop 1, solver off,
+    parallel_search_num 1), started in the steady state of continuous batching (every slot at a position drawn from the time share
+    of each ply, as the timed batch of the headline) and then PLAYED for `seconds`: games finish, their slots restart from the
+    opening on the next game id (raz_engine_harvest), pools are pruned by k_gc, the evaluation cache is attached as the worker
+    attaches it.  sims/s and games/hour are measured over the window (host clock around synchronised chunks).  Returns (result,
+    late-start games that finished inside the window - the complete-game check plays them again on the oracle)."""
     import numpy as np
     import torch
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine, raw_from_packed
@@ -517,73 +525,91 @@ def whole_games_leg(args, dev, blob, cfg, slots=1024, ids=1536):
     cache_log2 = None if args.no_leaf_cache else 26
     eng = SelfPlayEngine(cfg, net, n_games=slots, seed=0, sims_hint=args.sims, nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=1,
                          leaf_cache_log2=cache_log2, leaf_cache_max_discs=24)
-    marks = []
-
-    def on_chunk(steps, done, st):
-        marks.append((time.perf_counter(), steps, done, st["total_sims"], st["nn_leaves"]))
+    spare = slots   # ids for the refills of the window (a slot restarts at most a few times in two minutes)
+    eng.start(0, args.sims)
+    ply = stagger(eng, slots, args.sims, 2024, dev, weights)
+    start_pos = eng._staggered
+    outbox = eng.new_outbox(0, slots + spare)
+    eng.step(args.tree_warm)
+    nxt, done, steps, cap, gc_runs = slots, 0, 0, int(eng.cfg.nodes_per_game), 0
+    st0 = eng.stats()
+    c0 = eng.leaf_cache_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outbox, st = eng.play_continuous(0, ids, lambda gid: args.sims, chunk=256, on_chunk=on_chunk)
+    while time.perf_counter() - t0 < seconds:
+        eng.step(chunk)
+        steps += chunk
+        st = eng.stats()   # synchronises
+        if eng.pool_nearly_full(st, chunk):
+            eng.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
+            gc_runs += 1
+        k = min(slots, slots + spare - nxt)
+        h, r, skipped, playing = eng.harvest(outbox, nxt, [args.sims] * k)
+        nxt += r
+        done += h
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    pk = {k: outbox[k].cpu().numpy() for k in ("headers", "root_n", "summary")}
-    raw = raw_from_packed(pk["headers"], pk["root_n"], pk["summary"])
-    searched = int((raw["headers"]["sims"] > 0).sum())
-    # steady window: from the first chunk after which a slot had been refilled to the last chunk that still had unplayed ids
-    first_refill = next((i for i, m in enumerate(marks) if m[2] > 0), None)
-    last_full = max((i for i, m in enumerate(marks) if m[2] <= ids - slots), default=None)
-    steady = None
-    if first_refill is not None and last_full is not None and last_full > first_refill:
-        a, b = marks[first_refill], marks[last_full]
-        steady = {"seconds": b[0] - a[0], "sims_per_s": (b[3] - a[3]) / (b[0] - a[0]), "games_finished_in_the_window": b[2] - a[2],
-                  "net_evaluations_per_s": (b[4] - a[4]) / (b[0] - a[0]), "leaf_slot_occupancy": (b[4] - a[4]) / ((b[1] - a[1]) * slots),
-                  "what": "between the first refill and the last chunk that still had unplayed ids: every slot busy"}
-    cs = eng.leaf_cache_stats()
-    out = {"workload": f"{ids} COMPLETE self-play games on {slots} slots (continuous batching), 256x10 net ({net.kernel_name}), {args.sims} sims/move, "
-                       "ch5.yml play settings, thinking_loop=1, solver off, parallel_search_num=1, node pools 16 x sims (k_gc between harvests)",
-           "measured": "in this run, on complete games (not extrapolated)",
-           "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": ids / dt * 3600.0, "seconds": dt, "steps": st["steps"],
-           "ms_per_step": 1e3 * dt / st["steps"], "net_evaluations_per_s": st["nn_leaves"] / dt,
-           "sims_per_net_evaluation": st["total_sims"] / st["nn_leaves"], "searched_plies_per_game": searched / ids,
-           "plies_per_game": float(raw["n_plies"].mean()), "leaf_slot_occupancy_incl_ramp_down": st["leaf_slot_occupancy"],
-           "gc_runs": st["gc_runs"], "steady_window": steady,
-           "games_per_hour_at_the_steady_rate": (steady["sims_per_s"] / (st["total_sims"] / ids) * 3600.0) if steady else None,
-           "winners_black_white_draw": [int((raw["status"] & 0x0f == w).sum()) for w in (1, 2, 3)],
-           "resigned_games": int(((raw["status"] & 0x20) != 0).sum()), "range_ok": net.range_ok(),
-           "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table": int(cs["hits"] + cs["in_batch_duplicates"]),
-                           "share_of_leaf_requests": (cs["hits"] + cs["in_batch_duplicates"]) / max(1, st["nn_leaves"])} if cache_log2 else None),
+    st = eng.stats()
+    c1 = eng.leaf_cache_stats()
+    sims, leaves = st["total_sims"] - st0["total_sims"], st["nn_leaves"] - st0["nn_leaves"]
+    served = (c1["hits"] - c0["hits"]) + (c1["in_batch_duplicates"] - c0["in_batch_duplicates"])
+    # finished games: rows of the outbox that are done; the late-start ones (slot ids < slots) are partial games by construction
+    done_rows = torch.nonzero(outbox["done"]).flatten().cpu().numpy()
+    late = [int(g) for g in done_rows if g < slots and ply[g] >= 50][:2]
+    recs = {}
+    if late:
+        rows = torch.tensor(late, device=dev)
+        raw = raw_from_packed(*(outbox[k][rows].cpu().numpy() for k in ("headers", "root_n", "summary")))
+        b, w, p = start_pos
+        for i, g in enumerate(late):
+            n = int(raw["n_plies"][i])
+            recs[g] = (raw["headers"][i, :n].copy(), raw["root_n"][i, :n].copy(), int(raw["status"][i]),
+                       (int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g])))
+    out = {"workload": f"the headline configuration for a fixed window: {slots} slots, 256x10 net ({net.kernel_name}), {args.sims} sims/move, ch5.yml play settings, "
+                       "thinking_loop=1, solver off, parallel_search_num=1; slots start at positions drawn from the time share of each ply (the steady state of "
+                       f"continuous batching) and are PLAYED for {seconds:.0f} s: finished games restart from the opening on the next id, node pools 16 x sims "
+                       "pruned by k_gc, evaluation cache attached",
+           "measured": "in this run, host clock around synchronised chunks of 32 steps (not extrapolated)",
+           "value": sims / dt, "unit": "sims/s", "seconds": dt, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "net_evaluations_per_s": leaves / dt, "sims_per_net_evaluation": sims / max(1, leaves),
+           "leaf_slot_occupancy": leaves / max(1, steps * slots), "games_finished_in_the_window": int(done), "slots_restarted_from_the_opening": int(nxt - slots),
+           "games_per_hour": done / dt * 3600.0,
+           "games_per_hour_note": "games whose last move fell inside the window / window length: in the steady state that is the completion rate of whole games",
+           "gc_runs": gc_runs, "range_ok": net.range_ok(),
+           "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table": int(served),
+                           "share_of_leaf_requests": served / max(1, leaves)} if cache_log2 else None),
            "pool_bytes": int(eng.workspace_bytes)}
-    sample = [0, ids - 1]   # one game of the first wave, one that was started by a refill
-    recs = {gid: (raw["headers"][gid, :int(raw["n_plies"][gid])].copy(), raw["root_n"][gid, :int(raw["n_plies"][gid])].copy(), int(raw["status"][gid]))
-            for gid in sample}
     del eng, net, outbox
     torch.cuda.empty_cache()
     return out, recs
 
 
-def start_complete_game_checks(dev, args, blob, cfg, recs):
-    """Complete games of the whole-game leg against complete oracle games, the oracle evaluating every leaf (~45 000 per game)
-    through a device net of its own (the reference's NN seam, batch of 1) on its own stream: one host thread per game,
-    started here and joined by the caller after the CPU-baseline leg (the GPU is idle meanwhile)."""
+def start_complete_game_checks(dev, args, blob, cfg, recs, sims=None):
+    """Games of a leg against the games the CPU oracle plays for the same ids, the oracle evaluating every leaf through a device net
+    of its own (the reference's NN seam, batch of 1) on its own stream: one host thread per game, started here and joined by the
+    caller after other legs.  recs[id] = (ply headers, root N, status[, (black, white, next_player) the game was taken up at])."""
     import threading
     import numpy as np
     import torch
     import oracle as O
     from reversi_alpha_zero_amd.engine import DeviceNet
-    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=int(cfg.play.parallel_search_num))
     results = {}
 
     def check(gid):
         try:
             t0 = time.perf_counter()
+            hdr, rn, status = recs[gid][:3]
+            start = recs[gid][3] if len(recs[gid]) > 3 else None
             with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
                 dnet = DeviceNet(blob, dev, kernel=args.net_kernel)
-                plies, summ = O.selfplay_game(ocfg, None, 0, gid, args.sims, nn=device_nn(dnet))
-            hdr, rn, status = recs[gid]
+                plies, summ = O.selfplay_game(ocfg, None, 0, gid, sims or args.sims, nn=device_nn(dnet), start=start)
             ok = len(plies) == len(hdr) and (status & 0x0f) == summ["winner"] and \
                 [int(a) for a in hdr["action"]] == [p["action"] for p in plies] and \
                 all(np.array_equal(rn[i].astype(np.float64), np.array(p["root_n"])) for i, p in enumerate(plies))
             results[gid] = {"ok": bool(ok), "plies": len(plies), "leaf_evaluations": int(summ["n_expand"]), "seconds": time.perf_counter() - t0}
+            if start is not None:
+                results[gid]["taken_up_at_ply"] = bin(start[0] | start[1]).count("1") - 4
         except BaseException as e:   # noqa: B902 - reported by the joiner
             results[gid] = {"ok": False, "error": repr(e)}
     threads = [threading.Thread(target=check, args=(gid,), daemon=True) for gid in recs]
@@ -592,16 +618,15 @@ def start_complete_game_checks(dev, args, blob, cfg, recs):
     return threads, results
 
 
-def join_complete_game_checks(threads, results, timeout=900.0):
+def join_complete_game_checks(threads, results, what, timeout=900.0):
     for t in threads:
         t.join(timeout)
     if any(t.is_alive() for t in threads):
         raise AssertionError("complete-game parity check did not finish")
     bad = {g: r for g, r in results.items() if not r.get("ok")}
     if bad:
-        raise AssertionError(f"parity check FAILED: complete games of the whole-game leg differ from the oracle: {bad}")
-    return {"result": "ok", "what": "complete games of this leg (one of the first wave, one started by a refill): every action, the winner and every "
-                                    "ply's root N == the complete game the CPU oracle plays for that id with the device net's outputs (800 sims/move)",
+        raise AssertionError(f"parity check FAILED: games of the bench differ from the oracle: {bad}")
+    return {"result": "ok", "what": what,
             "games": [dict(game_id=g, **{k: v for k, v in r.items() if k != "ok"}) for g, r in sorted(results.items())]}
 
 
@@ -705,10 +730,65 @@ def config5_leg(args, dev, blob, weights, games=8192, sims=3200, steps=10):
     return out
 
 
-def config1_leg(dev, args, par=1, fused=False, net_kernel=None):
+def ch5_shipped_config(sims):
+    """config/ch5.yml:9-16 over config.py:128-166 with NOTHING overridden but the simulations per move (BASELINE configs[2]: 800):
+    thinking_loop 10 / required_visit_to_decide_action 400 / start_rethinking_turn 8 (config.py:133-135), parallel_search_num 8
+    (config.py:142), use_solver_turn = use_solver_turn_in_simulation = 50 (config.py:154-155)."""
+    cfg = ch5_config(sims, par=8)
+    cfg.play.thinking_loop = 10
+    cfg.play.use_solver_turn = 50
+    cfg.play.use_solver_turn_in_simulation = 50
+    return cfg
+
+
+def ch5_as_shipped_leg(args, dev, blob, weights, games=8192, steps=6, warm=12):
+    """The headline batch with ch5.yml AS SHIPPED (no declared override left: thinking_loop 10, parallel_search_num 8, the end-game
+    solver from turn 50): 8 simulations in flight per game (k_tree_par: up to 8 x 8192 leaves per net batch), re-think loops, the
+    exhaustive solver inside the tree kernel.  Same steady-state batch recipe as the headline.  Timed twice - with the solver and
+    with use_solver_turn = 0 - so that the solver's share of a step (it runs to completion inside the launch, every wave of the
+    batch waiting for the slowest DFS) is a measured number."""
+    import torch
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    res = {}
+    for label, solver in (("as_shipped", True), ("solver_off", False)):
+        cfg = ch5_shipped_config(args.sims)
+        if not solver:
+            cfg.play.use_solver_turn = cfg.play.use_solver_turn_in_simulation = 0
+        net = DeviceNet(blob, dev, kernel=args.net_kernel)
+        # a move's search holds up to thinking_loop x sims simulations (two nodes each with mirror keys) before k_gc prunes what the
+        # game has left behind: 5 x that, as the 16 x sims of the headline pools
+        nodes = 5 * 10 * args.sims
+        eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=args.sims, nodes_per_game=nodes, parts=1,
+                             leaf_cache_log2=None if args.no_leaf_cache else 26, leaf_cache_max_discs=24)
+        eng.start(0, args.sims)
+        stagger(eng, games, args.sims, 31337, dev, weights)
+        eng.step(warm)
+        st0 = eng.stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tree_ms, net_ms = eng.step_timed(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        sims_done, leaves = st["total_sims"] - st0["total_sims"], st["nn_leaves"] - st0["nn_leaves"]
+        res[label] = {"value": sims_done / dt, "unit": "sims/s", "ms_per_step": 1e3 * dt / steps, "k_tree_par_ms_per_step": tree_ms / steps,
+                      "net_forward_ms_per_step": net_ms / steps, "net_evaluations_per_step": leaves / steps, "sims_per_step": sims_done / steps,
+                      "leaf_slot_occupancy": leaves / (steps * games * 8), "engine_workspace_bytes": int(eng.workspace_bytes)}
+        del eng, net
+        torch.cuda.empty_cache()
+    a, b = res["as_shipped"], res["solver_off"]
+    return {"workload": f"the headline batch ({games} concurrent games, 256x10 net, {args.sims} sims/move) with ch5.yml AS SHIPPED: thinking_loop 10, parallel_search_num 8, "
+                        f"use_solver_turn 50 (config/ch5.yml:9-16, config.py:133-135,142,154-155); steady-state ply mix, {steps} timed steps after {warm}",
+            "value": a["value"], "unit": "sims/s", **{k: v for k, v in a.items() if k not in ("value", "unit")},
+            "same_with_the_solver_off": b,
+            "solver_share_of_a_step": {"tree_kernel_ms_with_solver": a["k_tree_par_ms_per_step"], "tree_kernel_ms_without": b["k_tree_par_ms_per_step"],
+                                       "share_of_step_time": max(0.0, a["k_tree_par_ms_per_step"] - b["k_tree_par_ms_per_step"]) / a["ms_per_step"]}}
+
+
+def config1_leg(dev, args, par=1, fused=True, net_kernel=None):
     """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch).
-    fused: tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip, opt-in).
-    net_kernel: a test variant of the narrow-net kernel for the engine's launches ("mfma_split2": one position on two waves)."""
+    fused: tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip: what the worker runs
+    for 16-filter nets); False = the two-kernel pipeline k_tree + k_net_mfma on three streams."""
     import numpy as np
     import torch
     from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
@@ -744,7 +824,8 @@ def config1_leg(dev, args, par=1, fused=False, net_kernel=None):
     dt = time.perf_counter() - t0
     lps = 3
     macs = macs_per_position(F, R, V)
-    out = {"workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
+    out = {"fused_tree_net_kernel": bool(fused),
+           "workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
                        f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)"
                        + ("; tree and net in ONE kernel (k_tree_net / k_tree_par_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else "")
                        + (f"; narrow-net kernel variant {net_kernel}" if net_kernel else ""),
@@ -870,41 +951,6 @@ def cpu_baseline_port(cfg, blob, sims, threads, stop_after_plies=0, what=""):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def config1_variant_child(args):
-    """configs[1] on the fused tree + net kernel (k_tree_net) or with a narrow-net kernel variant, in a process of its own: these are
-    opt-in and younger than the rest of the engine, and nothing they do may cost the parent its line.  Prints one JSON document."""
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(0)
-    import __graft_entry__ as g
-    g.build()
-    v = args.config1_variant
-    fused = v.startswith("fused")
-    out, _, _ = config1_leg(torch.device("cuda", 0), args, 4 if v == "fused_par4" else 1, fused=fused, net_kernel=(None if fused else v))
-    print(json.dumps(out))
-    return 0
-
-
-def child_leg(argv, timeout):
-    """Runs a leg in a child process and returns the JSON document it prints, or what went wrong.  A child that neither finishes
-    nor dies when killed (stuck in the driver) is abandoned, not waited for."""
-    p = subprocess.Popen([sys.executable] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    try:
-        so, se = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        try:
-            p.communicate(timeout=15)
-        except subprocess.TimeoutExpired:
-            pass
-        return {"error": f"the child process did not finish within {timeout:.0f} s"}
-    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
-    if p.returncode != 0 or not lines:
-        return {"error": f"child exit code {p.returncode}", "stderr_tail": se[-600:]}
-    return json.loads(lines[-1])
-
-
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` (N > 1) started without a launcher: become N ranks."""
     import socket
@@ -919,6 +965,66 @@ def respawn_under_torchrun(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd))
+
+
+def compact_line(full):
+    """The ONE line the driver records (<= 8 KB): the contract keys, `roofline`, `cpu_baseline`, and one short object per leg with its
+    value and its parity result.  Everything else (per-leg detail, notes, game lists) is in the full document (bench_full.json)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else d
+
+    def parity(d):
+        if not isinstance(d, dict):
+            return d
+        return {"result": d.get("result"), "games": len(d.get("games", d.get("game_ids", [])))}
+    line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = pick(full.get("config", {}), ("workload", "games_per_gpu", "sims_per_move", "net", "test_rig", "collective_backend"))
+    r = full.get("roofline", {})
+    line["roofline"] = pick(r, ("bound", "kernel_name", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "algorithmic_flops_per_launch",
+                                "algorithmic_hbm_bytes_per_launch", "executed_mfma_tflops", "executed_mfma_frac_of_pipe_peak", "achieved_over_f32_mfma_peak",
+                                "power_limited"))
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        line["cpu_baseline"] = pick(c, ("value", "unit", "cores", "kind", "sample"))
+        if isinstance(c.get("configs1_mini_200sims"), dict):
+            line["cpu_baseline"]["configs1_value"] = c["configs1_mini_200sims"].get("value")
+    line["games_per_hour"] = full.get("games_per_hour")
+    line["leaves_per_sec"] = full.get("leaves_per_sec")
+    line["parity_spotcheck"] = parity(full.get("parity_spotcheck"))
+    line["parity_spotcheck_timed_batch"] = parity(full.get("parity_spotcheck_timed_batch"))
+    w = full.get("whole_games_measured")
+    if isinstance(w, dict):
+        line["whole_games_measured"] = dict(pick(w, ("value", "unit", "seconds", "games_per_hour", "games_finished_in_the_window", "leaf_slot_occupancy",
+                                                     "sims_per_net_evaluation", "ms_per_step")),
+                                            slots=full.get("config", {}).get("games_per_gpu"), parity=parity(w.get("parity_check_complete_games")))
+        line["whole_games_measured"]["sims_per_s"] = w.get("value")
+    for key in ("headline_on_exact_f32_kernels", "ch5_yml_as_shipped", "config5_8192x3200_agz", "config1_4096x200_mini", "config1_mini_yml_parallel_search_num_4",
+                "config1_two_kernel_pipeline", "config1_two_kernel_pipeline_parallel_search_num_4", "config1_continuous_batching"):
+        d = full.get(key)
+        if isinstance(d, dict):
+            e = pick(d, ("value", "unit", "games_per_hour", "ms_per_step", "error", "fused_tree_net_kernel"))
+            if "parity_spotcheck" in d:
+                e["parity"] = parity(d["parity_spotcheck"])
+            if "roofline" in d:
+                e["roofline_frac"] = d["roofline"].get("frac")
+            if "solver_share_of_a_step" in d:
+                e["solver_share_of_step_time"] = d["solver_share_of_a_step"].get("share_of_step_time")
+                e["solver_off_value"] = d.get("same_with_the_solver_off", {}).get("value")
+            if "parity_check_complete_games" in d:
+                e["parity"] = parity(d["parity_check_complete_games"])
+            line[key] = e
+    sw = full.get("bitboard_sweep")
+    if isinstance(sw, dict) and "k_step" in sw:
+        line["bitboard_sweep"] = {k: pick(sw[k], ("achieved", "peak", "unit", "frac", "traffic_over_algorithmic")) for k in ("k_step", "k_legal_moves")}
+        b26 = sw.get("beyond_the_infinity_cache_2^26_boards", {})
+        line["bitboard_sweep"]["frac_at_2^26_boards"] = {k: b26.get(k, {}).get("frac") for k in ("k_step", "k_legal_moves")}
+    elif isinstance(sw, dict):
+        line["bitboard_sweep"] = sw
+    for key in ("record_gather", "config4_acceptance"):
+        if key in full:
+            line[key] = pick(full[key], ("collective", "bytes", "games", "seconds", "payload_check", "result", "gathered_bytes"))
+    line["full_document"] = full.get("_full_path")
+    return line
 
 
 def main():
@@ -938,16 +1044,11 @@ def main():
     ap.add_argument("--no-leaf-cache", action="store_true", help="headline engine without the cross-game evaluation cache")
     ap.add_argument("--fused", action="store_true", help="--net mini only: the headline leg on the fused tree + net kernel (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (whole-game, configs[1], par-4 and sweep legs skipped)")
-    ap.add_argument("--no-whole-games", action="store_true", help="skip the whole-game leg on the headline settings (~4 min)")
-    ap.add_argument("--whole-slots", type=int, default=1024, help="slots of the whole-game leg")
-    ap.add_argument("--whole-ids", type=int, default=1536, help="game ids the whole-game leg plays to the end")
-    ap.add_argument("--config1-variant", default=None, choices=["fused", "fused_par4", "classic", "classic_par4"],
-                    help="(child mode of the default run) ONLY the configs[1] whole-game batch, on the fused tree + net kernel or with a "
-                         "variant of the narrow-net kernel")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (every other leg skipped)")
+    ap.add_argument("--no-whole-games", action="store_true", help="skip the fixed-window leg on the headline configuration (~2.5 min)")
+    ap.add_argument("--window-seconds", type=float, default=120.0, help="length of the fixed window the headline configuration is played for")
+    ap.add_argument("--full-out", default=None, help="where the full document goes (default: gpurun_out/bench_full.json if gpurun_out/ exists, else ./bench_full.json)")
     args = ap.parse_args()
-    if args.config1_variant:
-        return config1_variant_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -962,18 +1063,23 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path is device-only; there is no CPU fallback)")
     # RAZ_BENCH_SHARED_GPU=1 (test rig only): several ranks share the visible GPUs and rendezvous over
     # gloo, to exercise the N > 1 code path on a 1-GPU box; the reported line says so.
+    # RAZ_BENCH_NCCL_WORLD1=1 (test rig only): at N = 1, join an nccl (RCCL) group of ONE rank and run everything the N > 1 path runs
+    # on it - barriers, the all-reduces of the timed region, the record gather from HBM with its payload check.
     shared_gpu = os.environ.get("RAZ_BENCH_SHARED_GPU") == "1"
+    nccl_world1 = world == 1 and os.environ.get("RAZ_BENCH_NCCL_WORLD1") == "1"
     if shared_gpu:
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if shared_gpu else dev   # where the collectives' tensors live
-    if world > 1:
+    if world > 1 or nccl_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    group = world > 1 or nccl_world1   # the collective code path runs
     import __graft_entry__ as g
     if world > 1:   # one rank builds (a no-op when the shipped .so files are current), the others wait
         if local == 0:
@@ -982,9 +1088,9 @@ def main():
     g.build()
 
     acceptance = None
-    if world > 1 and not args.no_extra_legs:
+    if group and (not args.no_extra_legs or nccl_world1):
         acceptance = config4_acceptance(dev, rank, world, cdev)
-    res = headline_leg(args, dev, rank, world, cdev)
+    res = headline_leg(args, dev, rank, world, cdev, group)
     if rank == 0:
         out, blob, cfg = res
         ply_weights = out.pop("_ply_weights", None)
@@ -992,27 +1098,30 @@ def main():
             out["config4_acceptance"] = acceptance
         if shared_gpu:
             out["config"]["test_rig"] = "RAZ_BENCH_SHARED_GPU=1: ranks share GPUs, gloo collectives - not a scaling measurement"
+        if nccl_world1:
+            out["config"]["test_rig"] = "RAZ_BENCH_NCCL_WORLD1=1: the N > 1 code path (barriers, all-reduces, record gather) on an RCCL group of one rank"
         import gc
         checks = None
         if world == 1 and not args.no_extra_legs and args.net == "ch5" and not args.no_whole_games:
             gc.collect()
             torch.cuda.empty_cache()
-            wg, recs = whole_games_leg(args, dev, blob, cfg, slots=args.whole_slots, ids=args.whole_ids)
+            wg, recs = steady_window_leg(args, dev, blob, cfg, ply_weights, slots=args.games, seconds=args.window_seconds)
             out["whole_games_measured"] = wg
-            # the line's games/hour is what was measured on complete games; the steady-state extrapolation stays beside it
-            out["games_per_hour_extrapolated_from_the_timed_steps"] = out["value"] / (args.sims * wg["searched_plies_per_game"]) * 3600.0
+            # the line's games/hour is what was measured over the window; the 20-step extrapolation stays beside it
+            out["games_per_hour_extrapolated_from_the_timed_steps"] = out["games_per_hour"]
             out["games_per_hour"] = wg["games_per_hour"]
-            out["games_per_hour_note"] = (f"MEASURED in this run on {args.whole_ids} complete games at {args.whole_slots} slots (whole_games_measured); at 8192 slots the "
-                                          "timed steps extrapolate to games_per_hour_extrapolated_from_the_timed_steps (sims/s / (sims/move x searched plies/game "
-                                          "measured on those complete games))")
+            out["games_per_hour_note"] = (f"MEASURED in this run: games finished inside a {wg['seconds']:.0f} s window of the headline configuration played with continuous "
+                                          "batching (whole_games_measured)")
             out["headline_over_whole_games_sims_per_s"] = out["value"] / wg["value"]
-            if not args.no_spotcheck:
+            if not args.no_spotcheck and recs:
                 checks = start_complete_game_checks(dev, args, blob, cfg, recs)
         if world == 1 and not args.no_cpu_baseline:
-            # the reference's own pure-Python self-play on this box's host cores, in this run (the complete-game checks above
-            # keep two host threads and an otherwise idle GPU busy meanwhile)
+            # the reference's own pure-Python self-play on this box's host cores, in this run (the game checks above keep two host
+            # threads and an otherwise idle GPU busy meanwhile)
             ref = cpu_baseline_reference()
             if ref is not None:
+                ref["sample"] = (ref.get("sample", "") + f"; the reference runs its yml's parallel_search_num 8 (throughput setting, SURVEY 8(d)), the GPU headline "
+                                 f"parallel_search_num 1 - ch5_yml_as_shipped is the GPU figure at 8").strip("; ")
                 out["cpu_baseline"] = ref
             else:   # no reference modules on this box (oracle/_ref not staged): the C port, labelled as such
                 threads = min(os.cpu_count() or 1, 128)
@@ -1022,13 +1131,18 @@ def main():
                     what=f"oracle/_ref absent: C port instead of the reference; bounded sample: the first {per_thread} simulations of the first searched "
                          f"move of {threads} games")
         if checks is not None:
-            out["whole_games_measured"]["parity_check_complete_games"] = join_complete_game_checks(*checks)
+            out["whole_games_measured"]["parity_check_complete_games"] = join_complete_game_checks(
+                *checks, what="games of the window that were taken up late (ply >= 50) and finished inside it: every action, the winner and every ply's root N == "
+                              "the game the CPU oracle plays for that id from the same position with the device net's outputs (800 sims/move)")
         if world == 1 and not args.no_extra_legs:
-            legs = ((("headline_on_exact_f32_kernels", lambda: exact_f32_leg(args, dev, blob, cfg, ply_weights)),)
+            legs = ((("headline_on_exact_f32_kernels", lambda: exact_f32_leg(args, dev, blob, cfg, ply_weights)),
+                     ("ch5_yml_as_shipped", lambda: ch5_as_shipped_leg(args, dev, blob, ply_weights, games=args.games)))
                     if "f16x3" in out["dtype"] else ()) + (
                     ("config5_8192x3200_agz", lambda: config5_leg(args, dev, blob, ply_weights)),
-                    ("config1_4096x200_mini", lambda: config1_leg(dev, args, 1)[0]),
-                    ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4)[0]),
+                    ("config1_4096x200_mini", lambda: config1_leg(dev, args, 1, fused=True)[0]),
+                    ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4, fused=True)[0]),
+                    ("config1_two_kernel_pipeline", lambda: config1_leg(dev, args, 1, fused=False)[0]),
+                    ("config1_two_kernel_pipeline_parallel_search_num_4", lambda: config1_leg(dev, args, 4, fused=False)[0]),
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             for key, leg in legs:
@@ -1040,20 +1154,15 @@ def main():
                     raise
                 except Exception as ex:   # never lose the main line over an extra leg
                     out[key] = {"error": repr(ex)}
-            # last, in processes of their own (a timeout each; after the first one that does not come back the rest is skipped, so
-            # that a wedged device costs the line 150 s at most): the configs[1] batches on the opt-in fused tree + net kernels, and
-            # the one-process A/B of the headline conv kernel's hand-scheduled variants (bit equality on the device + ms per
-            # 8192-position forward) - measurements for the next round, not part of the line's figures
-            gc.collect()
-            torch.cuda.empty_cache()
-            children = (("config1_4096x200_mini_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused"]),
-                        ("config1_mini_yml_parallel_search_num_4_fused_tree_net_kernel", [os.path.abspath(__file__), "--config1-variant", "fused_par4"]))
-            stuck = False
-            for key, argv in children:
-                out[key] = {"error": "skipped: an earlier child process did not come back"} if stuck else child_leg(argv, 150.0)
-                stuck = stuck or "did not finish" in str(out[key].get("error", ""))
-        print(json.dumps(out))
-    if world > 1:
+        path = args.full_out or os.path.join(ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "bench_full.json")
+        try:
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            out["_full_path"] = os.path.relpath(path, ROOT)
+        except OSError:
+            out["_full_path"] = None
+        print(json.dumps(compact_line(out)))
+    if group:
         dist.destroy_process_group()
 
 

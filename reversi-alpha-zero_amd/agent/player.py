@@ -84,6 +84,20 @@ class MCTSInfo:
         return idx
 
 
+def effective_play_config(config, play_config=None):
+    """The settings a reference ReversiPlayer built with `play_config` really plays under.  agent/player.py takes most of them from
+    self.play_config (= play_config or config.play, :39) but reads FIVE from the global config.play whatever play_config says:
+    allowed_resign_turn (:127), use_solver_turn_in_simulation (:237-238), virtual_loss (:264), policy_decay_turn / _power (:410-411) -
+    and the two sleep constants that only order events (:254, :341).  So an `eval` match (config.eval.play_config) resigns, solves
+    inside simulations and applies virtual losses by the SELF-PLAY section's values; pinned by tests/golden/eval_games.json."""
+    pc = copy.copy(play_config if play_config is not None else config.play)
+    g = config.play
+    for name in ("allowed_resign_turn", "use_solver_turn_in_simulation", "virtual_loss", "policy_decay_turn", "policy_decay_power"):
+        if hasattr(g, name):
+            setattr(pc, name, getattr(g, name))
+    return pc
+
+
 class ReversiPlayer:
     def __init__(self, config, model, play_config=None, enable_resign=True, mtcs_info=None, api=None):
         """config: Config; model: agent.model.ReversiModel (or anything with .model.to_blob() / .to_blob());
@@ -123,8 +137,7 @@ class ReversiPlayer:
             net = cache.get(info.device)
             if net is None:
                 net = cache[info.device] = DeviceNet(m.to_blob(), info.device)
-        pc = copy.copy(self.play_config)
-        pc.allowed_resign_turn = self.config.play.allowed_resign_turn   # player.py:127 reads config.play, not play_config
+        pc = effective_play_config(self.config, self.play_config)
         shim = SimpleNamespace(play=pc, play_data=self.config.play_data)
         sims = int(pc.simulation_num_per_move)
         return SelfPlayEngine(shim, net, 1, seed=info.seed, nodes_per_game=info.nodes, sims_hint=sims,

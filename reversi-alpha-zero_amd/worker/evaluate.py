@@ -56,8 +56,8 @@ class _Side:
 
     def __init__(self, config, model, n_games, seed, first_game_id, device):
         from ..engine import DeviceNet, SelfPlayEngine
-        pc = copy.copy(config.eval.play_config)
-        pc.allowed_resign_turn = config.play.allowed_resign_turn   # agent/player.py:127 reads config.play
+        from ..agent.player import effective_play_config
+        pc = effective_play_config(config, config.eval.play_config)   # five settings come from config.play whatever play_config says
         # (every ReversiPlayer of evaluate.py:69-70 has a tree of its own: here one engine slot per player, used by that
         #  player only, with the mirror-key updates of player.py:279-280 as the play config's tree mode implies)
         self.sims = int(pc.simulation_num_per_move)
@@ -83,11 +83,12 @@ class _Side:
         return st["idle_or_done"] < eng.n_games
 
     def answers(self):
-        """{slot: action or None (resigned)} of the slots armed in this round."""
+        """{slot: (action or None (resigned), the root's visit counts after the search)} of the slots armed in this round."""
         pk = self.engine.pack_records(0, self.engine.n_games, plies=1)
         from ..engine import PLY_HEADER
         hdr = pk["headers"].cpu().numpy().view(PLY_HEADER).reshape(-1)
-        out = {g: (int(hdr[g]["action"]) if int(hdr[g]["action"]) >= 0 else None) for g in self.armed}
+        root_n = pk["root_n"].cpu().numpy().reshape(self.engine.n_games, -1)[:, :64]
+        out = {g: ((int(hdr[g]["action"]) if int(hdr[g]["action"]) >= 0 else None), root_n[g].copy()) for g in self.armed}
         self.armed = []
         return out
 
@@ -136,6 +137,8 @@ class EvaluateWorker:
                  False: _Side(self.config, ng_model, n, 2 * self.seed + 1, first, self.device)}     # the challenger
         envs = [ReversiEnv().reset() for _ in range(n)]
         live = list(range(n))
+        # what the match looked like, ply by ply (tests compare it with games of the reference's evaluate.py:66-96)
+        self.last_games = [{"game_id": first + g, "best_is_black": best_is_black[g], "plies": []} for g in range(n)]
         while live:
             for g in live:
                 env = envs[g]
@@ -149,8 +152,9 @@ class EvaluateWorker:
                 # every side's busy() runs each round (it also does the side's pool and error-flag checks); a side whose
                 # slots have all decided is no longer stepped
                 stepping = [s for s, b in [(s, s.busy()) for s in stepping] if b]
-            for s in sides.values():
-                for g, action in s.answers().items():
+            for is_best, s in sides.items():
+                for g, (action, root_n) in s.answers().items():
+                    self.last_games[g]["plies"].append({"who": "best" if is_best else "ng", "action": -1 if action is None else action, "root_n": root_n})
                     envs[g].step(action)
             live = [g for g in live if not envs[g].done]
         out = []

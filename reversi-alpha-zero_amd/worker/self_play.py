@@ -591,27 +591,56 @@ class BatchedSelfPlayWorker:
         eng, n = self.play_batch_raw(game_idx, device_records=True)
         return (lambda plies, eng=eng, n=n: eng.pack_records(0, n, plies)), self.games_in_flight
 
+    BLOCK_OK, BLOCK_RANGE, BLOCK_FATAL = 0, 1, 2
+
     def _play_block_checked(self, game_idx):
-        """_play_block + the net's range flag.  A search fed with out-of-range priors may also trip an engine error flag
-        before the block ends: that is the same event, reported as ok = False (the block is void either way)."""
+        """_play_block + what became of it on THIS rank: BLOCK_OK; BLOCK_RANGE - the net's range flag is up (a search fed with
+        out-of-range priors may also trip an engine error flag before the block ends: the same event; the block is void either
+        way and is played again on the exact-f32 kernels); BLOCK_FATAL - anything else went wrong (pool / table / records full with
+        the net in range, a HIP error, ...): the exception is kept in self._block_error and raised once every rank knows, so
+        that no rank is left waiting in a collective for one that has gone."""
+        self._block_error = None
         try:
             packed, per_rank = self._play_block(game_idx)
-            return packed, per_rank, bool(self._net.range_ok())
-        except RuntimeError:
-            if self._net is None or self._net.range_ok():
-                raise
-            return None, 0, False
+            return packed, per_rank, (self.BLOCK_OK if self._net.range_ok() else self.BLOCK_RANGE)
+        except Exception as ex:   # noqa: BLE001 - re-raised by _all_ranks_state on every rank
+            in_range = True
+            try:
+                in_range = self._net is None or bool(self._net.range_ok())
+            except Exception:   # noqa: BLE001 - the device may be gone: fatal
+                pass
+            if isinstance(ex, RuntimeError) and not in_range:
+                return None, 0, self.BLOCK_RANGE
+            self._block_error = ex
+            return None, 0, self.BLOCK_FATAL
 
-    def _all_ranks_agree(self, ok):
-        """AND of a per-rank flag over all ranks (every rank must take the same branch before the next collective)."""
-        if self.world == 1:
-            return bool(ok)
-        import torch
-        import torch.distributed as dist
-        dev = torch.device(self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t.item()))
+    def _group(self):
+        """True when the collectives of the path run: more than one rank, or a process group of one (the nccl path exercised on a
+        single GPU - tests/test_multirank_gpu.py, bench.py RAZ_BENCH_NCCL_WORLD1)."""
+        if self.world > 1:
+            return True
+        try:
+            import torch.distributed as dist
+            return dist.is_available() and dist.is_initialized()
+        except Exception:   # noqa: BLE001
+            return False
+
+    def _all_ranks_state(self, state):
+        """MAX of the per-rank block state over all ranks: every rank takes the same branch before the next collective, and a
+        failure anywhere raises everywhere (the failing rank its own exception, the others a RuntimeError naming the event)."""
+        worst = state
+        if self._group():
+            import torch
+            import torch.distributed as dist
+            dev = torch.device(self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor([state], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = int(t.item())
+        if worst == self.BLOCK_FATAL:
+            if self._block_error is not None:
+                raise self._block_error
+            raise RuntimeError(f"rank {self.rank}: another rank failed while playing its block; this rank stops with it")
+        return worst
 
     def _broadcast_blob(self, blob):
         """Rank 0's decision about a new generation of weights, and the weights themselves, to every rank: ranks polling
@@ -654,8 +683,8 @@ class BatchedSelfPlayWorker:
         writer = _BackgroundWriter(self) if (background_emit and self.rank == 0) else None
         try:
             while total_games is None or local_idx <= total_games:
-                packed, per_rank, ok = self._play_block_checked(game_idx)
-                while not self._all_ranks_agree(ok):
+                packed, per_rank, state = self._play_block_checked(game_idx)
+                while self._all_ranks_state(state) == self.BLOCK_RANGE:
                     if self._f32_fallback or self._series_length() > 1:
                         raise RuntimeError("the net left its numeric range on the exact-f32 kernels too" if self._f32_fallback else
                                            "an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2) "
@@ -665,9 +694,10 @@ class BatchedSelfPlayWorker:
                     del packed
                     self._f32_fallback = True
                     self._drop_engine(net_too=True)
-                    packed, per_rank, ok = self._play_block_checked(game_idx)
-                if self.world > 1:
-                    allraw, _ = gather_packed(packed, self.rank, self.world)
+                    packed, per_rank, state = self._play_block_checked(game_idx)
+                if self._group():
+                    allraw, self.last_gather_bytes = gather_packed(packed, self.rank, self.world)
+                    self.last_gather_backend = dist.get_backend()
                 else:
                     pk = packed(None)
                     allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
@@ -681,14 +711,14 @@ class BatchedSelfPlayWorker:
                     else:
                         self.write_raw(allraw, local_idx)
                         self._write_game_idx(game_idx)
-                if self.world > 1:
+                if self._group():
                     t = [game_idx, self.config.play.resign_threshold]
                     dist.broadcast_object_list(t, src=0)
                     game_idx, self.config.play.resign_threshold = t
                 local_idx += per_rank * self.world
                 if reload_model is not None:
                     blob = reload_model() if self.rank == 0 else None   # rank 0 decides; the digest of ITS read is what counts
-                    if self.world > 1:
+                    if self._group():
                         blob = self._broadcast_blob(blob)
                     if blob is not None:
                         self.set_net_blob(blob)

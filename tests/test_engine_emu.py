@@ -219,3 +219,76 @@ def test_emulated_dirichlet_alpha_above_one(golden, blob, alpha):
     for i, (plies, summ) in enumerate(eng.records(save_policy_of_tau_1=True)):
         op, osum = O.selfplay_game(ocfg, blob, 19, 810 + i, 10)
         _same(f"alpha{alpha}/{i}", plies, summ, op, osum["winner"])
+
+
+def test_emulated_eval_matches_equal_the_reference_evaluate_games():
+    """tests/golden/eval_games.json (the UNMODIFIED reference's EvaluateWorker.play_game, worker/evaluate.py:66-96: best model against
+    challenger, two ReversiPlayers with trees and random streams of their own; tests/golden/make_golden_eval.py) replayed the way
+    reversi-alpha-zero_amd/worker/evaluate.py plays a match - one engine per model, slot g = that model's player of game g, armed move
+    by move with raz_engine_set_position - on the EMULATED tree kernels: every ply's mover, action (resignations included) and root
+    visit counts, and the outcome, are the reference's.  (The GPU form of this test drives the product's EvaluateWorker itself:
+    tests/test_engine_gpu.py.)"""
+    import hashlib
+    import json
+    import os
+    import types
+    from conftest import ROOT
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.env.reversi_env import Player, ReversiEnv, Winner
+    with open(os.path.join(ROOT, "tests", "golden", "eval_games.json")) as f:
+        gold = json.load(f)
+    blobs = []
+    for meta in gold["nets"]:
+        b = ReversiNet(meta["filters"], meta["res_layers"], meta["value_fc"]).keras_init_(meta["keras_init_seed"]).randomize_bn_(meta["randomize_bn_seed"]).to_blob()
+        assert hashlib.sha256(b).hexdigest() == meta["blob_sha256"]
+        blobs.append(b)
+    for m in gold["matches"]:
+        # the reference reads five settings from config.play whatever play_config says (agent/player.py:127,237,264,410): the product's
+        # effective_play_config makes that split, and the match "sections_disagree" pins it
+        from reversi_alpha_zero_amd.agent.player import effective_play_config
+        whole = types.SimpleNamespace(play=types.SimpleNamespace(**m["resolved_config_play"]))
+        pc = effective_play_config(whole, types.SimpleNamespace(**m["resolved_play_config"]))
+        if m["name"] == "eval_par4_sections_disagree":
+            assert pc.virtual_loss == 2 and pc.use_solver_turn_in_simulation == 48 and pc.use_solver_turn == 52
+        cfg = types.SimpleNamespace(play=pc, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+        n, first, sims = len(m["games"]), m["first_game_id"], int(pc.simulation_num_per_move)
+        sides = {}
+        for is_best, blob, seed in ((True, blobs[0], 2 * m["seed"]), (False, blobs[1], 2 * m["seed"] + 1)):
+            e = EmuEngine(cfg, blob, n, seed=seed, sims_hint=sims, max_plies=64)
+            e.start(first, sims, n_active=0)
+            sides[is_best] = e
+        envs = [ReversiEnv().reset() for _ in range(n)]
+        best_is_black = [g["best_is_black"] for g in m["games"]]
+        plies = [[] for _ in range(n)]
+        live = list(range(n))
+        while live:
+            armed = {True: [], False: []}
+            for g in live:
+                own, enemy = envs[g].get_own_and_enemy()
+                mover_is_best = (envs[g].next_player == Player.black) == best_is_black[g]
+                sides[mover_is_best].set_position(g, own, enemy, 1, sims, enable_resign=True, one_move=True)
+                armed[mover_is_best].append(g)
+            for is_best, e in sides.items():
+                if not armed[is_best]:
+                    continue
+                while e.stats()["idle_or_done"] < n:
+                    e.step(16)
+                raw = e.read_raw()
+                for g in armed[is_best]:
+                    a = int(raw["headers"][g, 0]["action"])
+                    plies[g].append(("best" if is_best else "ng", a, [float(x) for x in raw["root_n"][g, 0]]))
+                    envs[g].step(a if a >= 0 else None)
+            live = [g for g in live if not envs[g].done]
+        for g, ref in enumerate(m["games"]):
+            where = (m["name"], ref["game_id"])
+            for i, ((who, a, rn), p) in enumerate(zip(plies[g], ref["plies"])):
+                assert (who, a) == (p["who"], p["action"]), (where, i, (who, a), (p["who"], p["action"]))
+                if p["root_n"] is not None:
+                    want = [0.0] * 64
+                    for k, v in p["root_n"].items():
+                        want[int(k)] = v
+                    assert rn == want, (where, i)
+            assert len(plies[g]) == len(ref["plies"]), where
+            env = envs[g]
+            ng_win = None if env.winner not in (Winner.black, Winner.white) else int((env.winner == Winner.black) != best_is_black[g])
+            assert ng_win == ref["ng_win"] and list(env.observation.number_of_black_and_white) == ref["black_white"], where

@@ -151,6 +151,59 @@ def test_net_f16x3_within_tolerance_of_torch_and_exact_kernel(shape, n):
             assert torch.equal(pa[0].view(torch.int32), p2[i].view(torch.int32)) and torch.equal(qa.view(torch.int32), q2[i:i + 1].view(torch.int32))
 
 
+def test_net_f16x3_accuracy_on_4096_positions_of_three_nets():
+    """raznet-forward-v2 on the metric's shape (256x10), 4096 positions from random play (tools/bench_sweep.harvest_positions) x
+    three weight / BatchNorm-statistics variants of tools/check_net_accuracy.py: (1) the bench net (Keras initialisers, seed 0), (2)
+    BN statistics in [0.5, 1.5], (3) BN gamma / variance spread over 10^+-0.5 - the spread a trained checkpoint can show, where two
+    fp32 evaluations of the graph differ by more than 1e-5 from each other.  For (1) and (2): within the north star's 1e-5 of fp32
+    torch (ROCm).  For all three: no further from the f64 evaluation of the same graph than 1.25 x fp32 torch's own distance from it
+    (measured in round 3 over 131 072 positions: 2.1e-8 / 5.6e-6 / 1.25e-4 against torch's 2.0e-8 / 6.4e-6 / 1.26e-4) - i.e. the
+    split operands cost nothing fp32 arithmetic does not cost already.  The range flag stays clear."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_sweep import harvest_positions
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    dev = torch.device(DEV)
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    n, n64 = 4096, 1024
+    black, white, player, _ = harvest_positions(n, 99, dev)
+    own = torch.where(player == 1, black, white)
+    enemy = torch.where(player == 1, white, black)
+    sh = torch.arange(64, device=dev, dtype=torch.int64)
+    planes = torch.stack([((own[:, None] >> sh) & 1), ((enemy[:, None] >> sh) & 1)], dim=1).float().reshape(-1, 2, 8, 8)
+    for name, seed, bn_seed, decades, within_1e5 in (("bench net", 0, None, 0.0, True), ("BN stats in [0.5, 1.5]", 5, 6, 0.0, True),
+                                                      ("BN gamma / var over 10^+-0.5", 11, 12, 0.5, False)):
+        net = ReversiNet(256, 10, 256).keras_init_(seed)
+        if bn_seed is not None:
+            net.randomize_bn_(bn_seed, decades=decades)
+        net.eval()
+        n32 = ReversiNet(256, 10, 256)
+        n32.load_state_dict(net.state_dict())
+        n32 = n32.to(dev).eval()
+        n64net = ReversiNet(256, 10, 256)
+        n64net.load_state_dict(net.state_dict())
+        n64net = n64net.double().to(dev).eval()
+        with torch.no_grad():
+            tp, tv = n32(planes)
+            dp, dv = n64net(planes[:n64].double())
+        dn = DeviceNet(net.to_blob(), dev, kernel="f16x3")
+        p, v = dn.predict_bitboards(own, enemy)
+        assert dn.range_ok(), name
+        e32 = max(float((p - tp).abs().max()), float((v - tv[:, 0]).abs().max()))
+        e64 = max(float((p[:n64].double() - dp).abs().max()), float((v[:n64].double() - dv[:, 0]).abs().max()))
+        t64 = max(float((tp[:n64].double() - dp).abs().max()), float((tv[:n64, 0].double() - dv[:, 0]).abs().max()))
+        print(f"f16x3, 4096 positions, {name}: {e32:.2e} vs fp32 torch, {e64:.2e} vs f64 (fp32 torch itself: {t64:.2e})")
+        if within_1e5:
+            assert e32 <= 1e-5, (name, e32)
+        assert e64 <= 1.25 * t64 + 2e-8, (name, e64, t64)
+        del n32, n64net, dn
+        torch.cuda.empty_cache()
+
+
 def test_net_f16x3_range_flag():
     """A net whose activations leave the f16 range must say so (raz_net_range_check), not return garbage silently."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
@@ -628,6 +681,49 @@ def test_evaluate_worker_batched_match(tmp_path):
     assert decide([0, 0, 1, 0, 1, 1], 6, 0.55) == (False, 4, 0.25)
     assert decide([1, None, 1, 1, 1, 0], 6, 0.55) == (True, 5, 1.0)
     assert decide([None] * 6, 6, 0.55) == (False, 6, 0)
+
+
+def test_evaluate_worker_matches_equal_the_reference_evaluate_games():
+    """tests/golden/eval_games.json: games the UNMODIFIED reference's EvaluateWorker.play_game played (worker/evaluate.py:66-96 - two
+    ReversiPlayers with trees of their own, best model against challenger, colours drawn by evaluate.py:71; generated by
+    tests/golden/make_golden_eval.py) - replayed as batched matches on the device: every game's colour draw, every ply's mover,
+    action (resignations included) and root visit counts, the outcome (ng_win) and the final disc counts are the reference's.  Three
+    matches: evaluate.py as shipped (parallel_search_num 8 on the raz-sched-v1 schedule, root solver from turn 50 by play_config,
+    in-simulation solver from turn 50 by config.play), one simulation in flight with an early resign threshold and no solver, and
+    one whose two config sections DISAGREE where the reference's player reads the global one (virtual_loss,
+    use_solver_turn_in_simulation: agent/player.py:237,264)."""
+    import json
+    import os
+    import hashlib
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.worker.evaluate import EvaluateWorker
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "tests", "golden", "eval_games.json")) as f:
+        gold = json.load(f)
+    nets = []
+    for meta in gold["nets"]:
+        net = ReversiNet(meta["filters"], meta["res_layers"], meta["value_fc"]).keras_init_(meta["keras_init_seed"]).randomize_bn_(meta["randomize_bn_seed"])
+        assert hashlib.sha256(net.to_blob()).hexdigest() == meta["blob_sha256"], "seeded net init is not reproducible"
+        nets.append(net)
+    for m in gold["matches"]:
+        cfg = Config()
+        cfg.eval.play_config.update(m["resolved_play_config"])
+        cfg.play.update(m["resolved_config_play"])     # the section agent/player.py:127,237,264,410 reads whatever play_config says
+        w = EvaluateWorker(cfg, seed=m["seed"], device=DEV)
+        w.games_played = m["first_game_id"]
+        results = w.play_games(nets[0], nets[1], len(m["games"]))
+        for g, (ref, got, res) in enumerate(zip(m["games"], w.last_games, results)):
+            where = (m["name"], ref["game_id"])
+            assert got["game_id"] == ref["game_id"] and got["best_is_black"] == ref["best_is_black"], where
+            assert [(p["who"], p["action"]) for p in got["plies"]] == [(p["who"], p["action"]) for p in ref["plies"]], where
+            for i, (a, b) in enumerate(zip(got["plies"], ref["plies"])):
+                if b["root_n"] is not None:      # (a move the end-game solver decided has no search behind it)
+                    want = [0.0] * 64
+                    for k, v in b["root_n"].items():
+                        want[int(k)] = v
+                    assert [float(x) for x in a["root_n"]] == want, (where, i)
+            assert res[0] == ref["ng_win"] and res[1] == ref["best_is_black"] and list(res[2]) == ref["black_white"], where
 
 
 def test_training_tensors_on_device():

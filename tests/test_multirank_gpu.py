@@ -29,6 +29,9 @@ from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 if world > 1:
     dist.init_process_group("gloo")
+elif os.environ.get("RAZ_TEST_NCCL_WORLD1") == "1":   # the nccl (RCCL) code path on the one GPU there is: a group of one rank
+    os.environ.setdefault("MASTER_PORT", "29557")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
 gold = load_mcts_golden()
 g0 = next(g for g in gold["games"] if g["variant"] == "mini_shared")
 cfg = Config()
@@ -54,19 +57,22 @@ def check():
 w.check_and_update_resignation_threshold = check
 w.run(total_games={total})
 print("THRESHOLD", rank, repr(cfg.play.resign_threshold))
-if world > 1:
+print("GATHER", rank, getattr(w, "last_gather_backend", None), getattr(w, "last_gather_bytes", None))
+if dist.is_initialized():
     dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def _run(tmp_path, tag, world, per_rank, total):
+def _run(tmp_path, tag, world, per_rank, total, nccl_world1=False):
     out = tmp_path / tag
     out.mkdir()
     script = tmp_path / f"{tag}.py"
     script.write_text(_WORKER_SCRIPT.format(root=ROOT, out=str(out), per_rank=per_rank, total=total))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RAZ_TEST_NCCL_WORLD1"):
         env.pop(k, None)
+    if nccl_world1:
+        env["RAZ_TEST_NCCL_WORLD1"] = "1"
     if world == 1:
         cmd = [sys.executable, str(script)]
     else:
@@ -77,6 +83,8 @@ def _run(tmp_path, tag, world, per_rank, total):
     files = sorted(os.listdir(out / "play_data"))
     ggf = sorted(os.listdir(out / "ggf"))
     thr = sorted(line for line in r.stdout.splitlines() if line.startswith("THRESHOLD"))
+    if nccl_world1:
+        assert "GATHER 0 nccl" in r.stdout, r.stdout[-1500:]
     return ([open(out / "play_data" / f).read() for f in files], [open(out / "ggf" / f).read() for f in ggf],
             open(out / ".self-play-game-idx").read(), thr)
 
@@ -96,6 +104,19 @@ def test_two_rank_worker_files_equal_one_rank_files(tmp_path):
     t2 = {l.split()[2] for l in two[3]}
     assert len(two[3]) == 2 and len(t2) == 1 and t1 == t2, (one[3], two[3])
     assert t1 != {repr(-0.3)}, "the threshold never moved: the test does not exercise the broadcast"
+
+
+def test_worker_on_an_nccl_group_of_one_rank_writes_the_same_files(tmp_path):
+    """The nccl (RCCL) branch of the worker on the one GPU a test box has: BatchedSelfPlayWorker.run inside
+    init_process_group("nccl", world_size=1) takes every collective of the N > 1 path - the block-state all_reduce, gather_packed
+    with device tensors straight from HBM (all_reduce of the ply extent, gather), broadcast_object_list of game index and resign
+    threshold, barriers - and must write exactly the files of a run without a process group."""
+    plain = _run(tmp_path, "plain", 1, 12, 24)
+    nccl = _run(tmp_path, "nccl1", 1, 12, 24, nccl_world1=True)
+    import re
+    norm = lambda texts: [re.sub(r"DT\[[^\]]*\]", "DT[]", t) for t in texts]
+    assert len(plain[0]) >= 3 and plain[0] == nccl[0] and norm(plain[1]) == norm(nccl[1]) and plain[2] == nccl[2] == "24"
+    assert plain[3] == nccl[3]
 
 
 def test_pack_records_equals_read_records():

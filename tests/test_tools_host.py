@@ -69,16 +69,45 @@ def test_pmc_summary_tells_the_fused_kernels_from_the_classic_ones():
     assert P.short("(anonymous namespace)::k_conv3x3_f16x3(unsigned char const*, ...)") == "k_conv3x3_f16x3"
 
 
-def test_bench_child_legs_never_cost_the_parent_its_line():
-    """bench.child_leg: the document a child prints, or what went wrong - a child that crashes, prints nothing, or hangs (killed after
-    the timeout) yields an error entry, not an exception and not a hung parent."""
+def test_bench_line_is_compact_and_keeps_the_contract():
+    """bench.compact_line: whatever the legs put into the full document, the printed line stays below 8 KB and carries the contract
+    keys, `roofline`, `cpu_baseline`, every leg's value and every parity result (the driver's record keeps what is in the line)."""
     sys.path.insert(0, ROOT)
-    import time
     import bench
-    assert bench.child_leg(["-c", "print('noise'); print('{\"value\": 3}')"], 30.0) == {"value": 3}
-    assert "exit code 7" in bench.child_leg(["-c", "import sys; sys.exit(7)"], 30.0)["error"]
-    assert "exit code" in bench.child_leg(["-c", "import os; os.abort()"], 30.0)["error"]
-    assert "error" in bench.child_leg(["-c", "print('no json here')"], 30.0)
-    t0 = time.time()
-    assert "did not finish" in bench.child_leg(["-c", "import time; time.sleep(60)"], 1.0)["error"]
-    assert time.time() - t0 < 20
+    blah = "x" * 5000
+    games = [{"game_id": i, "sims": 800, "note": blah} for i in range(8)]
+    full = {"metric": "MCTS simulations/sec (self-play, NN included)", "value": 3.5e5, "unit": "sims/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 25.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 + f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] ...", "games_per_gpu": 8192, "sims_per_move": 800, "net": "ch5", "slices": 1, "junk": blah},
+            "roofline": {"bound": "mfma", "kernel": blah, "kernel_name": "k_conv3x3_f16x3", "achieved": 450.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.18,
+                         "traffic": 2.8e10, "peak_note": blah},
+            "cpu_baseline": {"value": 900.0, "unit": "sims/s", "cores": 256, "kind": "reference", "sample": "20 s window", "detail": blah,
+                             "configs1_mini_200sims": {"value": 28000.0}},
+            "games_per_hour": 27000.0, "leaves_per_sec": 3.0e5,
+            "parity_spotcheck": {"result": "ok", "what": blah, "games": games}, "parity_spotcheck_timed_batch": {"result": "ok", "what": blah, "games": games},
+            "whole_games_measured": {"value": 3.4e5, "unit": "sims/s", "seconds": 120.0, "games_per_hour": 26500.0, "workload": blah,
+                                     "parity_check_complete_games": {"result": "ok", "what": blah, "games": games[:2]}},
+            "ch5_yml_as_shipped": {"value": 3.0e5, "unit": "sims/s", "workload": blah, "same_with_the_solver_off": {"value": 3.1e5},
+                                   "solver_share_of_a_step": {"share_of_step_time": 0.03}},
+            "config1_4096x200_mini": {"value": 1.0e8, "unit": "sims/s", "games_per_hour": 3.0e7, "workload": blah, "fused_tree_net_kernel": True,
+                                      "parity_spotcheck": {"result": "ok", "games": games}},
+            "config5_8192x3200_agz": {"error": "RuntimeError('x')"},
+            "bitboard_sweep": {"k_step": {"achieved": 5000.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.63, "traffic_over_algorithmic": 1.0003, "note": blah},
+                               "k_legal_moves": {"achieved": 5600.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.70},
+                               "beyond_the_infinity_cache_2^26_boards": {"k_step": {"frac": 0.63}, "k_legal_moves": {"frac": 0.71}}},
+            "record_gather": {"collective": "none (1 GPU)", "bytes": 0, "seconds": 0.0}, "_full_path": "gpurun_out/bench_full.json"}
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 8192, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k]
+    assert line["config"]["workload"] == full["config"]["workload"] and "junk" not in line["config"]
+    assert line["roofline"]["frac"] == 0.18 and line["roofline"]["kernel_name"] == "k_conv3x3_f16x3" and "kernel" not in line["roofline"]
+    assert line["cpu_baseline"] == {"value": 900.0, "unit": "sims/s", "cores": 256, "kind": "reference", "sample": "20 s window", "configs1_value": 28000.0}
+    assert line["parity_spotcheck"] == {"result": "ok", "games": 8} and line["whole_games_measured"]["parity"] == {"result": "ok", "games": 2}
+    assert line["whole_games_measured"]["sims_per_s"] == 3.4e5 and line["whole_games_measured"]["games_per_hour"] == 26500.0
+    assert line["ch5_yml_as_shipped"]["solver_share_of_step_time"] == 0.03 and line["ch5_yml_as_shipped"]["solver_off_value"] == 3.1e5
+    assert line["config1_4096x200_mini"]["value"] == 1.0e8 and line["config1_4096x200_mini"]["parity"] == {"result": "ok", "games": 8}
+    assert line["config5_8192x3200_agz"] == {"error": "RuntimeError('x')"} and line["bitboard_sweep"]["k_step"]["frac"] == 0.63
+    assert line["full_document"] == "gpurun_out/bench_full.json"
+

@@ -290,3 +290,49 @@ def test_run_two_ranks_gloo_equals_one_rank(tmp_path):
     assert one[2] == two[2] == "200" and len(one[0]) >= 50
     assert [hashlib.sha256(b).hexdigest() for b in one[0]] == [hashlib.sha256(b).hexdigest() for b in two[0]] and one[1] == two[1]
     assert f"{w.thresholds_seen} {cfg1.play.resign_threshold}" == thr["0"]
+
+
+_FATAL_SCRIPT = r'''
+import os, sys, pathlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch.distributed as dist
+from test_worker_run_host import make_config, make_stub_worker
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = make_config(pathlib.Path({out!r}))
+w = make_stub_worker(cfg, games_in_flight=10, rank=rank, world=world)
+stub_play = type(w).play_batch_raw
+def play(first_game_idx=0, device_records=False):
+    if rank == 1 and first_game_idx >= 20:      # the second block: rank 1's node pools are "full"
+        raise RuntimeError("engine error flags 0x1 (1 node pool full)")
+    return stub_play(w, first_game_idx, device_records)
+w.play_batch_raw = play
+try:
+    w.run(total_games=60)
+    print("RANK", rank, "RETURNED")
+except RuntimeError as ex:
+    print("RANK", rank, "RAISED", str(ex)[:60])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_a_fatal_error_on_one_rank_raises_on_every_rank(tmp_path):
+    """A genuine engine error (not the net's range flag) on ONE rank in the middle of a run: every rank learns of it in the
+    block-state all_reduce and raises - the failing rank its own exception, the other one a RuntimeError naming the event - instead
+    of the healthy rank waiting forever in the record gather (2 ranks over gloo; the whole run must end within the timeout)."""
+    script = tmp_path / "fatal.py"
+    script.write_text(_FATAL_SCRIPT.format(root=ROOT, out=str(tmp_path / "f")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29553", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RANK 1 RAISED engine error flags 0x1" in r.stdout and "RANK 0 RAISED rank 0: another rank failed" in r.stdout, r.stdout[-1500:]
+    # and at world 1 the exception simply propagates
+    w = make_stub_worker(make_config(tmp_path / "one"), games_in_flight=10)
+
+    def boom(first_game_idx=0, device_records=False):
+        raise RuntimeError("engine error flags 0x4 (4 records full)")
+    w.play_batch_raw = boom
+    with pytest.raises(RuntimeError, match="records full"):
+        w.run(total_games=10)
