@@ -1047,6 +1047,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only (every other leg skipped)")
     ap.add_argument("--no-whole-games", action="store_true", help="skip the fixed-window leg on the headline configuration (~2.5 min)")
     ap.add_argument("--window-seconds", type=float, default=120.0, help="length of the fixed window the headline configuration is played for")
+    ap.add_argument("--legs", default=None, help="comma-separated keys: run only these extra legs (e.g. ch5_yml_as_shipped,config1_4096x200_mini)")
     ap.add_argument("--full-out", default=None, help="where the full document goes (default: gpurun_out/bench_full.json if gpurun_out/ exists, else ./bench_full.json)")
     args = ap.parse_args()
 
@@ -1145,7 +1146,10 @@ def main():
                     ("config1_two_kernel_pipeline_parallel_search_num_4", lambda: config1_leg(dev, args, 4, fused=False)[0]),
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
+            only = set(args.legs.split(",")) if args.legs else None
             for key, leg in legs:
+                if only is not None and key not in only:
+                    continue
                 gc.collect()
                 torch.cuda.empty_cache()
                 try:

@@ -115,7 +115,7 @@ int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* ene
 /* raz_net.reserved selects the forward kernels: 0 = the exact-f32 kernels chosen by shape ("raznet-forward-v1": every output
  * one k-ordered fmaf chain, bit-identical to the CPU oracle); 4 (filters % 128 == 0) = "raznet-forward-v2": the 3x3 trunk on
  * the f16 matrix cores with every f32 operand split into two halfs (csrc/raz_net_f16x3.hip: 3 f16 MFMAs per product, f32
- * accumulation, within 1e-5 of the fp32 graph, 16/3 of the f32-MFMA rate); 1, 2: test variants of v1 (same bits); 8: v2 with full tiles only (test variant, same bits as 4).  v2's split activations must
+ * accumulation, within 1e-5 of the fp32 graph, 16/3 of the f32-MFMA rate); 1, 2: test variants of v1 (same bits).  v2's split activations must
  * stay inside the f16 range; *overflowed = 1 reports that some activation since raz_net_load did not (sticky): run the net
  * with reserved = 0 then.  Synchronises `stream`. */
 int raz_net_range_check(const raz_net* net, int* overflowed, raz_stream_t stream);

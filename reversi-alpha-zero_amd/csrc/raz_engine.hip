@@ -38,7 +38,7 @@ namespace {
 // SOLVER = false compiles the end-game solver (and its LDS frames) out: the common case, and the
 // bench configuration.
 template <bool SOLVER>
-__global__ __launch_bounds__(64) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
     __shared__ float lds64[64];
     __shared__ SolverLDS slds_store;

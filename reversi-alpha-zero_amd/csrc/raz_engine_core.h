@@ -469,12 +469,14 @@ __device__ bool memo_find(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_b
     const raz_slot* tab = E.memo + (size_t)g * E.M;
     const uint32_t mask = E.M - 1;
     const uint32_t h = key_hash(own, enemy, 8u + exact);
+    const uint32_t memo_chk = (uint32_t)((((own * 0x9E3779B97F4A7C15ULL) ^ (enemy * 0xC2B2AE3D27D4EB4FULL)) >> 50) & 0x3fffu) | 1u;
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const raz_slot* s = tab + ((h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask);
         const raz_bb sb = s->black, sw = s->white;
         const uint32_t it = s->idx_tag;
         const bool used = (it >> 31) != 0;
-        const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact;
+        const uint32_t chk = (it >> 16) & 0x3fffu;   // 0: stored by the wave-wide memo_put; else 14 bits of the key's hash (memo_put_lane)
+        const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact && (chk == 0 || chk == memo_chk);
         const unsigned long long mm = __ballot(match) & 0xffffULL;
         const unsigned long long em = __ballot(!used) & 0xffffULL;
         if (mm) {
@@ -510,10 +512,11 @@ __device__ void memo_put(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb
     }  // 64 occupied slots in a row: the memo is (locally) full; skipping the insert only costs time
 }
 
-// ReversiSolver.solve for the side to move (own, enemy).  Returns false for the reference's
-// (None, None) (no legal move at the root: never the case for a running game).
-__device__ bool solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                             SolverLDS* S, int& out_move, int& out_score) {
+// ReversiSolver.solve for the side to move (own, enemy), wave-uniform: ONE depth-first search on the scalar unit.  Returns false
+// for the reference's (None, None) (no legal move at the root: never the case for a running game).  Used for the smallest trees
+// (<= RAZ_SOLVER_SCALAR_EMPTIES empties); solver_solve below spreads the larger ones over the wave's lanes.
+__device__ bool solver_solve_scalar(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                    SolverLDS* S, int& out_move, int& out_score) {
     int depth = 0;
     S->own[0] = own0;
     S->enemy[0] = enemy0;
@@ -581,6 +584,288 @@ __device__ bool solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_
             }
         }
     }
+}
+
+// ---- the same function, 64 searches at a time ---------------------------------------------------------------------------------
+// The reference's solver is a pure function f_mode(position) (see above): for the legal moves in ascending order - non-exact: until
+// the best score is > 0 - value = -f(child) / +f(child after a pass) / final disc difference, strict improvement keeps the first
+// maximum.  The scalar search above visits one node at a time and the whole LAUNCH waits for it: with ch5.yml as shipped (solver
+// from turn 50, inside simulations too) 8192 games spent 77 % of a step waiting for one or two waves' searches of 10^5..10^6 nodes
+// (profiles/r4/bench_reduced_1024_games_session5_full.json).  Here the moves of the root and of its children are expanded two
+// plies deep into TASKS (child i, its j-th move: <= 14 x 13), every lane takes tasks off a common counter and runs the reference's
+// depth-first search of its task's subtree by itself - private frames, one node per lane and iteration, every lane executing the
+// same instruction stream on its own position - and the two top plies are then scanned in ascending move order with the same strict
+// improvement and the same early stop.  f is a function of the position, so evaluating siblings side by side (and, in non-exact
+// mode, some the sequential scan would never have reached) changes no result; the memo (shared by all lanes of the game's wave,
+// result-neutral as in the reference) carries transpositions from lane to lane and from solve to solve.
+#define RAZ_SOLVER_SCALAR_EMPTIES 6
+#define RAZ_SOLVER_MAX_DEPTH 14
+// the lanes consult the memo only at nodes with at least this many empties: the 64 searches advance in lockstep, so ONE lane's probe
+// (dependent HBM round trips into the game's 2 MB table) is paid by all of them, and a probe at every node with >= 4 empties as in
+// the scalar search is some lane's probe in 96 % of the iterations - the first version ran a 10-empties exact solve no faster than the
+// scalar search (25 us per iteration; profiles/r4/ch5_as_shipped_8192_games_lane_solver_v1_memo_bound.json).  Subtrees below
+// this size are searched outright (<= 720 leaf paths); transpositions pay where the subtrees are large.
+#define RAZ_SOLVER_LANE_MEMO_EMPTIES 6
+
+// the memo, one lane on its own: the key's home slot and the next one.  Lanes of a wave may store to one slot in the same instruction
+// (their three field stores could then come from different lanes): the tag carries 14 bits of the key's hash, checked on a hit.
+__device__ __forceinline__ uint32_t memo_check_bits(raz_bb own, raz_bb enemy) {
+    const unsigned long long x = (own * 0x9E3779B97F4A7C15ULL) ^ (enemy * 0xC2B2AE3D27D4EB4FULL);
+    return (uint32_t)(x >> 50) & 0x3fffu;
+}
+__device__ bool memo_find_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int& move, int& score) {
+    const raz_slot* tab = E.memo + (size_t)g * E.M;
+    const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
+    for (uint32_t r = 0; r < 2; ++r) {
+        const raz_slot* s = tab + ((h + r) & mask);
+        const uint32_t it = s->idx_tag;
+        if (!(it >> 31)) return false;
+        if (s->black == own && s->white == enemy && ((it >> 30) & 1u) == exact) {
+            const uint32_t chk = (it >> 16) & 0x3fffu;
+            if (chk != 0 && chk != (memo_check_bits(own, enemy) | 1u)) continue;   // (0: written by the wave-wide memo_put, no check bits)
+            move = (int)((it >> 8) & 0xffu) - 1;
+            score = (int)(it & 0xffu) - 128;
+            return true;
+        }
+    }
+    return false;
+}
+__device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int move, int score) {
+    raz_slot* tab = E.memo + (size_t)g * E.M;
+    const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
+    for (uint32_t r = 0; r < 2; ++r) {
+        raz_slot* s = tab + ((h + r) & mask);
+        if (!(s->idx_tag >> 31)) {
+            s->black = own;
+            s->white = enemy;
+            s->idx_tag = 0x80000000u | (exact << 30) | ((memo_check_bits(own, enemy) | 1u) << 16) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
+            return;
+        }
+    }   // both slots occupied: skipping the insert only costs time
+}
+
+// LDS of the lane-parallel solve, overlaid on SolverLDS (704 B): the root's children and the tasks' results
+struct SolverPar {
+    unsigned long long c_own[RAZ_SOLVER_MAX_DEPTH], c_enemy[RAZ_SOLVER_MAX_DEPTH], c_moves[RAZ_SOLVER_MAX_DEPTH];   // child i: position (its mover's view), its moves
+    unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2];   // child i's first task
+    signed char result[RAZ_SOLVER_MAX_DEPTH * RAZ_SOLVER_MAX_DEPTH];   // task t: the value of that move for the child's mover
+};
+static_assert(sizeof(SolverPar) <= sizeof(SolverLDS), "the lane-parallel solver's LDS must fit the frames it replaces");
+
+// (not inlined: three call sites - the root, the descent of k_tree, the descent of k_tree_par - would each carry a copy of the
+//  per-lane 64-bit board arithmetic, and the tree kernels' 128-register budget at 4 waves per SIMD would spill on every path; as a
+//  function it has a register allocation of its own and its frames are scratch memory only while a solve runs)
+__device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                                             SolverLDS* S, int& out_move, int& out_score);
+
+__device__ __forceinline__ bool solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                             SolverLDS* S, int& out_move, int& out_score) {
+    const int empties = bb_popcount(~(own0 | enemy0));
+    if (empties <= RAZ_SOLVER_SCALAR_EMPTIES || empties > RAZ_SOLVER_MAX_DEPTH)
+        return solver_solve_scalar(E, g, lane, own0, enemy0, exact, S, out_move, out_score);
+    return solver_solve_lanes(E, g, lane, own0, enemy0, exact, S, out_move, out_score);
+}
+
+__device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                                             SolverLDS* S, int& out_move, int& out_score) {
+    {
+        int rm, rs;
+        wave_sync();
+        if (memo_find(E, g, own0, enemy0, exact, lane, rm, rs)) {
+            out_move = rm;
+            out_score = rs;
+            return rm >= 0;
+        }
+    }
+    SolverPar* P = (SolverPar*)S;
+    const raz_bb legal0 = bb_legal_moves(own0, enemy0);
+    const int k = bb_popcount(legal0);
+    if (k == 0) return false;
+    // ---- ply 1: lane i < k owns the root's i-th move
+    int my_a = -1, my_kind = 0, my_v = 0, my_tasks = 0;   // kind 0: the game ends there (my_v = disc difference); 1: the opponent moves; 2: the opponent passes; +4: f(child) came from the memo
+    raz_bb c_own = 0, c_enemy = 0, c_moves = 0;
+    if (lane < k) {
+        raz_bb m = legal0;
+        for (int i = 0; i < lane; ++i) m &= m - 1;
+        my_a = __ffsll((long long)m) - 1;
+        const raz_bb flipped = bb_calc_flip(my_a, own0, enemy0);
+        const raz_bb nown = (own0 ^ flipped) | (1ULL << my_a), nenemy = enemy0 ^ flipped;
+        const raz_bb l1 = bb_legal_moves(nenemy, nown);
+        const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+        if (l1 | l2) {
+            my_kind = l1 ? 1 : 2;
+            c_own = l1 ? nenemy : nown;
+            c_enemy = l1 ? nown : nenemy;
+            c_moves = l1 ? l1 : l2;
+            int rm, rs;
+            if (bb_popcount(~(c_own | c_enemy)) >= 4 && memo_find_lane(E, g, c_own, c_enemy, exact, rm, rs)) {
+                my_kind |= 4;
+                my_v = (my_kind & 1) ? -rs : rs;
+            } else
+                my_tasks = bb_popcount(c_moves);
+        } else
+            my_v = bb_popcount(nown) - bb_popcount(nenemy);
+    }
+    int first = 0;   // exclusive prefix sum of my_tasks over the lanes
+    for (int i = 0; i < k; ++i) {
+        const int ti = (int)lane_u32((uint32_t)my_tasks, i);
+        if (i < lane) first += ti;
+    }
+    int total = 0;
+    for (int i = 0; i < k; ++i) total += (int)lane_u32((uint32_t)my_tasks, i);
+    wave_sync();
+    if (lane < k) {
+        P->c_own[lane] = c_own;
+        P->c_enemy[lane] = c_enemy;
+        P->c_moves[lane] = c_moves;
+        P->c_first[lane] = (unsigned char)first;
+    }
+    if (lane == 0) P->c_first[k] = (unsigned char)total;
+    wave_sync();
+    // ---- the tasks: every lane searches subtrees until none is left
+    // the lane's search: the CURRENT node lives in registers, its ancestors' frames in private (scratch) memory indexed by the
+    // lane's own depth - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf.  volatile
+    // keeps the compiler from promoting the arrays to ~100 vector registers with a select chain per access, which would halve the
+    // tree kernels' occupancy for a path that rarely runs.
+    volatile raz_bb st_own[RAZ_SOLVER_MAX_DEPTH], st_enemy[RAZ_SOLVER_MAX_DEPTH], st_left[RAZ_SOLVER_MAX_DEPTH];
+    volatile uint32_t st_meta[RAZ_SOLVER_MAX_DEPTH];   // best move + 1 | (best score + 128) << 8 | (parent action + 1) << 16 | flip << 24
+    raz_bb own = 0, enemy = 0, left = 0;
+    int bmv = -1, bsc = -100, pact = -1, flip = 0, fresh = 0;
+    int next = 0, d = 0, task = -1, task_sign = 1;
+    bool have = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        if (idle && next < total) {
+            const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
+            const int t = next + rank;
+            next += __popcll(idle);
+            if (!have && t < total) {
+                int ci = 0;
+                while (ci + 1 < k && (int)P->c_first[ci + 1] <= t) ++ci;
+                const raz_bb co = P->c_own[ci], ce = P->c_enemy[ci];
+                raz_bb m = P->c_moves[ci];
+                for (int j = (int)P->c_first[ci]; j < t; ++j) m &= m - 1;
+                const int b = __ffsll((long long)m) - 1;
+                const raz_bb flipped = bb_calc_flip(b, co, ce);
+                const raz_bb nown = (co ^ flipped) | (1ULL << b), nenemy = ce ^ flipped;
+                const raz_bb l1 = bb_legal_moves(nenemy, nown);
+                const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+                if (l1 | l2) {
+                    task = t;
+                    task_sign = l1 ? -1 : 1;
+                    d = 0;
+                    own = l1 ? nenemy : nown;
+                    enemy = l1 ? nown : nenemy;
+                    left = l1 ? l1 : l2;
+                    bmv = -1;
+                    bsc = -100;
+                    pact = -1;
+                    flip = 0;
+                    fresh = 1;
+                    have = true;
+                } else
+                    P->result[t] = (signed char)(bb_popcount(nown) - bb_popcount(nenemy));
+            }
+        }
+        if (__ballot(have) == 0ULL) {
+            if (next >= total) break;
+            continue;
+        }
+        if (have) {   // one node of this lane's search: solver_solve_scalar's loop body
+            const bool big = bb_popcount(~(own | enemy)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES;
+            int rm = 0, rs = 0;
+            bool done = false;
+            if (fresh) {
+                fresh = 0;
+                if (big && memo_find_lane(E, g, own, enemy, exact, rm, rs)) done = true;
+            }
+            if (!done && (left == 0 || (!exact && bsc > 0))) {
+                if (big) memo_put_lane(E, g, own, enemy, exact, bmv, bsc);
+                rm = bmv;
+                rs = bsc;
+                done = true;
+            }
+            if (done) {
+                if (d == 0) {
+                    P->result[task] = (signed char)(task_sign * rs);
+                    have = false;
+                } else {   // back to the parent
+                    const int v = flip ? -rs : rs, a = pact;
+                    --d;
+                    own = st_own[d];
+                    enemy = st_enemy[d];
+                    left = st_left[d];
+                    const uint32_t meta = st_meta[d];
+                    bmv = (int)(meta & 0xffu) - 1;
+                    bsc = (int)((meta >> 8) & 0xffu) - 128;
+                    pact = (int)((meta >> 16) & 0xffu) - 1;
+                    flip = (int)((meta >> 24) & 1u);
+                    if (bsc < v) {
+                        bmv = a;
+                        bsc = v;
+                    }
+                }
+            } else {
+                const int a = __ffsll((long long)left) - 1;
+                left &= left - 1;
+                const raz_bb flipped = bb_calc_flip(a, own, enemy);
+                const raz_bb nown = (own ^ flipped) | (1ULL << a), nenemy = enemy ^ flipped;
+                const raz_bb l1 = bb_legal_moves(nenemy, nown);
+                const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+                if (l1 | l2) {   // down a ply
+                    st_own[d] = own;
+                    st_enemy[d] = enemy;
+                    st_left[d] = left;
+                    st_meta[d] = (uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24);
+                    ++d;
+                    own = l1 ? nenemy : nown;
+                    enemy = l1 ? nown : nenemy;
+                    left = l1 ? l1 : l2;
+                    bmv = -1;
+                    bsc = -100;
+                    pact = a;
+                    flip = l1 ? 1 : 0;
+                    fresh = 1;
+                } else {
+                    const int score = bb_popcount(nown) - bb_popcount(nenemy);
+                    if (bsc < score) {
+                        bmv = a;
+                        bsc = score;
+                    }
+                }
+            }
+        }
+    }
+    wave_sync();
+    // ---- ply 1 again: lane i scans its child's moves in ascending order (the reference's loop at that node)
+    if (lane < k && (my_kind & 3) && !(my_kind & 4)) {
+        int bm = -1, bs = -100, t = first;
+        for (raz_bb m = c_moves; m; m &= m - 1, ++t) {
+            const int v = P->result[t];
+            if (bs < v) {
+                bm = __ffsll((long long)m) - 1;
+                bs = v;
+            }
+            if (!exact && bs > 0) break;
+        }
+        if (bb_popcount(~(c_own | c_enemy)) >= 4) memo_put_lane(E, g, c_own, c_enemy, exact, bm, bs);
+        my_v = (my_kind & 1) ? -bs : bs;
+    }
+    // ---- the root
+    int bm = -1, bs = -100;
+    for (int i = 0; i < k; ++i) {
+        const int v = (int)lane_u32((uint32_t)my_v, i), a = (int)lane_u32((uint32_t)my_a, i);
+        if (bs < v) {
+            bm = a;
+            bs = v;
+        }
+        if (!exact && bs > 0) break;
+    }
+    wave_sync();
+    memo_put(E, g, own0, enemy0, exact, bm, bs, lane);
+    out_move = bm;
+    out_score = bs;
+    return bm >= 0;
 }
 
 // ------------------------------------------------------------------ backup of the previous leaf

@@ -35,7 +35,7 @@ size_t raz_net_f16x3_scratch_bytes(int F, size_t n);
 unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V);
 int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                           const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
-                          hipStream_t s, const uint32_t* list, const uint32_t* n_ptr, bool full_tiles_only);
+                          hipStream_t s, const uint32_t* list, const uint32_t* n_ptr);
 int raz_net_forward_mfma(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                          const uint8_t* active, float* policy, float* value, size_t n, hipStream_t s,
                          unsigned long long* prof);
@@ -319,9 +319,9 @@ extern "C" int raz_net_range_check(const raz_net* net, int* overflowed, raz_stre
 int raz_net_forward_compact(const raz_net* net, const uint64_t* own, const uint64_t* enemy, const uint8_t* active, float* policy,
                             float* value, size_t n, void* scratch, size_t scratch_bytes, hipStream_t stream, const uint32_t* list,
                             const uint32_t* n_ptr) {
-    if (n && net && f16x3_supported(net->filters) && (net->reserved == 4 || net->reserved == 8))
+    if (n && net && f16x3_supported(net->filters) && net->reserved == 4)
         return raz_net_forward_f16x3((const float*)net->d_weights, net->filters, net->res_layers, net->value_fc, own, enemy, active,
-                                     policy, value, n, scratch, scratch_bytes, stream, list, n_ptr, net->reserved == 8);
+                                     policy, value, n, scratch, scratch_bytes, stream, list, n_ptr);
     return raz_net_forward(net, own, enemy, active, policy, value, n, scratch, scratch_bytes, (raz_stream_t)stream);
 }
 
@@ -343,11 +343,10 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     }
     // reserved 4: raznet-forward-v2 - the trunk on the f16 matrix cores with split operands (raz_net_f16x3.hip), within 1e-5
     // of the fp32 graph but not bit-identical to the exact-f32 kernels (0 / 5: raznet-forward-v1)
-    // (8: the same with every tile a full tile - the test variant the half-tile last round is compared with, bit for bit)
-    if (f16x3_supported(F) && (net->reserved == 4 || net->reserved == 8))
+    if (f16x3_supported(F) && net->reserved == 4)
         return raz_net_forward_f16x3((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy, value, n,
-                                     scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr, net->reserved == 8);
-    if (net->reserved == 4 || net->reserved == 8) return raz_fail(RAZ_EINVAL, "raz_net_forward: the f16x3 kernel needs filters % 128 == 0");
+                                     scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr);
+    if (net->reserved == 4) return raz_fail(RAZ_EINVAL, "raz_net_forward: the f16x3 kernel needs filters % 128 == 0");
     if (wide_supported(F) && net->reserved != 1)
         return raz_net_forward_wide((const float*)net->d_weights, F, net->res_layers, V, own, enemy, active, policy,
                                     value, n, scratch, scratch_bytes, (hipStream_t)stream);

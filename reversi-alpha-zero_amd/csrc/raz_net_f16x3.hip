@@ -104,28 +104,10 @@ constexpr int Z_OFF = NWAVE * ACT_POS;           // the zero rows inside an imag
 // Pipeline: stage s+1 (the next tap group's weights, and with the first tap group of a chunk that chunk's activations) is
 // in flight as LDS-DMA into the other buffer while stage s is computed; ONE barrier per stage (it also drains this wave's
 // share of the DMA issued a whole stage earlier).
-//
-// THE LAST ROUND OF TILES.  A layer is ceil(n / 8) x F / 128 tiles for 256 CUs, one tile per CU at a time: 8 rounds at n = 8192, but
-// at the ~7,500 rows the evaluation cache leaves of a step, 7.33 - the 8th round runs on a third of the chip and the layer takes
-// as long as at 8192 (measured: 7168 -> 7501 positions +10 % time, profiles/r4/conv_f16x3_probe_session1.jsonl).  So the tiles are
-// taken in CHUNKS of 16 (8 position groups x both channel tiles, the unit of the XCD-aware numbering), 16 chunks = one round; when
-// the chunks left over after the whole rounds number 1..8 they are run as HALF tiles instead - MT = 2: 64 output channels per
-// workgroup, each wave 2 x 2 instead of 4 x 2 MFMA tiles, half the matrix instructions and half the weight bytes per stage - by a
-// second launch of up to 256 workgroups: a half-length last round.  Which launch takes a tile is decided on the device from the row
-// count (it lives there for compacted batches); every output element is the same instruction sequence either way (bit-identical).
-__device__ inline int f16x3_whole_round_chunks(int n, int noct, bool full_tiles_only) {   // chunks the full-tile launch takes; the rest go to the half-tile launch
-    const int chunks = ((n + NWAVE - 1) / NWAVE + 7) / 8;
-    if (full_tiles_only) return chunks;
-    const int per_round = 256 / (8 * noct);
-    const int tail = chunks % per_round;
-    return (tail >= 1 && tail * noct * 8 * 2 <= 256) ? chunks - tail : chunks;
-}
-
-template <int MT>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* __restrict__ Wl, const float* __restrict__ bias,
                                                           const float* __restrict__ inv_scale_ptr, const unsigned char* in, unsigned char* out,
                                                           const unsigned char* skip, const uint8_t* __restrict__ active, int n, int F,
-                                                          unsigned* __restrict__ flag, const uint32_t* __restrict__ n_ptr, int full_tiles_only RAZ_STAMP_PARAM) {
+                                                          unsigned* __restrict__ flag, const uint32_t* __restrict__ n_ptr RAZ_STAMP_PARAM) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     RAZ_STAMP_BEGIN;
@@ -134,18 +116,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
     // blocks b and b + 8 run on the same XCD (round-robin dispatch): give them the oc tiles of the SAME positions, so the
     // later one finds the activations in that XCD's L2
     const int b = blockIdx.x;
-    const int whole = f16x3_whole_round_chunks(n, noct, full_tiles_only != 0);
-    int ot, pg, half = 0;
-    if (MT == 4) {
-        if (b >= whole * 8 * noct) return;   // a left-over chunk: the half-tile launch has it
-        ot = (b >> 3) % noct;
-        pg = (b / (8 * noct)) * 8 + (b & 7);
-    } else {   // 4 noct workgroups per position group: (channel tile, half) - all on one XCD, like the two of the full-tile numbering
-        const int q = (b >> 3) % (2 * noct);
-        ot = q >> 1;
-        half = q & 1;
-        pg = (whole + b / (16 * noct)) * 8 + (b & 7);
-    }
+    const int ot = (b >> 3) % noct;
+    const int pg = (b / (8 * noct)) * 8 + (b & 7);
     const int p0 = pg * NWAVE, pos = p0 + wv;
     if (p0 >= n) return;
     const bool live = pos < n && (!active || active[pos]);
@@ -169,10 +141,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
             boff[nt][t] = ok ? (uint32_t)(wv * ACT_POS + kg * 2048 + s2 * 16) : (uint32_t)(Z_OFF + (s2 & 15) * 16);
         }
     }
-    const uint32_t aoff = (uint32_t)(kg * 4096 + (half * 2 * 32 + (lane & 31)) * 16);   // + tap*8192 + hl*2048 + mtile*512 inside a weight stage
-    f32x16 acc[MT][2];
+    const uint32_t aoff = (uint32_t)(kg * 4096 + (lane & 31) * 16);   // + tap*8192 + hl*2048 + mtile*512 inside a weight stage
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -185,13 +157,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
         const int st = c * 3 + tg;
         const unsigned char* src = wsrc + (size_t)st * W_STAGE;
         unsigned char* dst = lds + LDS_W + (st & 1) * W_STAGE;
-        if (MT == 4) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) GLDS16(src + (wv * 3 + i) * 1024, dst + (wv * 3 + i) * 1024);
-        } else {   // only this half's 64 channels: 12 pieces of 1 KiB, one per (tap, k-group, hi / lo) plane - waves 0..3 move two
-            GLDS16(src + wv * 2048 + half * 1024, dst + wv * 2048 + half * 1024);
-            if (wv < 4) GLDS16(src + (wv + 8) * 2048 + half * 1024, dst + (wv + 8) * 2048 + half * 1024);
-        }
+        for (int i = 0; i < 3; ++i) GLDS16(src + (wv * 3 + i) * 1024, dst + (wv * 3 + i) * 1024);
         if (tg == 0) {
             const unsigned char* a = asrc + (size_t)c * ACT_POS;
             unsigned char* ad = lds + LDS_ACT + (c & 1) * ACT_IMG + wv * ACT_POS;
@@ -221,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
                     bl[nt] = *(const h8*)(lds + abase + boff[nt][t] + 1024);
                 }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
+                for (int m = 0; m < 4; ++m) {
                     const h8 ah = *(const h8*)(lds + wbase + tt * 8192 + m * 512);
                     const h8 al = *(const h8*)(lds + wbase + tt * 8192 + m * 512 + 2048);
 #pragma unroll
@@ -242,10 +209,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
     const unsigned char* skip_pos = skip ? skip + (size_t)pos * pos_bytes : nullptr;
     bool over = false;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int oc8 = ot * OCT + (half * 2 + m) * 32 + q * 8;   // this lane pair's 8-channel group; this lane holds 4 of them
+            const int oc8 = ot * OCT + m * 32 + q * 8;   // this lane pair's 8-channel group; this lane holds 4 of them
             const f32x4 bv = *(const f32x4*)(bias + oc8 + 4 * kg);
             const size_t unit = (size_t)(oc8 >> 4) * ACT_POS + (size_t)((oc8 >> 3) & 1) * 2048;
 #pragma unroll
@@ -450,22 +417,20 @@ unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V) { return (unsi
 // densely in the activation buffers - *n_ptr lives on the device, so every launch keeps its full grid and surplus blocks exit.
 int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy,
                           const uint8_t* active, float* policy, float* value, size_t n, void* scratch, size_t scratch_bytes,
-                          hipStream_t s, const uint32_t* list, const uint32_t* n_ptr, bool full_tiles_only) {
+                          hipStream_t s, const uint32_t* list, const uint32_t* n_ptr) {
     if (!scratch || scratch_bytes < raz_net_f16x3_scratch_bytes(F, n))
         return raz_fail(RAZ_ENOMEM, "raz_net_forward: scratch too small (raz_net_scratch_bytes)");
     unsigned char* bufA = (unsigned char*)scratch;
     unsigned char* bufT = bufA + (size_t)n * F * 256;
     unsigned* flag = raz_net_f16x3_flag(W, F, R, V);
     const float* scales = W + f16x3_scale_off(F, R, V);
-    const auto conv = k_conv3x3_f16x3<4>;
-    const auto conv_half = k_conv3x3_f16x3<2>;
+    const auto conv = k_conv3x3_f16x3;
     {   // the kernel's LDS image exceeds the default dynamic limit: raise it once per device
         static unsigned long long attr_devices = 0;   // bit d = done on device d (one process drives one device; a second one still gets its call)
         int dev = 0;
         RAZ_HIP_TRY(hipGetDevice(&dev), "raz_net_forward: hipGetDevice");
         if (dev >= 64 || !(attr_devices >> dev & 1)) {
             RAZ_HIP_TRY(hipFuncSetAttribute((const void*)conv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "raz_net_forward: hipFuncSetAttribute");
-            RAZ_HIP_TRY(hipFuncSetAttribute((const void*)conv_half, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "raz_net_forward: hipFuncSetAttribute");
             if (dev < 64) attr_devices |= 1ull << dev;
         }
     }
@@ -473,25 +438,16 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
     hipLaunchKernelGGL(k_conv0_split, dim3((unsigned)n), dim3(256), 0, s, W + conv_off(F, 0), (const raz_bb*)own,
                        (const raz_bb*)enemy, active, bufA, (int)n, F, flag, list, n_ptr);
     const unsigned groups = (unsigned)((n + NWAVE - 1) / NWAVE);
-    const unsigned noct = (unsigned)(F / 128), chunks = (groups + 7) / 8;
-    // the full-tile launch covers every chunk (a block whose chunk went to the half-tile launch exits at once); the half-tile launch
-    // is sized for the largest tail it can be given - with the row count on the device (n_ptr) that is 256 workgroups whatever n
-    // is, else exactly the tail of n (none: no launch)
-    const unsigned grid = chunks * 8 * noct;
-    const unsigned per_round = 256 / (8 * noct), tail = chunks % per_round;
-    const unsigned grid_half = full_tiles_only ? 0u : n_ptr ? 256u : ((tail >= 1 && tail * noct * 16 <= 256) ? tail * noct * 16 : 0u);
-    auto layer = [&](int l, const unsigned char* in, unsigned char* out, const unsigned char* skip) {
-        const unsigned char* Wl = (const unsigned char*)(W + f16x3_layer_off(F, R, V, l));
-        const float* bias = W + conv_off(F, l) + (size_t)F * 9 * F;
-        hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s, Wl, bias, scales + (l - 1), in, out, skip, list ? nullptr : active, (int)n, F,
-                           flag, n_ptr, (int)full_tiles_only RAZ_STAMP_ARG);
-        if (grid_half)
-            hipLaunchKernelGGL(conv_half, dim3(grid_half), dim3(conv_threads), LDS_BYTES, s, Wl, bias, scales + (l - 1), in, out, skip,
-                               list ? nullptr : active, (int)n, F, flag, n_ptr, 0 RAZ_STAMP_ARG);
-    };
+    const unsigned tiles = ((groups + 7) / 8) * 8 * (unsigned)(F / 128);
+    const unsigned grid = tiles;
     for (int r = 0; r < R; ++r) {
-        layer(1 + 2 * r, bufA, bufT, nullptr);
-        layer(2 + 2 * r, bufT, bufA, bufA);
+        const int l1 = 1 + 2 * r, l2 = 2 + 2 * r;
+        hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
+                           (const unsigned char*)(W + f16x3_layer_off(F, R, V, l1)), W + conv_off(F, l1) + (size_t)F * 9 * F,
+                           scales + (l1 - 1), (const unsigned char*)bufA, bufT, (const unsigned char*)nullptr, list ? nullptr : active, (int)n, F, flag, n_ptr RAZ_STAMP_ARG);
+        hipLaunchKernelGGL(conv, dim3(grid), dim3(conv_threads), LDS_BYTES, s,
+                           (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
+                           scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr RAZ_STAMP_ARG);
     }
     return raz_net_heads_split(W, F, R, V, bufA, active, policy, value, n, s, list, n_ptr);
 }

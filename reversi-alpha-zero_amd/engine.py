@@ -35,8 +35,7 @@ class DeviceNet:
         """kernel: None / "f32" = the exact-f32 kernels chosen by shape (raznet-forward-v1, bit-identical to the CPU oracle);
         "f16x3" = raznet-forward-v2 for filters % 128 == 0: the 3x3 trunk on the f16 matrix cores with split operands, within
         1e-5 of the fp32 graph (include/raz.h raz_net_range_check); "auto" = "f16x3" where supported, else "f32".
-        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position; "f16x3_full_tiles" = v2 without the
-        half-tile last round (same bits)."""
+        Test variants: "valu" = k_net_wave; "mfma_wave" = one single-wave workgroup per position."""
         import torch
         import struct
         magic, ver, F, R, V = struct.unpack_from("<5i", blob, 0)
@@ -51,7 +50,7 @@ class DeviceNet:
         if kernel == "auto":
             kernel = "f16x3" if (F >= 128 and F % 128 == 0) else "f32"
         self.kernel_name = {None: "f32", "f32": "f32", "f16x3": "f16x3 split-operand MFMA trunk"}.get(kernel, kernel)
-        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4, "f16x3_full_tiles": 8}[kernel]
+        self.c.reserved = {None: 0, "f32": 0, "valu": 1, "mfma_wave": 2, "f16x3": 4}[kernel]
         with torch.cuda.device(self.device):
             check(lib.raz_net_load(ctypes.byref(self.c), blob, len(blob), self._weights.data_ptr(), nbytes,
                                    _stream()), "raz_net_load")

@@ -292,3 +292,40 @@ def test_emulated_eval_matches_equal_the_reference_evaluate_games():
             env = envs[g]
             ng_win = None if env.winner not in (Winner.black, Winner.white) else int((env.winner == Winner.black) != best_is_black[g])
             assert ng_win == ref["ng_win"] and list(env.observation.number_of_black_and_white) == ref["black_white"], where
+
+
+def test_emulated_device_solver_equals_compiled_cython():
+    """tests/golden/solver_kat.json (answers of the reference's COMPILED Cython solver: its three known answers and 120 late-game
+    positions) through the device solver on the emulator, exact mode at the root (agent/player.py:100-103,150-161): positions of
+    7..14 empties run the lane-parallel search (csrc/raz_engine_core.h solver_solve: the root's moves and their replies expanded into
+    tasks, one reference-shaped depth-first search per lane), smaller ones the scalar one; move and sign(score) must be the Cython
+    solver's.  (GPU form: tests/test_oracle_solver.py.)"""
+    import json
+    import os
+    import types
+    from conftest import ROOT
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    with open(os.path.join(ROOT, "tests", "golden", "solver_kat.json")) as f:
+        kat = json.load(f)
+    play = types.SimpleNamespace(
+        simulation_num_per_move=8, share_mtcs_info_in_self_play=True, thinking_loop=1, required_visit_to_decide_action=40,
+        start_rethinking_turn=10, c_puct=5, noise_eps=0.25, dirichlet_alpha=0.5, change_tau_turn=10, virtual_loss=3,
+        parallel_search_num=1, resign_threshold=None, allowed_resign_turn=10, disable_resignation_rate=0.0,
+        use_solver_turn=46, use_solver_turn_in_simulation=46)
+    cfg = types.SimpleNamespace(play=play, play_data=types.SimpleNamespace(save_policy_of_tau_1=True))
+    cases = [(int(k["black"], 16), int(k["white"], 16), k["next_player"], k["answer"] if k["exactly"] else k["answer_other_mode"]) for k in kat["kat"]]
+    cases += [(int(p["black"], 16), int(p["white"], 16), p["next_player"], p["exact"]) for p in kat["positions"]]
+    cases = [c for c in cases if bin(c[0] | c[1]).count("1") - 4 >= 46]
+    empties = sorted({64 - bin(c[0] | c[1]).count("1") for c in cases})
+    assert len(cases) >= 100 and empties[0] <= 6 and empties[-1] >= 10, empties     # both searches are exercised
+    eng = EmuEngine(cfg, ReversiNet(16, 1, 16).keras_init_(0).to_blob(), len(cases), seed=3, sims_hint=8)
+    eng.start(0, 8)
+    for g, (b, w, pl, _) in enumerate(cases):
+        eng.set_position(g, b, w, pl, 8, enable_resign=False, one_move=True)
+    eng.step(4)
+    eng.stats()
+    raw = eng.read_raw()
+    for g, (b, w, pl, (move, score)) in enumerate(cases):
+        h = raw["headers"][g, 0]
+        assert int(raw["n_plies"][g]) == 1 and int(h["flags"]) & 1, (g, "not solved")
+        assert int(h["action"]) == move and float(h["n"]) == 999.0 and float(h["q"]) == float(np.sign(score)), (g, int(h["action"]), move, float(h["q"]), score)

@@ -105,9 +105,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dP, (size_t)nmax * F * 256));
     CK(hipFuncSetAttribute((const void*)k_conv3x3_wino, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #else
-    CK(hipFuncSetAttribute((const void*)k_conv3x3_f16x3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)k_conv3x3_f16x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int tail_mode = 1;   // 1: the product's half-tile last round; 0: full tiles only
+    CK(hipFuncSetAttribute((const void*)k_conv3x3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #endif
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -123,12 +121,8 @@ int main(int argc, char** argv) {
                            (const uint8_t*)nullptr, n, F, dflag, (const uint32_t*)nullptr);
         (void)st;
 #else
-        hipLaunchKernelGGL(k_conv3x3_f16x3<4>, dim3(tiles), dim3(NWAVE * 64), LDS_BYTES, s, W, dbias, dscale, in, dB, (const unsigned char*)nullptr,
-                           (const uint8_t*)nullptr, n, F, dflag, (const uint32_t*)nullptr, tail_mode ? 0 : 1, st);
-        const unsigned chunks = (groups + 7) / 8, tail = chunks % 16;
-        if (tail_mode && tail >= 1 && tail <= 8)
-            hipLaunchKernelGGL(k_conv3x3_f16x3<2>, dim3(tail * 32), dim3(NWAVE * 64), LDS_BYTES, s, W, dbias, dscale, in, dB, (const unsigned char*)nullptr,
-                               (const uint8_t*)nullptr, n, F, dflag, (const uint32_t*)nullptr, 0, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_conv3x3_f16x3, dim3(tiles), dim3(NWAVE * 64), LDS_BYTES, s, W, dbias, dscale, in, dB, (const unsigned char*)nullptr,
+                           (const uint8_t*)nullptr, n, F, dflag, (const uint32_t*)nullptr, st);
 #endif
     };
     auto timeit = [&](const unsigned char* W, const unsigned char* in, int n) {
@@ -146,12 +140,6 @@ int main(int argc, char** argv) {
         const int ns[] = {8192, 7680, 7501, 7168, 6144, 4096, 2048, 1024};
         for (int n : ns) {
             const float r = timeit(dW, dA, n), z = timeit(dWz, dAz, n), r2 = timeit(dW, dA, n);
-#ifndef PROBE_WINO
-            tail_mode = 0;
-            const float rf = timeit(dW, dA, n);
-            tail_mode = 1;
-            printf("{\"experiment\": \"last_round\", \"positions\": %d, \"ms_with_half_tile_last_round\": %.4f, \"ms_full_tiles_only\": %.4f}\n", n, r2, rf);
-#endif
             const double flop = 2.0 * n * 64.0 * F * F * 9;
             printf("{\"experiment\": \"time\", \"positions\": %d, \"tiles\": %u, \"tile_rounds_over_256_cus\": %.3f, \"ms_random\": %.4f, \"ms_random_again\": %.4f, "
                    "\"ms_zero_operands\": %.4f, \"algorithmic_tflops_random\": %.1f, \"executed_f16_tflops_random\": %.1f, \"zero_over_random_speedup\": %.3f}\n",

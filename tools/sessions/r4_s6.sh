@@ -1,0 +1,8 @@
+#!/bin/bash
+# Round 4, GPU session 6: the lane-parallel end-game solver and the half-tile last round on hardware.
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=$PWD/gpurun_out/r4_s6; mkdir -p $O
+timeout 100 tools/probe_conv time 20 > $O/probe_conv_last_round.jsonl 2>&1; grep last_round $O/probe_conv_last_round.jsonl
+timeout 900 python -m pytest tests/test_oracle_solver.py tests/test_engine_gpu.py -x -q -m gpu -k "device_solver or with_solver or evaluate_worker or f16x3" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
+timeout 600 python bench.py --steps 8 --warmup 3 --no-whole-games --no-cpu-baseline --no-spotcheck --legs ch5_yml_as_shipped --full-out $O/bench_as_shipped_full.json > $O/bench_as_shipped.json 2> $O/bench_as_shipped.err; echo "bench rc=$?"; python3 -c "
+import json; d=json.load(open('$O/bench_as_shipped_full.json')); print(json.dumps({k: d[k] for k in ('value','ms_per_step')})); print(json.dumps(d.get('ch5_yml_as_shipped'))[:1500])"; tail -3 $O/bench_as_shipped.err
