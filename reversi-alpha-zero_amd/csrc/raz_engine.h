@@ -47,6 +47,9 @@
 #define RAZ_SIM_WAIT_NET 1     // its leaf is in the prediction queue (expand_and_evaluate awaits the future)
 #define RAZ_SIM_WAIT_EXPAND 2  // sleeping on now_expanding at node sim_parked
 
+// per-game workspace of the lane-parallel end-game solver (raz_engine_core.h solver_solve_lanes): a 1 KiB header + state block,
+// 4 KiB of per-lane state, 14 levels x 64 lanes x 32 B of frames
+#define RAZ_SOLVER_WS_BYTES (1024 + 4096 + 14 * 64 * 32)
 #define RAZ_PHASE_NEW_MOVE 0
 #define RAZ_PHASE_SEARCH 1
 #define RAZ_PHASE_DONE 2
@@ -167,6 +170,7 @@ struct raz_engine_dev {
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games, [6] idle or finished slots
     raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
     uint32_t M;
+    unsigned char* solver_ws;      // [B][RAZ_SOLVER_WS_BYTES] the lane-parallel solver's frames and, while a root solve is suspended, its state
     unsigned char* node_out;       // RAZ_NODE_OUT_BYTES + 64: staging of raz_engine_read_node
     uint32_t* gc_remap;            // [B][C] creation index -> link after compaction, during k_gc
     unsigned long long* counters;

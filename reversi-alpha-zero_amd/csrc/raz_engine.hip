@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     R.val = E.nn_value[g];
     R.nn = 0u;
     R.path_dirty = 0u;
+    R.solve_pending = 0u;
     path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int guard = 0; guard < 8; ++guard) {
             phase = G32(R, GW(phase));
             if (phase == RAZ_PHASE_NEW_MOVE) {
+                if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
                 begin_move<SOLVER>(E, R, g, lane, slds_p);
                 continue;
             }
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     R.val = 0.0f;
     R.nn = 0u;
     R.path_dirty = 0u;
+    R.solve_pending = 0u;
     Slots T;
     T.st = T.sq = T.pk = 0u;
     uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int guard = 0; guard < 8; ++guard) {
                 const uint32_t phase = G32(R, GW(phase));
                 if (phase == RAZ_PHASE_NEW_MOVE) {
+                    if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
                     begin_move<SOLVER>(E, R, g, lane, slds_p);
                     continue;
                 }
@@ -590,6 +594,7 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.rec_w = cfg.record_root_w ? (double*)take(B * MP * 64 * 8) : nullptr;
     d.M = cfg.solver_memo_slots;
     d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
+    d.solver_ws = cfg.solver_memo_slots ? take(B * (size_t)RAZ_SOLVER_WS_BYTES) : nullptr;
     d.gc_remap = (uint32_t*)take(B * C * 4);
     d.counters = (unsigned long long*)take(32 * 8);
     d.node_out = take(RAZ_NODE_OUT_BYTES + 64);
@@ -860,6 +865,7 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipStreamSynchronize(s), "raz_engine_start: sync");  // host array may be transient
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_start: clear solver memo");
+    if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.solver_ws, 0, (size_t)d.B * RAZ_SOLVER_WS_BYTES, s), "raz_engine_start: clear solver state");
     RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 256, s), "raz_engine_start: clear counters");
     if (d.par) {
         RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_start: clear simulation slots");

@@ -244,6 +244,7 @@ struct Regs {
     float pol_raw, val;             // the net's policy row (lane = square of the TRANSFORMED board) and value
     uint32_t nn;                    // this launch produced a leaf for the net
     uint32_t path_dirty;
+    uint32_t solve_pending;         // begin_move's end-game solve is suspended until the next launch (the phase stays NEW_MOVE)
 };
 __device__ __forceinline__ uint32_t G32(const Regs& R, int i) { return (uint32_t)__builtin_amdgcn_readlane(R.cw, i); }
 __device__ __forceinline__ raz_bb G64(const Regs& R, int i) {  // (the builtin returns int: widen through uint32_t)
@@ -654,87 +655,158 @@ static_assert(sizeof(SolverPar) <= sizeof(SolverLDS), "the lane-parallel solver'
 
 // (not inlined: three call sites - the root, the descent of k_tree, the descent of k_tree_par - would each carry a copy of the
 //  per-lane 64-bit board arithmetic, and the tree kernels' 128-register budget at 4 waves per SIMD would spill on every path; as a
-//  function it has a register allocation of its own and its frames are scratch memory only while a solve runs)
-__device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                                             SolverLDS* S, int& out_move, int& out_score);
+//  function it has a register allocation of its own)
+//
+// BUDGET.  An exact solve of a 10-empties root is 10^6 nodes - 140 ms on the device even with 64 lanes at work (profiles/r4/
+// device_solver_exact_root_solve_times.json), and a launch ends when its slowest wave does: with ch5.yml as shipped about one game
+// per step reaches use_solver_turn, so EVERY step of the 8192-game batch waited for such a solve (tree kernel 283 ms of a 446 ms
+// step).  The root's solve therefore runs for at most `budget` iterations per launch: when they are used up the wave parks the
+// search in the game's workspace (E.solver_ws: the frames live there anyway; the lanes' registers, the task counter and the LDS
+// block are added) and returns RAZ_SOLVE_PENDING; begin_move leaves the game in NEW_MOVE and the next launch picks the search up
+// where it stopped.  f is a function of the position, so when the answer arrives changes nothing but the game's wall time.  Solves
+// inside simulations (non-exact, 100x smaller) run to completion: budget 0.
+#define RAZ_SOLVE_NONE 0
+#define RAZ_SOLVE_DONE 1
+#define RAZ_SOLVE_PENDING 2
+#ifndef RAZ_SOLVER_ROOT_BUDGET
+#define RAZ_SOLVER_ROOT_BUDGET 384
+#endif
+__device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                                            SolverLDS* S, int budget, int& out_move, int& out_score);
 
-__device__ __forceinline__ bool solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                             SolverLDS* S, int& out_move, int& out_score) {
+__device__ __forceinline__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                            SolverLDS* S, int budget, int& out_move, int& out_score) {
     const int empties = bb_popcount(~(own0 | enemy0));
     if (empties <= RAZ_SOLVER_SCALAR_EMPTIES || empties > RAZ_SOLVER_MAX_DEPTH)
-        return solver_solve_scalar(E, g, lane, own0, enemy0, exact, S, out_move, out_score);
-    return solver_solve_lanes(E, g, lane, own0, enemy0, exact, S, out_move, out_score);
+        return solver_solve_scalar(E, g, lane, own0, enemy0, exact, S, out_move, out_score) ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
+    return solver_solve_lanes(E, g, lane, own0, enemy0, exact, S, budget, out_move, out_score);
 }
 
-__device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                                             SolverLDS* S, int& out_move, int& out_score) {
+__device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                                                            SolverLDS* S, int budget, int& out_move, int& out_score) {
     {
         int rm, rs;
         wave_sync();
         if (memo_find(E, g, own0, enemy0, exact, lane, rm, rs)) {
             out_move = rm;
             out_score = rs;
-            return rm >= 0;
+            return rm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
         }
     }
     SolverPar* P = (SolverPar*)S;
-    const raz_bb legal0 = bb_legal_moves(own0, enemy0);
-    const int k = bb_popcount(legal0);
-    if (k == 0) return false;
-    // ---- ply 1: lane i < k owns the root's i-th move
-    int my_a = -1, my_kind = 0, my_v = 0, my_tasks = 0;   // kind 0: the game ends there (my_v = disc difference); 1: the opponent moves; 2: the opponent passes; +4: f(child) came from the memo
+    // the game's workspace: [0, 256) header words, [256, 1024) the LDS block of a parked search, [1024, 5120) eight arrays of 64 lane
+    // words, then the frames [level][lane] x 32 B
+    unsigned long long* hdr = (unsigned long long*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES);
+    unsigned long long* lw = hdr + 128;                    // lane words: lw[field * 64 + lane]
+    unsigned long long* fr = hdr + 640 + (size_t)lane * 4;   // this lane's frame at level d: fr[d * 256 + {0 own, 1 enemy, 2 left, 3 meta}]
+    int my_a = -1, my_kind = 0, my_v = 0, my_tasks = 0, first = 0, total = 0, k = 0;
     raz_bb c_own = 0, c_enemy = 0, c_moves = 0;
-    if (lane < k) {
-        raz_bb m = legal0;
-        for (int i = 0; i < lane; ++i) m &= m - 1;
-        my_a = __ffsll((long long)m) - 1;
-        const raz_bb flipped = bb_calc_flip(my_a, own0, enemy0);
-        const raz_bb nown = (own0 ^ flipped) | (1ULL << my_a), nenemy = enemy0 ^ flipped;
-        const raz_bb l1 = bb_legal_moves(nenemy, nown);
-        const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
-        if (l1 | l2) {
-            my_kind = l1 ? 1 : 2;
-            c_own = l1 ? nenemy : nown;
-            c_enemy = l1 ? nown : nenemy;
-            c_moves = l1 ? l1 : l2;
-            int rm, rs;
-            if (bb_popcount(~(c_own | c_enemy)) >= 4 && memo_find_lane(E, g, c_own, c_enemy, exact, rm, rs)) {
-                my_kind |= 4;
-                my_v = (my_kind & 1) ? -rs : rs;
-            } else
-                my_tasks = bb_popcount(c_moves);
-        } else
-            my_v = bb_popcount(nown) - bb_popcount(nenemy);
-    }
-    int first = 0;   // exclusive prefix sum of my_tasks over the lanes
-    for (int i = 0; i < k; ++i) {
-        const int ti = (int)lane_u32((uint32_t)my_tasks, i);
-        if (i < lane) first += ti;
-    }
-    int total = 0;
-    for (int i = 0; i < k; ++i) total += (int)lane_u32((uint32_t)my_tasks, i);
-    wave_sync();
-    if (lane < k) {
-        P->c_own[lane] = c_own;
-        P->c_enemy[lane] = c_enemy;
-        P->c_moves[lane] = c_moves;
-        P->c_first[lane] = (unsigned char)first;
-    }
-    if (lane == 0) P->c_first[k] = (unsigned char)total;
-    wave_sync();
-    // ---- the tasks: every lane searches subtrees until none is left
-    // the lane's search: the CURRENT node lives in registers, its ancestors' frames in private (scratch) memory indexed by the
-    // lane's own depth - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf.  volatile
-    // keeps the compiler from promoting the arrays to ~100 vector registers with a select chain per access, which would halve the
-    // tree kernels' occupancy for a path that rarely runs.
-    volatile raz_bb st_own[RAZ_SOLVER_MAX_DEPTH], st_enemy[RAZ_SOLVER_MAX_DEPTH], st_left[RAZ_SOLVER_MAX_DEPTH];
-    volatile uint32_t st_meta[RAZ_SOLVER_MAX_DEPTH];   // best move + 1 | (best score + 128) << 8 | (parent action + 1) << 16 | flip << 24
     raz_bb own = 0, enemy = 0, left = 0;
     int bmv = -1, bsc = -100, pact = -1, flip = 0, fresh = 0;
     int next = 0, d = 0, task = -1, task_sign = 1;
     bool have = false;
-    for (;;) {
-        const unsigned long long idle = __ballot(!have);
+    const bool parked = uni((uint32_t)(hdr[0] == 0x5AULL && hdr[1] == own0 && hdr[2] == enemy0 && hdr[3] == (unsigned long long)exact)) != 0;
+    if (parked) {   // pick the search up where the last launch left it
+        k = (int)uni((uint32_t)hdr[4]);
+        total = (int)uni((uint32_t)hdr[5]);
+        next = (int)uni((uint32_t)hdr[6]);
+        for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) ((unsigned long long*)P)[i] = hdr[32 + i];
+        own = lw[0 * 64 + lane];
+        enemy = lw[1 * 64 + lane];
+        left = lw[2 * 64 + lane];
+        const unsigned long long m1 = lw[3 * 64 + lane], m2 = lw[7 * 64 + lane];
+        have = (m1 & 1ULL) != 0;
+        fresh = (int)((m1 >> 1) & 1ULL);
+        flip = (int)((m1 >> 2) & 1ULL);
+        task_sign = ((m1 >> 3) & 1ULL) ? -1 : 1;
+        d = (int)((m1 >> 8) & 0xffULL);
+        bmv = (int)((m1 >> 16) & 0xffULL) - 1;
+        bsc = (int)((m1 >> 24) & 0xffULL) - 128;
+        pact = (int)((m1 >> 32) & 0xffULL) - 1;
+        task = (int)((m1 >> 40) & 0xffffULL) - 1;
+        c_own = lw[4 * 64 + lane];
+        c_enemy = lw[5 * 64 + lane];
+        c_moves = lw[6 * 64 + lane];
+        my_a = (int)(m2 & 0xffULL) - 1;
+        my_kind = (int)((m2 >> 8) & 0xffULL);
+        my_v = (int)((m2 >> 16) & 0xffULL) - 128;
+        my_tasks = (int)((m2 >> 24) & 0xffULL);
+        first = (int)((m2 >> 32) & 0xffULL);
+        wave_sync();
+    } else {
+        const raz_bb legal0 = bb_legal_moves(own0, enemy0);
+        k = bb_popcount(legal0);
+        if (k == 0) return RAZ_SOLVE_NONE;
+        // ---- ply 1: lane i < k owns the root's i-th move.  kind 0: the game ends there (my_v = disc difference); 1: the opponent
+        // moves; 2: the opponent passes; +4: f(child) came from the memo
+        if (lane < k) {
+            raz_bb m = legal0;
+            for (int i = 0; i < lane; ++i) m &= m - 1;
+            my_a = __ffsll((long long)m) - 1;
+            const raz_bb flipped = bb_calc_flip(my_a, own0, enemy0);
+            const raz_bb nown = (own0 ^ flipped) | (1ULL << my_a), nenemy = enemy0 ^ flipped;
+            const raz_bb l1 = bb_legal_moves(nenemy, nown);
+            const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+            if (l1 | l2) {
+                my_kind = l1 ? 1 : 2;
+                c_own = l1 ? nenemy : nown;
+                c_enemy = l1 ? nown : nenemy;
+                c_moves = l1 ? l1 : l2;
+                int rm, rs;
+                if (bb_popcount(~(c_own | c_enemy)) >= 4 && memo_find_lane(E, g, c_own, c_enemy, exact, rm, rs)) {
+                    my_kind |= 4;
+                    my_v = (my_kind & 1) ? -rs : rs;
+                } else
+                    my_tasks = bb_popcount(c_moves);
+            } else
+                my_v = bb_popcount(nown) - bb_popcount(nenemy);
+        }
+        for (int i = 0; i < k; ++i) {   // exclusive prefix sum of my_tasks over the lanes
+            const int ti = (int)lane_u32((uint32_t)my_tasks, i);
+            if (i < lane) first += ti;
+            total += ti;
+        }
+        wave_sync();
+        if (lane < k) {
+            P->c_own[lane] = c_own;
+            P->c_enemy[lane] = c_enemy;
+            P->c_moves[lane] = c_moves;
+            P->c_first[lane] = (unsigned char)first;
+        }
+        if (lane == 0) P->c_first[k] = (unsigned char)total;
+        wave_sync();
+    }
+    // ---- the tasks: every lane searches subtrees until none is left.  The CURRENT node of a lane's search lives in registers, its
+    // ancestors' frames in the workspace - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf
+    for (int iter = 0;; ++iter) {
+        const unsigned long long idle = __ballot(!have);   // (also the point at which every lane is done with the previous iteration)
+        if (budget && iter >= budget) {   // park the search: the next launch goes on from here
+            wave_sync();
+            for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) hdr[32 + i] = ((const unsigned long long*)P)[i];
+            lw[0 * 64 + lane] = own;
+            lw[1 * 64 + lane] = enemy;
+            lw[2 * 64 + lane] = left;
+            lw[3 * 64 + lane] = (have ? 1ULL : 0ULL) | ((unsigned long long)(fresh & 1) << 1) | ((unsigned long long)(flip & 1) << 2) |
+                                ((task_sign < 0 ? 1ULL : 0ULL) << 3) | ((unsigned long long)(d & 0xff) << 8) | ((unsigned long long)((bmv + 1) & 0xff) << 16) |
+                                ((unsigned long long)((bsc + 128) & 0xff) << 24) | ((unsigned long long)((pact + 1) & 0xff) << 32) |
+                                ((unsigned long long)((task + 1) & 0xffff) << 40);
+            lw[4 * 64 + lane] = c_own;
+            lw[5 * 64 + lane] = c_enemy;
+            lw[6 * 64 + lane] = c_moves;
+            lw[7 * 64 + lane] = (unsigned long long)((my_a + 1) & 0xff) | ((unsigned long long)(my_kind & 0xff) << 8) | ((unsigned long long)((my_v + 128) & 0xff) << 16) |
+                                ((unsigned long long)(my_tasks & 0xff) << 24) | ((unsigned long long)(first & 0xff) << 32);
+            if (lane == 0) {
+                hdr[1] = own0;
+                hdr[2] = enemy0;
+                hdr[3] = (unsigned long long)exact;
+                hdr[4] = (unsigned long long)k;
+                hdr[5] = (unsigned long long)total;
+                hdr[6] = (unsigned long long)next;
+                hdr[0] = 0x5AULL;
+            }
+            wave_sync();
+            return RAZ_SOLVE_PENDING;
+        }
         if (idle && next < total) {
             const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
             const int t = next + rank;
@@ -792,10 +864,10 @@ __device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_de
                 } else {   // back to the parent
                     const int v = flip ? -rs : rs, a = pact;
                     --d;
-                    own = st_own[d];
-                    enemy = st_enemy[d];
-                    left = st_left[d];
-                    const uint32_t meta = st_meta[d];
+                    own = fr[d * 256 + 0];
+                    enemy = fr[d * 256 + 1];
+                    left = fr[d * 256 + 2];
+                    const uint32_t meta = (uint32_t)fr[d * 256 + 3];
                     bmv = (int)(meta & 0xffu) - 1;
                     bsc = (int)((meta >> 8) & 0xffu) - 128;
                     pact = (int)((meta >> 16) & 0xffu) - 1;
@@ -813,10 +885,10 @@ __device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_de
                 const raz_bb l1 = bb_legal_moves(nenemy, nown);
                 const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
                 if (l1 | l2) {   // down a ply
-                    st_own[d] = own;
-                    st_enemy[d] = enemy;
-                    st_left[d] = left;
-                    st_meta[d] = (uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24);
+                    fr[d * 256 + 0] = own;
+                    fr[d * 256 + 1] = enemy;
+                    fr[d * 256 + 2] = left;
+                    fr[d * 256 + 3] = (unsigned long long)((uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24));
                     ++d;
                     own = l1 ? nenemy : nown;
                     enemy = l1 ? nown : nenemy;
@@ -837,6 +909,7 @@ __device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_de
         }
     }
     wave_sync();
+    if (lane == 0) hdr[0] = 0ULL;   // nothing parked any more
     // ---- ply 1 again: lane i scans its child's moves in ascending order (the reference's loop at that node)
     if (lane < k && (my_kind & 3) && !(my_kind & 4)) {
         int bm = -1, bs = -100, t = first;
@@ -865,7 +938,7 @@ __device__ __attribute__((noinline)) bool solver_solve_lanes(const raz_engine_de
     memo_put(E, g, own0, enemy0, exact, bm, bs, lane);
     out_move = bm;
     out_score = bs;
-    return bm >= 0;
+    return bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
 }
 
 // ------------------------------------------------------------------ backup of the previous leaf
@@ -1165,7 +1238,17 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
     const bool on = (legal >> lane) & 1ULL;
     if (SOLVER && c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
         int sm, ss;
-        if (solver_solve(E, g, lane, own, enemy, 1u, S, sm, ss)) {
+#ifdef RAZ_WAVE_EMU
+        const int root_budget = getenv("RAZ_SOLVER_BUDGET") ? atoi(getenv("RAZ_SOLVER_BUDGET")) : RAZ_SOLVER_ROOT_BUDGET;   // (tests: park after a handful of iterations)
+#else
+        const int root_budget = RAZ_SOLVER_ROOT_BUDGET;
+#endif
+        const int solved = solver_solve(E, g, lane, own, enemy, 1u, S, root_budget, sm, ss);
+        if (solved == RAZ_SOLVE_PENDING) {   // the search is parked in the game's workspace; this launch is over for the game
+            R.solve_pending = 1u;
+            return;
+        }
+        if (solved == RAZ_SOLVE_DONE) {
             unsigned char* p = node_ptr(E, g, node);
             const double sg = ss > 0 ? 1.0 : (ss < 0 ? -1.0 : 0.0);
             if (on) node_P(p, L)[rk] = lane == sm ? 1.0f : 0.0f;
@@ -1264,7 +1347,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         if (SOLVER && t_insim && !(PAR && polling) && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
-            if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {  // `if action:` ignores square 0
+            if (solver_solve(E, g, lane, so, se, 0u, S, 0, sm, ss) == RAZ_SOLVE_DONE && sm != 0) {  // `if action:` ignores square 0
                 if (env.np != 1) ss = -ss;
                 kind = RAZ_LEAF_SOLVED;
                 solved_action = sm;
@@ -1342,7 +1425,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         if (SOLVER && t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // (:237-251) on a first arrival
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
-            if (solver_solve(E, g, lane, so, se, 0u, S, sm, ss) && sm != 0) {
+            if (solver_solve(E, g, lane, so, se, 0u, S, 0, sm, ss) == RAZ_SOLVE_DONE && sm != 0) {
                 if (env.np != 1) ss = -ss;
                 kind = RAZ_LEAF_SOLVED;
                 solved_action = sm;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     R.val = E.nn_value[g];
     R.nn = 0u;
     R.path_dirty = 0u;
+    R.solve_pending = 0u;
     path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int guard = 0; guard < 8; ++guard) {
             phase = G32(R, GW(phase));
             if (phase == RAZ_PHASE_NEW_MOVE) {
+                if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
                 begin_move<SOLVER>(E, R, g, lane, slds_p);
                 continue;
             }
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     R.val = 0.0f;
     R.nn = 0u;
     R.path_dirty = 0u;
+    R.solve_pending = 0u;
     Slots T;
     T.st = T.sq = T.pk = 0u;
     uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 for (int guard = 0; guard < 8; ++guard) {
                     const uint32_t phase = G32(R, GW(phase));
                     if (phase == RAZ_PHASE_NEW_MOVE) {
+                        if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
                         begin_move<SOLVER>(E, R, g, lane, slds_p);
                         continue;
                     }

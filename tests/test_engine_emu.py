@@ -294,8 +294,11 @@ def test_emulated_eval_matches_equal_the_reference_evaluate_games():
             assert ng_win == ref["ng_win"] and list(env.observation.number_of_black_and_white) == ref["black_white"], where
 
 
-def test_emulated_device_solver_equals_compiled_cython():
-    """tests/golden/solver_kat.json (answers of the reference's COMPILED Cython solver: its three known answers and 120 late-game
+@pytest.mark.parametrize("budget", [None, 7])
+def test_emulated_device_solver_equals_compiled_cython(budget, monkeypatch):
+    """(budget: iterations a root solve may run per launch before it is parked in the game's workspace - the product's 384, and 7:
+    hundreds of park / resume cycles per solve, on the positions of at most 9 empties.)
+    tests/golden/solver_kat.json (answers of the reference's COMPILED Cython solver: its three known answers and 120 late-game
     positions) through the device solver on the emulator, exact mode at the root (agent/player.py:100-103,150-161): positions of
     7..14 empties run the lane-parallel search (csrc/raz_engine_core.h solver_solve: the root's moves and their replies expanded into
     tasks, one reference-shaped depth-first search per lane), smaller ones the scalar one; move and sign(score) must be the Cython
@@ -318,12 +321,18 @@ def test_emulated_device_solver_equals_compiled_cython():
     cases = [c for c in cases if bin(c[0] | c[1]).count("1") - 4 >= 46]
     empties = sorted({64 - bin(c[0] | c[1]).count("1") for c in cases})
     assert len(cases) >= 100 and empties[0] <= 6 and empties[-1] >= 10, empties     # both searches are exercised
+    if budget is not None:
+        monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
+        cases = [c for c in cases if 7 <= 64 - bin(c[0] | c[1]).count("1") <= 9]
+        assert len(cases) >= 30
     eng = EmuEngine(cfg, ReversiNet(16, 1, 16).keras_init_(0).to_blob(), len(cases), seed=3, sims_hint=8)
     eng.start(0, 8)
     for g, (b, w, pl, _) in enumerate(cases):
         eng.set_position(g, b, w, pl, 8, enable_resign=False, one_move=True)
-    eng.step(4)
-    eng.stats()
+    for _ in range(40000):      # a 10-empties exact solve takes many launches: it runs on a per-launch budget and is parked in between
+        eng.step(4)
+        if eng.stats()["idle_or_done"] >= len(cases):
+            break
     raw = eng.read_raw()
     for g, (b, w, pl, (move, score)) in enumerate(cases):
         h = raw["headers"][g, 0]

@@ -103,8 +103,10 @@ def test_device_solver_equals_compiled_cython(kat):
     eng.start(0, 8)
     for g, (b, w, pl, _) in enumerate(cases):
         eng.set_position(g, b, w, pl, 8, enable_resign=False, one_move=True)
-    eng.step(4)
-    eng.stats()
+    for _ in range(4000):      # a 10-empties exact solve takes many launches: it runs on a per-launch budget and is parked in between
+        eng.step(4)
+        if eng.stats()["idle_or_done"] >= len(cases):
+            break
     raw = eng.read_raw()
     for g, (b, w, pl, (move, score)) in enumerate(cases):
         assert int(raw["n_plies"][g]) == 1, g
