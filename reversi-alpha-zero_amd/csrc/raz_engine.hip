@@ -36,9 +36,16 @@ namespace {
 
 // ------------------------------------------------------------------ the tree kernel
 // SOLVER = false compiles the end-game solver (and its LDS frames) out: the common case, and the
-// bench configuration.
+// bench configuration.  With the solver in, the kernel is sized for 2 waves per SIMD (256 VGPRs): the lane-parallel DFS
+// (raz_engine_core.h solver_solve_lanes, noinline, so it inherits the caller's register budget) spills 155 VGPRs into its
+// hot loop at 128, none at 256, and a configuration that solves is bound by the solves, not by tree occupancy.
+#ifdef RAZ_WAVE_EMU
+#define RAZ_TREE_WAVES(SOLVER)
+#else
+#define RAZ_TREE_WAVES(SOLVER) __attribute__((amdgpu_waves_per_eu((SOLVER) ? 2 : 4, (SOLVER) ? 2 : 4)))
+#endif
 template <bool SOLVER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
+__global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
     __shared__ float lds64[64];
     __shared__ SolverLDS slds_store;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // resume the oldest queued leaf (B), start a simulation in a free slot (C, C'), wake the next sleeper
 // (D) - then runs at most one slot load, one descent, one return.
 template <bool SOLVER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree_par(raz_engine_dev E, uint32_t g0, uint32_t count) {
+__global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
     __shared__ float lds64[64];
     __shared__ SolverLDS slds_store;

@@ -649,9 +649,52 @@ __device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, r
 struct SolverPar {
     unsigned long long c_own[RAZ_SOLVER_MAX_DEPTH], c_enemy[RAZ_SOLVER_MAX_DEPTH], c_moves[RAZ_SOLVER_MAX_DEPTH];   // child i: position (its mover's view), its moves
     unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2];   // child i's first task
-    signed char result[RAZ_SOLVER_MAX_DEPTH * RAZ_SOLVER_MAX_DEPTH];   // task t: the value of that move for the child's mover
+    signed char result[RAZ_SOLVER_MAX_DEPTH * RAZ_SOLVER_MAX_DEPTH];   // task t: the value of that move for the child's mover (RAZ_SOLVER_UNKNOWN: not there yet)
+    // non-exact mode: the reference's scans stop at the first winning move, so most tasks need not be finished - see solver_note_result
+    signed char c_v[RAZ_SOLVER_MAX_DEPTH];     // child i: the value of the root's i-th move once known, for the ROOT's mover (else RAZ_SOLVER_UNKNOWN)
+    signed char c_bm[RAZ_SOLVER_MAX_DEPTH], c_bs[RAZ_SOLVER_MAX_DEPTH];   // child i: f(child) = (move, score) once its scan is decided
+    unsigned char c_kind[RAZ_SOLVER_MAX_DEPTH];   // child i: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo)
+    unsigned char root_done;                   // the root's scan is decided: every search still running is moot
 };
+#define RAZ_SOLVER_UNKNOWN (-128)
 static_assert(sizeof(SolverPar) <= sizeof(SolverLDS), "the lane-parallel solver's LDS must fit the frames it replaces");
+
+// Non-exact mode (solves inside simulations, agent/player.py:237-251): the reference's loop at a node ends at the first move whose
+// value is > 0, so f(child) is decided as soon as the results of a PREFIX of the child's moves contain one - and the root's answer as
+// soon as a prefix of the children does.  Whenever a task's result lands, the lane that produced it re-runs those two scans over
+// what is known; a decided child cancels its remaining tasks, a decided root all of them (the lanes look at c_v / root_done before
+// every node).  Without this the 64 lanes finish ALL <= 182 subtrees of a position whose first move already wins - the sequential
+// search would have looked at one.  Several lanes may run the scans at once: they store the same values.
+__device__ void solver_note_result(SolverPar* P, int k, int ci) {
+    if (P->c_v[ci] == RAZ_SOLVER_UNKNOWN) {
+        int bm = -1, bs = -100, t = P->c_first[ci];
+        bool decided = true;
+        for (raz_bb m = P->c_moves[ci]; m; m &= m - 1, ++t) {
+            const int v = P->result[t];
+            if (v == RAZ_SOLVER_UNKNOWN) {
+                decided = false;
+                break;
+            }
+            if (bs < v) {
+                bm = __ffsll((long long)m) - 1;
+                bs = v;
+            }
+            if (bs > 0) break;
+        }
+        if (!decided) return;
+        P->c_bm[ci] = (signed char)bm;
+        P->c_bs[ci] = (signed char)bs;
+        P->c_v[ci] = (signed char)((P->c_kind[ci] & 1) ? -bs : bs);
+    }
+    int best = -100;
+    for (int i = 0; i < k; ++i) {
+        const int v = P->c_v[i];
+        if (v == RAZ_SOLVER_UNKNOWN) return;
+        if (best < v) best = v;
+        if (best > 0) break;
+    }
+    P->root_done = 1;
+}
 
 // (not inlined: three call sites - the root, the descent of k_tree, the descent of k_tree_par - would each carry a copy of the
 //  per-lane 64-bit board arithmetic, and the tree kernels' 128-register budget at 4 waves per SIMD would spill on every path; as a
@@ -772,10 +815,17 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             P->c_enemy[lane] = c_enemy;
             P->c_moves[lane] = c_moves;
             P->c_first[lane] = (unsigned char)first;
+            P->c_kind[lane] = (unsigned char)my_kind;
+            P->c_v[lane] = (signed char)((my_kind == 0 || (my_kind & 4)) ? my_v : RAZ_SOLVER_UNKNOWN);   // known now: the game ends there, or the memo had f(child)
         }
-        if (lane == 0) P->c_first[k] = (unsigned char)total;
+        for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
+        if (lane == 0) {
+            P->c_first[k] = (unsigned char)total;
+            P->root_done = 0;
+        }
         wave_sync();
     }
+    int task_ci = 0;   // the child this lane's task belongs to
     // ---- the tasks: every lane searches subtrees until none is left.  The CURRENT node of a lane's search lives in registers, its
     // ancestors' frames in the workspace - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf
     for (int iter = 0;; ++iter) {
@@ -814,6 +864,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             if (!have && t < total) {
                 int ci = 0;
                 while (ci + 1 < k && (int)P->c_first[ci + 1] <= t) ++ci;
+                task_ci = ci;
                 const raz_bb co = P->c_own[ci], ce = P->c_enemy[ci];
                 raz_bb m = P->c_moves[ci];
                 for (int j = (int)P->c_first[ci]; j < t; ++j) m &= m - 1;
@@ -835,9 +886,16 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
                     flip = 0;
                     fresh = 1;
                     have = true;
-                } else
+                } else {
                     P->result[t] = (signed char)(bb_popcount(nown) - bb_popcount(nenemy));
+                    if (!exact) solver_note_result(P, k, ci);
+                }
             }
+        }
+        if (!exact) {   // what other lanes found may have made this lane's search (or all of them) moot
+            const bool all_moot = __ballot(P->root_done != 0) != 0ULL;   // (wave-uniform: `next` must stay the same in every lane)
+            if (have && (all_moot || P->c_v[task_ci] != RAZ_SOLVER_UNKNOWN)) have = false;
+            if (all_moot) next = total;
         }
         if (__ballot(have) == 0ULL) {
             if (next >= total) break;
@@ -861,6 +919,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
                 if (d == 0) {
                     P->result[task] = (signed char)(task_sign * rs);
                     have = false;
+                    if (!exact) solver_note_result(P, k, task_ci);
                 } else {   // back to the parent
                     const int v = flip ? -rs : rs, a = pact;
                     --d;
@@ -910,24 +969,34 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
     }
     wave_sync();
     if (lane == 0) hdr[0] = 0ULL;   // nothing parked any more
-    // ---- ply 1 again: lane i scans its child's moves in ascending order (the reference's loop at that node)
+    // ---- ply 1 again: lane i scans its child's moves in ascending order (the reference's loop at that node).  Non-exact mode: only
+    // children whose scan was decided have an f(child) (the others were cancelled by an earlier winning move of the root)
+    bool child_known = (my_kind & 3) == 0 || (my_kind & 4) != 0;
     if (lane < k && (my_kind & 3) && !(my_kind & 4)) {
         int bm = -1, bs = -100, t = first;
+        child_known = true;
         for (raz_bb m = c_moves; m; m &= m - 1, ++t) {
             const int v = P->result[t];
+            if (v == RAZ_SOLVER_UNKNOWN) {
+                child_known = false;
+                break;
+            }
             if (bs < v) {
                 bm = __ffsll((long long)m) - 1;
                 bs = v;
             }
             if (!exact && bs > 0) break;
         }
-        if (bb_popcount(~(c_own | c_enemy)) >= 4) memo_put_lane(E, g, c_own, c_enemy, exact, bm, bs);
-        my_v = (my_kind & 1) ? -bs : bs;
+        if (child_known) {
+            if (bb_popcount(~(c_own | c_enemy)) >= 4) memo_put_lane(E, g, c_own, c_enemy, exact, bm, bs);
+            my_v = (my_kind & 1) ? -bs : bs;
+        }
     }
-    // ---- the root
+    // ---- the root (a child that is not known lies behind the move that decided the scan)
     int bm = -1, bs = -100;
     for (int i = 0; i < k; ++i) {
         const int v = (int)lane_u32((uint32_t)my_v, i), a = (int)lane_u32((uint32_t)my_a, i);
+        if (!lane_u32((uint32_t)child_known, i)) break;   // (cannot happen before the scan is decided)
         if (bs < v) {
             bm = a;
             bs = v;
