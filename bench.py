@@ -750,16 +750,19 @@ def ch5_as_shipped_leg(args, dev, blob, weights, games=8192, steps=6, warm=12):
     import torch
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
     res = {}
-    for label, solver in (("as_shipped", True), ("solver_off", False)):
+    for label in ("as_shipped", "root_solver_only", "solver_off"):
         cfg = ch5_shipped_config(args.sims)
-        if not solver:
-            cfg.play.use_solver_turn = cfg.play.use_solver_turn_in_simulation = 0
+        if label == "solver_off":
+            cfg.play.use_solver_turn = 0
+        if label != "as_shipped":
+            cfg.play.use_solver_turn_in_simulation = 0
         net = DeviceNet(blob, dev, kernel=args.net_kernel)
         # a move's search holds up to thinking_loop x sims simulations (two nodes each with mirror keys) before k_gc prunes what the
         # game has left behind: 5 x that, as the 16 x sims of the headline pools
         nodes = 5 * 10 * args.sims
         eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=args.sims, nodes_per_game=nodes, parts=1,
-                             leaf_cache_log2=None if args.no_leaf_cache else 26, leaf_cache_max_discs=24)
+                             leaf_cache_log2=None if args.no_leaf_cache else 26, leaf_cache_max_discs=24,
+                             solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")))
         eng.start(0, args.sims)
         stagger(eng, games, args.sims, 31337, dev, weights)
         eng.step(warm)
@@ -780,8 +783,9 @@ def ch5_as_shipped_leg(args, dev, blob, weights, games=8192, steps=6, warm=12):
     return {"workload": f"the headline batch ({games} concurrent games, 256x10 net, {args.sims} sims/move) with ch5.yml AS SHIPPED: thinking_loop 10, parallel_search_num 8, "
                         f"use_solver_turn 50 (config/ch5.yml:9-16, config.py:133-135,142,154-155); steady-state ply mix, {steps} timed steps after {warm}",
             "value": a["value"], "unit": "sims/s", **{k: v for k, v in a.items() if k not in ("value", "unit")},
-            "same_with_the_solver_off": b,
+            "same_with_the_solver_off": b, "same_with_the_solver_at_the_root_only": res["root_solver_only"],
             "solver_share_of_a_step": {"tree_kernel_ms_with_solver": a["k_tree_par_ms_per_step"], "tree_kernel_ms_without": b["k_tree_par_ms_per_step"],
+                                       "tree_kernel_ms_root_solver_only": res["root_solver_only"]["k_tree_par_ms_per_step"],
                                        "share_of_step_time": max(0.0, a["k_tree_par_ms_per_step"] - b["k_tree_par_ms_per_step"]) / a["ms_per_step"]}}
 
 
@@ -1010,6 +1014,7 @@ def compact_line(full):
             if "solver_share_of_a_step" in d:
                 e["solver_share_of_step_time"] = d["solver_share_of_a_step"].get("share_of_step_time")
                 e["solver_off_value"] = d.get("same_with_the_solver_off", {}).get("value")
+                e["root_solver_only_value"] = d.get("same_with_the_solver_at_the_root_only", {}).get("value")
             if "parity_check_complete_games" in d:
                 e["parity"] = parity(d["parity_check_complete_games"])
             line[key] = e

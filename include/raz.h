@@ -159,7 +159,10 @@ typedef struct {
                                                  ONE kernel, the game's wave evaluates its own leaves (csrc/raz_engine_fused.hip
                                                  k_tree_net / k_tree_par_net; same results); bits 8-11:
                                                  slices/streams (0 = 3); bits 12-15: max simulations per game per tree launch
-                                                 (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num) */
+                                                 (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num);
+                                                 bits 16-23: x 64 = iterations of the lane-parallel end-game solver a game may spend per
+                                                 tree launch (0 = 384); a solve that runs out - the root's or one inside a simulation -
+                                                 is suspended and goes on at the next launch: results do not depend on the value */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
                                                  (agent/player.py:100-103,150-161; lib/alt/reversi_solver_cython.pyx) */
     int32_t use_solver_turn_in_simulation;    /* config.py:155: 0 = off, else >= 46: win/loss solve inside simulations

@@ -41,11 +41,14 @@
 #define RAZ_LEAF_TERMINAL 2
 #define RAZ_LEAF_SOLVED 3   // the in-simulation solver answered (agent/player.py:237-251)
 #define RAZ_LEAF_PARKED 4   // parallel_search_num > 1: the key is in now_expanding (agent/player.py:253-254)
+#define RAZ_LEAF_SOLVE_PENDING 5   // the descent stands at an in-simulation solve that ran out of the launch's solver budget: leaf_node = the
+                                   // node to go on from, depth = its level, leaf_action = 1 + the rank of the edge already chosen there (0: none)
 
 // State of one of the parallel_search_num simulation slots of a game (k_tree_par)
 #define RAZ_SIM_FREE 0
 #define RAZ_SIM_WAIT_NET 1     // its leaf is in the prediction queue (expand_and_evaluate awaits the future)
 #define RAZ_SIM_WAIT_EXPAND 2  // sleeping on now_expanding at node sim_parked
+#define RAZ_SIM_SOLVING 3      // its descent is suspended at an in-simulation solve (RAZ_LEAF_SOLVE_PENDING in its block)
 
 // per-game workspace of the lane-parallel end-game solver (raz_engine_core.h solver_solve_lanes): a 1 KiB header + state block,
 // 4 KiB of per-lane state, 14 levels x 64 lanes x 32 B of frames
@@ -118,13 +121,14 @@ struct raz_game {
     // which only the in-flight-simulation fields (leaf_*, depth, sim_*) are meaningful, so that moving a slot
     // into / out of the register-resident control block is one masked select / one masked store.
     uint32_t sim_state, sim_seq, sim_parked;        // per slot: RAZ_SIM_*, order number (queue put order / sleep order), node slept on
-    uint32_t par_seq_next, par_stage;               // per game: next order number; 0 = round boundary, 1 = filling (C), 2 = refilling (C')
+    uint32_t par_seq_next, par_stage;               // per game: next order number; 0 = round boundary, 1 = filling (C), 2 = refilling (C'), 4 = polling sleepers (D: only while a solve is suspended)
     // continuous batching (raz_engine_harvest): a game started by a harvest carries the resign threshold it was started
     // under, so that its result does not depend on when other games finish (worker/self_play.py:250-260 mutates the value)
     unsigned long long resign_thr;                  // f64 bits, valid when resign_mode == 1
     uint32_t resign_mode;                           // 0 = the engine's run-time value (raz_engine_set_resign_threshold), 1 = resign_thr, 2 = no rule
     uint32_t node_count;                            // nodes in the pool (= entries of the node directory)
-    uint32_t pad[10];
+    uint32_t par_dmask;                             // stage D suspended by a solve: the sleepers still to poll
+    uint32_t pad[9];
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_game) == 256, "raz_game must be 64 dwords");

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_d
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
+    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
@@ -74,33 +75,38 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_d
         uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (G32(R, GW(error))) break;
+        // a descent suspended at an in-simulation solve (select_leaf) goes on where it stands, before anything else
+        const bool suspended = SOLVER && G32(R, GW(leaf_kind)) == RAZ_LEAF_SOLVE_PENDING;
         unsigned long long t0 = prof_now();
-        if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf<false>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
-        prof_add(E, g, 0, t0, lane);
-        t0 = prof_now();
-        // controller: loop because a decided move may immediately need another decision
-        // (turn-0 bypass) before a search with simulations starts
-        for (int guard = 0; guard < 8; ++guard) {
+        if (!suspended) {
+            if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf<false>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+            prof_add(E, g, 0, t0, lane);
+            t0 = prof_now();
+            // controller: loop because a decided move may immediately need another decision
+            // (turn-0 bypass) before a search with simulations starts
+            for (int guard = 0; guard < 8; ++guard) {
+                phase = G32(R, GW(phase));
+                if (phase == RAZ_PHASE_NEW_MOVE) {
+                    if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
+                    begin_move<SOLVER>(E, R, g, lane, slds_p);
+                    continue;
+                }
+                if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {
+                    decide_move(E, R, g, lane);
+                    continue;
+                }
+                break;
+            }
+            prof_add(E, g, 1, t0, lane);
             phase = G32(R, GW(phase));
-            if (phase == RAZ_PHASE_NEW_MOVE) {
-                if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
-                begin_move<SOLVER>(E, R, g, lane, slds_p);
-                continue;
-            }
-            if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {
-                decide_move(E, R, g, lane);
-                continue;
-            }
-            break;
+            if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
+            t0 = prof_now();
         }
-        prof_add(E, g, 1, t0, lane);
-        phase = G32(R, GW(phase));
-        if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
-        t0 = prof_now();
-        select_leaf<SOLVER, false>(E, R, g, lane, slds_p, g, 0u, 0, false);
+        select_leaf<SOLVER, false>(E, R, g, lane, slds_p, g, suspended ? G32(R, GW(leaf_node)) : G32(R, GW(root_node)),
+                                   suspended ? (int)G32(R, GW(depth)) : 0, false, suspended ? (int)G32(R, GW(leaf_action)) - 1 : -1);
         prof_add(E, g, 2, t0, lane);
         const uint32_t lk = G32(R, GW(leaf_kind));
-        if (lk != RAZ_LEAF_TERMINAL && lk != RAZ_LEAF_SOLVED) break;  // needs the net
+        if (lk != RAZ_LEAF_TERMINAL && lk != RAZ_LEAF_SOLVED) break;  // needs the net (or, suspended at a solve, the next launch)
     }
     // write the game back: one coalesced store (+ the path when a descent ran)
     gw[lane] = R.cw;
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
+    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     Slots T;
     T.st = T.sq = T.pk = 0u;
     uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
@@ -167,15 +174,20 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
     }
     if (RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
     int budget = (int)K + (((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax);
-    constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D never outlives a launch
+    constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D outlives a launch only under a suspended solve
     uint32_t stage = G32(R, GW(par_stage));
-    unsigned long long dmask = 0ULL;  // sleepers still to poll in D
+    unsigned long long dmask = stage == kStageD ? (unsigned long long)G32(R, GW(par_dmask)) : 0ULL;  // sleepers still to poll in D
     for (;;) {
         if (G32(R, GW(error))) break;
         // ---- the next operation of the round
         int j = -1;
-        bool resume = false, wake = false;
-        if (stage == kStageB) {
+        bool resume = false, wake = false, suspended = false;
+        const unsigned long long solving = SOLVER ? (__ballot(T.st == RAZ_SIM_SOLVING) & kmask) : 0ULL;
+        if (solving) {  // a descent suspended at an in-simulation solve goes on first: it was a start (C / C') or a wake (D)
+            j = __ffsll((long long)solving) - 1;
+            suspended = true;
+            wake = stage == kStageD;
+        } else if (stage == kStageB) {
             const unsigned long long m = __ballot(T.st == RAZ_SIM_WAIT_NET) & kmask;
             if (!m) {
                 stage = kStageC;
@@ -228,13 +240,21 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
         }
         // ---- at most one slot load, one descent, one return
         bool back = resume;
-        if (resume || wake) slot_load(E, R, g, (uint32_t)j, lane, resume);
+        if (resume || wake || suspended) slot_load(E, R, g, (uint32_t)j, lane, resume);
         if (!resume) {
             const unsigned long long t0 = prof_now();
             select_leaf<SOLVER, true>(E, R, g, lane, slds_p, g * K + (uint32_t)j,
-                                      wake ? lane_u32(T.pk, j) : G32(R, GW(root_node)), wake ? (int)G32(R, GW(depth)) : 0, wake);
+                                      suspended ? G32(R, GW(leaf_node)) : (wake ? lane_u32(T.pk, j) : G32(R, GW(root_node))),
+                                      (wake || suspended) ? (int)G32(R, GW(depth)) : 0, wake && !suspended,
+                                      suspended ? (int)G32(R, GW(leaf_action)) - 1 : -1);
             prof_add(E, g, 2, t0, lane);
             const uint32_t kind = G32(R, GW(leaf_kind));
+            if (SOLVER && kind == RAZ_LEAF_SOLVE_PENDING) {  // out of solver budget: the slot keeps the descent, the launch is over for the game
+                T.st = writelane_r(T.st, RAZ_SIM_SOLVING, j, lane);
+                slot_store(E, R, g, (uint32_t)j, lane);
+                S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
+                break;
+            }
             if (kind == RAZ_LEAF_TERMINAL || kind == RAZ_LEAF_SOLVED) {
                 back = true;  // ended on a finished game / a solved position: returns up its path at once
             } else if (kind == RAZ_LEAF_EXPAND || kind == RAZ_LEAF_PARKED) {
@@ -261,7 +281,11 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
             prof_add(E, g, 0, t0, lane);
         }
     }
-    S32(R, GW(par_stage), stage == kStageD ? kStageC2 : stage);
+    if (SOLVER && R.solve_pending && stage == kStageD) {
+        S32(R, GW(par_dmask), (uint32_t)dmask);
+        S32(R, GW(par_stage), kStageD);
+    } else
+        S32(R, GW(par_stage), stage == kStageD ? kStageC2 : stage);
     gw[lane] = R.cw;
     if (lane < (int)K) {
         myblk[GW(sim_state)] = T.st;
@@ -485,6 +509,7 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
                 if (lm != RAZ_NO_NODE) blk[GW(leaf_mirror)] = gc_translate(E, g, remap, lm);
                 blk[GW(leaf_slot)] = 0xfffffffeu;  // the slot found by select is gone: backup probes again
             }
+            if (lk == RAZ_LEAF_SOLVE_PENDING && ln != RAZ_NO_NODE) blk[GW(leaf_node)] = gc_translate(E, g, remap, ln);   // the node a suspended descent stands on
             if (E.par && blk[GW(sim_state)] == RAZ_SIM_WAIT_EXPAND) blk[GW(sim_parked)] = gc_translate(E, g, remap, blk[GW(sim_parked)]);
         }
     }

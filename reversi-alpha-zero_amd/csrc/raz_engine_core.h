@@ -244,7 +244,9 @@ struct Regs {
     float pol_raw, val;             // the net's policy row (lane = square of the TRANSFORMED board) and value
     uint32_t nn;                    // this launch produced a leaf for the net
     uint32_t path_dirty;
-    uint32_t solve_pending;         // begin_move's end-game solve is suspended until the next launch (the phase stays NEW_MOVE)
+    uint32_t solve_pending;         // an end-game solve is suspended until the next launch: begin_move's (the phase stays NEW_MOVE) or one
+                                    // inside a simulation (leaf_kind RAZ_LEAF_SOLVE_PENDING); the game does nothing more in this launch
+    int solve_budget;               // solver iterations this game may still spend in this launch (solver_launch_budget)
 };
 __device__ __forceinline__ uint32_t G32(const Regs& R, int i) { return (uint32_t)__builtin_amdgcn_readlane(R.cw, i); }
 __device__ __forceinline__ raz_bb G64(const Regs& R, int i) {  // (the builtin returns int: widen through uint32_t)
@@ -706,19 +708,30 @@ __device__ void solver_note_result(SolverPar* P, int k, int ci) {
 // step).  The root's solve therefore runs for at most `budget` iterations per launch: when they are used up the wave parks the
 // search in the game's workspace (E.solver_ws: the frames live there anyway; the lanes' registers, the task counter and the LDS
 // block are added) and returns RAZ_SOLVE_PENDING; begin_move leaves the game in NEW_MOVE and the next launch picks the search up
-// where it stopped.  f is a function of the position, so when the answer arrives changes nothing but the game's wall time.  Solves
-// inside simulations (non-exact, 100x smaller) run to completion: budget 0.
+// where it stopped.  f is a function of the position, so when the answer arrives changes nothing but the game's wall time.
+// Solves inside simulations (non-exact) are 100x smaller on average, but there are hundreds per move from turn 47 on and their tail
+// is what a launch then waits for (8192 games as shipped: tree kernel 97 ms per step with them, 1.6 ms with the root's solves alone):
+// they draw on the SAME per-launch budget (Regs::solve_budget, `budget` below: in = iterations left, out = what this call left of
+// it), and a descent whose solve runs out is suspended where it stands (select_leaf: RAZ_LEAF_SOLVE_PENDING).
 #define RAZ_SOLVE_NONE 0
 #define RAZ_SOLVE_DONE 1
 #define RAZ_SOLVE_PENDING 2
 #ifndef RAZ_SOLVER_ROOT_BUDGET
 #define RAZ_SOLVER_ROOT_BUDGET 384
 #endif
+// iterations of the lane-parallel solver a game may spend per launch: raz_engine_config.reserved bits 16-23 x 64, or the default
+__device__ __forceinline__ int solver_launch_budget(const raz_engine_dev& E) {
+#ifdef RAZ_WAVE_EMU
+    if (getenv("RAZ_SOLVER_BUDGET")) return atoi(getenv("RAZ_SOLVER_BUDGET"));   // (tests: suspend after a handful of iterations)
+#endif
+    const int units = (int)((E.cfg.reserved >> 16) & 0xffu);
+    return units ? units * 64 : RAZ_SOLVER_ROOT_BUDGET;
+}
 __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                                            SolverLDS* S, int budget, int& out_move, int& out_score);
+                                                            SolverLDS* S, int& budget, int& out_move, int& out_score);
 
 __device__ __forceinline__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                            SolverLDS* S, int budget, int& out_move, int& out_score) {
+                                            SolverLDS* S, int& budget, int& out_move, int& out_score) {
     const int empties = bb_popcount(~(own0 | enemy0));
     if (empties <= RAZ_SOLVER_SCALAR_EMPTIES || empties > RAZ_SOLVER_MAX_DEPTH)
         return solver_solve_scalar(E, g, lane, own0, enemy0, exact, S, out_move, out_score) ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
@@ -726,7 +739,7 @@ __device__ __forceinline__ int solver_solve(const raz_engine_dev& E, uint32_t g,
 }
 
 __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                                            SolverLDS* S, int budget, int& out_move, int& out_score) {
+                                                            SolverLDS* S, int& budget, int& out_move, int& out_score) {
     {
         int rm, rs;
         wave_sync();
@@ -747,6 +760,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
     raz_bb own = 0, enemy = 0, left = 0;
     int bmv = -1, bsc = -100, pact = -1, flip = 0, fresh = 0;
     int next = 0, d = 0, task = -1, task_sign = 1;
+    int task_ci = 0;   // the child this lane's task belongs to
     bool have = false;
     const bool parked = uni((uint32_t)(hdr[0] == 0x5AULL && hdr[1] == own0 && hdr[2] == enemy0 && hdr[3] == (unsigned long long)exact)) != 0;
     if (parked) {   // pick the search up where the last launch left it
@@ -775,6 +789,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
         my_v = (int)((m2 >> 16) & 0xffULL) - 128;
         my_tasks = (int)((m2 >> 24) & 0xffULL);
         first = (int)((m2 >> 32) & 0xffULL);
+        task_ci = (int)((m2 >> 40) & 0xffULL);
         wave_sync();
     } else {
         const raz_bb legal0 = bb_legal_moves(own0, enemy0);
@@ -825,12 +840,12 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
         }
         wave_sync();
     }
-    int task_ci = 0;   // the child this lane's task belongs to
     // ---- the tasks: every lane searches subtrees until none is left.  The CURRENT node of a lane's search lives in registers, its
     // ancestors' frames in the workspace - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf
     for (int iter = 0;; ++iter) {
         const unsigned long long idle = __ballot(!have);   // (also the point at which every lane is done with the previous iteration)
-        if (budget && iter >= budget) {   // park the search: the next launch goes on from here
+        if (iter >= budget) {   // park the search: the next launch goes on from here
+            budget = 0;
             wave_sync();
             for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) hdr[32 + i] = ((const unsigned long long*)P)[i];
             lw[0 * 64 + lane] = own;
@@ -844,7 +859,8 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             lw[5 * 64 + lane] = c_enemy;
             lw[6 * 64 + lane] = c_moves;
             lw[7 * 64 + lane] = (unsigned long long)((my_a + 1) & 0xff) | ((unsigned long long)(my_kind & 0xff) << 8) | ((unsigned long long)((my_v + 128) & 0xff) << 16) |
-                                ((unsigned long long)(my_tasks & 0xff) << 24) | ((unsigned long long)(first & 0xff) << 32);
+                                ((unsigned long long)(my_tasks & 0xff) << 24) | ((unsigned long long)(first & 0xff) << 32) |
+                                ((unsigned long long)(task_ci & 0xff) << 40);
             if (lane == 0) {
                 hdr[1] = own0;
                 hdr[2] = enemy0;
@@ -898,7 +914,10 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             if (all_moot) next = total;
         }
         if (__ballot(have) == 0ULL) {
-            if (next >= total) break;
+            if (next >= total) {
+                budget -= iter;
+                break;
+            }
             continue;
         }
         if (have) {   // one node of this lane's search: solver_solve_scalar's loop body
@@ -1307,12 +1326,7 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
     const bool on = (legal >> lane) & 1ULL;
     if (SOLVER && c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
         int sm, ss;
-#ifdef RAZ_WAVE_EMU
-        const int root_budget = getenv("RAZ_SOLVER_BUDGET") ? atoi(getenv("RAZ_SOLVER_BUDGET")) : RAZ_SOLVER_ROOT_BUDGET;   // (tests: park after a handful of iterations)
-#else
-        const int root_budget = RAZ_SOLVER_ROOT_BUDGET;
-#endif
-        const int solved = solver_solve(E, g, lane, own, enemy, 1u, S, root_budget, sm, ss);
+        const int solved = solver_solve(E, g, lane, own, enemy, 1u, S, R.solve_budget, sm, ss);
         if (solved == RAZ_SOLVE_PENDING) {   // the search is parked in the game's workspace; this launch is over for the game
             R.solve_pending = 1u;
             return;
@@ -1360,9 +1374,15 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
 // loss stored at once (:270-271), a leaf being expanded is flagged in its node's tag (now_expanding,
 // :294) - a brand-new position gets its node right here for that - and a descent that meets such a
 // flag stops there (RAZ_LEAF_PARKED, :253-254).  nn_index: the slot of the leaf exchange arrays.
+// A solve inside the simulation (:237-251) that runs out of the launch's solver budget SUSPENDS the descent: leaf_kind
+// RAZ_LEAF_SOLVE_PENDING, leaf_node / depth = where it stands, the path so far stored like any other.  The caller ends the game's
+// launch there and calls again at the next one with start_node / start_depth = that place: the solve goes on from its parked state
+// (it is a function of the position alone) and the descent from its answer, so nothing but wall time depends on the budget.  A
+// solve on a FIRST arrival has no node to stand on: it stands on the parent with forced_rank = the edge it took (selected, given
+// its virtual loss and put on the path exactly once, before the suspension), replays the move and meets the same solve again.
 template <bool SOLVER, bool PAR>
 __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int lane, SolverLDS* S, uint32_t nn_index,
-                            uint32_t start_node, int start_depth, bool polling) {
+                            uint32_t start_node, int start_depth, bool polling, int forced_rank) {
     const raz_engine_config& c = E.cfg;
     const uint32_t player = G32(R, GW(player));
     const uint32_t pl = player - 1;
@@ -1375,9 +1395,10 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
     env.np = 1;
     env.status = 0;
     env.legal = 0;
-    int depth = PAR ? start_depth : 0;
+    int depth = start_depth;
     uint32_t kind = RAZ_LEAF_NONE;
-    uint32_t node = PAR ? start_node : G32(R, GW(root_node));  // always exists (begin_move)
+    uint32_t node = start_node;  // always exists (begin_move)
+    const int first_depth = start_depth;
     uint32_t leaf_node = RAZ_NO_NODE, leaf_slot = 0xffffffffu, leaf_tag = 0, leaf_mirror = RAZ_NO_NODE;
     raz_bb leaf_legal = 0;
     int solved_action = 0;
@@ -1413,10 +1434,16 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         env.white = uni(hw);
         env.np = uni(tag) & 3u;
         env.legal = uni(legal);
-        if (SOLVER && t_insim && !(PAR && polling) && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
+        if (SOLVER && t_insim && !(PAR && polling) && forced_rank < 0 && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
-            if (solver_solve(E, g, lane, so, se, 0u, S, 0, sm, ss) == RAZ_SOLVE_DONE && sm != 0) {  // `if action:` ignores square 0
+            const int solved = solver_solve(E, g, lane, so, se, 0u, S, R.solve_budget, sm, ss);
+            if (solved == RAZ_SOLVE_PENDING) {
+                kind = RAZ_LEAF_SOLVE_PENDING;
+                leaf_node = node;
+                break;
+            }
+            if (solved == RAZ_SOLVE_DONE && sm != 0) {  // `if action:` ignores square 0
                 if (env.np != 1) ss = -ss;
                 kind = RAZ_LEAF_SOLVED;
                 solved_action = sm;
@@ -1428,7 +1455,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
                 break;
             }
         }
-        if (PAR) {
+        if (PAR && forced_rank < 0) {
             polling = false;
             if ((uni(tag) >> (6 + pl)) & 1u) {  // while key in self.now_expanding: await asyncio.sleep(...) (:253-254)
                 kind = RAZ_LEAF_PARKED;
@@ -1436,7 +1463,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
                 break;
             }
         }
-        if (!((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
+        if (forced_rank < 0 && !((uni(tag) >> (4 + pl)) & 1u)) {  // key not in this player's `expanded` (:257)
             kind = RAZ_LEAF_EXPAND;
             leaf_node = node;
             leaf_legal = env.legal;
@@ -1449,9 +1476,11 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
             flag_error(R, RAZ_ERR_PATH_FULL);
             break;
         }
-        const int r = select_action(E, R, g, Wi, Ni, Pi, L, env.np, depth == 0, game_id, lane);   // rank of the move
+        const bool replay = SOLVER && forced_rank >= 0;   // (the edge was chosen before the suspension: no second draw, no second virtual loss)
+        const int r = replay ? forced_rank : select_action(E, R, g, Wi, Ni, Pi, L, env.np, depth == 0, game_id, lane);   // rank of the move
         const int a = square_of_rank(env.legal, r, lane);
-        if (PAR && lane == r) {  // var_n[key][action_t] += virtual_loss; var_w[key][action_t] -= virtual_loss_for_w (:270-271)
+        forced_rank = -1;
+        if (PAR && lane == r && !replay) {  // var_n[key][action_t] += virtual_loss; var_w[key][action_t] -= virtual_loss_for_w (:270-271)
             const double vl = (double)c.virtual_loss;
             node_N(p, L)[r] = Ni + (uint32_t)c.virtual_loss;
             node_W(p, L)[r] = Wi - (env.np == 1 ? vl : -vl);
@@ -1494,7 +1523,15 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         if (SOLVER && t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // (:237-251) on a first arrival
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
-            if (solver_solve(E, g, lane, so, se, 0u, S, 0, sm, ss) == RAZ_SOLVE_DONE && sm != 0) {
+            const int solved = solver_solve(E, g, lane, so, se, 0u, S, R.solve_budget, sm, ss);
+            if (solved == RAZ_SOLVE_PENDING) {   // stand on the parent, the edge taken
+                kind = RAZ_LEAF_SOLVE_PENDING;
+                leaf_node = node;
+                solved_action = r + 1;
+                --depth;
+                break;
+            }
+            if (solved == RAZ_SOLVE_DONE && sm != 0) {
                 if (env.np != 1) ss = -ss;
                 kind = RAZ_LEAF_SOLVED;
                 solved_action = sm;
@@ -1547,11 +1584,16 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         R.nn = 1u;
     }
     if (kind == RAZ_LEAF_SOLVED) S32(R, GW(leaf_action), (uint32_t)solved_action);
+    if (SOLVER && kind == RAZ_LEAF_SOLVE_PENDING) {
+        S32(R, GW(leaf_action), (uint32_t)solved_action);
+        S32(R, GW(leaf_node), leaf_node);
+        R.solve_pending = 1u;
+    }
     if (PAR && kind == RAZ_LEAF_PARKED) S32(R, GW(sim_parked), leaf_node);
     S32(R, GW(leaf_term_v), __float_as_uint(term_v));
     S32(R, GW(leaf_kind), kind);
     S32(R, GW(depth), (uint32_t)depth);
-    ADD64(R, GW(selections), (raz_bb)(depth - (PAR ? start_depth : 0)));
+    ADD64(R, GW(selections), (raz_bb)(depth - first_depth));
     wave_sync();
 }
 

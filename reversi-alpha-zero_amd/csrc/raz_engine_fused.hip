@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
+    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
@@ -52,23 +53,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (G32(R, GW(error))) break;
-        if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf<false>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
-        for (int guard = 0; guard < 8; ++guard) {
+        // a descent suspended at an in-simulation solve (select_leaf) goes on where it stands, before anything else
+        const bool suspended = SOLVER && G32(R, GW(leaf_kind)) == RAZ_LEAF_SOLVE_PENDING;
+        if (!suspended) {
+            if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf<false>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+            for (int guard = 0; guard < 8; ++guard) {
+                phase = G32(R, GW(phase));
+                if (phase == RAZ_PHASE_NEW_MOVE) {
+                    if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
+                    begin_move<SOLVER>(E, R, g, lane, slds_p);
+                    continue;
+                }
+                if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {
+                    decide_move(E, R, g, lane);
+                    continue;
+                }
+                break;
+            }
             phase = G32(R, GW(phase));
-            if (phase == RAZ_PHASE_NEW_MOVE) {
-                if (R.solve_pending) break;   // the root's end-game solve ran out of this launch's budget: it goes on at the next launch
-                begin_move<SOLVER>(E, R, g, lane, slds_p);
-                continue;
-            }
-            if (phase == RAZ_PHASE_SEARCH && (int32_t)G32(R, GW(sims_left)) <= 0) {
-                decide_move(E, R, g, lane);
-                continue;
-            }
-            break;
+            if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
         }
-        phase = G32(R, GW(phase));
-        if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
-        select_leaf<SOLVER, false>(E, R, g, lane, slds_p, g, 0u, 0, false);
+        select_leaf<SOLVER, false>(E, R, g, lane, slds_p, g, suspended ? G32(R, GW(leaf_node)) : G32(R, GW(root_node)),
+                                   suspended ? (int)G32(R, GW(depth)) : 0, false, suspended ? (int)G32(R, GW(leaf_action)) - 1 : -1);
         const uint32_t lk = G32(R, GW(leaf_kind));
         if (lk == RAZ_LEAF_EXPAND) {
             // what select_leaf handed to the leaf exchange (nn_own / nn_enemy), recomputed from the control block: the
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
+    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     Slots T;
     T.st = T.sq = T.pk = 0u;
     uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
@@ -139,8 +146,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
     raz_net16_zero_planes(netbuf, lane);
-    constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D never outlives an iteration
+    constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D outlives an iteration only under a suspended solve
     uint32_t stage = G32(R, GW(par_stage));
+    unsigned long long dmask = stage == kStageD ? (unsigned long long)G32(R, GW(par_dmask)) : 0ULL;  // sleepers still to poll in D
     for (uint32_t it = 0; it < iters; ++it) {
         {
             const uint32_t phase = G32(R, GW(phase));
@@ -148,13 +156,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         uint32_t nnmask = 0u;
         int budget = (int)K + (((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax);
-        unsigned long long dmask = 0ULL;  // sleepers still to poll in D
         for (;;) {
             if (G32(R, GW(error))) break;
             // ---- the next operation of the round
             int j = -1;
-            bool resume = false, wake = false;
-            if (stage == kStageB) {
+            bool resume = false, wake = false, suspended = false;
+            const unsigned long long solving = SOLVER ? (__ballot(T.st == RAZ_SIM_SOLVING) & kmask) : 0ULL;
+            if (solving) {  // a descent suspended at an in-simulation solve goes on first: it was a start (C / C') or a wake (D)
+                j = __ffsll((long long)solving) - 1;
+                suspended = true;
+                wake = stage == kStageD;
+            } else if (stage == kStageB) {
                 const unsigned long long m = __ballot(T.st == RAZ_SIM_WAIT_NET) & kmask;
                 if (!m) {
                     stage = kStageC;
@@ -206,11 +218,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             // ---- at most one slot load, one descent, one return
             bool back = resume;
-            if (resume || wake) slot_load(E, R, g, (uint32_t)j, lane, resume);
+            if (resume || wake || suspended) slot_load(E, R, g, (uint32_t)j, lane, resume);
             if (!resume) {
                 select_leaf<SOLVER, true>(E, R, g, lane, slds_p, g * K + (uint32_t)j,
-                                          wake ? lane_u32(T.pk, j) : G32(R, GW(root_node)), wake ? (int)G32(R, GW(depth)) : 0, wake);
+                                          suspended ? G32(R, GW(leaf_node)) : (wake ? lane_u32(T.pk, j) : G32(R, GW(root_node))),
+                                          (wake || suspended) ? (int)G32(R, GW(depth)) : 0, wake && !suspended,
+                                          suspended ? (int)G32(R, GW(leaf_action)) - 1 : -1);
                 const uint32_t kind = G32(R, GW(leaf_kind));
+                if (SOLVER && kind == RAZ_LEAF_SOLVE_PENDING) {  // out of solver budget: the slot keeps the descent, the launch is over for the game
+                    T.st = writelane_r(T.st, RAZ_SIM_SOLVING, j, lane);
+                    slot_store(E, R, g, (uint32_t)j, lane);
+                    S32(R, GW(leaf_kind), RAZ_LEAF_NONE);
+                    break;
+                }
                 if (kind == RAZ_LEAF_TERMINAL || kind == RAZ_LEAF_SOLVED) {
                     back = true;
                 } else if (kind == RAZ_LEAF_EXPAND || kind == RAZ_LEAF_PARKED) {
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 T.st = writelane_r(T.st, RAZ_SIM_FREE, j, lane);
             }
         }
-        if (stage == kStageD) stage = kStageC2;   // (what the classic kernel stores at the end of a launch)
+        if (stage == kStageD && !(SOLVER && R.solve_pending)) stage = kStageC2;   // (what the classic kernel stores at the end of a launch)
         // ---- the net batch of this iteration: the leaves queued above, evaluated by this wave (their answers go where the net
         // kernel would have put them; the B phase of the next iteration picks them up with slot_load)
         wave_sync();
@@ -249,7 +269,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (lane == 0) E.nn_value[gi] = val;
         }
         wave_sync();
+        if (SOLVER && R.solve_pending) break;   // a solve (the root's, or one inside a simulation) waits for the next launch's budget
     }
+    if (SOLVER && stage == kStageD) S32(R, GW(par_dmask), (uint32_t)dmask);
     S32(R, GW(par_stage), stage);
     gw[lane] = R.cw;
     if (lane < (int)K) {

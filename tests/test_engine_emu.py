@@ -76,8 +76,13 @@ def test_emulated_batch_equals_oracle_with_and_without_pruning(golden, blob, var
         _same(f"{variant}/{pool}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
-def test_emulated_solver_games_equal_oracle(golden, blob):
-    """mini.yml as shipped: exact solver at the root, win/loss solver inside simulations (LDS frames, per-game memo)."""
+@pytest.mark.parametrize("budget", [None, 5])
+def test_emulated_solver_games_equal_oracle(golden, blob, budget, monkeypatch):
+    """mini.yml as shipped: exact solver at the root, win/loss solver inside simulations (per-game memo).  budget: the solver
+    iterations a game may spend per launch - with 5, every solve of more than a handful of nodes is suspended many times (the
+    root's in begin_move, the ones inside simulations in the middle of a descent) and the records must not notice."""
+    if budget is not None:
+        monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
     cfg = config_of(_variant(golden, "mini_solver_noresign"))
     eng = EmuEngine(cfg, blob, n_games=1, seed=41, sims_hint=10)
     eng.start(900, 10)
@@ -109,6 +114,28 @@ def test_emulated_slot_kernel_equals_oracle(blob, k, pool):
     for i in range(2):
         plies, summ = O.selfplay_game(ocfg, blob, 7, 40 + i, 14)
         _same(f"par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
+
+
+@pytest.mark.parametrize("k,pool,budget", [(4, None, None), (3, 500, 3)])
+def test_emulated_slot_kernel_with_the_solver_equals_oracle(golden, blob, k, pool, budget, monkeypatch):
+    """k_tree_par with the end-game solver on: simulations suspended at a solve that ran out of the launch's budget (as new
+    simulations in C / C' and as woken sleepers in D) go on at the next launch with the schedule untouched."""
+    if budget is not None:
+        monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
+    cfg = config_of(_variant(golden, "mini_solver_noresign"))
+    cfg.play.parallel_search_num = k
+    cfg.play.thinking_loop = 1
+    eng = EmuEngine(cfg, blob, n_games=2, seed=43, sims_hint=12, nodes_per_game=pool)
+    eng.start(70, 12)
+    eng.run(chunk=8 if pool else 32)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=k)
+    solved = 0
+    for i in range(2):
+        plies, summ = O.selfplay_game(ocfg, blob, 43, 70 + i, 12)
+        _same(f"par{k}/solver/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        solved += sum(p["solved"] for p in plies)
+    assert solved > 0
 
 
 def test_emulated_series_on_a_carried_tree_and_position_api(golden, blob):
@@ -221,8 +248,11 @@ def test_emulated_dirichlet_alpha_above_one(golden, blob, alpha):
         _same(f"alpha{alpha}/{i}", plies, summ, op, osum["winner"])
 
 
-def test_emulated_eval_matches_equal_the_reference_evaluate_games():
-    """tests/golden/eval_games.json (the UNMODIFIED reference's EvaluateWorker.play_game, worker/evaluate.py:66-96: best model against
+@pytest.mark.parametrize("budget", [None, 4])
+def test_emulated_eval_matches_equal_the_reference_evaluate_games(budget, monkeypatch):
+    """(budget: solver iterations per game and launch, see test_emulated_solver_games_equal_oracle - the as-shipped match has 8
+    simulations in flight and the solver both at the root and inside them.)
+    tests/golden/eval_games.json (the UNMODIFIED reference's EvaluateWorker.play_game, worker/evaluate.py:66-96: best model against
     challenger, two ReversiPlayers with trees and random streams of their own; tests/golden/make_golden_eval.py) replayed the way
     reversi-alpha-zero_amd/worker/evaluate.py plays a match - one engine per model, slot g = that model's player of game g, armed move
     by move with raz_engine_set_position - on the EMULATED tree kernels: every ply's mover, action (resignations included) and root
@@ -234,6 +264,8 @@ def test_emulated_eval_matches_equal_the_reference_evaluate_games():
     import types
     from conftest import ROOT
     from reversi_alpha_zero_amd.agent.model import ReversiNet
+    if budget is not None:
+        monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
     from reversi_alpha_zero_amd.env.reversi_env import Player, ReversiEnv, Winner
     with open(os.path.join(ROOT, "tests", "golden", "eval_games.json")) as f:
         gold = json.load(f)

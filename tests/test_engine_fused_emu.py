@@ -82,14 +82,20 @@ def test_fused_slot_kernel_equals_oracle(blob, k, pool):
         _same(f"fused/par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
-def test_fused_solver_game_equals_oracle(golden, blob):
-    """mini.yml as shipped (exact solver at the root, win/loss solver inside simulations): the SOLVER = true form of k_tree_net."""
+@pytest.mark.parametrize("k,budget", [(1, None), (1, 5), (3, 4)])
+def test_fused_solver_game_equals_oracle(golden, blob, k, budget, monkeypatch):
+    """mini.yml as shipped (exact solver at the root, win/loss solver inside simulations): the SOLVER = true forms of k_tree_net and
+    k_tree_par_net.  budget: solver iterations per game and launch - solves that run out are suspended (the root's in begin_move,
+    the others in the middle of their descent) and go on at the next launch."""
+    if budget is not None:
+        monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
     cfg = config_of(_variant(golden, "mini_solver_noresign"))
+    cfg.play.parallel_search_num = k
     eng = EmuEngine(cfg, blob, n_games=1, seed=41, sims_hint=10, fused=True)
     eng.start(900, 10)
-    eng.run(chunk=32)
+    eng.run(chunk=32 if budget is None else 1)   # (a launch is over for a game whose solve is suspended, however many iterations it had left)
     (plies, summ), = eng.records(save_policy_of_tau_1=True)
-    oplies, osum = O.selfplay_game(O.play_cfg_from_config(cfg), blob, 41, 900, 10)
+    oplies, osum = O.selfplay_game(O.play_cfg_from_config(cfg, parallel_search_num=k), blob, 41, 900, 10)
     _same("fused/solver", plies, summ, oplies, osum["winner"])
     assert sum(p["solved"] for p in oplies) > 0
 
