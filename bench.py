@@ -256,14 +256,14 @@ def calibrate_ply_weights(eng, n, sims, seed, dev, first_id, steps=12):
 def conv_traffic():
     """HBM bytes per net forward from the committed PMC passes (separate rocprofv3 --pmc runs of this command:
     tools/run_profiles.sh -> tools/pmc_summary.py); None when no pass is committed for this build."""
-    path = os.path.join(ROOT, "profiles", "r3_pmc", "headline_config3_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r4_pmc", "headline_config3_traffic.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         t = json.load(f)
     if not t.get("fetch_pass_present") or not t.get("write_pass_present"):   # never report half a measurement
         return None, None
-    return t.get("net_forward_hbm_bytes_per_launch"), ("profiles/r3_pmc/headline_config3_traffic.json (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes "
+    return t.get("net_forward_hbm_bytes_per_launch"), ("profiles/r4_pmc/headline_config3_traffic.json (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes "
                                                        "of this command, summed over the launches of one net forward; FETCH doubled as MI355X_MICROARCH.md prescribes)")
 
 
@@ -839,6 +839,12 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None):
     if fused:
         out["k_tree_net_ms_per_simulation_step"] = tree_ms / timed
         out["matrix_core_tflops_inside_the_fused_kernel"] = 2.0 * macs * st["nn_leaves"] / dt / 1e12
+        ach = 2.0 * macs * st["nn_leaves"] / dt / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "k_tree_par_net" if par > 1 else "k_tree_net", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP32_PEAK_TFLOPS, "avg_kernel_ms_per_simulation_step": tree_ms / timed,
+                           "note": "net flops of the leaves evaluated / the WHOLE leg's time: the kernel is tree descent + backup + net in one wave per game, so this is "
+                                   "the matrix cores' share of a kernel that is bound by one wave's dependent-instruction latency (profiles/r4_pmc/config1_fused_*: "
+                                   "matrix pipe busy 38 %, SQ_WAIT_INST_ANY 53 %), not a GEMM efficiency"}
     else:
         leaves_per_launch = st["nn_leaves"] / (steps * lps)
         net_avg = net_ms / (timed * lps)

@@ -50,7 +50,7 @@ def test_bench_reports_no_traffic_without_both_passes(tmp_path, monkeypatch):
     """bench.conv_traffic: a committed summary that lacks a pass yields None, never a partial sum."""
     sys.path.insert(0, ROOT)
     import bench
-    d = tmp_path / "profiles" / "r3_pmc"
+    d = tmp_path / "profiles" / "r4_pmc"
     d.mkdir(parents=True)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.conv_traffic() == (None, None)
