@@ -190,6 +190,51 @@ def spotcheck_steady_state(eng, cfg, dnet, seed, first_id, start, n_check=8):
     return checked
 
 
+def spotcheck_first_moves(eng, cfg, dnet, seed, first_id, start, ply, sims, plies=(47, 48, 49), want=4, max_extra_steps=384):
+    """ch5.yml AS SHIPPED, the batch that was timed: slots taken up 1-3 plies before use_solver_turn play on (untimed) until they have
+    decided their FIRST move - a search with 8 simulations in flight whose descents end in win/loss solves (suspended and resumed on the
+    solver budget), re-thinking loops included - and that move (action, root visit counts) must equal the first move of the game the
+    oracle plays for the same id from the same position with the same settings, leaves through the device net.  Returns what was checked."""
+    import numpy as np
+    import oracle as O
+    from reversi_alpha_zero_amd.engine import GAME_SUMMARY, raw_from_packed
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=int(cfg.play.parallel_search_num))
+    nn = device_nn(dnet)
+    b, w, p = start
+    cand = np.nonzero(np.isin(ply, plies))[0]
+    if len(cand) < want:
+        raise AssertionError("as-shipped spot check: too few slots start just before use_solver_turn")
+    cand = cand[np.linspace(0, len(cand) - 1, min(len(cand), 6 * want)).astype(int)]
+    extra = 0
+    while True:
+        summ = eng.pack_records(0, eng.n_games, plies=1)["summary"].cpu().numpy().view(GAME_SUMMARY).reshape(-1)
+        ready = [int(g) for g in cand if summ["n_plies"][g] >= 1]
+        if len(ready) >= want or extra >= max_extra_steps:
+            break
+        eng.step(16)
+        extra += 16
+        st = eng.stats()
+        if eng.pool_nearly_full(st, 16):
+            eng.gc(min(int(eng.cfg.nodes_per_game) // 4, st["max_pool_used"] // 2))
+    if len(ready) < want:
+        raise AssertionError(f"as-shipped spot check: only {len(ready)} of the sampled slots decided a move within {extra} extra steps")
+    checked = []
+    for g in ready[:want]:
+        pk = eng.pack_records(g, 1, plies=1)
+        raw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
+        act, rn = int(raw["headers"][0, 0]["action"]), raw["root_n"][0, 0].astype(np.float64)
+        oplies, _ = O.selfplay_game(ocfg, None, seed, first_id + g, sims, nn=nn, stop_after_plies=1,
+                                    start=(int(b[g]) & (2**64 - 1), int(w[g]) & (2**64 - 1), int(p[g])))
+        if act != oplies[0]["action"] or not np.array_equal(rn, np.array(oplies[0]["root_n"])):
+            raise AssertionError(f"parity spot check FAILED: ch5.yml as shipped, slot {g} (game id {first_id + g}, taken up at ply {int(ply[g])}): "
+                                 f"first move {act} / root N differ from the oracle's {oplies[0]['action']}")
+        checked.append({"game_id": first_id + g, "taken_up_at_ply": int(ply[g]), "action": act, "root_visits": int(rn.sum()),
+                        "solved_by_the_root_solver": bool(oplies[0].get("solved", 0))})
+    return {"result": "ok", "what": "slots of the TIMED as-shipped batch taken up 1-3 plies before use_solver_turn: their first decided move (action, root N; 8 simulations "
+                                    "in flight, in-simulation solves on the solver budget, re-thinking) == the oracle's for the same id from the same position, leaves "
+                                    "through the device net", "untimed_steps_played_on": extra, "games": checked}
+
+
 def spotcheck_whole_games(eng, cfg, blob, seed, first_id, slots, sims):
     """Finished games of the batch against complete oracle games (C net): every action and every root visit count."""
     import concurrent.futures as cf
@@ -764,7 +809,7 @@ def ch5_as_shipped_leg(args, dev, blob, weights, games=8192, steps=6, warm=12):
                              leaf_cache_log2=None if args.no_leaf_cache else 26, leaf_cache_max_discs=24,
                              solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")))
         eng.start(0, args.sims)
-        stagger(eng, games, args.sims, 31337, dev, weights)
+        ply = stagger(eng, games, args.sims, 31337, dev, weights)
         eng.step(warm)
         st0 = eng.stats()
         torch.cuda.synchronize()
@@ -777,6 +822,8 @@ def ch5_as_shipped_leg(args, dev, blob, weights, games=8192, steps=6, warm=12):
         res[label] = {"value": sims_done / dt, "unit": "sims/s", "ms_per_step": 1e3 * dt / steps, "k_tree_par_ms_per_step": tree_ms / steps,
                       "net_forward_ms_per_step": net_ms / steps, "net_evaluations_per_step": leaves / steps, "sims_per_step": sims_done / steps,
                       "leaf_slot_occupancy": leaves / (steps * games * 8), "engine_workspace_bytes": int(eng.workspace_bytes)}
+        if label == "as_shipped" and not args.no_spotcheck:
+            res[label]["parity_spotcheck"] = spotcheck_first_moves(eng, cfg, net, 0, 0, eng._staggered, ply, args.sims)
         del eng, net
         torch.cuda.empty_cache()
     a, b = res["as_shipped"], res["solver_off"]

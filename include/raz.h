@@ -116,9 +116,15 @@ int raz_net_forward(const raz_net* net, const uint64_t* own, const uint64_t* ene
  * one k-ordered fmaf chain, bit-identical to the CPU oracle); 4 (filters % 128 == 0) = "raznet-forward-v2": the 3x3 trunk on
  * the f16 matrix cores with every f32 operand split into two halfs (csrc/raz_net_f16x3.hip: 3 f16 MFMAs per product, f32
  * accumulation, within 1e-5 of the fp32 graph, 16/3 of the f32-MFMA rate); 1, 2: test variants of v1 (same bits).  v2's split activations must
- * stay inside the f16 range; *overflowed = 1 reports that some activation since raz_net_load did not (sticky): run the net
- * with reserved = 0 then.  Synchronises `stream`. */
+ * stay inside the f16 range: a row (position) whose activations do not is evaluated by the exact-f32 chains inside the same
+ * forward; *overflowed = 1 reports that some forward since raz_net_load had more such rows than it repairs (32; sticky): run the
+ * net with reserved = 0 then.  Synchronises `stream`. */
 int raz_net_range_check(const raz_net* net, int* overflowed, raz_stream_t stream);
+/* The same plus *rows_repaired: v2 rows (positions) since raz_net_load whose activations left the f16 range and were therefore
+ * evaluated by the exact-f32 chains instead, inside the forward that met them (at most 32 rows per forward; a forward with more
+ * raises the sticky flag reported by *overflowed).  A row's answer is a function of its position alone either way.  No reference
+ * counterpart (Keras computes in fp32 throughout, agent/api.py:30-45).  Synchronises `stream`. */
+int raz_net_range_stats(const raz_net* net, int* overflowed, unsigned long long* rows_repaired, raz_stream_t stream);
 
 /* ---- batched self-play engine --------------------------------------------------------------------
  * Replaces, for n_games concurrent games, SelfPlayWorker.start_game (worker/self_play.py:139-175)

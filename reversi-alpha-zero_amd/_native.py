@@ -91,6 +91,7 @@ SIGNATURES.update({
     "raz_net_forward": (c_int, [POINTER(RazNet), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                 c_void_p, c_size_t, c_void_p]),
     "raz_net_range_check": (c_int, [POINTER(RazNet), POINTER(c_int), c_void_p]),
+    "raz_net_range_stats": (c_int, [POINTER(RazNet), POINTER(c_int), POINTER(ctypes.c_ulonglong), c_void_p]),
     "raz_engine_workspace_bytes": (c_size_t, [POINTER(RazEngineConfig)]),
     "raz_engine_create": (c_int, [POINTER(RazEngineConfig), POINTER(RazNet), c_void_p, c_size_t, c_void_p,
                                   c_size_t, POINTER(c_void_p)]),

@@ -48,17 +48,14 @@ struct NetDims {
     int F, R, V;
 };
 
-template <bool LDS_ACT>
-__global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, NetDims d,
-                                                 const raz_bb* __restrict__ own,
-                                                 const raz_bb* __restrict__ enemy,
-                                                 const uint8_t* __restrict__ active,
-                                                 float* __restrict__ policy, float* __restrict__ value,
-                                                 float* __restrict__ scratch, int n) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int pos = blockIdx.x;
-    if (pos >= n) return;
-    if (active && !active[pos]) return;
+// One position on one wave: bo / be = the position, policy_row / value_out = where its answer goes, slot = its activation
+// buffers in `scratch` when they do not live in LDS.  TWO_BUF: two activation buffers instead of three - the second conv of a
+// block writes relu(conv + skip) IN PLACE over its skip input (element (channel, square) reads the skip value it overwrites and
+// nothing else of that buffer) - so that a 256-filter position fits the LDS of a CU (128 KB + heads); same chains, same bits.
+template <bool LDS_ACT, bool TWO_BUF = false>
+__device__ __forceinline__ void net_wave_position(const float* __restrict__ W, NetDims d, raz_bb bo, raz_bb be,
+                                                  float* __restrict__ policy_row, float* __restrict__ value_out,
+                                                  float* __restrict__ scratch, size_t slot, float* smem) {
     const int lane = threadIdx.x;
     const int F = d.F, R = d.R, V = d.V;
     float* buf0;
@@ -68,16 +65,15 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
     if (LDS_ACT) {
         buf0 = smem;
         buf1 = smem + F * 64;
-        buf2 = smem + 2 * F * 64;
-        head = smem + 3 * F * 64;
+        buf2 = TWO_BUF ? buf0 : smem + 2 * F * 64;
+        head = smem + (TWO_BUF ? 2 : 3) * F * 64;
     } else {
-        float* base = scratch + (size_t)pos * 3 * F * 64;
+        float* base = scratch + slot * 3 * F * 64;
         buf0 = base;
         buf1 = base + F * 64;
         buf2 = base + 2 * F * 64;
         head = smem;
     }
-    const raz_bb bo = own[pos], be = enemy[pos];
     // neighbour index and validity for the 9 taps
     const int y = lane >> 3, x = lane & 7;
     int nbr[9];
@@ -99,7 +95,7 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
         const bool second = (l > 0) && ((l & 1) == 0);
         const float* in = l == 0 ? nullptr : (second ? bufs[(ia + 1) % 3] : bufs[ia]);
         const float* skip = second ? bufs[ia] : nullptr;
-        float* out = l == 0 ? bufs[0] : (second ? bufs[(ia + 2) % 3] : bufs[(ia + 1) % 3]);
+        float* out = l == 0 ? bufs[0] : (second ? bufs[TWO_BUF ? ia : (ia + 2) % 3] : bufs[(ia + 1) % 3]);
         for (int ocb = 0; ocb < F / 16; ++ocb) {
             float acc[16];
 #pragma unroll
@@ -137,7 +133,7 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
         }
         if (!LDS_ACT) __threadfence_block();
         __syncthreads();  // single-wave block: orders this layer's writes before neighbour reads
-        if (second) ia = (ia + 2) % 3;
+        if (second && !TWO_BUF) ia = (ia + 2) % 3;
     }
     const float* a = bufs[ia];  // trunk output [F][64]
     const float* H = W + heads_off(F, R);
@@ -178,7 +174,7 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
     float sum = e;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) sum = sum + __shfl_xor(sum, s);
-    policy[(size_t)pos * 64 + lane] = e / sum;
+    policy_row[lane] = e / sum;
     // value dense 64 -> V (relu), lane = hidden unit (loop if V > 64)
     for (int o0 = 0; o0 < V; o0 += 64) {
         const int o = o0 + lane;
@@ -192,7 +188,42 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
     __syncthreads();
     float acc = v2_b[0];
     for (int j = 0; j < V; ++j) acc = fmaf(h1[j], v2_w[j], acc);
-    if (lane == 0) value[pos] = raz_det_tanhf(acc);
+    if (lane == 0) *value_out = raz_det_tanhf(acc);
+}
+
+template <bool LDS_ACT>
+__global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, NetDims d,
+                                                 const raz_bb* __restrict__ own,
+                                                 const raz_bb* __restrict__ enemy,
+                                                 const uint8_t* __restrict__ active,
+                                                 float* __restrict__ policy, float* __restrict__ value,
+                                                 float* __restrict__ scratch, int n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pos = blockIdx.x;
+    if (pos >= n) return;
+    if (active && !active[pos]) return;
+    net_wave_position<LDS_ACT>(W, d, own[pos], enemy[pos], policy + (size_t)pos * 64, value + pos, scratch, (size_t)pos, smem);
+}
+
+// The rows of a split-f16 forward whose activations left the f16 range, once more on the exact-f32 chains (raz_internal.h
+// raz_net_repair_rows).  One block per row of the forward; a block whose row is in range - all of them, normally - reads one
+// word and exits.  The row's activations live in LDS (two buffers, in-place second conv): no scratch, no limit on the rows.
+__global__ __launch_bounds__(64) void k_net_wave_repair(const float* __restrict__ W, NetDims d, const raz_bb* __restrict__ own,
+                                                        const raz_bb* __restrict__ enemy, float* __restrict__ policy,
+                                                        float* __restrict__ value, int n, unsigned* __restrict__ rowflag,
+                                                        unsigned* __restrict__ sticky, const uint32_t* __restrict__ list,
+                                                        const uint32_t* __restrict__ n_ptr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int i = blockIdx.x;
+    const int rows = n_ptr ? ((int)*n_ptr < n ? (int)*n_ptr : n) : n;
+    if (i >= rows || !rowflag[(size_t)i * RAZ_NET_ROWFLAG_WORDS]) return;
+    if (threadIdx.x == 0) {
+        atomicAdd(sticky + 1, 1u);   // rows repaired since the net was loaded
+        // a forward with many rows out of range belongs on the exact-f32 matrix-core kernels: tell the caller (raz_net_range_check)
+        if (atomicAdd(rowflag + 1, 1u) >= RAZ_NET_REPAIR_ROWS) atomicOr(sticky, 1u);
+    }
+    const size_t row = list ? list[i] : (size_t)i;
+    net_wave_position<true, true>(W, d, own[row], enemy[row], policy + row * 64, value + row, nullptr, 0, smem);
 }
 
 }  // namespace
@@ -211,7 +242,8 @@ extern "C" size_t raz_net_scratch_bytes(int filters, int value_fc, size_t n) {
     if (raz_net_mfma_supported(filters, value_fc) || use_lds(filters, value_fc)) return 0;
     if (wide_supported(filters)) {  // the larger of the two paths (reserved==1 forces the VALU kernel)
         const size_t a = raz_net_wide_scratch_bytes(filters, n), b = n * 3 * (size_t)filters * 64 * sizeof(float);
-        return a > b ? a : b;
+        const size_t c = f16x3_supported(filters) ? raz_net_f16x3_scratch_bytes(filters, n) : 0;   // (its repair rows make it the largest for small n)
+        return a > b ? (a > c ? a : c) : (b > c ? b : c);
     }
     return n * 3 * (size_t)filters * 64 * sizeof(float);
 }
@@ -299,9 +331,11 @@ extern "C" int raz_net_load(raz_net* net, const void* blob, size_t blob_bytes, v
 }
 
 // raznet-forward-v2 carries activations as pairs of halfs: an activation beyond the f16 range (>= 60000; none in any
-// net we have seen: BatchNorm keeps them O(1)) would become inf.  The kernels raise a sticky flag in the weight image
-// instead of failing silently; *overflowed = 1 means the outputs since the net was loaded cannot be trusted and the net
-// must be run with the exact-f32 kernels (raz_net.reserved = 0).  Synchronises `stream`.
+// net we have seen: BatchNorm keeps them O(1)) would become inf.  The kernels flag the ROW instead of failing silently, and
+// the forward evaluates flagged rows again on the exact-f32 chains (k_net_wave_repair: a row's answer stays a function of its
+// position alone).  Only when more than RAZ_NET_REPAIR_ROWS rows of ONE forward are out of range is the sticky flag in the weight
+// image raised: *overflowed = 1 means outputs since the net was loaded cannot be trusted and the net must be run with the
+// exact-f32 kernels (raz_net.reserved = 0).  Synchronises `stream`.
 extern "C" int raz_net_range_check(const raz_net* net, int* overflowed, raz_stream_t stream) {
     if (!net || !net->d_weights || !overflowed) return raz_fail(RAZ_EINVAL, "raz_net_range_check: NULL argument");
     *overflowed = 0;
@@ -312,6 +346,38 @@ extern "C" int raz_net_range_check(const raz_net* net, int* overflowed, raz_stre
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_range_check: sync");
     *overflowed = v != 0;
     return RAZ_OK;
+}
+
+extern "C" int raz_net_range_stats(const raz_net* net, int* overflowed, unsigned long long* rows_repaired, raz_stream_t stream) {
+    if (!net || !net->d_weights || !overflowed || !rows_repaired) return raz_fail(RAZ_EINVAL, "raz_net_range_stats: NULL argument");
+    *overflowed = 0;
+    *rows_repaired = 0;
+    if (!f16x3_supported(net->filters)) return RAZ_OK;
+    unsigned v[2] = {0, 0};
+    RAZ_HIP_TRY(hipMemcpyAsync(v, raz_net_f16x3_flag((const float*)net->d_weights, net->filters, net->res_layers, net->value_fc), 8,
+                               hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_net_range_stats: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_net_range_stats: sync");
+    *overflowed = v[0] != 0;
+    *rows_repaired = v[1];
+    return RAZ_OK;
+}
+
+int raz_net_repair_rows(const float* W, int F, int R, int V, const uint64_t* own, const uint64_t* enemy, float* policy, float* value,
+                        size_t n, unsigned* rowflag, unsigned* sticky, const uint32_t* list, const uint32_t* n_ptr, hipStream_t s) {
+    NetDims d = {F, R, V};
+    const size_t shm = ((size_t)2 * F * 64 + 192 + (size_t)V) * sizeof(float);   // two activation buffers + the heads' scratch
+    {   // 130 KB for F = 256: above the default dynamic limit - raise it once per device
+        static unsigned long long attr_devices = 0;
+        int dev = 0;
+        RAZ_HIP_TRY(hipGetDevice(&dev), "raz_net_forward: hipGetDevice");
+        if (dev >= 64 || !(attr_devices >> dev & 1)) {
+            RAZ_HIP_TRY(hipFuncSetAttribute((const void*)k_net_wave_repair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "raz_net_forward: hipFuncSetAttribute (repair)");
+            if (dev < 64) attr_devices |= 1ull << dev;
+        }
+    }
+    hipLaunchKernelGGL(k_net_wave_repair, dim3((unsigned)n), dim3(64), shm, s, W, d, (const raz_bb*)own, (const raz_bb*)enemy, policy, value,
+                       (int)n, rowflag, sticky, list, n_ptr);
+    return raz_check_launch("raz_net_forward (range repair)");
 }
 
 // Engine-internal: raz_net_forward over a compacted batch (raz_leaf_cache.hip).  Only the f16x3 path has the indexed form;

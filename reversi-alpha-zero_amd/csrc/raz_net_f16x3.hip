@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_f16x3(const unsigned char* _
                 *(h4*)(out_pos + o + 1024) = lo;
             }
         }
-    if (over) atomicOr(flag, 1u);   // an activation beyond the f16 range: the caller must fall back to the f32 kernel
+    if (over) flag[(size_t)pos * RAZ_NET_ROWFLAG_WORDS] = 1u;   // an activation beyond the f16 range: this ROW is evaluated again by the exact-f32 kernel (raz_net_repair_rows)
     RAZ_STAMP_END;
 }
 
@@ -251,6 +251,12 @@ __global__ __launch_bounds__(256) void k_conv0_split(const float* __restrict__ W
                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr) {
     const int pos = blockIdx.x, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the weight reads below stay scalar loads
+    // the forward's first kernel clears the per-row range flags (word 0 of every row's area) and the repair counter (word 1 of row 0's)
+    if (threadIdx.x == 0) {
+        flag[(size_t)pos * RAZ_NET_ROWFLAG_WORDS] = 0u;
+        if (pos == 0) flag[1] = 0u;
+    }
+    __syncthreads();
     if (n_ptr) n = (int)*n_ptr < n ? (int)*n_ptr : n;
     if (pos >= n || (!list && active && !active[pos])) return;
     bool over = false;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void k_conv0_split(const float* __restrict__ W
             *(h8*)(op + (size_t)ocb * ACT_POS + (g * 2 + 1) * 1024 + lane * 16) = lo;
         }
     }
-    if (over) atomicOr(flag, 1u);
+    if (over) flag[(size_t)pos * RAZ_NET_ROWFLAG_WORDS] = 1u;
 }
 
 // Heads as in k_heads_wide (exact f32 chains), reading the trunk output in the split layout: x = hi + lo (exact in f32).
@@ -408,7 +414,20 @@ int raz_net_heads_split(const float* W, int F, int R, int V, const unsigned char
     return raz_check_launch("raz_net_forward (split heads)");
 }
 
-size_t raz_net_f16x3_scratch_bytes(int F, size_t n) { return (size_t)2 * n * F * 256; }
+// two activation buffers, then a 64-byte area per row for its range flag (raz_internal.h raz_net_repair_rows): linear in n
+size_t raz_net_f16x3_scratch_bytes(int F, size_t n) { return n * ((size_t)2 * F * 256 + RAZ_NET_ROWFLAG_WORDS * 4); }
+
+// F > 256 (a row's f32 activations do not fit a CU's LDS, so there is no in-forward repair): any row out of range raises the sticky flag
+__global__ __launch_bounds__(256) void k_flag_unrepaired(const unsigned* __restrict__ rowflag, unsigned* __restrict__ sticky, int n,
+                                                         const uint32_t* __restrict__ n_ptr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int rows = n_ptr ? ((int)*n_ptr < n ? (int)*n_ptr : n) : n;
+    if (i < rows && rowflag[(size_t)i * RAZ_NET_ROWFLAG_WORDS]) atomicOr(sticky, 1u);
+}
+static int raz_net_flag_unrepaired(const unsigned* rowflag, unsigned* sticky, size_t n, const uint32_t* n_ptr, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_unrepaired, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rowflag, sticky, (int)n, n_ptr);
+    return raz_check_launch("raz_net_forward (range flags)");
+}
 
 // The sticky range flag lives in the device weight image, after the per-layer scales (raz_net_layout.h leaves 64 floats there).
 unsigned* raz_net_f16x3_flag(const float* W, int F, int R, int V) { return (unsigned*)(W + f16x3_scale_off(F, R, V) + (size_t)2 * R + 8); }
@@ -422,7 +441,8 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
         return raz_fail(RAZ_ENOMEM, "raz_net_forward: scratch too small (raz_net_scratch_bytes)");
     unsigned char* bufA = (unsigned char*)scratch;
     unsigned char* bufT = bufA + (size_t)n * F * 256;
-    unsigned* flag = raz_net_f16x3_flag(W, F, R, V);
+    unsigned* sticky = raz_net_f16x3_flag(W, F, R, V);
+    unsigned* flag = (unsigned*)(bufT + (size_t)n * F * 256);   // per-row range flags
     const float* scales = W + f16x3_scale_off(F, R, V);
     const auto conv = k_conv3x3_f16x3;
     {   // the kernel's LDS image exceeds the default dynamic limit: raise it once per device
@@ -449,5 +469,11 @@ int raz_net_forward_f16x3(const float* W, int F, int R, int V, const uint64_t* o
                            (const unsigned char*)(W + f16x3_layer_off(F, R, V, l2)), W + conv_off(F, l2) + (size_t)F * 9 * F,
                            scales + (l2 - 1), (const unsigned char*)bufT, bufA, (const unsigned char*)bufA, list ? nullptr : active, (int)n, F, flag, n_ptr RAZ_STAMP_ARG);
     }
-    return raz_net_heads_split(W, F, R, V, bufA, active, policy, value, n, s, list, n_ptr);
+    const int rc = raz_net_heads_split(W, F, R, V, bufA, active, policy, value, n, s, list, n_ptr);
+    if (rc != RAZ_OK) return rc;
+    // rows whose activations left the f16 range: the same position through the exact-f32 chains (raznet-forward-v1), so a row's
+    // answer is a function of its position alone - v2's when it stays in range, v1's when it does not
+    if (((size_t)2 * F * 64 + 192 + (size_t)V) * sizeof(float) > 160 * 1024)   // (F > 256: a row does not fit a CU's LDS - not repaired, see raz_net_range_check)
+        return raz_net_flag_unrepaired(flag, sticky, n, n_ptr, s);
+    return raz_net_repair_rows(W, F, R, V, own, enemy, policy, value, n, flag, sticky, list, n_ptr, s);
 }

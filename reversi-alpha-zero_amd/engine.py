@@ -71,6 +71,15 @@ class DeviceNet:
             check(lib.raz_net_range_check(ctypes.byref(self.c), ctypes.byref(v), _stream()), "raz_net_range_check")
         return v.value == 0
 
+    def range_stats(self):
+        """(in range, rows repaired): rows of split-f16 forwards since the net was loaded whose activations left the f16 range and
+        were evaluated on the exact-f32 chains instead (include/raz.h raz_net_range_stats)."""
+        import torch
+        v, r = ctypes.c_int(0), ctypes.c_ulonglong(0)
+        with torch.cuda.device(self.device):
+            check(lib.raz_net_range_stats(ctypes.byref(self.c), ctypes.byref(v), ctypes.byref(r), _stream()), "raz_net_range_stats")
+        return v.value == 0, int(r.value)
+
     def predict_bitboards(self, own, enemy, active=None):
         """own/enemy: int64 device tensors (side to move's view).  -> (policy (n,64), value (n,)).
         active (uint8 device tensor, optional): positions with 0 are skipped, their outputs stay 0."""

@@ -151,6 +151,66 @@ def test_net_f16x3_within_tolerance_of_torch_and_exact_kernel(shape, n):
             assert torch.equal(pa[0].view(torch.int32), p2[i].view(torch.int32)) and torch.equal(qa.view(torch.int32), q2[i:i + 1].view(torch.int32))
 
 
+def test_net_f16x3_rows_that_leave_the_f16_range_are_evaluated_by_the_exact_f32_chains():
+    """raznet-forward-v2's range repair on the device (csrc/raz_net.hip k_net_wave_repair; the emulated form of this test is in
+    tests/test_net_emu.py): a 256-filter net whose stem activations are 10^4 x the discs around a square.  In a batch of 4096
+    harvested positions with 20 completely filled boards mixed in, the filled rows (beyond 60000) equal the exact-f32 kernels' outputs bit
+    for bit, every other row equals the v2 forward of the in-range rows alone (bitwise batch invariance), the sticky flag stays down
+    (20 <= 32 rows in one forward) and the repair counter says 20.  Then a forward in which most rows are out of range raises the flag:
+    that is the case the worker answers by moving the block to the f32 kernels (tests/test_worker_scale_gpu.py)."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_sweep import harvest_positions
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    dev = torch.device(DEV)
+    net = ReversiNet(256, 2, 64).keras_init_(6)
+    with torch.no_grad():
+        net.stem.conv.weight.fill_(1.0e4)
+        net.stem.conv.bias.zero_()
+        for blk in net.res:
+            for cb in blk:
+                cb.conv.weight.mul_(1.0e-7)
+    blob = net.to_blob()
+    n, n_full = 4096, 20
+    black, white, player, _ = harvest_positions(n, 41, dev, None)
+    own = torch.where(player == 1, black, white)
+    enemy = torch.where(player == 1, white, black)
+    # early positions only (at most 3 discs around any square would be too strict for real play: keep the rows whose stem stays in range
+    # by construction instead - boards of <= 5 discs per 3x3 neighbourhood, i.e. < 60000)
+    sh = torch.arange(64, device=dev, dtype=torch.int64)
+    occ = (((own | enemy)[:, None] >> sh) & 1).float().reshape(-1, 1, 8, 8)
+    crowd = torch.nn.functional.conv2d(occ, torch.ones(1, 1, 3, 3, device=dev), padding=1).amax(dim=(1, 2, 3))
+    keep = crowd <= 5
+    own, enemy = own[keep].contiguous(), enemy[keep].contiguous()
+    assert own.numel() >= 100
+    g = torch.Generator(device="cpu").manual_seed(3)
+    full_own = torch.randint(-2**63, 2**63 - 1, (n_full,), generator=g, dtype=torch.int64).to(dev)
+    where = torch.randperm(own.numel() + n_full, generator=g).to(dev)
+    mixed_own = torch.cat([own, full_own])[where].contiguous()
+    mixed_enemy = torch.cat([enemy, ~full_own])[where].contiguous()
+    is_full = (where >= own.numel())
+    v2, v1 = DeviceNet(blob, dev, kernel="f16x3"), DeviceNet(blob, dev, kernel="f32")
+    p2, q2 = v2.predict_bitboards(mixed_own, mixed_enemy)
+    p1, q1 = v1.predict_bitboards(mixed_own, mixed_enemy)
+    assert torch.isfinite(p2).all() and torch.isfinite(q2).all()
+    assert torch.equal(p2[is_full].view(torch.int32), p1[is_full].view(torch.int32)) and torch.equal(q2[is_full].view(torch.int32), q1[is_full].view(torch.int32))
+    assert v2.range_stats() == (True, n_full)
+    alone = DeviceNet(blob, dev, kernel="f16x3")
+    pa, qa = alone.predict_bitboards(own, enemy)
+    assert alone.range_stats() == (True, 0)
+    idx = where[~is_full]   # mixed row j holds own[where[j]]
+    assert torch.equal(p2[~is_full].view(torch.int32), pa[idx].view(torch.int32)) and torch.equal(q2[~is_full].view(torch.int32), qa[idx].view(torch.int32))
+    # most rows out of range in ONE forward: answers are still the exact-f32 ones, and the sticky flag tells the caller to change kernels
+    many = torch.cat([full_own, full_own ^ 0x5555, full_own ^ 0x3333]).contiguous()
+    pm, qm = v2.predict_bitboards(many, ~many)
+    p1m, q1m = v1.predict_bitboards(many, ~many)
+    assert torch.equal(pm.view(torch.int32), p1m.view(torch.int32)) and torch.equal(qm.view(torch.int32), q1m.view(torch.int32))
+    assert v2.range_stats() == (False, n_full + 3 * n_full) and not v2.range_ok()
+
+
 def test_net_f16x3_accuracy_on_4096_positions_of_three_nets():
     """raznet-forward-v2 on the metric's shape (256x10), 4096 positions from random play (tools/bench_sweep.harvest_positions) x
     three weight / BatchNorm-statistics variants of tools/check_net_accuracy.py: (1) the bench net (Keras initialisers, seed 0), (2)
@@ -210,18 +270,25 @@ def test_net_f16x3_accuracy_on_4096_positions_of_three_nets():
 
 
 def test_net_f16x3_range_flag():
-    """A net whose activations leave the f16 range must say so (raz_net_range_check), not return garbage silently."""
+    """A net whose activations leave the f16 range must never return garbage silently: up to 32 such rows per forward are evaluated
+    by the exact-f32 chains inside the forward (answers == the f32 kernels', bit for bit; raz_net_range_stats counts them), a forward
+    with more raises the sticky flag (raz_net_range_check) while still answering every row exactly."""
     from reversi_alpha_zero_amd.agent.model import ReversiNet
     from reversi_alpha_zero_amd.engine import DeviceNet
     net = ReversiNet(128, 1, 64).keras_init_(5)
     with torch.no_grad():
         net.stem.conv.weight.mul_(1.0e6)
-    own, enemy = _harvested_positions(8, 2)
-    o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
-    v2 = DeviceNet(net.to_blob(), DEV, kernel="f16x3")
-    assert v2.range_ok()
-    v2.predict_bitboards(o, e)
-    assert not v2.range_ok()
+    blob = net.to_blob()
+    v1 = DeviceNet(blob, DEV, kernel="f32")
+    for n, in_range in ((8, True), (40, False)):
+        own, enemy = _harvested_positions(n, 2)
+        o, e = torch.from_numpy(own.view(np.int64)).to(DEV), torch.from_numpy(enemy.view(np.int64)).to(DEV)
+        v2 = DeviceNet(blob, DEV, kernel="f16x3")
+        assert v2.range_ok()
+        p2, q2 = v2.predict_bitboards(o, e)
+        p1, q1 = v1.predict_bitboards(o, e)
+        assert torch.equal(p2.view(torch.int32), p1.view(torch.int32)) and torch.equal(q2.view(torch.int32), q1.view(torch.int32))
+        assert v2.range_stats() == (in_range, n) and v2.range_ok() == in_range
 
 
 @pytest.mark.parametrize("par", [1, 4])

@@ -23,6 +23,8 @@ int raz_net_heads_split(const float*, int, int, int, const unsigned char*, const
 #define IN_BYTES_PER_F 256
 #define W_TAPS 9
 #define POS_PER_WG NWAVE
+// (the forward's range repair lives in raz_net.hip, which the probe does not link)
+int raz_net_repair_rows(const float*, int, int, int, const uint64_t*, const uint64_t*, float*, float*, size_t, unsigned*, unsigned*, const uint32_t*, const uint32_t*, hipStream_t) { return 0; }
 #endif
 
 #include <stdio.h>
@@ -77,7 +79,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dB, nmax * pos_bytes));
     CK(hipMalloc(&dbias, F * 4));
     CK(hipMalloc(&dscale, 4));
-    CK(hipMalloc(&dflag, 4));
+    CK(hipMalloc(&dflag, (size_t)nmax * 64 + 64));   // a 64-byte range-flag area per row (raz_internal.h)
     const size_t nblocks = (size_t)nmax / POS_PER_WG * 2;
     CK(hipMalloc(&dstamps, nblocks * 8 * 8 * 8));
     {
@@ -98,7 +100,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dbias, b.data(), F * 4, hipMemcpyHostToDevice));
         const float sc = 1.0f / 32768.f / 2304.f;   // keeps the outputs O(1): no range flag
         CK(hipMemcpy(dscale, &sc, 4, hipMemcpyHostToDevice));
-        CK(hipMemset(dflag, 0, 4));
+        CK(hipMemset(dflag, 0, (size_t)nmax * 64 + 64));
     }
 #ifdef PROBE_WINO
     unsigned char* dP;
