@@ -493,9 +493,9 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
     k["peak"], k["unit"] = HBM_PEAK_GBS, "GB/s"
     k["frac"] = k["achieved"] / HBM_PEAK_GBS if k["achieved"] else None
     k["note"] = "latency-bound (one wave per game, dependent round trips): the HBM fraction is nominal"
-    # counter traffic of the tree kernel: profiles/r3_pmc/headline_ktree_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this
+    # counter traffic of the tree kernel: profiles/r4_pmc/headline_ktree_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this
     # command; "games_per_launch" says how many games the profiled launches covered - traffic per game is what is compared)
-    tpath = os.path.join(ROOT, "profiles", "r3_pmc", ("headline_ktree" if args.net == "ch5" else "config1") + "_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r4_pmc", ("headline_ktree" if args.net == "ch5" else "config1") + "_traffic.json")
     tgames = None
     if os.path.exists(tpath):   # counter traffic of the same command (tools/run_profiles.sh): FETCH_SIZE / WRITE_SIZE passes
         with open(tpath) as f:

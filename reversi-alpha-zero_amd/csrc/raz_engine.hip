@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void k_gc(raz_engine_dev E, uint32_t threshold
         const raz_node_hdr* h = node_hdr(node_ptr(E, g, link));
         const raz_bb kb = h->black, kw = h->white;
         const uint32_t tagkey = h->tag & RAZ_SLOT_KEYMASK;
-        uint32_t si = key_hash(kb, kw, tagkey) & mask;
+        uint32_t si = key_hash(kb, kw, tagkey) & mask & ~(uint32_t)(RAZ_TABLE_PROBE - 1);   // table_find's order: the aligned group first
         const uint32_t val = RAZ_SLOT_USED | tagkey;
         for (;;) {
             if (atomicCAS(&tab[si].idx_tag, 0u, val) == 0u) {

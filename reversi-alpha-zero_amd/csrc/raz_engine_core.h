@@ -176,20 +176,27 @@ __device__ Found table_find(const raz_engine_dev& E, uint32_t g, raz_bb b, raz_b
                             int lane) {
     const raz_slot* tab = E.table + (size_t)g * E.H;
     const uint32_t mask = E.H - 1;
-    const uint32_t h = key_hash(b, w, tagkey);
+    const uint32_t h = key_hash(b, w, tagkey) & ~(uint32_t)(RAZ_TABLE_PROBE - 1);   // aligned groups: one 128-byte line per request
     Found f;
     f.found = false;
     f.node = 0;
     f.slot = 0xffffffffu;
-    for (uint32_t r = 0; r < E.H; r += RAZ_PROBE) {
-        const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
+    const bool probing = lane < RAZ_TABLE_PROBE;   // (the other lanes request nothing)
+    for (uint32_t r = 0; r < E.H; r += RAZ_TABLE_PROBE) {
+        const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_TABLE_PROBE - 1))) & mask;
         const raz_slot* s = tab + si;
-        const raz_bb sb = s->black, sw = s->white;
-        const uint32_t it = s->idx_tag, lk = s->link;
+        raz_bb sb = 0, sw = 0;
+        uint32_t it = RAZ_SLOT_USED, lk = 0;
+        if (probing) {
+            sb = s->black;
+            sw = s->white;
+            it = s->idx_tag;
+            lk = s->link;
+        }
         const bool used = (it & RAZ_SLOT_USED) != 0;
-        const bool match = used && sb == b && sw == w && (it & RAZ_SLOT_KEYMASK) == tagkey;
-        const unsigned long long mm = __ballot(match) & 0xffffULL;
-        const unsigned long long em = __ballot(!used) & 0xffffULL;
+        const bool match = probing && used && sb == b && sw == w && (it & RAZ_SLOT_KEYMASK) == tagkey;
+        const unsigned long long mm = __ballot(match) & ((1ULL << RAZ_TABLE_PROBE) - 1ULL);
+        const unsigned long long em = __ballot(probing && !used) & ((1ULL << RAZ_TABLE_PROBE) - 1ULL);
         if (mm) {
             const int jj = __ffsll((long long)mm) - 1;
             f.found = true;
