@@ -134,7 +134,7 @@ def _net_that_overflows_on_crowded_boards(F, V):
     return net.to_blob()
 
 
-@pytest.mark.parametrize("shape,n_crowded", [((128, 1, 32), 3), ((256, 1, 16), 40)])
+@pytest.mark.parametrize("shape,n_crowded", [((128, 1, 32), 40), ((256, 1, 16), 2)])
 def test_emulated_rows_that_leave_the_f16_range_are_evaluated_by_the_exact_f32_chains(lib, shape, n_crowded):
     """raznet-forward-v2's range repair (csrc/raz_net.hip k_net_wave_repair): in a batch mixing sparse boards (in range) and crowded
     boards (stem activations beyond 60000), the crowded rows come out as raznet-forward-v1 evaluates them - the oracle, bit for bit -
