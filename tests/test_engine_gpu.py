@@ -482,6 +482,31 @@ def test_engine_with_node_pruning_equals_oracle(golden, blob, variant, pool):
         _compare_game(f"gc/{variant}/{500 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
+@pytest.mark.parametrize("par,fused", [(1, False), (4, False), (1, True), (3, True)])
+def test_engine_solves_suspended_on_the_smallest_budget_equal_the_oracle(golden, blob, par, fused):
+    """raz_engine_config.reserved bits 16-23 = 1: a game may spend 64 solver iterations per launch (default 384), so every end-game
+    solve of more than a few hundred nodes - the exact ones at the root and the win/loss ones in the middle of a descent, whose
+    simulation then waits in its slot - is suspended and resumed many times, on k_tree (par 1), k_tree_par (4), k_tree_net and
+    k_tree_par_net (fused).  Records == the oracle's, which has no budget (mini.yml as shipped, resignation off, 12 games)."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    g0 = next(g for g in golden["games"] if g["variant"] == "mini_solver_noresign")
+    cfg = config_of(g0)
+    cfg.play.parallel_search_num = par
+    n, sims = 12, 14
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, DEV), n_games=n, seed=43, sims_hint=sims, record_root_w=True, fused=fused, solver_budget=64)
+    assert (int(eng.cfg.reserved) >> 16) & 0xff == 1
+    eng.start(first_game_id=700, sims_per_move=sims)
+    eng.run(chunk=48)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=par) if par > 1 else O.play_cfg_from_config(cfg)
+    nsolved = 0
+    for i in range(0, n, 3):
+        plies, summ = O.selfplay_game(ocfg, blob, 43, 700 + i, sims)
+        _compare_game(f"budget64/par{par}/{700 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        nsolved += sum(p["solved"] for p in plies)
+    assert nsolved > 0
+
+
 def test_engine_with_solver_batch_vs_oracle(golden, blob):
     """End-game solver on (mini.yml as shipped: exact at the root from turn 50, win/loss inside
     simulations from turn 50), resignation off so every game reaches the solver: 24 games == oracle."""
