@@ -206,6 +206,9 @@ def spotcheck_first_moves(eng, cfg, dnet, seed, first_id, start, ply, sims, plie
         return {"result": "not_checked", "why": "too few slots of the batch start 1-3 plies before use_solver_turn"}
     cand = cand[np.linspace(0, len(cand) - 1, min(len(cand), 6 * want)).astype(int)]
     extra = 0
+    import torch
+    torch.cuda.synchronize()
+    t0, sims0 = time.perf_counter(), eng.stats()["total_sims"]
     while True:
         summ = eng.pack_records(0, eng.n_games, plies=1)["summary"].cpu().numpy().view(GAME_SUMMARY).reshape(-1)
         ready = [int(g) for g in cand if summ["n_plies"][g] >= 1]
@@ -216,8 +219,12 @@ def spotcheck_first_moves(eng, cfg, dnet, seed, first_id, start, ply, sims, plie
         st = eng.stats()
         if eng.pool_nearly_full(st, 16):
             eng.gc(min(int(eng.cfg.nodes_per_game) // 4, st["max_pool_used"] // 2))
+    torch.cuda.synchronize()
+    sustained = {"steps": extra, "seconds": time.perf_counter() - t0, "sims_per_s": (eng.stats()["total_sims"] - sims0) / max(time.perf_counter() - t0, 1e-9),
+                 "note": "the batch played on after the timed steps (no refill: finished games leave their slots idle), host clock incl. the polls: "
+                         "what the as-shipped rate is once the games that reach the solver have queued up behind their budgets"} if extra else None
     if not ready:
-        return {"result": "not_checked", "why": f"none of the sampled slots decided a move within {extra} extra steps"}
+        return {"result": "not_checked", "why": f"none of the sampled slots decided a move within {extra} extra steps", "played_on": sustained}
     checked = []
     for g in ready[:want]:
         pk = eng.pack_records(g, 1, plies=1)
@@ -232,7 +239,7 @@ def spotcheck_first_moves(eng, cfg, dnet, seed, first_id, start, ply, sims, plie
                         "solved_by_the_root_solver": bool(oplies[0].get("solved", 0))})
     return {"result": "ok", "what": "slots of the TIMED as-shipped batch taken up 1-3 plies before use_solver_turn: their first decided move (action, root N; 8 simulations "
                                     "in flight, in-simulation solves on the solver budget, re-thinking) == the oracle's for the same id from the same position, leaves "
-                                    "through the device net", "untimed_steps_played_on": extra, "games": checked}
+                                    "through the device net", "untimed_steps_played_on": extra, "played_on": sustained, "games": checked}
 
 
 def spotcheck_whole_games(eng, cfg, blob, seed, first_id, slots, sims):
@@ -1068,6 +1075,9 @@ def compact_line(full):
                 e["solver_share_of_step_time"] = d["solver_share_of_a_step"].get("share_of_step_time")
                 e["solver_off_value"] = d.get("same_with_the_solver_off", {}).get("value")
                 e["root_solver_only_value"] = d.get("same_with_the_solver_at_the_root_only", {}).get("value")
+                po = (d.get("parity_spotcheck") or {}).get("played_on") if isinstance(d.get("parity_spotcheck"), dict) else None
+                if po:
+                    e["played_on_steps"], e["played_on_sims_per_s"] = po.get("steps"), po.get("sims_per_s")
             if "parity_check_complete_games" in d:
                 e["parity"] = parity(d["parity_check_complete_games"])
             line[key] = e
