@@ -843,20 +843,24 @@ def ch5_as_shipped_leg(args, dev, blob, weights, games=8192, steps=6, warm=12):
                                        "share_of_step_time": max(0.0, a["k_tree_par_ms_per_step"] - b["k_tree_par_ms_per_step"]) / a["ms_per_step"]}}
 
 
-def config1_leg(dev, args, par=1, fused=True, net_kernel=None):
+def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
     """BASELINE configs[1]: 4096 concurrent games, mini.yml net, 200 sims/move, WHOLE games (lock-step batch).
     fused: tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip: what the worker runs
-    for 16-filter nets); False = the two-kernel pipeline k_tree + k_net_mfma on three streams."""
+    for 16-filter nets); False = the two-kernel pipeline k_tree + k_net_mfma on three streams.
+    shipped: mini.yml's play section with no declared override left (config/mini.yml:10-26: thinking_loop 2, parallel_search_num 4,
+    end-game solver at the root and inside simulations from turn 50) - only the simulations per move stay BASELINE's 200."""
     import numpy as np
     import torch
     from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
     games, sims, chunk = 4096, 200, 200
     cfg = mini_config(sims, par)
+    if shipped:
+        cfg.play.thinking_loop, cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = 2, 50, 50
     F, R, V = NETS["mini"]
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     net = DeviceNet(blob, dev, kernel=net_kernel)
-    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims, fused=fused)
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=fused)
     eng.start(0, sims)
     eng.step(50)
     eng.stats()
@@ -876,7 +880,7 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None):
             eng.gc(min(eng.cfg.nodes_per_game // 4, st["max_pool_used"] // 2))
         if st["finished_games"] >= games:
             break
-        if steps > 80 * sims * 4 + 4000:
+        if steps > (80 * sims * 4 + 4000) * (40 if shipped else 1):   # (a game whose solve is suspended ends its launch: more launches, not more work)
             raise RuntimeError("engine did not finish")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -884,7 +888,8 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None):
     macs = macs_per_position(F, R, V)
     out = {"fused_tree_net_kernel": bool(fused),
            "workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
-                       f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, whole games (lock-step batch)"
+                       + ("play section AS SHIPPED (thinking_loop 2, parallel_search_num 4, end-game solver from turn 50: exact at the root, win/loss inside simulations), "
+                          if shipped else f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, ") + "whole games (lock-step batch)"
                        + ("; tree and net in ONE kernel (k_tree_net / k_tree_par_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else "")
                        + (f"; narrow-net kernel variant {net_kernel}" if net_kernel else ""),
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
@@ -908,8 +913,8 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None):
                            "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
                            "note": "3 slices on 3 streams overlap, so the per-launch duration is stretched by co-residency"}
         out["k_tree_avg_ms"] = tree_ms / (timed * lps)
-    if par == 1 and not args.no_spotcheck:
-        slots = [int(x) for x in np.linspace(0, games - 1, 8).astype(int)]
+    if (par == 1 or shipped) and not args.no_spotcheck:
+        slots = [int(x) for x in np.linspace(0, games - 1, 4 if shipped else 8).astype(int)]
         t1 = time.perf_counter()
         checked = spotcheck_whole_games(eng, cfg, blob, 0, 0, slots, sims)
         out["parity_spotcheck"] = {"result": "ok", "what": "8 game ids sampled from the finished batch: every action and root N == complete oracle games",
@@ -1062,7 +1067,7 @@ def compact_line(full):
                                                      "sims_per_net_evaluation", "ms_per_step")),
                                             slots=full.get("config", {}).get("games_per_gpu"), parity=parity(w.get("parity_check_complete_games")))
         line["whole_games_measured"]["sims_per_s"] = w.get("value")
-    for key in ("headline_on_exact_f32_kernels", "ch5_yml_as_shipped", "config5_8192x3200_agz", "config1_4096x200_mini", "config1_mini_yml_parallel_search_num_4",
+    for key in ("headline_on_exact_f32_kernels", "ch5_yml_as_shipped", "config5_8192x3200_agz", "config1_4096x200_mini", "config1_mini_yml_parallel_search_num_4", "config1_mini_yml_as_shipped", "config1_mini_yml_as_shipped_two_kernel_pipeline",
                 "config1_two_kernel_pipeline", "config1_two_kernel_pipeline_parallel_search_num_4", "config1_continuous_batching"):
         d = full.get(key)
         if isinstance(d, dict):
@@ -1210,6 +1215,8 @@ def main():
                     ("config5_8192x3200_agz", lambda: config5_leg(args, dev, blob, ply_weights)),
                     ("config1_4096x200_mini", lambda: config1_leg(dev, args, 1, fused=True)[0]),
                     ("config1_mini_yml_parallel_search_num_4", lambda: config1_leg(dev, args, 4, fused=True)[0]),
+                    ("config1_mini_yml_as_shipped", lambda: config1_leg(dev, args, 4, fused=True, shipped=True)[0]),
+                    ("config1_mini_yml_as_shipped_two_kernel_pipeline", lambda: config1_leg(dev, args, 4, fused=False, shipped=True)[0]),
                     ("config1_two_kernel_pipeline", lambda: config1_leg(dev, args, 1, fused=False)[0]),
                     ("config1_two_kernel_pipeline_parallel_search_num_4", lambda: config1_leg(dev, args, 4, fused=False)[0]),
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),

@@ -38,12 +38,8 @@ namespace {
 // SOLVER = false compiles the end-game solver (and its LDS frames) out: the common case, and the
 // bench configuration.  With the solver in, the kernel is sized for 2 waves per SIMD (256 VGPRs): the lane-parallel DFS
 // (raz_engine_core.h solver_solve_lanes, noinline, so it inherits the caller's register budget) spills 155 VGPRs into its
-// hot loop at 128, none at 256, and a configuration that solves is bound by the solves, not by tree occupancy.
-#ifdef RAZ_WAVE_EMU
-#define RAZ_TREE_WAVES(SOLVER)
-#else
-#define RAZ_TREE_WAVES(SOLVER) __attribute__((amdgpu_waves_per_eu((SOLVER) ? 2 : 4, (SOLVER) ? 2 : 4)))
-#endif
+// hot loop at 128, none at 256, and a configuration that solves is bound by the solves, not by tree occupancy
+// (RAZ_TREE_WAVES, raz_engine_core.h).
 template <bool SOLVER>
 __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;

@@ -720,6 +720,18 @@ __device__ void solver_note_result(SolverPar* P, int k, int ci) {
 // is what a launch then waits for (8192 games as shipped: tree kernel 97 ms per step with them, 1.6 ms with the root's solves alone):
 // they draw on the SAME per-launch budget (Regs::solve_budget, `budget` below: in = iterations left, out = what this call left of
 // it), and a descent whose solve runs out is suspended where it stands (select_leaf: RAZ_LEAF_SOLVE_PENDING).
+// Register budget of the tree kernels: 4 waves per SIMD (128 VGPRs) without the solver, 2 (256 VGPRs) with it - the lane-parallel
+// DFS inherits its caller's budget and spills 155 VGPRs (239 inside the fused slot kernel) at 128, none at 256.  Measured on
+// mini.yml as shipped, where the solves are 15/16 of the work: two-kernel pipeline 12.1 M sims/s with the 256-register solver
+// kernel against 7.6 M on fused kernels built for 128.
+#ifdef RAZ_WAVE_EMU
+#define RAZ_TREE_WAVES(SOLVER)
+#else
+#ifndef RAZ_SOLVER_WAVES
+#define RAZ_SOLVER_WAVES 2   // (-DRAZ_SOLVER_WAVES=4: the A/B build)
+#endif
+#define RAZ_TREE_WAVES(SOLVER) __attribute__((amdgpu_waves_per_eu((SOLVER) ? RAZ_SOLVER_WAVES : 4, (SOLVER) ? RAZ_SOLVER_WAVES : 4)))
+#endif
 #define RAZ_SOLVE_NONE 0
 #define RAZ_SOLVE_DONE 1
 #define RAZ_SOLVE_PENDING 2

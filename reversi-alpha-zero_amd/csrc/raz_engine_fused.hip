@@ -20,7 +20,7 @@
 namespace {
 
 template <bool SOLVER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree_net(raz_engine_dev E, uint32_t g0, uint32_t count,
+__global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engine_dev E, uint32_t g0, uint32_t count,
                                                                                           uint32_t iters, const float* __restrict__ net_w,
                                                                                           int net_R, int net_V) {
     if (blockIdx.x >= count) return;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // the raz-sched-v1 schedule, and with it every record, is unchanged.  The slot states stay in registers across iterations; the
 // leaves' positions and answers still travel through the leaf-exchange rows (written and read by this wave only).
 template <bool SOLVER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tree_par_net(raz_engine_dev E, uint32_t g0, uint32_t count,
+__global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_engine_dev E, uint32_t g0, uint32_t count,
                                                                                               uint32_t iters, const float* __restrict__ net_w,
                                                                                               int net_R, int net_V) {
     if (blockIdx.x >= count) return;

@@ -206,7 +206,8 @@ class BatchedSelfPlayWorker:
         self.leaf_cache_log2 = leaf_cache_log2
         self.leaf_cache_max_discs = leaf_cache_max_discs
         # 16-filter nets: tree and net in ONE kernel, the game's wave evaluating its own leaves (csrc/raz_engine_fused.hip; the same
-        # files bit for bit, +40 % on BASELINE configs[1]).  "auto" = wherever it applies; False = the two-kernel pipeline
+        # files bit for bit, +30 % on BASELINE configs[1]).  "auto" = wherever it applies and pays (not with the end-game solver on,
+        # see _get_engine); True = wherever it applies; False = the two-kernel pipeline
         self.fused_tree_net = fused_tree_net if fused_tree_net in ("auto", True, False) else bool(fused_tree_net)
         self.seed = seed
         self.device = device
@@ -288,9 +289,14 @@ class BatchedSelfPlayWorker:
                 if free is not None and self.games_in_flight * (pool_bytes + nodes * (4 * 32 + 8)) > free:   # pools + table slots + directory
                     raise RuntimeError(f"{self.games_in_flight} games in flight with never-pruned trees of {r} games at {max_sims} sims/move need "
                                        f"{self.games_in_flight * pool_bytes / 2**30:.0f} GiB of node pools; {free / 2**30:.0f} GiB are free: lower games_in_flight")
-            # 16-filter nets: tree and net in one kernel unless told otherwise ("auto"; the evaluation cache is for wide nets only)
+            # 16-filter nets: tree and net in one kernel unless told otherwise ("auto"; the evaluation cache is for wide nets only).
+            # With the end-game solver on, "auto" keeps the two-kernel pipeline: such a configuration is bound by its solves (mini.yml as
+            # shipped: 15/16 of the work), which the stand-alone tree kernel runs 12 % faster (12.1 M against 10.8 M sims/s, bench.py
+            # config1_mini_yml_as_shipped*)
+            p = self.config.play
+            solver_on = bool(getattr(p, "use_solver_turn", 0) or getattr(p, "use_solver_turn_in_simulation", 0))
             fused = (self._net.filters == 16 and self._net.value_fc <= 1024 and self._net.c.reserved == 0
-                     and (self.fused_tree_net is True or (self.fused_tree_net == "auto" and not cache)))
+                     and (self.fused_tree_net is True or (self.fused_tree_net == "auto" and not cache and not solver_on)))
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=None if fused else cache,
                                           leaf_cache_max_discs=self.leaf_cache_max_discs, pool_bytes_per_game=pool_bytes, fused=fused)
