@@ -8,11 +8,15 @@
 // k_net_mfma) returns the policy row and the value into the registers backup_leaf reads, and the loop goes on with the next
 // simulation - `iters` of them per launch, the control block and the path staying in registers throughout.  No leaf exchange, no
 // second kernel, no slices; one launch per `iters` simulation steps of the whole batch.  4 waves per SIMD (128 VGPRs, 9.7 KB of
-// LDS per wave): 4096 games are resident at once.  Every game performs exactly the operations it performs under k_tree +
-// k_net_mfma, in the same order: results are bit-identical (tests/test_engine_fused_emu.py on the wave emulator,
-// tests/test_engine_gpu.py).  Opt-in (raz_engine_config.reserved bit 4) for parallel_search_num == 1 without the evaluation
-// cache; at the end of a launch the last leaf's answer is parked in nn_policy / nn_value exactly where k_net_mfma would have
-// put it, so the two forms can even alternate.
+// LDS per wave): 4096 games are resident at once.  Measured resources (-Rpass-analysis=kernel-resource-usage): k_tree_net<false>
+// spills 30 VGPRs (124 B of scratch per lane) around the in-wave net call, k_tree_par_net<false> 56 (216 B) - most of the kernel's
+// counter traffic (profiles/r4_pmc/config1_fused_*); the SOLVER forms are built for 2 waves per SIMD (RAZ_TREE_WAVES: 213 / 236
+// VGPRs, no spill - the lane-parallel DFS is what such a configuration spends its time in).  Every game performs exactly the
+// operations it performs under k_tree + k_net_mfma, in the same order: results are bit-identical (tests/test_engine_fused_emu.py
+// on the wave emulator, tests/test_engine_gpu.py, tests/test_zz_fused_gpu.py).  raz_engine_config.reserved bit 4, without the
+// evaluation cache; the worker's default for 16-filter nets when the solver is off (105 M against 77 M sims/s on BASELINE
+// configs[1]).  At the end of a launch the last leaf's answer is parked in nn_policy / nn_value exactly where k_net_mfma would
+// have put it, so the two forms can even alternate.
 #include <hip/hip_runtime.h>
 #include "raz_engine_core.h"
 #include "raz_net_wave.h"   // raz_net16_forward_in_wave

@@ -512,3 +512,20 @@ def test_threshold_update_once_per_emitted_batch(tmp_path):
     w._defer_threshold_update = False
     w.check_and_update_resignation_threshold()
     assert abs(cfg.play.resign_threshold - (t0 - cfg.play.resign_threshold_delta)) < 1e-12 and w.resign_test_game_count == 0
+
+
+def test_the_fused_kernel_is_chosen_where_it_applies_and_pays():
+    """worker/self_play.py wants_fused_tree_net: 16-filter nets on the default net kernels; "auto" not with the evaluation cache and
+    not with the end-game solver on (a solver-bound configuration runs faster on the stand-alone tree kernel)."""
+    import types
+    from reversi_alpha_zero_amd.worker.self_play import wants_fused_tree_net
+    off = types.SimpleNamespace(use_solver_turn=0, use_solver_turn_in_simulation=0)
+    on = types.SimpleNamespace(use_solver_turn=50, use_solver_turn_in_simulation=50)
+    insim = types.SimpleNamespace(use_solver_turn=0, use_solver_turn_in_simulation=50)
+    assert wants_fused_tree_net("auto", 16, 16, 0, None, off)
+    assert not wants_fused_tree_net("auto", 16, 16, 0, None, on) and not wants_fused_tree_net("auto", 16, 16, 0, None, insim)
+    assert not wants_fused_tree_net("auto", 16, 16, 0, 20, off)            # evaluation cache attached
+    assert wants_fused_tree_net(True, 16, 16, 0, 20, on)                   # forced: wherever it applies
+    assert not wants_fused_tree_net(False, 16, 16, 0, None, off)
+    assert not wants_fused_tree_net(True, 32, 16, 0, None, off) and not wants_fused_tree_net(True, 16, 2048, 0, None, off)
+    assert not wants_fused_tree_net(True, 16, 16, 1, None, off)            # a forced net kernel (tests)
