@@ -338,6 +338,8 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
     F, R, V = NETS[args.net]
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     cfg = ch5_config(args.sims) if args.net == "ch5" else mini_config(args.sims)
+    if args.net == "mini" and os.environ.get("RAZ_BENCH_MINI_SHIPPED") == "1":   # profiling runs of the solver-bound regime (tools/sessions/r4_s22.sh)
+        cfg.play.parallel_search_num, cfg.play.thinking_loop, cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = 4, 2, 50, 50
     net = DeviceNet(blob, dev, kernel=args.net_kernel)
     parts = args.parts or (1 if args.net == "ch5" else 3)   # a 256x10 forward dwarfs the tree kernel: nothing to overlap
     # the cross-game evaluation cache as the worker attaches it for wide nets (2^26 entries, positions of <= 24 discs): the
