@@ -54,9 +54,9 @@
 #define RAZ_SIM_WAIT_EXPAND 2  // sleeping on now_expanding at node sim_parked
 #define RAZ_SIM_SOLVING 3      // its descent is suspended at an in-simulation solve (RAZ_LEAF_SOLVE_PENDING in its block)
 
-// per-game workspace of the lane-parallel end-game solver (raz_engine_core.h solver_solve_lanes): a 1 KiB header + state block,
-// 4 KiB of per-lane state, 14 levels x 64 lanes x 32 B of frames
-#define RAZ_SOLVER_WS_BYTES (1024 + 4096 + 14 * 64 * 32)
+// per-game workspace of the lane-parallel end-game solver (raz_engine_core.h solver_solve_lanes): a 1 KiB header, 4 KiB of per-lane
+// state, 14 levels x 64 lanes x 32 B of frames, and room for the LDS block (the three-ply task tree) of a suspended solve
+#define RAZ_SOLVER_WS_BYTES (1024 + 4096 + 14 * 64 * 32 + 7680)
 #define RAZ_PHASE_NEW_MOVE 0
 #define RAZ_PHASE_SEARCH 1
 #define RAZ_PHASE_DONE 2

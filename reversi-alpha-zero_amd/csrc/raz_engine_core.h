@@ -25,6 +25,13 @@ constexpr int kInnerMax = 2;  // max simulations completed per game per launch (
 // model, gfx942 table: "fence acq_rel - wavefront: none") — in particular no s_waitcnt vmcnt(0)
 // that would stall the wave until its stores are acknowledged.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// the same where one lane reads what ANOTHER lane of the wave has just written and no cross-lane instruction lies in between: the wave
+// barrier costs nothing on the hardware (one wave executes in lock-step) and is the meeting point of the lanes on the wave emulator
+__device__ __forceinline__ void wave_sync_lanes() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Values every lane holds identically (game state, keys, node indices) are moved to SGPRs so the
 // 64-bit board arithmetic and the address math run on the scalar unit.
@@ -469,10 +476,13 @@ __device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal
 // disc difference, strict improvement keeps the first maximum.  Here: the same DFS, wave-uniform
 // (scalar unit), frames in LDS (depth <= empties <= 14), with a per-game memo in HBM (positions
 // with >= 4 empties; the memo only saves time, exactly as the reference's dict does).
+#define RAZ_SOLVER_LDS_BYTES 7680
 struct SolverLDS {
     unsigned long long own[16], enemy[16], left[16];
     int best_move[16], best_score[16], paction[16], flip[16], fresh[16];
+    unsigned char room[RAZ_SOLVER_LDS_BYTES - 704];   // the lane-parallel search keeps its three-ply task tree here (SolverPar)
 };
+static_assert(sizeof(SolverLDS) == RAZ_SOLVER_LDS_BYTES, "SolverLDS layout");
 
 __device__ bool memo_find(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int lane,
                           int& move, int& score) {
@@ -601,11 +611,12 @@ __device__ bool solver_solve_scalar(const raz_engine_dev& E, uint32_t g, int lan
 // the best score is > 0 - value = -f(child) / +f(child after a pass) / final disc difference, strict improvement keeps the first
 // maximum.  The scalar search above visits one node at a time and the whole LAUNCH waits for it: with ch5.yml as shipped (solver
 // from turn 50, inside simulations too) 8192 games spent 77 % of a step waiting for one or two waves' searches of 10^5..10^6 nodes
-// (profiles/r4/bench_reduced_1024_games_session5_full.json).  Here the moves of the root and of its children are expanded two
-// plies deep into TASKS (child i, its j-th move: <= 14 x 13), every lane takes tasks off a common counter and runs the reference's
-// depth-first search of its task's subtree by itself - private frames, one node per lane and iteration, every lane executing the
-// same instruction stream on its own position - and the two top plies are then scanned in ascending move order with the same strict
-// improvement and the same early stop.  f is a function of the position, so evaluating siblings side by side (and, in non-exact
+// (profiles/r4/bench_reduced_1024_games_session5_full.json).  Here the top of the tree is expanded THREE plies deep - child i, its
+// j-th move, the m-th move after that: <= 14 x 13 x 12 TASKS (the first form expanded two plies: a non-exact solve then has only
+// ~7 tasks the sequential scan really needs, the longest a fifth of the work, and 8 lanes of 64 were busy) - every lane takes tasks
+// off a common counter and runs the reference's depth-first search of its task's subtree by itself - private frames, one node per
+// lane and iteration, every lane executing the same instruction stream on its own position - and the three top plies are then
+// scanned in ascending move order with the same strict improvement and the same early stop.  f is a function of the position, so evaluating siblings side by side (and, in non-exact
 // mode, some the sequential scan would never have reached) changes no result; the memo (shared by all lanes of the game's wave,
 // result-neutral as in the reference) carries transpositions from lane to lane and from solve to solve.
 #define RAZ_SOLVER_SCALAR_EMPTIES 6
@@ -654,45 +665,59 @@ __device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, r
     }   // both slots occupied: skipping the insert only costs time
 }
 
-// LDS of the lane-parallel solve, overlaid on SolverLDS (704 B): the root's children and the tasks' results
+// LDS of the lane-parallel solve (inside SolverLDS): the root's moves (level 1), the replies to them (level 2) and the tasks' results
+#define RAZ_SOLVER_MAX_L2 (RAZ_SOLVER_MAX_DEPTH * (RAZ_SOLVER_MAX_DEPTH - 1))        // 182 positions two plies below the root
+#define RAZ_SOLVER_MAX_TASKS (RAZ_SOLVER_MAX_L2 * (RAZ_SOLVER_MAX_DEPTH - 2))        // 2184 subtrees three plies below it
 struct SolverPar {
     unsigned long long c_own[RAZ_SOLVER_MAX_DEPTH], c_enemy[RAZ_SOLVER_MAX_DEPTH], c_moves[RAZ_SOLVER_MAX_DEPTH];   // child i: position (its mover's view), its moves
-    unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2];   // child i's first task
-    signed char result[RAZ_SOLVER_MAX_DEPTH * RAZ_SOLVER_MAX_DEPTH];   // task t: the value of that move for the child's mover (RAZ_SOLVER_UNKNOWN: not there yet)
-    // non-exact mode: the reference's scans stop at the first winning move, so most tasks need not be finished - see solver_note_result
-    signed char c_v[RAZ_SOLVER_MAX_DEPTH];     // child i: the value of the root's i-th move once known, for the ROOT's mover (else RAZ_SOLVER_UNKNOWN)
-    signed char c_bm[RAZ_SOLVER_MAX_DEPTH], c_bs[RAZ_SOLVER_MAX_DEPTH];   // child i: f(child) = (move, score) once its scan is decided
-    unsigned char c_kind[RAZ_SOLVER_MAX_DEPTH];   // child i: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo)
-    unsigned char root_done;                   // the root's scan is decided: every search still running is moot
+    unsigned long long g_own[RAZ_SOLVER_MAX_L2], g_enemy[RAZ_SOLVER_MAX_L2], g_moves[RAZ_SOLVER_MAX_L2];           // level-2 node n, likewise
+    unsigned short g_first[RAZ_SOLVER_MAX_L2 + 2];   // node n's first task
+    unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2]; // child i's first level-2 node
+    signed char result[RAZ_SOLVER_MAX_TASKS];        // task t: the value of that move for the level-2 node's mover (RAZ_SOLVER_UNKNOWN: not there yet)
+    signed char c_v[RAZ_SOLVER_MAX_DEPTH];           // child i: the value of the root's i-th move once known, for the ROOT's mover (else RAZ_SOLVER_UNKNOWN)
+    signed char g_v[RAZ_SOLVER_MAX_L2];              // node n: the value of the reply that leads to it once known, for the CHILD's mover
+    unsigned char c_kind[RAZ_SOLVER_MAX_DEPTH];      // child i: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo)
+    unsigned char g_kind[RAZ_SOLVER_MAX_L2];         // node n, likewise (seen from the child's mover)
+    unsigned char root_done;                         // the root's scan is decided: every search still running is moot
 };
 #define RAZ_SOLVER_UNKNOWN (-128)
-static_assert(sizeof(SolverPar) <= sizeof(SolverLDS), "the lane-parallel solver's LDS must fit the frames it replaces");
+static_assert(sizeof(SolverPar) <= sizeof(SolverLDS), "the lane-parallel solver's LDS must fit SolverLDS");
+
+// the reference's loop over a node's moves, on values that are already there: `vals` in ascending move order, RAZ_SOLVER_UNKNOWN =
+// not there yet.  Returns false while the scan is not decided.  Non-exact: it ends at the first value > 0
+__device__ __forceinline__ bool solver_scan(const signed char* vals, int n, raz_bb moves, bool exact, int& bm, int& bs) {
+    bm = -1;
+    bs = -100;
+    raz_bb m = moves;
+    for (int j = 0; j < n; ++j, m &= m - 1) {
+        const int v = vals[j];
+        if (v == RAZ_SOLVER_UNKNOWN) return false;
+        if (bs < v) {
+            bm = __ffsll((long long)m) - 1;
+            bs = v;
+        }
+        if (!exact && bs > 0) break;
+    }
+    return true;
+}
 
 // Non-exact mode (solves inside simulations, agent/player.py:237-251): the reference's loop at a node ends at the first move whose
-// value is > 0, so f(child) is decided as soon as the results of a PREFIX of the child's moves contain one - and the root's answer as
-// soon as a prefix of the children does.  Whenever a task's result lands, the lane that produced it re-runs those two scans over
-// what is known; a decided child cancels its remaining tasks, a decided root all of them (the lanes look at c_v / root_done before
-// every node).  Without this the 64 lanes finish ALL <= 182 subtrees of a position whose first move already wins - the sequential
-// search would have looked at one.  Several lanes may run the scans at once: they store the same values.
-__device__ void solver_note_result(SolverPar* P, int k, int ci) {
+// value is > 0, so a level-2 node is decided as soon as the results of a PREFIX of its tasks contain one, a child as soon as a prefix
+// of its level-2 nodes does, and the root's answer as soon as a prefix of the children does.  Whenever a task's result lands, the
+// lane that produced it re-runs those scans over what is known; a decided node cancels the tasks below it, a decided root all of
+// them (the lanes look at g_v / c_v / root_done before every node).  Without this the 64 lanes finish ALL subtrees of a position
+// whose first move already wins - the sequential search would have looked at one.  Several lanes may run the scans at once: they
+// store the same values.
+__device__ void solver_note_result(SolverPar* P, int k, int ci, int n) {
+    int bm, bs;
+    if (P->g_v[n] == RAZ_SOLVER_UNKNOWN) {
+        const int t0 = P->g_first[n];
+        if (!solver_scan(P->result + t0, (int)P->g_first[n + 1] - t0, P->g_moves[n], false, bm, bs)) return;
+        P->g_v[n] = (signed char)((P->g_kind[n] & 1) ? -bs : bs);
+    }
     if (P->c_v[ci] == RAZ_SOLVER_UNKNOWN) {
-        int bm = -1, bs = -100, t = P->c_first[ci];
-        bool decided = true;
-        for (raz_bb m = P->c_moves[ci]; m; m &= m - 1, ++t) {
-            const int v = P->result[t];
-            if (v == RAZ_SOLVER_UNKNOWN) {
-                decided = false;
-                break;
-            }
-            if (bs < v) {
-                bm = __ffsll((long long)m) - 1;
-                bs = v;
-            }
-            if (bs > 0) break;
-        }
-        if (!decided) return;
-        P->c_bm[ci] = (signed char)bm;
-        P->c_bs[ci] = (signed char)bs;
+        const int n0 = P->c_first[ci];
+        if (!solver_scan(P->g_v + n0, (int)P->c_first[ci + 1] - n0, P->c_moves[ci], false, bm, bs)) return;
         P->c_v[ci] = (signed char)((P->c_kind[ci] & 1) ? -bs : bs);
     }
     int best = -100;
@@ -769,24 +794,26 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
         }
     }
     SolverPar* P = (SolverPar*)S;
-    // the game's workspace: [0, 256) header words, [256, 1024) the LDS block of a parked search, [1024, 5120) eight arrays of 64 lane
-    // words, then the frames [level][lane] x 32 B
+    // the game's workspace: [0, 256) header words, [1024, 5120) eight arrays of 64 lane words, the frames [level][lane] x 32 B, then
+    // the LDS block of a parked search
     unsigned long long* hdr = (unsigned long long*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES);
     unsigned long long* lw = hdr + 128;                    // lane words: lw[field * 64 + lane]
     unsigned long long* fr = hdr + 640 + (size_t)lane * 4;   // this lane's frame at level d: fr[d * 256 + {0 own, 1 enemy, 2 left, 3 meta}]
-    int my_a = -1, my_kind = 0, my_v = 0, my_tasks = 0, first = 0, total = 0, k = 0;
+    unsigned long long* ldsave = hdr + 640 + RAZ_SOLVER_MAX_DEPTH * 256;   // sizeof(SolverPar) bytes
+    int my_a = -1, my_kind = 0, my_v = 0, my_tasks = 0, first = 0, total = 0, k = 0, n2 = 0;   // (my_tasks / first: this child's level-2 nodes)
     raz_bb c_own = 0, c_enemy = 0, c_moves = 0;
     raz_bb own = 0, enemy = 0, left = 0;
     int bmv = -1, bsc = -100, pact = -1, flip = 0, fresh = 0;
     int next = 0, d = 0, task = -1, task_sign = 1;
-    int task_ci = 0;   // the child this lane's task belongs to
+    int task_ci = 0, task_n = 0;   // the child and the level-2 node this lane's task belongs to
     bool have = false;
     const bool parked = uni((uint32_t)(hdr[0] == 0x5AULL && hdr[1] == own0 && hdr[2] == enemy0 && hdr[3] == (unsigned long long)exact)) != 0;
     if (parked) {   // pick the search up where the last launch left it
         k = (int)uni((uint32_t)hdr[4]);
         total = (int)uni((uint32_t)hdr[5]);
         next = (int)uni((uint32_t)hdr[6]);
-        for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) ((unsigned long long*)P)[i] = hdr[32 + i];
+        n2 = (int)uni((uint32_t)hdr[7]);
+        for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) ((unsigned long long*)P)[i] = ldsave[i];
         own = lw[0 * 64 + lane];
         enemy = lw[1 * 64 + lane];
         left = lw[2 * 64 + lane];
@@ -809,6 +836,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
         my_tasks = (int)((m2 >> 24) & 0xffULL);
         first = (int)((m2 >> 32) & 0xffULL);
         task_ci = (int)((m2 >> 40) & 0xffULL);
+        task_n = (int)((m2 >> 48) & 0xffULL);
         wave_sync();
     } else {
         const raz_bb legal0 = bb_legal_moves(own0, enemy0);
@@ -838,10 +866,10 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             } else
                 my_v = bb_popcount(nown) - bb_popcount(nenemy);
         }
-        for (int i = 0; i < k; ++i) {   // exclusive prefix sum of my_tasks over the lanes
+        for (int i = 0; i < k; ++i) {   // exclusive prefix sum over the lanes: child i's level-2 nodes are [first, first + my_tasks)
             const int ti = (int)lane_u32((uint32_t)my_tasks, i);
             if (i < lane) first += ti;
-            total += ti;
+            n2 += ti;
         }
         wave_sync();
         if (lane < k) {
@@ -852,12 +880,70 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             P->c_kind[lane] = (unsigned char)my_kind;
             P->c_v[lane] = (signed char)((my_kind == 0 || (my_kind & 4)) ? my_v : RAZ_SOLVER_UNKNOWN);   // known now: the game ends there, or the memo had f(child)
         }
-        for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
         if (lane == 0) {
-            P->c_first[k] = (unsigned char)total;
+            P->c_first[k] = (unsigned char)n2;
             P->root_done = 0;
         }
-        wave_sync();
+        wave_sync_lanes();
+        // ---- ply 2: level-2 node n = the position after child ci's j-th move, seen from the side to move there (kinds as at ply 1,
+        // from the CHILD's mover's point of view).  Its moves are the tasks
+        for (int n = lane; n < n2; n += 64) {
+            int ci = 0;
+            while (ci + 1 < k && (int)P->c_first[ci + 1] <= n) ++ci;
+            const raz_bb co = P->c_own[ci], ce = P->c_enemy[ci];
+            raz_bb m = P->c_moves[ci];
+            for (int j = (int)P->c_first[ci]; j < n; ++j) m &= m - 1;
+            const int b = __ffsll((long long)m) - 1;
+            const raz_bb flipped = bb_calc_flip(b, co, ce);
+            const raz_bb nown = (co ^ flipped) | (1ULL << b), nenemy = ce ^ flipped;
+            const raz_bb l1 = bb_legal_moves(nenemy, nown);
+            const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+            int gk = 0, gv = RAZ_SOLVER_UNKNOWN, tasks = 0;
+            raz_bb go = 0, ge = 0, gm = 0;
+            if (l1 | l2) {
+                gk = l1 ? 1 : 2;
+                go = l1 ? nenemy : nown;
+                ge = l1 ? nown : nenemy;
+                gm = l1 ? l1 : l2;
+                int rm, rs;
+                if (bb_popcount(~(go | ge)) >= 4 && memo_find_lane(E, g, go, ge, exact, rm, rs)) {
+                    gk |= 4;
+                    gv = (gk & 1) ? -rs : rs;
+                } else
+                    tasks = bb_popcount(gm);
+            } else
+                gv = bb_popcount(nown) - bb_popcount(nenemy);
+            P->g_own[n] = go;
+            P->g_enemy[n] = ge;
+            P->g_moves[n] = gm;
+            P->g_kind[n] = (unsigned char)gk;
+            P->g_v[n] = (signed char)gv;
+            P->g_first[n] = (unsigned short)tasks;   // (a count for now)
+        }
+        wave_sync_lanes();
+        if (lane == 0) {   // counts -> first task of every node
+            int acc = 0;
+            for (int n = 0; n < n2; ++n) {
+                const int c = P->g_first[n];
+                P->g_first[n] = (unsigned short)acc;
+                acc += c;
+            }
+            P->g_first[n2] = (unsigned short)acc;
+        }
+        wave_sync_lanes();
+        total = (int)uni((uint32_t)P->g_first[n2]);
+        for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
+        wave_sync_lanes();
+        if (!exact) {   // what is known already (finished games, the memo) may decide children - or the root - before any search runs
+            for (int n = lane; n < n2; n += 64) {
+                if (P->g_v[n] != RAZ_SOLVER_UNKNOWN) {
+                    int ci = 0;
+                    while (ci + 1 < k && (int)P->c_first[ci + 1] <= n) ++ci;
+                    solver_note_result(P, k, ci, n);
+                }
+            }
+            wave_sync_lanes();
+        }
     }
     // ---- the tasks: every lane searches subtrees until none is left.  The CURRENT node of a lane's search lives in registers, its
     // ancestors' frames in the workspace - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf
@@ -866,7 +952,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
         if (iter >= budget) {   // park the search: the next launch goes on from here
             budget = 0;
             wave_sync();
-            for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) hdr[32 + i] = ((const unsigned long long*)P)[i];
+            for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) ldsave[i] = ((const unsigned long long*)P)[i];
             lw[0 * 64 + lane] = own;
             lw[1 * 64 + lane] = enemy;
             lw[2 * 64 + lane] = left;
@@ -879,7 +965,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             lw[6 * 64 + lane] = c_moves;
             lw[7 * 64 + lane] = (unsigned long long)((my_a + 1) & 0xff) | ((unsigned long long)(my_kind & 0xff) << 8) | ((unsigned long long)((my_v + 128) & 0xff) << 16) |
                                 ((unsigned long long)(my_tasks & 0xff) << 24) | ((unsigned long long)(first & 0xff) << 32) |
-                                ((unsigned long long)(task_ci & 0xff) << 40);
+                                ((unsigned long long)(task_ci & 0xff) << 40) | ((unsigned long long)(task_n & 0xff) << 48);
             if (lane == 0) {
                 hdr[1] = own0;
                 hdr[2] = enemy0;
@@ -887,6 +973,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
                 hdr[4] = (unsigned long long)k;
                 hdr[5] = (unsigned long long)total;
                 hdr[6] = (unsigned long long)next;
+                hdr[7] = (unsigned long long)n2;
                 hdr[0] = 0x5AULL;
             }
             wave_sync();
@@ -897,12 +984,19 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             const int t = next + rank;
             next += __popcll(idle);
             if (!have && t < total) {
+                int lo = 0, hi = n2;   // the task's level-2 node: the last n with g_first[n] <= t
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)P->g_first[mid] <= t) lo = mid;
+                    else hi = mid;
+                }
                 int ci = 0;
-                while (ci + 1 < k && (int)P->c_first[ci + 1] <= t) ++ci;
+                while (ci + 1 < k && (int)P->c_first[ci + 1] <= lo) ++ci;
                 task_ci = ci;
-                const raz_bb co = P->c_own[ci], ce = P->c_enemy[ci];
-                raz_bb m = P->c_moves[ci];
-                for (int j = (int)P->c_first[ci]; j < t; ++j) m &= m - 1;
+                task_n = lo;
+                const raz_bb co = P->g_own[lo], ce = P->g_enemy[lo];
+                raz_bb m = P->g_moves[lo];
+                for (int j = (int)P->g_first[lo]; j < t; ++j) m &= m - 1;
                 const int b = __ffsll((long long)m) - 1;
                 const raz_bb flipped = bb_calc_flip(b, co, ce);
                 const raz_bb nown = (co ^ flipped) | (1ULL << b), nenemy = ce ^ flipped;
@@ -923,13 +1017,13 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
                     have = true;
                 } else {
                     P->result[t] = (signed char)(bb_popcount(nown) - bb_popcount(nenemy));
-                    if (!exact) solver_note_result(P, k, ci);
+                    if (!exact) solver_note_result(P, k, ci, lo);
                 }
             }
         }
         if (!exact) {   // what other lanes found may have made this lane's search (or all of them) moot
             const bool all_moot = __ballot(P->root_done != 0) != 0ULL;   // (wave-uniform: `next` must stay the same in every lane)
-            if (have && (all_moot || P->c_v[task_ci] != RAZ_SOLVER_UNKNOWN)) have = false;
+            if (have && (all_moot || P->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || P->g_v[task_n] != RAZ_SOLVER_UNKNOWN)) have = false;
             if (all_moot) next = total;
         }
         if (__ballot(have) == 0ULL) {
@@ -957,7 +1051,7 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
                 if (d == 0) {
                     P->result[task] = (signed char)(task_sign * rs);
                     have = false;
-                    if (!exact) solver_note_result(P, k, task_ci);
+                    if (!exact) solver_note_result(P, k, task_ci, task_n);
                 } else {   // back to the parent
                     const int v = flip ? -rs : rs, a = pact;
                     --d;
@@ -1005,26 +1099,28 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             }
         }
     }
-    wave_sync();
+    wave_sync_lanes();
     if (lane == 0) hdr[0] = 0ULL;   // nothing parked any more
-    // ---- ply 1 again: lane i scans its child's moves in ascending order (the reference's loop at that node).  Non-exact mode: only
-    // children whose scan was decided have an f(child) (the others were cancelled by an earlier winning move of the root)
+    // ---- ply 2 again: every level-2 node's tasks are scanned in ascending move order (the reference's loop at that node).  Non-exact
+    // mode: only nodes whose scan was decided have an f (the others were cancelled by an earlier winning move further up)
+    for (int n = lane; n < n2; n += 64) {
+        const int gk = P->g_kind[n];
+        if ((gk & 3) && !(gk & 4)) {
+            const int t0 = P->g_first[n];
+            const raz_bb go = P->g_own[n], ge = P->g_enemy[n];
+            int bm, bs;
+            if (solver_scan(P->result + t0, (int)P->g_first[n + 1] - t0, P->g_moves[n], exact != 0, bm, bs)) {
+                if (bb_popcount(~(go | ge)) >= 4) memo_put_lane(E, g, go, ge, exact, bm, bs);
+                P->g_v[n] = (signed char)((gk & 1) ? -bs : bs);
+            }
+        }
+    }
+    wave_sync_lanes();
+    // ---- ply 1 again: lane i scans its child's level-2 nodes the same way
     bool child_known = (my_kind & 3) == 0 || (my_kind & 4) != 0;
     if (lane < k && (my_kind & 3) && !(my_kind & 4)) {
-        int bm = -1, bs = -100, t = first;
-        child_known = true;
-        for (raz_bb m = c_moves; m; m &= m - 1, ++t) {
-            const int v = P->result[t];
-            if (v == RAZ_SOLVER_UNKNOWN) {
-                child_known = false;
-                break;
-            }
-            if (bs < v) {
-                bm = __ffsll((long long)m) - 1;
-                bs = v;
-            }
-            if (!exact && bs > 0) break;
-        }
+        int bm, bs;
+        child_known = solver_scan(P->g_v + first, my_tasks, c_moves, exact != 0, bm, bs);
         if (child_known) {
             if (bb_popcount(~(c_own | c_enemy)) >= 4) memo_put_lane(E, g, c_own, c_enemy, exact, bm, bs);
             my_v = (my_kind & 1) ? -bs : bs;

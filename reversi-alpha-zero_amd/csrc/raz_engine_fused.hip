@@ -291,7 +291,10 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
 // `n_steps` simulation steps of the whole batch in ceil(n_steps / 32) launches on stream s (raz_engine_step, reserved bit 4)
 int raz_launch_tree_net(const raz_engine_dev& d, bool solver, uint32_t n_steps, const float* W, int R, int V, hipStream_t s) {
     constexpr uint32_t kFusedIters = 32;
-    const int head = 192 + V > 64 + (int)(sizeof(SolverLDS) / sizeof(float)) ? 192 + V : 64 + (int)(sizeof(SolverLDS) / sizeof(float));
+    // behind the plane buffer: the heads' scratch of a forward, shared in time with backup_leaf's 64 floats and - solver forms only - the
+    // solver's block (7.5 KB: the solver forms run 2 waves per SIMD, 8 per CU x 16.6 KB; the others 16 per CU x 9.7 KB)
+    const int between = 64 + (solver ? (int)(sizeof(SolverLDS) / sizeof(float)) : 0);
+    const int head = 192 + V > between ? 192 + V : between;
     const size_t shm = ((size_t)16 * PS + head) * sizeof(float);
     int rc = RAZ_OK;
     while (n_steps && rc == RAZ_OK) {

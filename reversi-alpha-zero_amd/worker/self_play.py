@@ -187,15 +187,14 @@ def gather_packed(packed, rank, world):
 
 def wants_fused_tree_net(setting, filters, value_fc, net_reserved, cache_log2, play):
     """Whether the games are stepped by the fused tree + net kernel (csrc/raz_engine_fused.hip).  It applies to 16-filter nets on the
-    default net kernels (value_fc_size <= 1024); setting True = wherever it applies, False = never, "auto" = where it applies AND pays:
-    not with the evaluation cache (wide nets only anyway) and not with the end-game solver on - such a configuration is bound by its
-    solves, which the stand-alone tree kernel runs faster (mini.yml as shipped: 12.1 M against 10.8 M sims/s)."""
+    default net kernels (value_fc_size <= 1024); setting True = wherever it applies, False = never, "auto" = where it applies and
+    the evaluation cache (wide nets only anyway) is not attached.  With the end-game solver on the two forms are level (mini.yml as
+    shipped, solver-bound: 15.7 M sims/s fused, 15.0 M on the two-kernel pipeline), so `play` does not enter the decision."""
     if not (filters == 16 and value_fc <= 1024 and net_reserved == 0):
         return False
     if setting is True:
         return True
-    solver_on = bool(getattr(play, "use_solver_turn", 0) or getattr(play, "use_solver_turn_in_simulation", 0))
-    return setting == "auto" and not cache_log2 and not solver_on
+    return setting == "auto" and not cache_log2
 
 
 class BatchedSelfPlayWorker:
@@ -219,8 +218,7 @@ class BatchedSelfPlayWorker:
         self.leaf_cache_log2 = leaf_cache_log2
         self.leaf_cache_max_discs = leaf_cache_max_discs
         # 16-filter nets: tree and net in ONE kernel, the game's wave evaluating its own leaves (csrc/raz_engine_fused.hip; the same
-        # files bit for bit, +30 % on BASELINE configs[1]).  "auto" = wherever it applies and pays (not with the end-game solver on,
-        # see _get_engine); True = wherever it applies; False = the two-kernel pipeline
+        # files bit for bit, +30 % on BASELINE configs[1]).  "auto" = wherever it applies (wants_fused_tree_net); False = the two-kernel pipeline
         self.fused_tree_net = fused_tree_net if fused_tree_net in ("auto", True, False) else bool(fused_tree_net)
         self.seed = seed
         self.device = device
@@ -302,10 +300,7 @@ class BatchedSelfPlayWorker:
                 if free is not None and self.games_in_flight * (pool_bytes + nodes * (4 * 32 + 8)) > free:   # pools + table slots + directory
                     raise RuntimeError(f"{self.games_in_flight} games in flight with never-pruned trees of {r} games at {max_sims} sims/move need "
                                        f"{self.games_in_flight * pool_bytes / 2**30:.0f} GiB of node pools; {free / 2**30:.0f} GiB are free: lower games_in_flight")
-            # 16-filter nets: tree and net in one kernel unless told otherwise ("auto"; the evaluation cache is for wide nets only).
-            # With the end-game solver on, "auto" keeps the two-kernel pipeline: such a configuration is bound by its solves (mini.yml as
-            # shipped: 15/16 of the work), which the stand-alone tree kernel runs 12 % faster (12.1 M against 10.8 M sims/s, bench.py
-            # config1_mini_yml_as_shipped*)
+            # 16-filter nets: tree and net in one kernel unless told otherwise ("auto"; the evaluation cache is for wide nets only)
             fused = wants_fused_tree_net(self.fused_tree_net, self._net.filters, self._net.value_fc, self._net.c.reserved, cache, self.config.play)
             self._engine = SelfPlayEngine(self.config, self._net, self.games_in_flight, seed=self.seed,
                                           sims_hint=max_sims, nodes_per_game=nodes, leaf_cache_log2=None if fused else cache,
