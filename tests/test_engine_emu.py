@@ -370,3 +370,63 @@ def test_emulated_device_solver_equals_compiled_cython(budget, monkeypatch):
         h = raw["headers"][g, 0]
         assert int(raw["n_plies"][g]) == 1 and int(h["flags"]) & 1, (g, "not solved")
         assert int(h["action"]) == move and float(h["n"]) == 999.0 and float(h["q"]) == float(np.sign(score)), (g, int(h["action"]), move, float(h["q"]), score)
+
+
+@pytest.mark.parametrize("par,budget", [(1, None), (4, 40)])
+def test_emulated_in_simulation_solves_of_11_to_13_empties_equal_oracle(golden, blob, par, budget, monkeypatch):
+    """The lane-parallel solver on LARGE task trees (three plies below a position of 11-13 empties: up to ~150 level-2 nodes - three
+    rounds of the 64 lanes - and ~1500 tasks), non-exact mode: positions taken up by raz_engine_set_position with the in-simulation
+    solver from turn 46 (the declared limit) and no solver at the root, three simulations - the first solves the root position
+    itself, the next ones its children - one simulation in flight and four (with a budget of 40 iterations per launch: the 7.5 KB
+    task tree is parked and restored many times).  The decided move and the root statistics == the oracle's for the same id from
+    the same position."""
+    import random
+    from reversi_alpha_zero_amd.lib import bitboard as bb
+    if budget is not None:
+        monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
+    cfg = config_of(_variant(golden, "mini_solver_noresign"))
+    cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = 0, 46
+    cfg.play.parallel_search_num, cfg.play.thinking_loop = par, 1
+    rng = random.Random(2024)
+    starts = []
+    while len(starts) < 6:
+        b, w, p = 0x0000000810000000, 0x0000001008000000, 1
+        want = 64 - (11 + len(starts) % 3)     # discs on the board: 11, 12, 13 empties in turn
+        while bin(b | w).count("1") < want:
+            own, enemy = (b, w) if p == 1 else (w, b)
+            legal = int(bb.find_correct_moves(own, enemy))
+            if not legal:
+                if not int(bb.find_correct_moves(enemy, own)):
+                    break
+                p = 3 - p
+                continue
+            a = rng.choice([i for i in range(64) if legal >> i & 1])
+            fl = int(bb.calc_flip(a, own, enemy))
+            own, enemy = (own ^ fl) | (1 << a), enemy ^ fl
+            b, w = (own, enemy) if p == 1 else (enemy, own)
+            p = 3 - p
+        own, enemy = (b, w) if p == 1 else (w, b)
+        if bin(b | w).count("1") == want and int(bb.find_correct_moves(own, enemy)):
+            starts.append((b, w, p))
+    sims = 3
+    eng = EmuEngine(cfg, blob, n_games=len(starts), seed=9, sims_hint=sims)
+    eng.start(300, sims)
+    for g, (b, w, p) in enumerate(starts):
+        eng.set_position(g, b, w, p, sims, enable_resign=False, one_move=True)
+    for _ in range(200000):
+        eng.step(8)
+        if eng.stats()["idle_or_done"] >= len(starts):
+            break
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=par) if par > 1 else O.play_cfg_from_config(cfg)
+    cfg.play.use_solver_turn_in_simulation = 0
+    ocfg_off = O.play_cfg_from_config(cfg, parallel_search_num=par) if par > 1 else O.play_cfg_from_config(cfg)
+    mattered = 0
+    for g, start in enumerate(starts):
+        oplies, _ = O.selfplay_game(ocfg, blob, 9, 300 + g, sims, stop_after_plies=1, start=start)
+        a, ref = recs[g][0][0], oplies[0]
+        for key in ("player", "own", "enemy", "action", "root_n", "root_w", "n", "q"):
+            assert a[key] == ref[key], (g, key, a[key], ref[key])
+        off, _ = O.selfplay_game(ocfg_off, blob, 9, 300 + g, sims, stop_after_plies=1, start=start)
+        mattered += off[0]["root_w"] != ref["root_w"] or off[0]["root_n"] != ref["root_n"]
+    assert mattered >= 3      # (the solves decided what the simulations returned: without them the statistics differ)
