@@ -507,6 +507,61 @@ def test_engine_solves_suspended_on_the_smallest_budget_equal_the_oracle(golden,
     assert nsolved > 0
 
 
+@pytest.mark.parametrize("par", [1, 4])
+def test_engine_solves_of_11_to_13_empties_equal_the_oracle(golden, blob, par):
+    """The lane-parallel solver on LARGE task trees (three plies below positions of 11-13 empties: up to ~150 level-2 nodes and
+    ~1500 tasks; the goldens' solves have at most 10): (a) non-exact - positions taken up with the in-simulation solver from turn 46
+    and no root solver, three simulations (the first solves the root position itself, the next ones its children); (b) exact -
+    positions of 11 empties decided by the root solver (use_solver_turn 46).  Decided move, root statistics and (b) the solved flag
+    == the oracle's for the same id from the same position.  (Emulator form of (a): tests/test_engine_emu.py.)"""
+    import random
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    from reversi_alpha_zero_amd.lib import bitboard as bb
+    rng = random.Random(2024 + par)
+
+    def position(empties):
+        while True:
+            b, w, p = 0x0000000810000000, 0x0000001008000000, 1
+            want = 64 - empties
+            while bin(b | w).count("1") < want:
+                own, enemy = (b, w) if p == 1 else (w, b)
+                legal = int(bb.find_correct_moves(own, enemy))
+                if not legal:
+                    if not int(bb.find_correct_moves(enemy, own)):
+                        break
+                    p = 3 - p
+                    continue
+                a = rng.choice([i for i in range(64) if legal >> i & 1])
+                fl = int(bb.calc_flip(a, own, enemy))
+                own, enemy = (own ^ fl) | (1 << a), enemy ^ fl
+                b, w = (own, enemy) if p == 1 else (enemy, own)
+                p = 3 - p
+            own, enemy = (b, w) if p == 1 else (w, b)
+            if bin(b | w).count("1") == want and int(bb.find_correct_moves(own, enemy)):
+                return b, w, p
+    for mode, root_turn, insim_turn, sims, empties in (("non-exact", 0, 46, 3, (11, 12, 13, 11, 12, 13, 12, 13)), ("exact", 46, 46, 2, (11, 11, 11, 11))):
+        cfg = config_of(next(g for g in golden["games"] if g["variant"] == "mini_solver_noresign"))
+        cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = root_turn, insim_turn
+        cfg.play.parallel_search_num, cfg.play.thinking_loop = par, 1
+        starts = [position(e) for e in empties]
+        eng = SelfPlayEngine(cfg, DeviceNet(blob, DEV), n_games=len(starts), seed=9, sims_hint=sims, record_root_w=True)
+        eng.start(first_game_id=300, sims_per_move=sims)
+        for g, (b, w, p) in enumerate(starts):
+            eng.set_position(g, b, w, p, sims, enable_resign=False, one_move=True)
+        for _ in range(100000):
+            eng.step(16)
+            if eng.stats()["idle_or_done"] >= len(starts):
+                break
+        recs = eng.records(save_policy_of_tau_1=True)
+        ocfg = O.play_cfg_from_config(cfg, parallel_search_num=par) if par > 1 else O.play_cfg_from_config(cfg)
+        for g, start in enumerate(starts):
+            oplies, _ = O.selfplay_game(ocfg, blob, 9, 300 + g, sims, stop_after_plies=1, start=start)
+            a, ref = recs[g][0][0], oplies[0]
+            for key in ("player", "own", "enemy", "action", "root_n", "root_w", "n", "q"):
+                assert a[key] == ref[key], (mode, g, key, a[key], ref[key])
+            assert a["solved"] == ref.get("solved", False) == (mode == "exact"), (mode, g)
+
+
 def test_engine_with_solver_batch_vs_oracle(golden, blob):
     """End-game solver on (mini.yml as shipped: exact at the root from turn 50, win/loss inside
     simulations from turn 50), resignation off so every game reaches the solver: 24 games == oracle."""
