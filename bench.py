@@ -37,6 +37,12 @@ parallel_search_num 1 and mini.yml's 4, and on the two-kernel pipeline beside it
 At N > 1 (and at N = 1 under RAZ_BENCH_NCCL_WORLD1=1, an RCCL group of one rank): the record gather is timed and its payload
 verified (per-rank checksums), and a small whole-game batch is played sharded AND on rank 0 alone: the gathered records must be
 byte-identical (SURVEY 8(d) Config 4's acceptance).
+`config1_mini_yml_as_shipped*`: mini.yml's play section with no declared override (thinking_loop 2, 4 simulations in flight, solver
+from turn 50) on both kernel forms - the solver-bound regime.
+
+Environment (test rigs and profiling runs only; the driver's form uses none): RAZ_BENCH_SHARED_GPU=1 (N ranks on the visible GPUs over
+gloo), RAZ_BENCH_NCCL_WORLD1=1 (the N > 1 path on an RCCL group of one rank), RAZ_BENCH_SOLVER_BUDGET=<iterations> (ch5_yml_as_shipped:
+the per-launch solver budget), RAZ_BENCH_MINI_SHIPPED=1 (--net mini: the headline leg on mini.yml's play section as shipped).
 """
 import argparse
 import json
