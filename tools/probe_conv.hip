@@ -28,6 +28,7 @@ int raz_net_repair_rows(const float*, int, int, int, const uint64_t*, const uint
 #endif
 
 #include <stdio.h>
+#include <time.h>
 #include <algorithm>
 #include <map>
 
@@ -222,6 +223,37 @@ int main(int argc, char** argv) {
         const int n = argc > 3 ? atoi(argv[3]) : 8192;
         const float r = timeit(dW, dA, n);
         printf("{\"experiment\": \"pmc\", \"positions\": %d, \"ms_random\": %.4f}\n", n, r);
+    }
+    if (!strcmp(mode, "power")) {   // sustained phases for the SMI sampler (tools/smi_sampler.py): argv[2] = seconds per phase, argv[3] = positions
+        const double secs = argc > 2 ? atof(argv[2]) : 6.0;
+        const int n = argc > 3 ? atoi(argv[3]) : 8192;
+        auto wall = [] { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+        const char* names[] = {"idle", "random_operands", "zero_operands", "random_operands_again", "idle_after"};
+        for (int ph = 0; ph < 5; ++ph) {
+            const double t0 = wall();
+            long launches = 0;
+            double gpu_ms = 0;
+            if (ph == 0 || ph == 4) {
+                timespec req = {(time_t)(secs / 2), (long)((secs / 2 - (time_t)(secs / 2)) * 1e9)};
+                nanosleep(&req, nullptr);
+            } else {
+                const unsigned char *W = ph == 2 ? dWz : dW, *A = ph == 2 ? dAz : dA;
+                while (wall() - t0 < secs) {   // chunks of 100 launches (~0.12 s), timed with events: ms per launch over the phase
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 100; ++i) launch(W, A, n, nullptr);
+                    CK(hipEventRecord(e1, s));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    gpu_ms += ms;
+                    launches += 100;
+                }
+            }
+            const double t1 = wall();
+            printf("{\"experiment\": \"power\", \"phase\": \"%s\", \"positions\": %d, \"t_start_unix\": %.4f, \"t_end_unix\": %.4f, \"launches\": %ld, \"ms_per_launch\": %.4f}\n",
+                   names[ph], n, t0, t1, launches, launches ? gpu_ms / launches : 0.0);
+            fflush(stdout);
+        }
     }
 #ifndef PROBE_WINO
     if (all || !strcmp(mode, "stamps")) {
