@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define RAZ_ABI_VERSION 2   /* 2: compact tree nodes - raz_engine_config.pool_bytes_per_game, raz_engine_stats.max_pool_bytes */
+#define RAZ_ABI_VERSION 3   /* 2: compact tree nodes - raz_engine_config.pool_bytes_per_game, raz_engine_stats.max_pool_bytes.
+                               3: the end-game solver is a pool of worker waves shared by all games - raz_engine_config.solver_pool_waves,
+                                  reserved bits 16-23 now budget the pool's launches; raz_engine_uses_graph is gone, raz_net_range_stats
+                                  was added, raz_engine_config.reserved bit 2 and raz_net.reserved 5/6 are rejected */
 
 #define RAZ_OK 0
 #define RAZ_EINVAL (-1)   /* bad argument (range, NULL, alignment)            */
@@ -166,9 +169,10 @@ typedef struct {
                                                  k_tree_net / k_tree_par_net; same results); bits 8-11:
                                                  slices/streams (0 = 3); bits 12-15: max simulations per game per tree launch
                                                  (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num);
-                                                 bits 16-23: x 64 = iterations of the lane-parallel end-game solver a game may spend per
-                                                 tree launch (0 = 384); a solve that runs out - the root's or one inside a simulation -
-                                                 is suspended and goes on at the next launch: results do not depend on the value */
+                                                 bits 16-23: x 64 = iterations a worker lane of the end-game solver's pool runs between two
+                                                 tree launches (0 = 384); a game whose solve - the root's or one inside a simulation - is
+                                                 not answered yet stays suspended: results do not depend on the value.
+                                                 Every other bit must be 0 (RAZ_EINVAL) */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
                                                  (agent/player.py:100-103,150-161; lib/alt/reversi_solver_cython.pyx) */
     int32_t use_solver_turn_in_simulation;    /* config.py:155: 0 = off, else >= 46: win/loss solve inside simulations
@@ -181,6 +185,12 @@ typedef struct {
                                                  LEGAL move of the position (the reference keeps three f64[64] per key = 1536 B,
                                                  agent/player.py:62-66), ~212 B on average over a game, 704 B at most.
                                                  0 = nodes_per_game x 232 + 64 x 704; at most 256 MB */
+    uint32_t solver_pool_waves;               /* worker wavefronts of the end-game solver's pool (csrc/raz_solver_pool.h): positions of 7..14
+                                                 empties are solved by a pool of lanes shared by all games, one subtree per lane, instead
+                                                 of inside the game's own wave.  0 = one per two games, at most 2048 (two per SIMD); 32 KB
+                                                 of workspace each.  Results do not depend on the value.  No reference counterpart
+                                                 (lib/alt/reversi_solver_cython.pyx runs one position at a time) */
+    uint32_t reserved2;                       /* must be 0 */
 } raz_engine_config;
 
 typedef struct raz_engine raz_engine; /* opaque host handle; not re-entrant */

@@ -71,7 +71,8 @@ class RazEngineConfig(ctypes.Structure):
                 ("n_games", c_uint32), ("nodes_per_game", c_uint32), ("table_slots", c_uint32),
                 ("max_plies", c_uint32), ("seed", c_uint32), ("reserved", c_uint32),
                 ("use_solver_turn", ctypes.c_int32), ("use_solver_turn_in_simulation", ctypes.c_int32),
-                ("solver_memo_slots", c_uint32), ("parallel_search_num", c_uint32), ("pool_bytes_per_game", c_uint64)]
+                ("solver_memo_slots", c_uint32), ("parallel_search_num", c_uint32), ("pool_bytes_per_game", c_uint64),
+                ("solver_pool_waves", c_uint32), ("reserved2", c_uint32)]
 
 
 class RazHarvestResult(ctypes.Structure):
@@ -129,8 +130,8 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.raz_abi_version() != 2:
-    raise ImportError(f"libraz ABI version {lib.raz_abi_version()} != 2 (stale build?)")
+if lib.raz_abi_version() != 3:
+    raise ImportError(f"libraz ABI version {lib.raz_abi_version()} != 3 (stale build?)")
 
 
 def last_error() -> str:

@@ -54,9 +54,37 @@
 #define RAZ_SIM_WAIT_EXPAND 2  // sleeping on now_expanding at node sim_parked
 #define RAZ_SIM_SOLVING 3      // its descent is suspended at an in-simulation solve (RAZ_LEAF_SOLVE_PENDING in its block)
 
-// per-game workspace of the lane-parallel end-game solver (raz_engine_core.h solver_solve_lanes): a 1 KiB header, 4 KiB of per-lane
-// state, 14 levels x 64 lanes x 32 B of frames, and room for the LDS block (the three-ply task tree) of a suspended solve
-#define RAZ_SOLVER_WS_BYTES (1024 + 4096 + 14 * 64 * 32 + 7680)
+// End-game solver, POOLED across games (raz_solver_pool.h).  A tree kernel that needs f_mode(position) for a position with 7..14
+// empties POSTS a request in its game's block of E.solver_ws (header below, then the three-ply task tree) and suspends where it
+// stands; between tree launches k_solve_scan builds the task trees of new requests and folds finished tasks into answers, and
+// k_solve_run - a fixed pool of worker waves that belongs to no game - hands ONE subtree to every LANE, whatever game it comes from.
+#define RAZ_SOLVE_IDLE 0u
+#define RAZ_SOLVE_REQUESTED 1u   // posted by a tree kernel: own0 / enemy0 / exact are valid, gen was bumped
+#define RAZ_SOLVE_RUNNING 2u     // its task tree is built; workers take tasks off `next`
+#define RAZ_SOLVE_ANSWERED 3u    // ans_* hold f(own0, enemy0): stays until another position is requested
+struct raz_solve_hdr {           // 64 bytes at the start of a game's solver block
+    uint32_t state, gen;
+    unsigned long long own0, enemy0;
+    uint32_t exact;
+    uint32_t k, n2, total;       // root moves, level-2 nodes, tasks
+    uint32_t next;               // next task to hand out (workers: atomicAdd)
+    int32_t ans_move, ans_score;
+    uint32_t ans_kind;           // RAZ_SOLVE_DONE / RAZ_SOLVE_NONE
+    uint32_t pad[2];
+};
+#ifdef __cplusplus
+static_assert(sizeof(raz_solve_hdr) == 64, "raz_solve_hdr layout");
+#endif
+#define RAZ_SOLVER_TREE_BYTES 10240   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there)
+#define RAZ_SOLVER_WS_BYTES (64 + RAZ_SOLVER_TREE_BYTES)
+// a worker wave of the pool: 8 words of lane state and 14 frames of 32 B per lane
+#define RAZ_SOLVER_WORKER_STATE_BYTES (8 * 64 * 8)
+#define RAZ_SOLVER_WORKER_FRAME_BYTES (14 * 64 * 32)
+struct raz_solver_pool_hdr {     // one per slice of the batch (64 bytes)
+    uint32_t n_active;           // solves with tasks left to hand out, listed in `active`
+    uint32_t cursor;             // round-robin draw over them (workers: atomicAdd)
+    uint32_t pad[14];
+};
 #define RAZ_PHASE_NEW_MOVE 0
 #define RAZ_PHASE_SEARCH 1
 #define RAZ_PHASE_DONE 2
@@ -178,7 +206,13 @@ struct raz_engine_dev {
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games, [6] idle or finished slots
     raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
     uint32_t M;
-    unsigned char* solver_ws;      // [B][RAZ_SOLVER_WS_BYTES] the lane-parallel solver's frames and, while a root solve is suspended, its state
+    unsigned char* solver_ws;      // [B][RAZ_SOLVER_WS_BYTES] per game: raz_solve_hdr + the three-ply task tree of the solve in flight
+    // the worker pool of the end-game solver (raz_solver_pool.h): W waves, split evenly over the slices of the batch
+    uint32_t W;                    // worker waves
+    raz_solver_pool_hdr* pool_hdr; // [kMaxParts]
+    uint32_t* pool_active;         // [B] slice h lists its active solves (game slots) from its first game's index on
+    unsigned long long* pool_state;   // [W][8][64] parked lane state
+    unsigned long long* pool_frames;  // [W][14][64][4] the lanes' DFS frames
     unsigned char* node_out;       // RAZ_NODE_OUT_BYTES + 64: staging of raz_engine_read_node
     uint32_t* gc_remap;            // [B][C] creation index -> link after compaction, during k_gc
     unsigned long long* counters;

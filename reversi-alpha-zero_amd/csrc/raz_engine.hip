@@ -30,16 +30,15 @@
 #include "raz_engine.h"
 #include "raz_internal.h"
 
-#include "raz_engine_core.h"   // the per-game device code: helpers, PUCT, solver, backup, controller, descent
+#include "raz_engine_core.h"   // the per-game device code: helpers, PUCT, solver requests, backup, controller, descent
+#include "raz_solver_pool.h"   // the end-game solver's worker pool: k_solve_scan, k_solve_run
 
 namespace {
 
 // ------------------------------------------------------------------ the tree kernel
-// SOLVER = false compiles the end-game solver (and its LDS frames) out: the common case, and the
-// bench configuration.  With the solver in, the kernel is sized for 2 waves per SIMD (256 VGPRs): the lane-parallel DFS
-// (raz_engine_core.h solver_solve_lanes, noinline, so it inherits the caller's register budget) spills 155 VGPRs into its
-// hot loop at 128, none at 256, and a configuration that solves is bound by the solves, not by tree occupancy
-// (RAZ_TREE_WAVES, raz_engine_core.h).
+// SOLVER = false compiles the end-game solver's call sites (and the scalar search's LDS frames) out: the common case, and the
+// bench configuration.  With the solver in, the kernel only solves the smallest positions itself (<= 6 empties, wave-uniform);
+// larger ones are posted to the solver pool (raz_solver_pool.h) and the game suspends until the answer is there.
 template <bool SOLVER>
 __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {
     if (blockIdx.x >= count) return;
@@ -59,7 +58,6 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_d
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
-    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
@@ -151,7 +149,6 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
-    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     Slots T;
     T.st = T.sq = T.pk = 0u;
     uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
@@ -582,6 +579,17 @@ inline size_t slots_of(const raz_engine_config& cfg) { return cfg.parallel_searc
 // k_tree_par drives the games when more than one simulation is in flight (or when reserved bit 3 asks for it)
 inline bool uses_slot_kernel(const raz_engine_config& cfg) { return slots_of(cfg) > 1 || (cfg.reserved & 8u); }
 
+// Worker waves of the solver pool: the caller's figure, or one per two games up to two per SIMD of the chip (1024 SIMDs) - enough
+// lanes for every running solve's next tasks, few enough that lanes looking for work do not crowd out the ones that have it.
+// At least kPoolParts, so that every slice of the batch has a wave.
+constexpr uint32_t kPoolParts = 8;   // == kMaxParts below
+inline uint32_t pool_waves_of(const raz_engine_config& cfg) {
+    uint32_t w = cfg.solver_pool_waves ? cfg.solver_pool_waves : (cfg.n_games + 1) / 2;
+    if (w > 2048u && !cfg.solver_pool_waves) w = 2048u;
+    if (w > 16384u) w = 16384u;
+    return w < kPoolParts ? kPoolParts : w;
+}
+
 // Bytes of one game's node pool: the caller's figure (rounded up to 8), or nodes_per_game average-size nodes plus room
 // for 64 nodes of the largest size (small pools: a burst of wide positions must not trip the byte limit first).
 inline unsigned long long pool_bytes_of(const raz_engine_config& cfg) {
@@ -623,6 +631,11 @@ size_t carve(const raz_engine_config& cfg, unsigned char* base, raz_engine_dev* 
     d.M = cfg.solver_memo_slots;
     d.memo = (raz_slot*)take(B * (size_t)cfg.solver_memo_slots * sizeof(raz_slot));
     d.solver_ws = cfg.solver_memo_slots ? take(B * (size_t)RAZ_SOLVER_WS_BYTES) : nullptr;
+    d.W = cfg.solver_memo_slots ? pool_waves_of(cfg) : 0u;
+    d.pool_hdr = (raz_solver_pool_hdr*)take(d.W ? kPoolParts * sizeof(raz_solver_pool_hdr) : 0);
+    d.pool_active = (uint32_t*)take(d.W ? B * 4 : 0);
+    d.pool_state = (unsigned long long*)take((size_t)d.W * RAZ_SOLVER_WORKER_STATE_BYTES);
+    d.pool_frames = (unsigned long long*)take((size_t)d.W * RAZ_SOLVER_WORKER_FRAME_BYTES);
     d.gc_remap = (uint32_t*)take(B * C * 4);
     d.counters = (unsigned long long*)take(32 * 8);
     d.node_out = take(RAZ_NODE_OUT_BYTES + 64);
@@ -649,6 +662,8 @@ int validate(const raz_engine_config* cfg) {
     if ((cfg->use_solver_turn || cfg->use_solver_turn_in_simulation) &&
         (cfg->solver_memo_slots < 1024 || (cfg->solver_memo_slots & (cfg->solver_memo_slots - 1))))
         return raz_fail(RAZ_EINVAL, "raz_engine: solver_memo_slots must be a power of two >= 1024 when the solver is on");
+    if ((cfg->reserved & ~0x00ffff1bu) || cfg->reserved2)
+        return raz_fail(RAZ_EINVAL, "raz_engine: reserved bits 2, 5-7 and 24-31 and reserved2 must be 0 (ABI 3: bit 2 - hipGraph replay - is gone)");
     if (cfg->share_mtcs_info && !cfg->mirror_updates)
         return raz_fail(RAZ_EINVAL, "raz_engine: share_mtcs_info=1 requires mirror_updates=1 (player.py:279-280)");
     return RAZ_OK;
@@ -657,6 +672,7 @@ int validate(const raz_engine_config* cfg) {
 }  // namespace
 
 constexpr int kMaxParts = 8;
+static_assert(kMaxParts == (int)kPoolParts, "one pool header per slice");
 
 // raz_leaf_cache.hip / raz_net.hip
 size_t raz_leaf_cache_layout(uint32_t log2_entries, size_t rows, unsigned char* base, raz_leaf_cache_dev* out);
@@ -707,6 +723,7 @@ struct raz_engine {
     hipStream_t aux[kMaxParts];
     hipEvent_t ev_fork, ev_join[kMaxParts];
     bool fused;                 // cfg.reserved bit 4: k_tree_net drives the games (tree + narrow net in one kernel)
+    bool pool_reset_pending;    // the batch was re-partitioned (raz_engine_set_parts): parked solver searches are re-dispatched first
 };
 
 namespace {
@@ -722,6 +739,29 @@ inline Half half_of(const raz_engine* e, int h) {
     return Half{g0, g1 - g0};
 }
 inline hipStream_t stream_of(const raz_engine* e, int h, hipStream_t s) { return h == 0 ? s : e->aux[h]; }
+
+// iterations of a worker lane per k_solve_run launch: raz_engine_config.reserved bits 16-23 x 64, or the default
+inline int pool_budget_of(const raz_engine_dev& d) {
+#ifdef RAZ_WAVE_EMU
+    if (getenv("RAZ_SOLVER_BUDGET")) return atoi(getenv("RAZ_SOLVER_BUDGET"));   // (tests: park every search after a handful of iterations)
+#endif
+    const int units = (int)((d.cfg.reserved >> 16) & 0xffu);
+    return units ? units * 64 : RAZ_SOLVER_POOL_BUDGET;
+}
+
+// The solver pool's round for slice h, between two tree launches (raz_solver_pool.h): task trees for the requests the tree kernel
+// just posted, `budget` iterations of the slice's share of the worker waves, answers for the scans that are decided.
+int launch_solver_pool(raz_engine* e, int h, hipStream_t s) {
+    const raz_engine_dev& d = e->dev;
+    if (!d.W) return RAZ_OK;
+    const Half hf = half_of(e, h);
+    if (hf.count == 0) return RAZ_OK;
+    const uint32_t wp = d.W / (uint32_t)e->parts;   // (W >= kMaxParts >= parts)
+    hipLaunchKernelGGL(k_solve_scan, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count, (uint32_t)h, 1u);
+    hipLaunchKernelGGL(k_solve_run, dim3(wp), dim3(64), 0, s, d, (uint32_t)h, wp * (uint32_t)h, wp, hf.g0, pool_budget_of(d));
+    hipLaunchKernelGGL(k_solve_scan, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count, (uint32_t)h, 0u);
+    return raz_check_launch("raz_engine_step: solver pool");
+}
 
 // one simulation step of one slice on stream s; ev (nullable) = 3 events bracketing the two kernels
 int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
@@ -741,6 +781,7 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
         hipLaunchKernelGGL(k_tree<false>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
     int rc = raz_check_launch("raz_engine_step: k_tree");
     if (rc != RAZ_OK) return rc;
+    if (solver && (rc = launch_solver_pool(e, h, s)) != RAZ_OK) return rc;
     if (ev) hipEventRecord(ev[1], s);
     // the slices run concurrently: each gets its own part of the net scratch (size is linear in n);
     // a game contributes one leaf-exchange row per simulation slot
@@ -770,7 +811,17 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
 // k_tree_net (raz_engine_fused.hip): `n_steps` simulation steps of the whole batch
 int launch_fused_steps(raz_engine* e, uint32_t n_steps, hipStream_t s) {
     const bool solver = e->dev.cfg.use_solver_turn || e->dev.cfg.use_solver_turn_in_simulation;
-    return raz_launch_tree_net(e->dev, solver, n_steps, (const float*)e->net.d_weights, e->net.res_layers, e->net.value_fc, s);
+    if (!solver) return raz_launch_tree_net(e->dev, false, n_steps, (const float*)e->net.d_weights, e->net.res_layers, e->net.value_fc, s);
+    // a game that posts a solve leaves its launch, so the solver pool gets its round after every launch of <= kFusedSolverIters steps
+    constexpr uint32_t kFusedSolverIters = 8;
+    int rc = RAZ_OK;
+    while (n_steps && rc == RAZ_OK) {
+        const uint32_t it = n_steps < kFusedSolverIters ? n_steps : kFusedSolverIters;
+        rc = raz_launch_tree_net(e->dev, true, it, (const float*)e->net.d_weights, e->net.res_layers, e->net.value_fc, s);
+        if (rc == RAZ_OK) rc = launch_solver_pool(e, 0, s);
+        n_steps -= it;
+    }
+    return rc;
 }
 
 int fork_aux(raz_engine* e, hipStream_t s) {
@@ -819,6 +870,7 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     e->net_scratch = d_net_scratch;
     e->net_scratch_bytes = net_scratch_bytes;
     e->started = false;
+    e->pool_reset_pending = false;
     memset(&e->cache, 0, sizeof e->cache);
     e->cache_step = 1;
     // reserved bit 1: single stream; bits 8..11: number of slices (default 3); bits 12..15: kInnerMax override
@@ -869,6 +921,7 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
         if (err == hipSuccess && !e->ev_join[h]) err = hipEventCreateWithFlags(&e->ev_join[h], hipEventDisableTiming);
     }
     if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_set_parts");
+    if (parts != e->parts && e->dev.W) e->pool_reset_pending = true;   // worker waves change slices: raz_engine_step re-dispatches the parked searches
     e->parts = parts;
     return RAZ_OK;
 }
@@ -894,6 +947,11 @@ extern "C" int raz_engine_start(raz_engine* e, uint32_t first_game_id, const uin
     RAZ_HIP_TRY(hipMemsetAsync(d.table, 0, (size_t)d.B * d.H * sizeof(raz_slot), s), "raz_engine_start: clear tables");
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.memo, 0, (size_t)d.B * d.M * sizeof(raz_slot), s), "raz_engine_start: clear solver memo");
     if (d.M) RAZ_HIP_TRY(hipMemsetAsync(d.solver_ws, 0, (size_t)d.B * RAZ_SOLVER_WS_BYTES, s), "raz_engine_start: clear solver state");
+    if (d.W) {
+        RAZ_HIP_TRY(hipMemsetAsync(d.pool_hdr, 0, kPoolParts * sizeof(raz_solver_pool_hdr), s), "raz_engine_start: clear solver pool");
+        RAZ_HIP_TRY(hipMemsetAsync(d.pool_state, 0, (size_t)d.W * RAZ_SOLVER_WORKER_STATE_BYTES, s), "raz_engine_start: clear solver pool");
+        e->pool_reset_pending = false;
+    }
     RAZ_HIP_TRY(hipMemsetAsync(d.counters, 0, 256, s), "raz_engine_start: clear counters");
     if (d.par) {
         RAZ_HIP_TRY(hipMemsetAsync(d.sim, 0, (size_t)d.B * d.K * sizeof(raz_game), s), "raz_engine_start: clear simulation slots");
@@ -934,6 +992,11 @@ extern "C" int raz_engine_next_game(raz_engine* e, uint32_t first_game_id, const
 
 namespace {
 int launch_steps_direct(raz_engine* e, uint32_t n_steps, hipStream_t s) {
+    if (e->pool_reset_pending) {
+        const size_t n = (size_t)e->dev.W * 64 > e->dev.B ? (size_t)e->dev.W * 64 : e->dev.B;
+        hipLaunchKernelGGL(k_solve_pool_reset, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->dev);
+        e->pool_reset_pending = false;
+    }
     if (e->fused) return launch_fused_steps(e, n_steps, s);
     int rc = fork_aux(e, s);
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {

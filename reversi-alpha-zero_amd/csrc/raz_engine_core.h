@@ -258,9 +258,8 @@ struct Regs {
     float pol_raw, val;             // the net's policy row (lane = square of the TRANSFORMED board) and value
     uint32_t nn;                    // this launch produced a leaf for the net
     uint32_t path_dirty;
-    uint32_t solve_pending;         // an end-game solve is suspended until the next launch: begin_move's (the phase stays NEW_MOVE) or one
+    uint32_t solve_pending;         // an end-game solve waits for the solver pool: begin_move's (the phase stays NEW_MOVE) or one
                                     // inside a simulation (leaf_kind RAZ_LEAF_SOLVE_PENDING); the game does nothing more in this launch
-    int solve_budget;               // solver iterations this game may still spend in this launch (solver_launch_budget)
 };
 __device__ __forceinline__ uint32_t G32(const Regs& R, int i) { return (uint32_t)__builtin_amdgcn_readlane(R.cw, i); }
 __device__ __forceinline__ raz_bb G64(const Regs& R, int i) {  // (the builtin returns int: widen through uint32_t)
@@ -473,32 +472,47 @@ __device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal
 // lib/alt/reversi_solver_cython.pyx:40-127.  The reference's explicit-stack DFS returns a function of
 // the position and the mode alone (see oracle/orc_solver.c): for the legal moves in ascending order
 // [non-exact: stop once the best score is > 0], value = -f(child) / +f(child after a pass) / final
-// disc difference, strict improvement keeps the first maximum.  Here: the same DFS, wave-uniform
-// (scalar unit), frames in LDS (depth <= empties <= 14), with a per-game memo in HBM (positions
-// with >= 4 empties; the memo only saves time, exactly as the reference's dict does).
-#define RAZ_SOLVER_LDS_BYTES 7680
-struct SolverLDS {
+// disc difference, strict improvement keeps the first maximum.  Three places compute it:
+//   * positions with <= RAZ_SOLVER_SCALAR_EMPTIES empties: right here, one wave-uniform DFS on the scalar unit, frames in LDS;
+//   * larger ones (<= RAZ_SOLVER_MAX_DEPTH empties): the tree kernel only POSTS the position in its game's request block and
+//     suspends (RAZ_SOLVE_PENDING); the solver pool (raz_solver_pool.h: k_solve_scan / k_solve_run, launched between tree
+//     launches) answers it, and the next call for the same position returns the answer;
+//   * a per-game memo in HBM (positions with >= 4 empties; it only saves time, exactly as the reference's dict does) is shared by
+//     all of them.
+// f is a function of the position, so WHEN an answer arrives changes nothing but a game's wall time.
+struct SolverLDS {   // the scalar search's frames (depth <= RAZ_SOLVER_SCALAR_EMPTIES + passes < 16)
     unsigned long long own[16], enemy[16], left[16];
     int best_move[16], best_score[16], paction[16], flip[16], fresh[16];
-    unsigned char room[RAZ_SOLVER_LDS_BYTES - 704];   // the lane-parallel search keeps its three-ply task tree here (SolverPar)
 };
+#define RAZ_SOLVER_LDS_BYTES 704
 static_assert(sizeof(SolverLDS) == RAZ_SOLVER_LDS_BYTES, "SolverLDS layout");
+
+// A memo slot is written ONCE between two clears of the table: a writer CLAIMS it (idx_tag 0 -> RAZ_MEMO_CLAIMED, one atomic, so
+// of several lanes - of this wave or of any worker wave of the pool - exactly one wins), stores the key, then publishes the tag
+// (bit 31).  Readers take a slot whose bit 31 is clear for empty, so a claimed slot is a miss, never a torn entry.
+#define RAZ_MEMO_CLAIMED 0x20000000u
+__device__ __forceinline__ bool memo_claim_and_write(raz_slot* s, raz_bb own, raz_bb enemy, uint32_t tag) {
+    if (atomicCAS(&s->idx_tag, 0u, RAZ_MEMO_CLAIMED) != 0u) return false;
+    s->black = own;
+    s->white = enemy;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler order; one lane's stores to one 32-byte slot reach memory in order)
+    __hip_atomic_store(&s->idx_tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 
 __device__ bool memo_find(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int lane,
                           int& move, int& score) {
     const raz_slot* tab = E.memo + (size_t)g * E.M;
     const uint32_t mask = E.M - 1;
     const uint32_t h = key_hash(own, enemy, 8u + exact);
-    const uint32_t memo_chk = (uint32_t)((((own * 0x9E3779B97F4A7C15ULL) ^ (enemy * 0xC2B2AE3D27D4EB4FULL)) >> 50) & 0x3fffu) | 1u;
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const raz_slot* s = tab + ((h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask);
         const raz_bb sb = s->black, sw = s->white;
         const uint32_t it = s->idx_tag;
         const bool used = (it >> 31) != 0;
-        const uint32_t chk = (it >> 16) & 0x3fffu;   // 0: stored by the wave-wide memo_put; else 14 bits of the key's hash (memo_put_lane)
-        const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact && (chk == 0 || chk == memo_chk);
+        const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact;
         const unsigned long long mm = __ballot(match) & 0xffffULL;
-        const unsigned long long em = __ballot(!used) & 0xffffULL;
+        const unsigned long long em = __ballot(it == 0u) & 0xffffULL;
         if (mm) {
             const uint32_t v = lane_u32(it, __ffsll((long long)mm) - 1);
             move = (int)((v >> 8) & 0xffu) - 1;
@@ -515,26 +529,51 @@ __device__ void memo_put(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb
     raz_slot* tab = E.memo + (size_t)g * E.M;
     const uint32_t mask = E.M - 1;
     const uint32_t h = key_hash(own, enemy, 8u + exact);
+    const uint32_t tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
-        const bool used = (tab[si].idx_tag >> 31) != 0;
-        const unsigned long long em = __ballot(!used) & 0xffffULL;
-        if (em) {
-            if (lane == 0) {
-                raz_slot* s = tab + ((h + r + (uint32_t)(__ffsll((long long)em) - 1)) & mask);
-                s->black = own;
-                s->white = enemy;
-                s->idx_tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
+        unsigned long long em = __ballot(tab[si].idx_tag == 0u) & 0xffffULL;
+        while (em) {   // (wave-uniform) the first free slot of the group - or the next one, if a worker wave of the pool claimed it meanwhile
+            const int j = __ffsll((long long)em) - 1;
+            em &= em - 1;
+            uint32_t ok = 0u;
+            if (lane == 0) ok = memo_claim_and_write(tab + ((h + r + (uint32_t)j) & mask), own, enemy, tag) ? 1u : 0u;
+            if (uni(ok)) {
+                wave_sync();
+                return;
             }
-            wave_sync();
-            return;
         }
     }  // 64 occupied slots in a row: the memo is (locally) full; skipping the insert only costs time
 }
 
+// the memo, one lane on its own (the pool's workers, the scans of k_solve_scan): the key's home slot and the next one
+__device__ bool memo_find_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int& move, int& score) {
+    const raz_slot* tab = E.memo + (size_t)g * E.M;
+    const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
+    for (uint32_t r = 0; r < 2; ++r) {
+        const raz_slot* s = tab + ((h + r) & mask);
+        const uint32_t it = s->idx_tag;
+        if (!(it >> 31)) return false;
+        if (s->black == own && s->white == enemy && ((it >> 30) & 1u) == exact) {
+            move = (int)((it >> 8) & 0xffu) - 1;
+            score = (int)(it & 0xffu) - 128;
+            return true;
+        }
+    }
+    return false;
+}
+__device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int move, int score) {
+    raz_slot* tab = E.memo + (size_t)g * E.M;
+    const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
+    const uint32_t tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
+    for (uint32_t r = 0; r < 2; ++r)
+        if (memo_claim_and_write(tab + ((h + r) & mask), own, enemy, tag)) return;
+    // both slots taken: skipping the insert only costs time
+}
+
 // ReversiSolver.solve for the side to move (own, enemy), wave-uniform: ONE depth-first search on the scalar unit.  Returns false
 // for the reference's (None, None) (no legal move at the root: never the case for a running game).  Used for the smallest trees
-// (<= RAZ_SOLVER_SCALAR_EMPTIES empties); solver_solve below spreads the larger ones over the wave's lanes.
+// (<= RAZ_SOLVER_SCALAR_EMPTIES empties); the pool takes the larger ones.
 __device__ bool solver_solve_scalar(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
                                     SolverLDS* S, int& out_move, int& out_score) {
     int depth = 0;
@@ -606,184 +645,32 @@ __device__ bool solver_solve_scalar(const raz_engine_dev& E, uint32_t g, int lan
     }
 }
 
-// ---- the same function, 64 searches at a time ---------------------------------------------------------------------------------
-// The reference's solver is a pure function f_mode(position) (see above): for the legal moves in ascending order - non-exact: until
-// the best score is > 0 - value = -f(child) / +f(child after a pass) / final disc difference, strict improvement keeps the first
-// maximum.  The scalar search above visits one node at a time and the whole LAUNCH waits for it: with ch5.yml as shipped (solver
-// from turn 50, inside simulations too) 8192 games spent 77 % of a step waiting for one or two waves' searches of 10^5..10^6 nodes
-// (profiles/r4/bench_reduced_1024_games_session5_full.json).  Here the top of the tree is expanded THREE plies deep - child i, its
-// j-th move, the m-th move after that: <= 14 x 13 x 12 TASKS (the first form expanded two plies: a non-exact solve then has only
-// ~7 tasks the sequential scan really needs, the longest a fifth of the work, and 8 lanes of 64 were busy) - every lane takes tasks
-// off a common counter and runs the reference's depth-first search of its task's subtree by itself - private frames, one node per
-// lane and iteration, every lane executing the same instruction stream on its own position - and the three top plies are then
-// scanned in ascending move order with the same strict improvement and the same early stop.  f is a function of the position, so evaluating siblings side by side (and, in non-exact
-// mode, some the sequential scan would never have reached) changes no result; the memo (shared by all lanes of the game's wave,
-// result-neutral as in the reference) carries transpositions from lane to lane and from solve to solve.
 #define RAZ_SOLVER_SCALAR_EMPTIES 6
 #define RAZ_SOLVER_MAX_DEPTH 14
-// the lanes consult the memo only at nodes with at least this many empties: the 64 searches advance in lockstep, so ONE lane's probe
-// (dependent HBM round trips into the game's 2 MB table) is paid by all of them, and a probe at every node with >= 4 empties as in
-// the scalar search is some lane's probe in 96 % of the iterations - the first version ran a 10-empties exact solve no faster than the
-// scalar search (25 us per iteration; profiles/r4/ch5_as_shipped_8192_games_lane_solver_v1_memo_bound.json).  Subtrees below
-// this size are searched outright (<= 720 leaf paths); transpositions pay where the subtrees are large.
-#define RAZ_SOLVER_LANE_MEMO_EMPTIES 6
-
-// the memo, one lane on its own: the key's home slot and the next one.  Lanes of a wave may store to one slot in the same instruction
-// (their three field stores could then come from different lanes): the tag carries 14 bits of the key's hash, checked on a hit.
-__device__ __forceinline__ uint32_t memo_check_bits(raz_bb own, raz_bb enemy) {
-    const unsigned long long x = (own * 0x9E3779B97F4A7C15ULL) ^ (enemy * 0xC2B2AE3D27D4EB4FULL);
-    return (uint32_t)(x >> 50) & 0x3fffu;
-}
-__device__ bool memo_find_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int& move, int& score) {
-    const raz_slot* tab = E.memo + (size_t)g * E.M;
-    const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
-    for (uint32_t r = 0; r < 2; ++r) {
-        const raz_slot* s = tab + ((h + r) & mask);
-        const uint32_t it = s->idx_tag;
-        if (!(it >> 31)) return false;
-        if (s->black == own && s->white == enemy && ((it >> 30) & 1u) == exact) {
-            const uint32_t chk = (it >> 16) & 0x3fffu;
-            if (chk != 0 && chk != (memo_check_bits(own, enemy) | 1u)) continue;   // (0: written by the wave-wide memo_put, no check bits)
-            move = (int)((it >> 8) & 0xffu) - 1;
-            score = (int)(it & 0xffu) - 128;
-            return true;
-        }
-    }
-    return false;
-}
-__device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int move, int score) {
-    raz_slot* tab = E.memo + (size_t)g * E.M;
-    const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
-    for (uint32_t r = 0; r < 2; ++r) {
-        raz_slot* s = tab + ((h + r) & mask);
-        if (!(s->idx_tag >> 31)) {
-            s->black = own;
-            s->white = enemy;
-            s->idx_tag = 0x80000000u | (exact << 30) | ((memo_check_bits(own, enemy) | 1u) << 16) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
-            return;
-        }
-    }   // both slots occupied: skipping the insert only costs time
-}
-
-// LDS of the lane-parallel solve (inside SolverLDS): the root's moves (level 1), the replies to them (level 2) and the tasks' results
-#define RAZ_SOLVER_MAX_L2 (RAZ_SOLVER_MAX_DEPTH * (RAZ_SOLVER_MAX_DEPTH - 1))        // 182 positions two plies below the root
-#define RAZ_SOLVER_MAX_TASKS (RAZ_SOLVER_MAX_L2 * (RAZ_SOLVER_MAX_DEPTH - 2))        // 2184 subtrees three plies below it
-struct SolverPar {
-    unsigned long long c_own[RAZ_SOLVER_MAX_DEPTH], c_enemy[RAZ_SOLVER_MAX_DEPTH], c_moves[RAZ_SOLVER_MAX_DEPTH];   // child i: position (its mover's view), its moves
-    unsigned long long g_own[RAZ_SOLVER_MAX_L2], g_enemy[RAZ_SOLVER_MAX_L2], g_moves[RAZ_SOLVER_MAX_L2];           // level-2 node n, likewise
-    unsigned short g_first[RAZ_SOLVER_MAX_L2 + 2];   // node n's first task
-    unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2]; // child i's first level-2 node
-    signed char result[RAZ_SOLVER_MAX_TASKS];        // task t: the value of that move for the level-2 node's mover (RAZ_SOLVER_UNKNOWN: not there yet)
-    signed char c_v[RAZ_SOLVER_MAX_DEPTH];           // child i: the value of the root's i-th move once known, for the ROOT's mover (else RAZ_SOLVER_UNKNOWN)
-    signed char g_v[RAZ_SOLVER_MAX_L2];              // node n: the value of the reply that leads to it once known, for the CHILD's mover
-    unsigned char c_kind[RAZ_SOLVER_MAX_DEPTH];      // child i: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo)
-    unsigned char g_kind[RAZ_SOLVER_MAX_L2];         // node n, likewise (seen from the child's mover)
-    unsigned char root_done;                         // the root's scan is decided: every search still running is moot
-};
-#define RAZ_SOLVER_UNKNOWN (-128)
-static_assert(sizeof(SolverPar) <= sizeof(SolverLDS), "the lane-parallel solver's LDS must fit SolverLDS");
-
-// the reference's loop over a node's moves, on values that are already there: `vals` in ascending move order, RAZ_SOLVER_UNKNOWN =
-// not there yet.  Returns false while the scan is not decided.  Non-exact: it ends at the first value > 0
-__device__ __forceinline__ bool solver_scan(const signed char* vals, int n, raz_bb moves, bool exact, int& bm, int& bs) {
-    bm = -1;
-    bs = -100;
-    raz_bb m = moves;
-    for (int j = 0; j < n; ++j, m &= m - 1) {
-        const int v = vals[j];
-        if (v == RAZ_SOLVER_UNKNOWN) return false;
-        if (bs < v) {
-            bm = __ffsll((long long)m) - 1;
-            bs = v;
-        }
-        if (!exact && bs > 0) break;
-    }
-    return true;
-}
-
-// Non-exact mode (solves inside simulations, agent/player.py:237-251): the reference's loop at a node ends at the first move whose
-// value is > 0, so a level-2 node is decided as soon as the results of a PREFIX of its tasks contain one, a child as soon as a prefix
-// of its level-2 nodes does, and the root's answer as soon as a prefix of the children does.  Whenever a task's result lands, the
-// lane that produced it re-runs those scans over what is known; a decided node cancels the tasks below it, a decided root all of
-// them (the lanes look at g_v / c_v / root_done before every node).  Without this the 64 lanes finish ALL subtrees of a position
-// whose first move already wins - the sequential search would have looked at one.  Several lanes may run the scans at once: they
-// store the same values.
-__device__ void solver_note_result(SolverPar* P, int k, int ci, int n) {
-    int bm, bs;
-    if (P->g_v[n] == RAZ_SOLVER_UNKNOWN) {
-        const int t0 = P->g_first[n];
-        if (!solver_scan(P->result + t0, (int)P->g_first[n + 1] - t0, P->g_moves[n], false, bm, bs)) return;
-        P->g_v[n] = (signed char)((P->g_kind[n] & 1) ? -bs : bs);
-    }
-    if (P->c_v[ci] == RAZ_SOLVER_UNKNOWN) {
-        const int n0 = P->c_first[ci];
-        if (!solver_scan(P->g_v + n0, (int)P->c_first[ci + 1] - n0, P->c_moves[ci], false, bm, bs)) return;
-        P->c_v[ci] = (signed char)((P->c_kind[ci] & 1) ? -bs : bs);
-    }
-    int best = -100;
-    for (int i = 0; i < k; ++i) {
-        const int v = P->c_v[i];
-        if (v == RAZ_SOLVER_UNKNOWN) return;
-        if (best < v) best = v;
-        if (best > 0) break;
-    }
-    P->root_done = 1;
-}
-
-// (not inlined: three call sites - the root, the descent of k_tree, the descent of k_tree_par - would each carry a copy of the
-//  per-lane 64-bit board arithmetic, and the tree kernels' 128-register budget at 4 waves per SIMD would spill on every path; as a
-//  function it has a register allocation of its own)
-//
-// BUDGET.  An exact solve of a 10-empties root is 10^6 nodes - 140 ms on the device even with 64 lanes at work (profiles/r4/
-// device_solver_exact_root_solve_times.json), and a launch ends when its slowest wave does: with ch5.yml as shipped about one game
-// per step reaches use_solver_turn, so EVERY step of the 8192-game batch waited for such a solve (tree kernel 283 ms of a 446 ms
-// step).  The root's solve therefore runs for at most `budget` iterations per launch: when they are used up the wave parks the
-// search in the game's workspace (E.solver_ws: the frames live there anyway; the lanes' registers, the task counter and the LDS
-// block are added) and returns RAZ_SOLVE_PENDING; begin_move leaves the game in NEW_MOVE and the next launch picks the search up
-// where it stopped.  f is a function of the position, so when the answer arrives changes nothing but the game's wall time.
-// Solves inside simulations (non-exact) are 100x smaller on average, but there are hundreds per move from turn 47 on and their tail
-// is what a launch then waits for (8192 games as shipped: tree kernel 97 ms per step with them, 1.6 ms with the root's solves alone):
-// they draw on the SAME per-launch budget (Regs::solve_budget, `budget` below: in = iterations left, out = what this call left of
-// it), and a descent whose solve runs out is suspended where it stands (select_leaf: RAZ_LEAF_SOLVE_PENDING).
-// Register budget of the tree kernels: 4 waves per SIMD (128 VGPRs) without the solver, 2 (256 VGPRs) with it - the lane-parallel
-// DFS inherits its caller's budget and spills 155 VGPRs (239 inside the fused slot kernel) at 128, none at 256.  Measured on
-// mini.yml as shipped, where the solves are 15/16 of the work: two-kernel pipeline 12.1 M sims/s with the 256-register solver
-// kernel against 7.6 M on fused kernels built for 128.
-#ifdef RAZ_WAVE_EMU
-#define RAZ_TREE_WAVES(SOLVER)
-#else
-#ifndef RAZ_SOLVER_WAVES
-#define RAZ_SOLVER_WAVES 2   // (-DRAZ_SOLVER_WAVES=4: the A/B build)
-#endif
-#define RAZ_TREE_WAVES(SOLVER) __attribute__((amdgpu_waves_per_eu((SOLVER) ? RAZ_SOLVER_WAVES : 4, (SOLVER) ? RAZ_SOLVER_WAVES : 4)))
-#endif
 #define RAZ_SOLVE_NONE 0
 #define RAZ_SOLVE_DONE 1
 #define RAZ_SOLVE_PENDING 2
-#ifndef RAZ_SOLVER_ROOT_BUDGET
-#define RAZ_SOLVER_ROOT_BUDGET 384
-#endif
-// iterations of the lane-parallel solver a game may spend per launch: raz_engine_config.reserved bits 16-23 x 64, or the default
-__device__ __forceinline__ int solver_launch_budget(const raz_engine_dev& E) {
+// the tree kernels: 4 waves per SIMD whether the solver is compiled in or not (the lane-parallel search that needed 256 registers in
+// round 4 now lives in the pool's own kernel)
 #ifdef RAZ_WAVE_EMU
-    if (getenv("RAZ_SOLVER_BUDGET")) return atoi(getenv("RAZ_SOLVER_BUDGET"));   // (tests: suspend after a handful of iterations)
+#define RAZ_TREE_WAVES(SOLVER)
+#else
+#define RAZ_TREE_WAVES(SOLVER) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-    const int units = (int)((E.cfg.reserved >> 16) & 0xffu);
-    return units ? units * 64 : RAZ_SOLVER_ROOT_BUDGET;
-}
-__device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                                            SolverLDS* S, int& budget, int& out_move, int& out_score);
 
-__device__ __forceinline__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                            SolverLDS* S, int& budget, int& out_move, int& out_score) {
+__device__ __forceinline__ raz_solve_hdr* solve_hdr(const raz_engine_dev& E, uint32_t g) {
+    return (raz_solve_hdr*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES);
+}
+
+// f_mode(own0, enemy0) for the game's wave: RAZ_SOLVE_DONE (out_move / out_score), RAZ_SOLVE_NONE (the reference's (None, None)) or
+// RAZ_SOLVE_PENDING - the position now stands in the game's request block and the caller suspends: begin_move leaves the phase at
+// NEW_MOVE, a descent stops where it stands (select_leaf: RAZ_LEAF_SOLVE_PENDING); both call again at the next launch.  A game
+// has ONE request in flight: it does nothing else until the answer is there.
+__device__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
+                            SolverLDS* S, int& out_move, int& out_score) {
     const int empties = bb_popcount(~(own0 | enemy0));
     if (empties <= RAZ_SOLVER_SCALAR_EMPTIES || empties > RAZ_SOLVER_MAX_DEPTH)
         return solver_solve_scalar(E, g, lane, own0, enemy0, exact, S, out_move, out_score) ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
-    return solver_solve_lanes(E, g, lane, own0, enemy0, exact, S, budget, out_move, out_score);
-}
-
-__device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev& E, uint32_t g, int lane, raz_bb own0, raz_bb enemy0, uint32_t exact,
-                                                            SolverLDS* S, int& budget, int& out_move, int& out_score) {
     {
         int rm, rs;
         wave_sync();
@@ -793,355 +680,25 @@ __device__ __attribute__((noinline)) int solver_solve_lanes(const raz_engine_dev
             return rm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
         }
     }
-    SolverPar* P = (SolverPar*)S;
-    // the game's workspace: [0, 256) header words, [1024, 5120) eight arrays of 64 lane words, the frames [level][lane] x 32 B, then
-    // the LDS block of a parked search
-    unsigned long long* hdr = (unsigned long long*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES);
-    unsigned long long* lw = hdr + 128;                    // lane words: lw[field * 64 + lane]
-    unsigned long long* fr = hdr + 640 + (size_t)lane * 4;   // this lane's frame at level d: fr[d * 256 + {0 own, 1 enemy, 2 left, 3 meta}]
-    unsigned long long* ldsave = hdr + 640 + RAZ_SOLVER_MAX_DEPTH * 256;   // sizeof(SolverPar) bytes
-    int my_a = -1, my_kind = 0, my_v = 0, my_tasks = 0, first = 0, total = 0, k = 0, n2 = 0;   // (my_tasks / first: this child's level-2 nodes)
-    raz_bb c_own = 0, c_enemy = 0, c_moves = 0;
-    raz_bb own = 0, enemy = 0, left = 0;
-    int bmv = -1, bsc = -100, pact = -1, flip = 0, fresh = 0;
-    int next = 0, d = 0, task = -1, task_sign = 1;
-    int task_ci = 0, task_n = 0;   // the child and the level-2 node this lane's task belongs to
-    bool have = false;
-    const bool parked = uni((uint32_t)(hdr[0] == 0x5AULL && hdr[1] == own0 && hdr[2] == enemy0 && hdr[3] == (unsigned long long)exact)) != 0;
-    if (parked) {   // pick the search up where the last launch left it
-        k = (int)uni((uint32_t)hdr[4]);
-        total = (int)uni((uint32_t)hdr[5]);
-        next = (int)uni((uint32_t)hdr[6]);
-        n2 = (int)uni((uint32_t)hdr[7]);
-        for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) ((unsigned long long*)P)[i] = ldsave[i];
-        own = lw[0 * 64 + lane];
-        enemy = lw[1 * 64 + lane];
-        left = lw[2 * 64 + lane];
-        const unsigned long long m1 = lw[3 * 64 + lane], m2 = lw[7 * 64 + lane];
-        have = (m1 & 1ULL) != 0;
-        fresh = (int)((m1 >> 1) & 1ULL);
-        flip = (int)((m1 >> 2) & 1ULL);
-        task_sign = ((m1 >> 3) & 1ULL) ? -1 : 1;
-        d = (int)((m1 >> 8) & 0xffULL);
-        bmv = (int)((m1 >> 16) & 0xffULL) - 1;
-        bsc = (int)((m1 >> 24) & 0xffULL) - 128;
-        pact = (int)((m1 >> 32) & 0xffULL) - 1;
-        task = (int)((m1 >> 40) & 0xffffULL) - 1;
-        c_own = lw[4 * 64 + lane];
-        c_enemy = lw[5 * 64 + lane];
-        c_moves = lw[6 * 64 + lane];
-        my_a = (int)(m2 & 0xffULL) - 1;
-        my_kind = (int)((m2 >> 8) & 0xffULL);
-        my_v = (int)((m2 >> 16) & 0xffULL) - 128;
-        my_tasks = (int)((m2 >> 24) & 0xffULL);
-        first = (int)((m2 >> 32) & 0xffULL);
-        task_ci = (int)((m2 >> 40) & 0xffULL);
-        task_n = (int)((m2 >> 48) & 0xffULL);
-        wave_sync();
-    } else {
-        const raz_bb legal0 = bb_legal_moves(own0, enemy0);
-        k = bb_popcount(legal0);
-        if (k == 0) return RAZ_SOLVE_NONE;
-        // ---- ply 1: lane i < k owns the root's i-th move.  kind 0: the game ends there (my_v = disc difference); 1: the opponent
-        // moves; 2: the opponent passes; +4: f(child) came from the memo
-        if (lane < k) {
-            raz_bb m = legal0;
-            for (int i = 0; i < lane; ++i) m &= m - 1;
-            my_a = __ffsll((long long)m) - 1;
-            const raz_bb flipped = bb_calc_flip(my_a, own0, enemy0);
-            const raz_bb nown = (own0 ^ flipped) | (1ULL << my_a), nenemy = enemy0 ^ flipped;
-            const raz_bb l1 = bb_legal_moves(nenemy, nown);
-            const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
-            if (l1 | l2) {
-                my_kind = l1 ? 1 : 2;
-                c_own = l1 ? nenemy : nown;
-                c_enemy = l1 ? nown : nenemy;
-                c_moves = l1 ? l1 : l2;
-                int rm, rs;
-                if (bb_popcount(~(c_own | c_enemy)) >= 4 && memo_find_lane(E, g, c_own, c_enemy, exact, rm, rs)) {
-                    my_kind |= 4;
-                    my_v = (my_kind & 1) ? -rs : rs;
-                } else
-                    my_tasks = bb_popcount(c_moves);
-            } else
-                my_v = bb_popcount(nown) - bb_popcount(nenemy);
-        }
-        for (int i = 0; i < k; ++i) {   // exclusive prefix sum over the lanes: child i's level-2 nodes are [first, first + my_tasks)
-            const int ti = (int)lane_u32((uint32_t)my_tasks, i);
-            if (i < lane) first += ti;
-            n2 += ti;
-        }
-        wave_sync();
-        if (lane < k) {
-            P->c_own[lane] = c_own;
-            P->c_enemy[lane] = c_enemy;
-            P->c_moves[lane] = c_moves;
-            P->c_first[lane] = (unsigned char)first;
-            P->c_kind[lane] = (unsigned char)my_kind;
-            P->c_v[lane] = (signed char)((my_kind == 0 || (my_kind & 4)) ? my_v : RAZ_SOLVER_UNKNOWN);   // known now: the game ends there, or the memo had f(child)
-        }
-        if (lane == 0) {
-            P->c_first[k] = (unsigned char)n2;
-            P->root_done = 0;
-        }
-        wave_sync_lanes();
-        // ---- ply 2: level-2 node n = the position after child ci's j-th move, seen from the side to move there (kinds as at ply 1,
-        // from the CHILD's mover's point of view).  Its moves are the tasks
-        for (int n = lane; n < n2; n += 64) {
-            int ci = 0;
-            while (ci + 1 < k && (int)P->c_first[ci + 1] <= n) ++ci;
-            const raz_bb co = P->c_own[ci], ce = P->c_enemy[ci];
-            raz_bb m = P->c_moves[ci];
-            for (int j = (int)P->c_first[ci]; j < n; ++j) m &= m - 1;
-            const int b = __ffsll((long long)m) - 1;
-            const raz_bb flipped = bb_calc_flip(b, co, ce);
-            const raz_bb nown = (co ^ flipped) | (1ULL << b), nenemy = ce ^ flipped;
-            const raz_bb l1 = bb_legal_moves(nenemy, nown);
-            const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
-            int gk = 0, gv = RAZ_SOLVER_UNKNOWN, tasks = 0;
-            raz_bb go = 0, ge = 0, gm = 0;
-            if (l1 | l2) {
-                gk = l1 ? 1 : 2;
-                go = l1 ? nenemy : nown;
-                ge = l1 ? nown : nenemy;
-                gm = l1 ? l1 : l2;
-                int rm, rs;
-                if (bb_popcount(~(go | ge)) >= 4 && memo_find_lane(E, g, go, ge, exact, rm, rs)) {
-                    gk |= 4;
-                    gv = (gk & 1) ? -rs : rs;
-                } else
-                    tasks = bb_popcount(gm);
-            } else
-                gv = bb_popcount(nown) - bb_popcount(nenemy);
-            P->g_own[n] = go;
-            P->g_enemy[n] = ge;
-            P->g_moves[n] = gm;
-            P->g_kind[n] = (unsigned char)gk;
-            P->g_v[n] = (signed char)gv;
-            P->g_first[n] = (unsigned short)tasks;   // (a count for now)
-        }
-        wave_sync_lanes();
-        if (lane == 0) {   // counts -> first task of every node
-            int acc = 0;
-            for (int n = 0; n < n2; ++n) {
-                const int c = P->g_first[n];
-                P->g_first[n] = (unsigned short)acc;
-                acc += c;
-            }
-            P->g_first[n2] = (unsigned short)acc;
-        }
-        wave_sync_lanes();
-        total = (int)uni((uint32_t)P->g_first[n2]);
-        for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
-        wave_sync_lanes();
-        if (!exact) {   // what is known already (finished games, the memo) may decide children - or the root - before any search runs
-            for (int n = lane; n < n2; n += 64) {
-                if (P->g_v[n] != RAZ_SOLVER_UNKNOWN) {
-                    int ci = 0;
-                    while (ci + 1 < k && (int)P->c_first[ci + 1] <= n) ++ci;
-                    solver_note_result(P, k, ci, n);
-                }
-            }
-            wave_sync_lanes();
-        }
+    raz_solve_hdr* h = solve_hdr(E, g);
+    const uint32_t st = uni(h->state), gen = uni(h->gen);
+    const bool same = uni((uint32_t)(h->own0 == own0 && h->enemy0 == enemy0 && h->exact == exact)) != 0u;
+    if (same && st == RAZ_SOLVE_ANSWERED) {   // (the block keeps the last answer: the memo may have had no room for it)
+        out_move = uni(h->ans_move);
+        out_score = uni(h->ans_score);
+        return (int)uni(h->ans_kind);
     }
-    // ---- the tasks: every lane searches subtrees until none is left.  The CURRENT node of a lane's search lives in registers, its
-    // ancestors' frames in the workspace - four stores when the search goes down a ply, four loads when it comes back, nothing at a leaf
-    for (int iter = 0;; ++iter) {
-        const unsigned long long idle = __ballot(!have);   // (also the point at which every lane is done with the previous iteration)
-        if (iter >= budget) {   // park the search: the next launch goes on from here
-            budget = 0;
-            wave_sync();
-            for (int i = lane; i < (int)(sizeof(SolverPar) + 7) / 8; i += 64) ldsave[i] = ((const unsigned long long*)P)[i];
-            lw[0 * 64 + lane] = own;
-            lw[1 * 64 + lane] = enemy;
-            lw[2 * 64 + lane] = left;
-            lw[3 * 64 + lane] = (have ? 1ULL : 0ULL) | ((unsigned long long)(fresh & 1) << 1) | ((unsigned long long)(flip & 1) << 2) |
-                                ((task_sign < 0 ? 1ULL : 0ULL) << 3) | ((unsigned long long)(d & 0xff) << 8) | ((unsigned long long)((bmv + 1) & 0xff) << 16) |
-                                ((unsigned long long)((bsc + 128) & 0xff) << 24) | ((unsigned long long)((pact + 1) & 0xff) << 32) |
-                                ((unsigned long long)((task + 1) & 0xffff) << 40);
-            lw[4 * 64 + lane] = c_own;
-            lw[5 * 64 + lane] = c_enemy;
-            lw[6 * 64 + lane] = c_moves;
-            lw[7 * 64 + lane] = (unsigned long long)((my_a + 1) & 0xff) | ((unsigned long long)(my_kind & 0xff) << 8) | ((unsigned long long)((my_v + 128) & 0xff) << 16) |
-                                ((unsigned long long)(my_tasks & 0xff) << 24) | ((unsigned long long)(first & 0xff) << 32) |
-                                ((unsigned long long)(task_ci & 0xff) << 40) | ((unsigned long long)(task_n & 0xff) << 48);
-            if (lane == 0) {
-                hdr[1] = own0;
-                hdr[2] = enemy0;
-                hdr[3] = (unsigned long long)exact;
-                hdr[4] = (unsigned long long)k;
-                hdr[5] = (unsigned long long)total;
-                hdr[6] = (unsigned long long)next;
-                hdr[7] = (unsigned long long)n2;
-                hdr[0] = 0x5AULL;
-            }
-            wave_sync();
-            return RAZ_SOLVE_PENDING;
-        }
-        if (idle && next < total) {
-            const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
-            const int t = next + rank;
-            next += __popcll(idle);
-            if (!have && t < total) {
-                int lo = 0, hi = n2;   // the task's level-2 node: the last n with g_first[n] <= t
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if ((int)P->g_first[mid] <= t) lo = mid;
-                    else hi = mid;
-                }
-                int ci = 0;
-                while (ci + 1 < k && (int)P->c_first[ci + 1] <= lo) ++ci;
-                task_ci = ci;
-                task_n = lo;
-                const raz_bb co = P->g_own[lo], ce = P->g_enemy[lo];
-                raz_bb m = P->g_moves[lo];
-                for (int j = (int)P->g_first[lo]; j < t; ++j) m &= m - 1;
-                const int b = __ffsll((long long)m) - 1;
-                const raz_bb flipped = bb_calc_flip(b, co, ce);
-                const raz_bb nown = (co ^ flipped) | (1ULL << b), nenemy = ce ^ flipped;
-                const raz_bb l1 = bb_legal_moves(nenemy, nown);
-                const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
-                if (l1 | l2) {
-                    task = t;
-                    task_sign = l1 ? -1 : 1;
-                    d = 0;
-                    own = l1 ? nenemy : nown;
-                    enemy = l1 ? nown : nenemy;
-                    left = l1 ? l1 : l2;
-                    bmv = -1;
-                    bsc = -100;
-                    pact = -1;
-                    flip = 0;
-                    fresh = 1;
-                    have = true;
-                } else {
-                    P->result[t] = (signed char)(bb_popcount(nown) - bb_popcount(nenemy));
-                    if (!exact) solver_note_result(P, k, ci, lo);
-                }
-            }
-        }
-        if (!exact) {   // what other lanes found may have made this lane's search (or all of them) moot
-            const bool all_moot = __ballot(P->root_done != 0) != 0ULL;   // (wave-uniform: `next` must stay the same in every lane)
-            if (have && (all_moot || P->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || P->g_v[task_n] != RAZ_SOLVER_UNKNOWN)) have = false;
-            if (all_moot) next = total;
-        }
-        if (__ballot(have) == 0ULL) {
-            if (next >= total) {
-                budget -= iter;
-                break;
-            }
-            continue;
-        }
-        if (have) {   // one node of this lane's search: solver_solve_scalar's loop body
-            const bool big = bb_popcount(~(own | enemy)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES;
-            int rm = 0, rs = 0;
-            bool done = false;
-            if (fresh) {
-                fresh = 0;
-                if (big && memo_find_lane(E, g, own, enemy, exact, rm, rs)) done = true;
-            }
-            if (!done && (left == 0 || (!exact && bsc > 0))) {
-                if (big) memo_put_lane(E, g, own, enemy, exact, bmv, bsc);
-                rm = bmv;
-                rs = bsc;
-                done = true;
-            }
-            if (done) {
-                if (d == 0) {
-                    P->result[task] = (signed char)(task_sign * rs);
-                    have = false;
-                    if (!exact) solver_note_result(P, k, task_ci, task_n);
-                } else {   // back to the parent
-                    const int v = flip ? -rs : rs, a = pact;
-                    --d;
-                    own = fr[d * 256 + 0];
-                    enemy = fr[d * 256 + 1];
-                    left = fr[d * 256 + 2];
-                    const uint32_t meta = (uint32_t)fr[d * 256 + 3];
-                    bmv = (int)(meta & 0xffu) - 1;
-                    bsc = (int)((meta >> 8) & 0xffu) - 128;
-                    pact = (int)((meta >> 16) & 0xffu) - 1;
-                    flip = (int)((meta >> 24) & 1u);
-                    if (bsc < v) {
-                        bmv = a;
-                        bsc = v;
-                    }
-                }
-            } else {
-                const int a = __ffsll((long long)left) - 1;
-                left &= left - 1;
-                const raz_bb flipped = bb_calc_flip(a, own, enemy);
-                const raz_bb nown = (own ^ flipped) | (1ULL << a), nenemy = enemy ^ flipped;
-                const raz_bb l1 = bb_legal_moves(nenemy, nown);
-                const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
-                if (l1 | l2) {   // down a ply
-                    fr[d * 256 + 0] = own;
-                    fr[d * 256 + 1] = enemy;
-                    fr[d * 256 + 2] = left;
-                    fr[d * 256 + 3] = (unsigned long long)((uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24));
-                    ++d;
-                    own = l1 ? nenemy : nown;
-                    enemy = l1 ? nown : nenemy;
-                    left = l1 ? l1 : l2;
-                    bmv = -1;
-                    bsc = -100;
-                    pact = a;
-                    flip = l1 ? 1 : 0;
-                    fresh = 1;
-                } else {
-                    const int score = bb_popcount(nown) - bb_popcount(nenemy);
-                    if (bsc < score) {
-                        bmv = a;
-                        bsc = score;
-                    }
-                }
-            }
-        }
-    }
-    wave_sync_lanes();
-    if (lane == 0) hdr[0] = 0ULL;   // nothing parked any more
-    // ---- ply 2 again: every level-2 node's tasks are scanned in ascending move order (the reference's loop at that node).  Non-exact
-    // mode: only nodes whose scan was decided have an f (the others were cancelled by an earlier winning move further up)
-    for (int n = lane; n < n2; n += 64) {
-        const int gk = P->g_kind[n];
-        if ((gk & 3) && !(gk & 4)) {
-            const int t0 = P->g_first[n];
-            const raz_bb go = P->g_own[n], ge = P->g_enemy[n];
-            int bm, bs;
-            if (solver_scan(P->result + t0, (int)P->g_first[n + 1] - t0, P->g_moves[n], exact != 0, bm, bs)) {
-                if (bb_popcount(~(go | ge)) >= 4) memo_put_lane(E, g, go, ge, exact, bm, bs);
-                P->g_v[n] = (signed char)((gk & 1) ? -bs : bs);
-            }
-        }
-    }
-    wave_sync_lanes();
-    // ---- ply 1 again: lane i scans its child's level-2 nodes the same way
-    bool child_known = (my_kind & 3) == 0 || (my_kind & 4) != 0;
-    if (lane < k && (my_kind & 3) && !(my_kind & 4)) {
-        int bm, bs;
-        child_known = solver_scan(P->g_v + first, my_tasks, c_moves, exact != 0, bm, bs);
-        if (child_known) {
-            if (bb_popcount(~(c_own | c_enemy)) >= 4) memo_put_lane(E, g, c_own, c_enemy, exact, bm, bs);
-            my_v = (my_kind & 1) ? -bs : bs;
-        }
-    }
-    // ---- the root (a child that is not known lies behind the move that decided the scan)
-    int bm = -1, bs = -100;
-    for (int i = 0; i < k; ++i) {
-        const int v = (int)lane_u32((uint32_t)my_v, i), a = (int)lane_u32((uint32_t)my_a, i);
-        if (!lane_u32((uint32_t)child_known, i)) break;   // (cannot happen before the scan is decided)
-        if (bs < v) {
-            bm = a;
-            bs = v;
-        }
-        if (!exact && bs > 0) break;
+    if (same && (st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING)) return RAZ_SOLVE_PENDING;
+    wave_sync();
+    if (lane == 0) {   // a new request (an abandoned one - another position - is overwritten: its workers see the new gen and drop their tasks)
+        h->own0 = own0;
+        h->enemy0 = enemy0;
+        h->exact = exact;
+        h->gen = gen + 1u;
+        h->state = RAZ_SOLVE_REQUESTED;
     }
     wave_sync();
-    memo_put(E, g, own0, enemy0, exact, bm, bs, lane);
-    out_move = bm;
-    out_score = bs;
-    return bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
+    return RAZ_SOLVE_PENDING;
 }
 
 // ------------------------------------------------------------------ backup of the previous leaf
@@ -1260,7 +817,7 @@ __device__ void backup_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, uint32
         // (:248-250) writes to the mirror key are dead without a shared tree
         const bool ok = place_leaf(E, R, g, lane, owner, np, kb, kw, lg, 0u, onehot, c.mirror_updates != 0, depth, node, mirror, used, count);
         if (ok) {
-            wave_sync();
+            wave_sync_lanes();   // lane 0 adds to cells that OTHER lanes have just initialised (place_leaf: a brand-new node or mirror)
             if (lane == 0) {
                 const int L = __popcll(lg), ra = rank_of(lg, (int)act);
                 unsigned char* pp = node_ptr(E, g, node);
@@ -1441,7 +998,7 @@ __device__ void begin_move(const raz_engine_dev& E, Regs& R, uint32_t g, int lan
     const bool on = (legal >> lane) & 1ULL;
     if (SOLVER && c.use_solver_turn && turn >= c.use_solver_turn && node != RAZ_NO_NODE) {  // action_by_searching (:100-103,150-161)
         int sm, ss;
-        const int solved = solver_solve(E, g, lane, own, enemy, 1u, S, R.solve_budget, sm, ss);
+        const int solved = solver_solve(E, g, lane, own, enemy, 1u, S, sm, ss);
         if (solved == RAZ_SOLVE_PENDING) {   // the search is parked in the game's workspace; this launch is over for the game
             R.solve_pending = 1u;
             return;
@@ -1552,7 +1109,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         if (SOLVER && t_insim && !(PAR && polling) && forced_rank < 0 && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // solver inside simulations (:237-251)
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
-            const int solved = solver_solve(E, g, lane, so, se, 0u, S, R.solve_budget, sm, ss);
+            const int solved = solver_solve(E, g, lane, so, se, 0u, S, sm, ss);
             if (solved == RAZ_SOLVE_PENDING) {
                 kind = RAZ_LEAF_SOLVE_PENDING;
                 leaf_node = node;
@@ -1638,7 +1195,7 @@ __device__ void select_leaf(const raz_engine_dev& E, Regs& R, uint32_t g, int la
         if (SOLVER && t_insim && bb_popcount(env.black | env.white) - 4 >= t_insim) {  // (:237-251) on a first arrival
             const raz_bb so = env.np == 1 ? env.black : env.white, se = env.np == 1 ? env.white : env.black;
             int sm, ss;
-            const int solved = solver_solve(E, g, lane, so, se, 0u, S, R.solve_budget, sm, ss);
+            const int solved = solver_solve(E, g, lane, so, se, 0u, S, sm, ss);
             if (solved == RAZ_SOLVE_PENDING) {   // stand on the parent, the edge taken
                 kind = RAZ_LEAF_SOLVE_PENDING;
                 leaf_node = node;

@@ -46,7 +46,6 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
-    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     path_load_rest(E, R, (size_t)g, lane);
     {
         const uint32_t phase = G32(R, GW(phase));
@@ -133,7 +132,6 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
     R.nn = 0u;
     R.path_dirty = 0u;
     R.solve_pending = 0u;
-    R.solve_budget = SOLVER ? solver_launch_budget(E) : 0;
     Slots T;
     T.st = T.sq = T.pk = 0u;
     uint32_t* myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;

@@ -398,6 +398,8 @@ extern "C" int raz_net_forward(const raz_net* net, const uint64_t* own, const ui
     if (!net || !net->d_weights || !own || !enemy || !policy || !value)
         return raz_fail(RAZ_EINVAL, "raz_net_forward: NULL argument");
     const int F = net->filters, V = net->value_fc;
+    if (net->reserved != 0 && net->reserved != 1 && net->reserved != 2 && net->reserved != 4)
+        return raz_fail(RAZ_EINVAL, "raz_net_forward: raz_net.reserved must be 0, 1, 2 or 4 (5 and 6 selected kernels that were removed in ABI 3)");
     // reserved (tests): 1 forces the VALU kernel, 2 the one-wave-per-position MFMA kernel
     if (raz_net_mfma_supported(F, V) && net->reserved != 1)
     {

@@ -1,0 +1,473 @@
+// raz_solver_pool.h — the end-game solver as a POOL OF WORKER LANES shared by all games (lib/alt/reversi_solver_cython.pyx:40-127;
+// call sites agent/player.py:100-103,150-161 - exact, at the root - and :237-251 - win/loss, inside simulations).
+//
+// Round 4 searched a game's position inside the game's own wave: the top three plies became <= 2184 TASKS (subtrees), the wave's 64
+// lanes ran them.  A win/loss solve needs only the few tasks the reference's early-stopping scan really visits, so on mini.yml as
+// shipped 13 of a wave's 64 lanes executed an instruction (profiles/r5_pmc/solver_bound_*three_ply_build*: 20 %; 12.7 % with two-ply
+// tasks) - and every game held a whole wave (and 248 registers of the tree kernel) for it.  Here the tree kernels only POST the
+// position (raz_engine_core.h solver_solve) and three kernels between two tree launches do the work:
+//   k_solve_scan (one wave per game that has a request)  builds the three-ply task tree of a new request in the game's block of
+//       E.solver_ws - child i, its j-th move, the m-th move after that, as before - and lists the game as ACTIVE;
+//   k_solve_run  (W worker waves that belong to no game)  every LANE takes a task - the next one of the next active solve, drawn
+//       round-robin over the active list, so each solve's tasks leave in the reference's scan order and the lanes go first to the
+//       tasks the sequential search needs - and runs the reference's depth-first search on its subtree: current node in registers,
+//       ancestors' frames in the worker's own frames in HBM, the per-game memo shared with everybody.  After `budget` iterations the
+//       lanes park their searches in the pool's state arrays; the next launch picks them up;
+//   k_solve_scan again  folds the finished tasks into level-2 values, those into the root's children, those into the root's answer -
+//       each scan the reference's loop over a node's moves in ascending order, strict improvement, win/loss mode stopping at the first
+//       value > 0 - and publishes an answer as soon as the scan is decided; tasks behind a decided node are never started, searches
+//       of them are dropped at the next launch.
+// f is a function of (position, mode): which lane searches a subtree, in which launch, or whether a subtree the sequential scan
+// would have skipped is searched as well changes no answer.  Workers never talk to each other inside a launch (only the two atomic
+// counters of the queue and the claim of a memo slot); everything else crosses kernel boundaries.
+#pragma once
+#include "raz_engine_core.h"
+
+namespace {
+
+#define RAZ_SOLVER_MAX_L2 (RAZ_SOLVER_MAX_DEPTH * (RAZ_SOLVER_MAX_DEPTH - 1))        // 182 positions two plies below the root
+#define RAZ_SOLVER_MAX_TASKS (RAZ_SOLVER_MAX_L2 * (RAZ_SOLVER_MAX_DEPTH - 2))        // 2184 subtrees three plies below it
+#define RAZ_SOLVER_UNKNOWN (-128)
+struct SolverTree {   // in the game's block of E.solver_ws behind the header; k_solve_scan works on a copy in LDS
+    unsigned long long c_own[RAZ_SOLVER_MAX_DEPTH], c_enemy[RAZ_SOLVER_MAX_DEPTH], c_moves[RAZ_SOLVER_MAX_DEPTH];   // child i: position (its mover's view), its moves
+    unsigned long long g_own[RAZ_SOLVER_MAX_L2], g_enemy[RAZ_SOLVER_MAX_L2], g_moves[RAZ_SOLVER_MAX_L2];           // level-2 node n, likewise
+    unsigned short g_first[RAZ_SOLVER_MAX_L2 + 2];   // node n's first task
+    unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2]; // child i's first level-2 node
+    signed char result[RAZ_SOLVER_MAX_TASKS];        // task t: the value of that move for the level-2 node's mover (RAZ_SOLVER_UNKNOWN: not there yet)
+    signed char c_v[RAZ_SOLVER_MAX_DEPTH];           // child i: the value of the root's i-th move once known, for the ROOT's mover (else RAZ_SOLVER_UNKNOWN)
+    signed char g_v[RAZ_SOLVER_MAX_L2];              // node n: the value of the reply that leads to it once known, for the CHILD's mover
+    unsigned char c_kind[RAZ_SOLVER_MAX_DEPTH];      // child i: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo)
+    unsigned char g_kind[RAZ_SOLVER_MAX_L2];         // node n, likewise (seen from the child's mover)
+    unsigned char c_a[RAZ_SOLVER_MAX_DEPTH];         // the square of the root's i-th move
+    unsigned char g_child[RAZ_SOLVER_MAX_L2];        // node n's child
+    unsigned char task_node[RAZ_SOLVER_MAX_TASKS];   // task t's level-2 node
+};
+static_assert(sizeof(SolverTree) <= RAZ_SOLVER_TREE_BYTES, "SolverTree must fit the game's solver block");
+static_assert(sizeof(SolverTree) % 8 == 0, "SolverTree is copied in 8-byte words");
+
+__device__ __forceinline__ SolverTree* solve_tree(const raz_engine_dev& E, uint32_t g) {
+    return (SolverTree*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES + sizeof(raz_solve_hdr));
+}
+
+// the reference's loop over a node's moves, on values that are already there: `vals` in ascending move order, RAZ_SOLVER_UNKNOWN =
+// not there yet.  Returns false while the scan is not decided.  Non-exact: it ends at the first value > 0
+__device__ __forceinline__ bool solver_scan(const signed char* vals, int n, raz_bb moves, bool exact, int& bm, int& bs) {
+    bm = -1;
+    bs = -100;
+    raz_bb m = moves;
+    for (int j = 0; j < n; ++j, m &= m - 1) {
+        const int v = vals[j];
+        if (v == RAZ_SOLVER_UNKNOWN) return false;
+        if (bs < v) {
+            bm = __ffsll((long long)m) - 1;
+            bs = v;
+        }
+        if (!exact && bs > 0) break;
+    }
+    return true;
+}
+
+// a position after `mover` (own, enemy) played square a: who moves next.  kind 0: the game ends (v = disc difference for `mover`);
+// 1: the opponent moves; 2: the opponent passes (the mover again); (no, ne, nm) = the next position from ITS mover's view and its moves
+__device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_bb& no, raz_bb& ne, raz_bb& nm, int& v) {
+    const raz_bb flipped = bb_calc_flip(a, own, enemy);
+    const raz_bb nown = (own ^ flipped) | (1ULL << a), nenemy = enemy ^ flipped;
+    const raz_bb l1 = bb_legal_moves(nenemy, nown);
+    const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+    if (!(l1 | l2)) {
+        v = bb_popcount(nown) - bb_popcount(nenemy);
+        no = ne = nm = 0ULL;
+        return 0;
+    }
+    no = l1 ? nenemy : nown;
+    ne = l1 ? nown : nenemy;
+    nm = l1 ? l1 : l2;
+    v = 0;
+    return l1 ? 1 : 2;
+}
+
+// ------------------------------------------------------------------ k_solve_scan
+// collect = 1 (before k_solve_run): new requests get their task tree, every solve with tasks left is listed as active.
+// collect = 0 (after it): the workers' results are folded in; block 0 clears the list for the next round.
+// Both passes run the same scans, so an answer is published by whichever pass first sees its last missing value.
+__global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0, uint32_t count, uint32_t part, uint32_t collect) {
+    if (blockIdx.x >= count) return;
+    const int lane = threadIdx.x;
+    raz_solver_pool_hdr* ph = E.pool_hdr + part;
+    if (!collect && blockIdx.x == 0 && lane == 0) ph->n_active = 0u;   // (nobody reads it between k_solve_run and the next collect pass)
+    const uint32_t g = g0 + blockIdx.x;
+    if (g >= E.B) return;
+    raz_solve_hdr* h = solve_hdr(E, g);
+    const uint32_t st = uni(h->state);
+    if (st != RAZ_SOLVE_REQUESTED && st != RAZ_SOLVE_RUNNING) return;
+    __shared__ SolverTree tree_lds;
+    SolverTree* P = &tree_lds;
+    SolverTree* T = solve_tree(E, g);
+    const raz_bb own0 = uni((raz_bb)h->own0), enemy0 = uni((raz_bb)h->enemy0);
+    const uint32_t exact = uni(h->exact);
+    int k = 0, n2 = 0, total = 0;
+    if (st == RAZ_SOLVE_REQUESTED) {
+        const raz_bb legal0 = bb_legal_moves(own0, enemy0);
+        k = bb_popcount(legal0);
+        if (k == 0) {   // the reference's (None, None): never the case for a running game
+            if (lane == 0) {
+                h->ans_move = -1;
+                h->ans_score = -100;
+                h->ans_kind = RAZ_SOLVE_NONE;
+                h->state = RAZ_SOLVE_ANSWERED;
+            }
+            return;
+        }
+        // ---- ply 1: lane i < k owns the root's i-th move.  kind 0: the game ends there (my_v = disc difference); 1: the opponent
+        // moves; 2: the opponent passes; +4: f(child) came from the memo
+        int my_a = -1, my_kind = 0, my_v = 0, my_nodes = 0, first = 0;
+        raz_bb c_own = 0, c_enemy = 0, c_moves = 0;
+        if (lane < k) {
+            raz_bb m = legal0;
+            for (int i = 0; i < lane; ++i) m &= m - 1;
+            my_a = __ffsll((long long)m) - 1;
+            my_kind = solver_play(my_a, own0, enemy0, c_own, c_enemy, c_moves, my_v);
+            if (my_kind) {
+                int rm, rs;
+                if (bb_popcount(~(c_own | c_enemy)) >= 4 && memo_find_lane(E, g, c_own, c_enemy, exact, rm, rs)) {
+                    my_kind |= 4;
+                    my_v = (my_kind & 1) ? -rs : rs;
+                } else
+                    my_nodes = bb_popcount(c_moves);
+            }
+        }
+        for (int i = 0; i < k; ++i) {   // exclusive prefix sum over the lanes: child i's level-2 nodes are [first, first + my_nodes)
+            const int ti = (int)lane_u32((uint32_t)my_nodes, i);
+            if (i < lane) first += ti;
+            n2 += ti;
+        }
+        wave_sync();
+        if (lane < k) {
+            P->c_own[lane] = c_own;
+            P->c_enemy[lane] = c_enemy;
+            P->c_moves[lane] = c_moves;
+            P->c_first[lane] = (unsigned char)first;
+            P->c_kind[lane] = (unsigned char)my_kind;
+            P->c_a[lane] = (unsigned char)my_a;
+            P->c_v[lane] = (signed char)((my_kind == 0 || (my_kind & 4)) ? my_v : RAZ_SOLVER_UNKNOWN);   // known now: the game ends there, or the memo had f(child)
+        }
+        if (lane == 0) P->c_first[k] = (unsigned char)n2;
+        wave_sync_lanes();
+        // ---- ply 2: level-2 node n = the position after child ci's j-th move, seen from the side to move there (kinds as at ply 1,
+        // from the CHILD's mover's point of view).  Its moves are the tasks
+        for (int n = lane; n < n2; n += 64) {
+            int ci = 0;
+            while (ci + 1 < k && (int)P->c_first[ci + 1] <= n) ++ci;
+            raz_bb m = P->c_moves[ci];
+            for (int j = (int)P->c_first[ci]; j < n; ++j) m &= m - 1;
+            raz_bb go, ge, gm;
+            int gv;
+            int gk = solver_play(__ffsll((long long)m) - 1, P->c_own[ci], P->c_enemy[ci], go, ge, gm, gv);
+            int tasks = 0;
+            if (gk) {
+                int rm, rs;
+                gv = RAZ_SOLVER_UNKNOWN;
+                if (bb_popcount(~(go | ge)) >= 4 && memo_find_lane(E, g, go, ge, exact, rm, rs)) {
+                    gk |= 4;
+                    gv = (gk & 1) ? -rs : rs;
+                } else
+                    tasks = bb_popcount(gm);
+            }
+            P->g_own[n] = go;
+            P->g_enemy[n] = ge;
+            P->g_moves[n] = gm;
+            P->g_kind[n] = (unsigned char)gk;
+            P->g_v[n] = (signed char)gv;
+            P->g_child[n] = (unsigned char)ci;
+            P->g_first[n] = (unsigned short)tasks;   // (a count for now)
+        }
+        wave_sync_lanes();
+        if (lane == 0) {   // counts -> first task of every node
+            int acc = 0;
+            for (int n = 0; n < n2; ++n) {
+                const int c = P->g_first[n];
+                P->g_first[n] = (unsigned short)acc;
+                acc += c;
+            }
+            P->g_first[n2] = (unsigned short)acc;
+        }
+        wave_sync_lanes();
+        total = (int)uni((uint32_t)P->g_first[n2]);
+        for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
+        for (int n = lane; n < n2; n += 64)
+            for (int t = P->g_first[n]; t < (int)P->g_first[n + 1]; ++t) P->task_node[t] = (unsigned char)n;
+    } else {
+        k = (int)uni(h->k);
+        n2 = (int)uni(h->n2);
+        total = (int)uni(h->total);
+        for (int i = lane; i < (int)(sizeof(SolverTree) / 8); i += 64) ((unsigned long long*)P)[i] = ((const unsigned long long*)T)[i];
+    }
+    wave_sync_lanes();
+    // ---- level-2 nodes: the reference's loop over the node's moves, on the results that are there.  A value is f of that position
+    // whoever asked for it, so it goes to the memo the moment it is known
+    for (int n = lane; n < n2; n += 64) {
+        const int gk = P->g_kind[n];
+        if (P->g_v[n] == RAZ_SOLVER_UNKNOWN && (gk & 3) && !(gk & 4)) {
+            const int t0 = P->g_first[n];
+            int bm, bs;
+            if (solver_scan(P->result + t0, (int)P->g_first[n + 1] - t0, P->g_moves[n], exact != 0, bm, bs)) {
+                const raz_bb go = P->g_own[n], ge = P->g_enemy[n];
+                if (bb_popcount(~(go | ge)) >= 4) memo_put_lane(E, g, go, ge, exact, bm, bs);
+                P->g_v[n] = (signed char)((gk & 1) ? -bs : bs);
+            }
+        }
+    }
+    wave_sync_lanes();
+    // ---- the root's children: lane i scans child i's level-2 nodes the same way
+    if (lane < k) {
+        const int ck = P->c_kind[lane];
+        if (P->c_v[lane] == RAZ_SOLVER_UNKNOWN && (ck & 3) && !(ck & 4)) {
+            const int n0 = P->c_first[lane];
+            int bm, bs;
+            if (solver_scan(P->g_v + n0, (int)P->c_first[lane + 1] - n0, P->c_moves[lane], exact != 0, bm, bs)) {
+                const raz_bb co = P->c_own[lane], ce = P->c_enemy[lane];
+                if (bb_popcount(~(co | ce)) >= 4) memo_put_lane(E, g, co, ce, exact, bm, bs);
+                P->c_v[lane] = (signed char)((ck & 1) ? -bs : bs);
+            }
+        }
+    }
+    wave_sync_lanes();
+    // ---- the root (every lane runs the same scan over LDS: the outcome is wave-uniform)
+    int bm = -1, bs = -100;
+    bool decided = true;
+    for (int i = 0; i < k; ++i) {
+        const int v = P->c_v[i];
+        if (v == RAZ_SOLVER_UNKNOWN) {
+            decided = false;
+            break;
+        }
+        if (bs < v) {
+            bm = P->c_a[i];
+            bs = v;
+        }
+        if (!exact && bs > 0) break;
+    }
+    decided = uni((uint32_t)decided) != 0u;
+    if (decided) {
+        bm = uni(bm);
+        bs = uni(bs);
+        wave_sync();
+        memo_put(E, g, own0, enemy0, exact, bm, bs, lane);
+        if (lane == 0) {
+            h->ans_move = bm;
+            h->ans_score = bs;
+            h->ans_kind = bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
+            h->state = RAZ_SOLVE_ANSWERED;
+        }
+        return;
+    }
+    // ---- not decided yet: what the workers look at goes (back) to the game's block
+    if (st == RAZ_SOLVE_REQUESTED) {
+        for (int i = lane; i < (int)(sizeof(SolverTree) / 8); i += 64) ((unsigned long long*)T)[i] = ((const unsigned long long*)P)[i];
+        if (lane == 0) {
+            h->k = (uint32_t)k;
+            h->n2 = (uint32_t)n2;
+            h->total = (uint32_t)total;
+            h->next = 0u;
+            h->state = RAZ_SOLVE_RUNNING;
+        }
+    } else {
+        for (int n = lane; n < n2; n += 64) T->g_v[n] = P->g_v[n];
+        if (lane < k) T->c_v[lane] = P->c_v[lane];
+    }
+    if (collect) {
+        const uint32_t next = st == RAZ_SOLVE_REQUESTED ? 0u : uni(h->next);
+        if (next < (uint32_t)total && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
+    }
+}
+
+// ------------------------------------------------------------------ k_solve_run
+// Worker wave w of the pool: lane state in E.pool_state[w][word][lane] - 0 own, 1 enemy, 2 moves left, 3 the search's small fields,
+// 4 game slot | request generation << 32, 5 task | level-2 node << 16 | child << 24 - and frames in E.pool_frames[w][level][lane].
+// The lanes consult the memo only at nodes with at least RAZ_SOLVER_LANE_MEMO_EMPTIES empties: the 64 searches advance in lockstep,
+// so ONE lane's probe (dependent HBM round trips into a 2 MB table) is paid by all of them; subtrees below that size are searched
+// outright (<= 720 leaf paths).  A wave looks for new tasks when a quarter of its lanes are idle, or every 16th iteration: the draw
+// is five dependent round trips for the whole wave.
+#define RAZ_SOLVER_LANE_MEMO_EMPTIES 6
+#ifndef RAZ_SOLVER_POOL_BUDGET
+#define RAZ_SOLVER_POOL_BUDGET 384
+#endif
+#ifdef RAZ_WAVE_EMU
+#define RAZ_POOL_WAVES
+#else
+#define RAZ_POOL_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+__global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev E, uint32_t part, uint32_t w0, uint32_t wcount, uint32_t a0, int budget) {
+    if (blockIdx.x >= wcount) return;
+    const int lane = threadIdx.x;
+    const uint32_t w = w0 + blockIdx.x;
+    unsigned long long* lw = E.pool_state + (size_t)w * 512;                  // lw[word * 64 + lane]
+    unsigned long long* fr = E.pool_frames + ((size_t)w * RAZ_SOLVER_MAX_DEPTH * 64 + (size_t)lane) * 4;   // this lane's frame at level d: fr[d * 256 + {0 own, 1 enemy, 2 left, 3 meta}]
+    raz_solver_pool_hdr* ph = E.pool_hdr + part;
+    const uint32_t nact = uni(ph->n_active);
+    const uint32_t* active = E.pool_active + a0;
+    const unsigned long long m1 = lw[3 * 64 + lane];
+    bool have = (m1 & 1ULL) != 0;
+    if (__ballot(have) == 0ULL && nact == 0u) return;   // nothing parked here, nothing to hand out
+    raz_bb own = lw[0 * 64 + lane], enemy = lw[1 * 64 + lane], left = lw[2 * 64 + lane];
+    int fresh = (int)((m1 >> 1) & 1ULL), flip = (int)((m1 >> 2) & 1ULL), task_sign = ((m1 >> 3) & 1ULL) ? -1 : 1;
+    uint32_t exact = (uint32_t)((m1 >> 4) & 1ULL);
+    int d = (int)((m1 >> 8) & 0xffULL), bmv = (int)((m1 >> 16) & 0xffULL) - 1, bsc = (int)((m1 >> 24) & 0xffULL) - 128, pact = (int)((m1 >> 32) & 0xffULL) - 1;
+    uint32_t g = (uint32_t)lw[4 * 64 + lane], gen = (uint32_t)(lw[4 * 64 + lane] >> 32);
+    const unsigned long long m2 = lw[5 * 64 + lane];
+    int task = (int)(m2 & 0xffffULL), task_n = (int)((m2 >> 16) & 0xffULL), task_ci = (int)((m2 >> 24) & 0xffULL);
+    if (have) {   // is the parked search still wanted?  Its request may have been answered (a decided scan) or replaced, its node decided
+        const raz_solve_hdr* hh = solve_hdr(E, g);
+        if (hh->gen != gen || hh->state != RAZ_SOLVE_RUNNING) have = false;
+        else if (!exact) {
+            const SolverTree* T = solve_tree(E, g);
+            if (T->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || T->g_v[task_n] != RAZ_SOLVER_UNKNOWN) have = false;
+        }
+    }
+    bool dry = nact == 0u;
+    int empty_draws = 0;
+    for (int iter = 0; iter < budget; ++iter) {
+        const unsigned long long idle = __ballot(!have);
+        const int nidle = __popcll(idle);
+        if (!dry && nidle && (nidle >= 16 || (iter & 15) == 0)) {
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(&ph->cursor, (uint32_t)nidle);
+            base = uni(base);
+            bool got = false;
+            if (!have) {
+                const uint32_t c = base + (uint32_t)__popcll(idle & ((1ULL << lane) - 1ULL));
+                const uint32_t gg = active[c % nact];
+                raz_solve_hdr* hh = solve_hdr(E, gg);
+                const uint32_t t = atomicAdd(&hh->next, 1u);
+                if (t < hh->total) {
+                    got = true;
+                    SolverTree* T = solve_tree(E, gg);
+                    const uint32_t ex = hh->exact;
+                    const int n = T->task_node[t], ci = T->g_child[n];
+                    // (a task that has its result: dispatch restarted after the pool was re-partitioned; a node that is decided: moot)
+                    if (T->result[t] == RAZ_SOLVER_UNKNOWN && (ex || (T->c_v[ci] == RAZ_SOLVER_UNKNOWN && T->g_v[n] == RAZ_SOLVER_UNKNOWN))) {
+                        raz_bb m = T->g_moves[n];
+                        for (int j = (int)T->g_first[n]; j < (int)t; ++j) m &= m - 1;
+                        raz_bb no, ne, nm;
+                        int v;
+                        const int kind = solver_play(__ffsll((long long)m) - 1, T->g_own[n], T->g_enemy[n], no, ne, nm, v);
+                        if (kind) {
+                            g = gg;
+                            gen = hh->gen;
+                            exact = ex;
+                            task = (int)t;
+                            task_n = n;
+                            task_ci = ci;
+                            task_sign = kind == 1 ? -1 : 1;
+                            d = 0;
+                            own = no;
+                            enemy = ne;
+                            left = nm;
+                            bmv = -1;
+                            bsc = -100;
+                            pact = -1;
+                            flip = 0;
+                            fresh = 1;
+                            have = true;
+                        } else
+                            T->result[t] = (signed char)v;
+                    }
+                }
+            }
+            if (__ballot(got) == 0ULL) {
+                if (++empty_draws >= 2) dry = true;   // the listed solves have handed out everything (this launch)
+            } else
+                empty_draws = 0;
+        }
+        if (__ballot(have) == 0ULL) {
+            if (dry) break;
+            continue;
+        }
+        if (have) {   // one node of this lane's search: solver_solve_scalar's loop body
+            const bool big = bb_popcount(~(own | enemy)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES;
+            int rm = 0, rs = 0;
+            bool done = false;
+            if (fresh) {
+                fresh = 0;
+                if (big && memo_find_lane(E, g, own, enemy, exact, rm, rs)) done = true;
+            }
+            if (!done && (left == 0 || (!exact && bsc > 0))) {
+                if (big) memo_put_lane(E, g, own, enemy, exact, bmv, bsc);
+                rm = bmv;
+                rs = bsc;
+                done = true;
+            }
+            if (done) {
+                if (d == 0) {
+                    solve_tree(E, g)->result[task] = (signed char)(task_sign * rs);
+                    have = false;
+                } else {   // back to the parent
+                    const int v = flip ? -rs : rs, a = pact;
+                    --d;
+                    own = fr[d * 256 + 0];
+                    enemy = fr[d * 256 + 1];
+                    left = fr[d * 256 + 2];
+                    const uint32_t meta = (uint32_t)fr[d * 256 + 3];
+                    bmv = (int)(meta & 0xffu) - 1;
+                    bsc = (int)((meta >> 8) & 0xffu) - 128;
+                    pact = (int)((meta >> 16) & 0xffu) - 1;
+                    flip = (int)((meta >> 24) & 1u);
+                    if (bsc < v) {
+                        bmv = a;
+                        bsc = v;
+                    }
+                }
+            } else {
+                const int a = __ffsll((long long)left) - 1;
+                left &= left - 1;
+                raz_bb no, ne, nm;
+                int score;
+                const int kind = solver_play(a, own, enemy, no, ne, nm, score);
+                if (kind) {   // down a ply
+                    fr[d * 256 + 0] = own;
+                    fr[d * 256 + 1] = enemy;
+                    fr[d * 256 + 2] = left;
+                    fr[d * 256 + 3] = (unsigned long long)((uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24));
+                    ++d;
+                    own = no;
+                    enemy = ne;
+                    left = nm;
+                    bmv = -1;
+                    bsc = -100;
+                    pact = a;
+                    flip = kind == 1 ? 1 : 0;
+                    fresh = 1;
+                } else if (bsc < score) {
+                    bmv = a;
+                    bsc = score;
+                }
+            }
+        }
+    }
+    // park: the next launch goes on from here
+    lw[0 * 64 + lane] = own;
+    lw[1 * 64 + lane] = enemy;
+    lw[2 * 64 + lane] = left;
+    lw[3 * 64 + lane] = (have ? 1ULL : 0ULL) | ((unsigned long long)(fresh & 1) << 1) | ((unsigned long long)(flip & 1) << 2) | ((task_sign < 0 ? 1ULL : 0ULL) << 3) |
+                        ((unsigned long long)(exact & 1u) << 4) | ((unsigned long long)(d & 0xff) << 8) | ((unsigned long long)((bmv + 1) & 0xff) << 16) |
+                        ((unsigned long long)((bsc + 128) & 0xff) << 24) | ((unsigned long long)((pact + 1) & 0xff) << 32);
+    lw[4 * 64 + lane] = (unsigned long long)g | ((unsigned long long)gen << 32);
+    lw[5 * 64 + lane] = (unsigned long long)(task & 0xffff) | ((unsigned long long)(task_n & 0xff) << 16) | ((unsigned long long)(task_ci & 0xff) << 24);
+}
+
+// after the batch was re-partitioned into a different number of slices (raz_engine_set_parts): parked searches may sit in another
+// slice's part of the pool than their game - drop them all and hand every running solve's tasks out again (the ones that have their
+// result are skipped at the draw).  One thread per worker lane / per game.
+__global__ __launch_bounds__(256) void k_solve_pool_reset(raz_engine_dev E) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)E.W * 64) E.pool_state[(i / 64) * 512 + 3 * 64 + (i % 64)] = 0ULL;
+    if (i < E.B) {
+        raz_solve_hdr* h = solve_hdr(E, (uint32_t)i);
+        if (h->state == RAZ_SOLVE_RUNNING) {
+            h->gen += 1u;
+            h->next = 0u;
+        }
+    }
+}
+
+}  // namespace

@@ -98,10 +98,12 @@ class DeviceNet:
 
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
                        record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
-                       force_slot_kernel=False, pool_bytes_per_game=0, fused=False, solver_budget=0):
+                       force_slot_kernel=False, pool_bytes_per_game=0, fused=False, solver_budget=0, solver_pool_waves=0):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
-    that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par)."""
+    that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par).
+    solver_budget: iterations a worker lane of the end-game solver's pool runs between two tree launches (rounded up to 64; 0 = 384);
+    solver_pool_waves: worker wavefronts of that pool (0 = one per two games, at most 2048).  Neither changes a result."""
     p = config.play
     par = int(getattr(p, "parallel_search_num", 1) or 1)
     if not 1 <= par <= 16:
@@ -134,14 +136,15 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12) | ((min(255, (int(solver_budget) + 63) // 64) & 0xff) << 16),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
         solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par,
-        pool_bytes_per_game=int(pool_bytes_per_game or 0))
+        pool_bytes_per_game=int(pool_bytes_per_game or 0), solver_pool_waves=int(solver_pool_waves or 0))
     return c
 
 
 class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
-                 force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False, solver_budget=0):
+                 force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False, solver_budget=0,
+                 solver_pool_waves=0):
         """fused: 16-filter nets - tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip:
         k_tree_net, k_tree_par_net for parallel_search_num > 1; the same results bit for bit, +40 % on BASELINE configs[1]; what
         BatchedSelfPlayWorker selects for 16-filter nets).  No evaluation cache in that form.
@@ -182,7 +185,7 @@ class SelfPlayEngine:
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
                                       record_root_w, phase_profile, single_stream, parts, inner_max,
                                       force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused,
-                                      solver_budget=solver_budget)
+                                      solver_budget=solver_budget, solver_pool_waves=solver_pool_waves)
         self.fused = bool(fused)
         self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
         self.slots = int(self.cfg.parallel_search_num) or 1   # simulation slots (leaf-exchange rows) per game

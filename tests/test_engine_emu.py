@@ -116,7 +116,30 @@ def test_emulated_slot_kernel_equals_oracle(blob, k, pool):
         _same(f"par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
-@pytest.mark.parametrize("k,pool,budget", [(4, None, None), (3, 500, 3)])
+@pytest.mark.parametrize("k,waves,budget", [(1, 8, 6), (2, 9, 3), (3, 64, 17)])
+def test_emulated_solver_pool_serves_several_games_from_one_set_of_worker_lanes(golden, blob, k, waves, budget, monkeypatch):
+    """The end-game solver's pool (csrc/raz_solver_pool.h): five games post their solves - exact at the root, win/loss inside
+    simulations - into ONE pool of `waves` worker waves whose lanes take subtrees of whichever game is next in the queue and park
+    every search after `budget` iterations; each game must still be the oracle's game, whatever the pool's size or budget.
+    (parallel_search_num 2 and 3 with the solver on were not covered before round 5.)"""
+    monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
+    cfg = config_of(_variant(golden, "mini_solver_noresign"))
+    cfg.play.parallel_search_num = k
+    cfg.play.thinking_loop = 1
+    eng = EmuEngine(cfg, blob, n_games=5, seed=43, sims_hint=10, solver_pool_waves=waves)
+    eng.start(70, 10)
+    eng.run(chunk=32)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=k)
+    solved = 0
+    for i in range(5):
+        plies, summ = O.selfplay_game(ocfg, blob, 43, 70 + i, 10)
+        _same(f"pool/par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        solved += sum(p["solved"] for p in plies)
+    assert solved > 0
+
+
+@pytest.mark.parametrize("k,pool,budget", [(4, None, None), (3, 500, 3), (2, None, None)])
 def test_emulated_slot_kernel_with_the_solver_equals_oracle(golden, blob, k, pool, budget, monkeypatch):
     """k_tree_par with the end-game solver on: simulations suspended at a solve that ran out of the launch's budget (as new
     simulations in C / C' and as woken sleepers in D) go on at the next launch with the schedule untouched."""

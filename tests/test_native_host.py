@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(_native.lib, name), f"{name} declared in include/raz.h but not exported"
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature in _native.py"
-    assert _native.lib.raz_abi_version() == 2
+    assert _native.lib.raz_abi_version() == 3
 
 
 def test_scalar_primitives_vs_golden(golden_bb):
