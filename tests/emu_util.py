@@ -136,6 +136,12 @@ class EmuEngine:
         _check(self.lib, self.lib.raz_engine_set_positions(self._h, first_slot, b.size, b.ctypes.data, w.ctypes.data, p.ctypes.data, sims,
                                                            int(enable_resign), int(one_move), None), "raz_engine_set_positions")
 
+    def stop_thinking(self, slot):
+        _check(self.lib, self.lib.raz_engine_stop_thinking(self._h, slot, None), "raz_engine_stop_thinking")
+
+    def adopt_tree(self, slot, player_index):
+        _check(self.lib, self.lib.raz_engine_adopt_tree(self._h, slot, int(player_index), None), "raz_engine_adopt_tree")
+
     def read_node(self, slot, black, white, next_player=1, owner=0):
         w, n, p = np.zeros(64), np.zeros(64, dtype=np.uint32), np.zeros(64, dtype=np.float32)
         found = ctypes.c_int(0)
