@@ -868,7 +868,8 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
     F, R, V = NETS["mini"]
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     net = DeviceNet(blob, dev, kernel=net_kernel)
-    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=fused)
+    eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=fused,
+                         solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")))
     eng.start(0, sims)
     eng.step(50)
     eng.stats()
@@ -903,6 +904,11 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
            "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims}
+    if shipped:
+        out["solver_pool"] = dict(eng.solver_stats(), worker_waves=int(eng.cfg.solver_pool_waves) or min(2048, (games + 1) // 2),
+                                  iterations_per_round=(int(eng.cfg.reserved) >> 16 & 0xff) * 64 or 384,
+                                  what="the end-game solver's pool of worker lanes (csrc/raz_solver_pool.h) over the whole leg: solves, rounds of the pool per answer, "
+                                       "share of the worker lanes' iterations spent searching a subtree")
     if fused:
         out["k_tree_net_ms_per_simulation_step"] = tree_ms / timed
         out["matrix_core_tflops_inside_the_fused_kernel"] = 2.0 * macs * st["nn_leaves"] / dt / 1e12

@@ -70,7 +70,8 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
     uint32_t next;               // next task to hand out (workers: atomicAdd)
     int32_t ans_move, ans_score;
     uint32_t ans_kind;           // RAZ_SOLVE_DONE / RAZ_SOLVE_NONE
-    uint32_t pad[2];
+    uint32_t rounds;             // rounds of the pool the solve has been listed in (statistics)
+    uint32_t pad[1];
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_solve_hdr) == 64, "raz_solve_hdr layout");
@@ -215,6 +216,6 @@ struct raz_engine_dev {
     unsigned long long* pool_frames;  // [W][14][64][4] the lanes' DFS frames
     unsigned char* node_out;       // RAZ_NODE_OUT_BYTES + 64: staging of raz_engine_read_node
     uint32_t* gc_remap;            // [B][C] creation index -> link after compaction, during k_gc
-    unsigned long long* counters;
+    unsigned long long* counters;  // ... [20..27] the solver pool's statistics (raz_engine_solver_stats)
     unsigned long long* prof;      // [B][8] optional phase profile (cfg.reserved & 1)
 };

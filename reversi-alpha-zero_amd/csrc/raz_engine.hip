@@ -1562,6 +1562,14 @@ extern "C" int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_st
     return RAZ_OK;
 }
 
+extern "C" int raz_engine_solver_stats(raz_engine* e, uint64_t* out8, raz_stream_t stream) {
+    if (!e || !out8) return raz_fail(RAZ_EINVAL, "raz_engine_solver_stats: NULL argument");
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    RAZ_HIP_TRY(hipMemcpyAsync(out8, e->dev.counters + 20, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_solver_stats: copy");
+    RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_solver_stats: sync");
+    return RAZ_OK;
+}
+
 extern "C" int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold, double threshold) {
     if (!e) return raz_fail(RAZ_EINVAL, "raz_engine_set_resign_threshold: NULL engine");
     e->dev.cfg.has_resign_threshold = has_threshold ? 1 : 0;

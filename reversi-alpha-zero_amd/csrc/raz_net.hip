@@ -17,6 +17,7 @@
 // (mini.yml: F=16, R=1) where a GEMM tile would be mostly padding; wide nets (F=256) go to the
 // MFMA kernel.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -206,24 +207,32 @@ __global__ __launch_bounds__(64) void k_net_wave(const float* __restrict__ W, Ne
 }
 
 // The rows of a split-f16 forward whose activations left the f16 range, once more on the exact-f32 chains (raz_internal.h
-// raz_net_repair_rows).  One block per row of the forward; a block whose row is in range - all of them, normally - reads one
-// word and exits.  The row's activations live in LDS (two buffers, in-place second conv): no scratch, no limit on the rows.
+// raz_net_repair_rows).  A FIXED grid (<= 256 blocks: each block's 130 KB of LDS holds a CU): block b looks at its contiguous
+// share of the row flags 64 at a time and repairs the rows whose flag is up - none, normally.  The row's activations live in
+// LDS (two buffers, in-place second conv): no scratch, no limit on the rows.
 __global__ __launch_bounds__(64) void k_net_wave_repair(const float* __restrict__ W, NetDims d, const raz_bb* __restrict__ own,
                                                         const raz_bb* __restrict__ enemy, float* __restrict__ policy,
                                                         float* __restrict__ value, int n, unsigned* __restrict__ rowflag,
                                                         unsigned* __restrict__ sticky, const uint32_t* __restrict__ list,
                                                         const uint32_t* __restrict__ n_ptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int i = blockIdx.x;
     const int rows = n_ptr ? ((int)*n_ptr < n ? (int)*n_ptr : n) : n;
-    if (i >= rows || !rowflag[(size_t)i * RAZ_NET_ROWFLAG_WORDS]) return;
-    if (threadIdx.x == 0) {
-        atomicAdd(sticky + 1, 1u);   // rows repaired since the net was loaded
-        // a forward with many rows out of range belongs on the exact-f32 matrix-core kernels: tell the caller (raz_net_range_check)
-        if (atomicAdd(rowflag + 1, 1u) >= RAZ_NET_REPAIR_ROWS) atomicOr(sticky, 1u);
+    const int per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = (int)blockIdx.x * per, hi = lo + per < rows ? lo + per : rows;
+    for (int base = lo; base < hi; base += 64) {
+        const int mine = base + (int)threadIdx.x;
+        unsigned long long m = __ballot(mine < hi && rowflag[(size_t)mine * RAZ_NET_ROWFLAG_WORDS] != 0u);
+        for (; m; m &= m - 1) {
+            const int i = base + __ffsll((long long)m) - 1;
+            if (threadIdx.x == 0) {
+                atomicAdd(sticky + 1, 1u);   // rows repaired since the net was loaded
+                // a forward with many rows out of range belongs on the exact-f32 matrix-core kernels: tell the caller (raz_net_range_check)
+                if (atomicAdd(rowflag + 1, 1u) >= RAZ_NET_REPAIR_ROWS) atomicOr(sticky, 1u);
+            }
+            const size_t row = list ? list[i] : (size_t)i;
+            net_wave_position<true, true>(W, d, own[row], enemy[row], policy + row * 64, value + row, nullptr, 0, smem);
+        }
     }
-    const size_t row = list ? list[i] : (size_t)i;
-    net_wave_position<true, true>(W, d, own[row], enemy[row], policy + row * 64, value + row, nullptr, 0, smem);
 }
 
 }  // namespace
@@ -366,16 +375,17 @@ int raz_net_repair_rows(const float* W, int F, int R, int V, const uint64_t* own
                         size_t n, unsigned* rowflag, unsigned* sticky, const uint32_t* list, const uint32_t* n_ptr, hipStream_t s) {
     NetDims d = {F, R, V};
     const size_t shm = ((size_t)2 * F * 64 + 192 + (size_t)V) * sizeof(float);   // two activation buffers + the heads' scratch
-    {   // 130 KB for F = 256: above the default dynamic limit - raise it once per device
-        static unsigned long long attr_devices = 0;
+    {   // 130 KB for F = 256: above the default dynamic limit - raise it once per device (two threads racing here both set it: harmless)
+        static std::atomic<unsigned long long> attr_devices{0};
         int dev = 0;
         RAZ_HIP_TRY(hipGetDevice(&dev), "raz_net_forward: hipGetDevice");
-        if (dev >= 64 || !(attr_devices >> dev & 1)) {
+        if (dev >= 64 || !(attr_devices.load(std::memory_order_acquire) >> dev & 1)) {
             RAZ_HIP_TRY(hipFuncSetAttribute((const void*)k_net_wave_repair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "raz_net_forward: hipFuncSetAttribute (repair)");
-            if (dev < 64) attr_devices |= 1ull << dev;
+            if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(k_net_wave_repair, dim3((unsigned)n), dim3(64), shm, s, W, d, (const raz_bb*)own, (const raz_bb*)enemy, policy, value,
+    const unsigned grid = n < 256 ? (unsigned)n : 256u;   // one block per CU reads ceil(n / 256) row flags; a flagged row is repaired by the block that found it
+    hipLaunchKernelGGL(k_net_wave_repair, dim3(grid), dim3(64), shm, s, W, d, (const raz_bb*)own, (const raz_bb*)enemy, policy, value,
                        (int)n, rowflag, sticky, list, n_ptr);
     return raz_check_launch("raz_net_forward (range repair)");
 }

@@ -22,6 +22,7 @@
 // counters of the queue and the claim of a memo slot); everything else crosses kernel boundaries.
 #pragma once
 #include "raz_engine_core.h"
+#include "raz_bitboard_valu.h"   // the per-LANE forms of the bitboard primitives (same results for every input)
 
 namespace {
 
@@ -70,10 +71,10 @@ __device__ __forceinline__ bool solver_scan(const signed char* vals, int n, raz_
 // a position after `mover` (own, enemy) played square a: who moves next.  kind 0: the game ends (v = disc difference for `mover`);
 // 1: the opponent moves; 2: the opponent passes (the mover again); (no, ne, nm) = the next position from ITS mover's view and its moves
 __device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_bb& no, raz_bb& ne, raz_bb& nm, int& v) {
-    const raz_bb flipped = bb_calc_flip(a, own, enemy);
+    const raz_bb flipped = bbv_calc_flip(a, own, enemy);
     const raz_bb nown = (own ^ flipped) | (1ULL << a), nenemy = enemy ^ flipped;
-    const raz_bb l1 = bb_legal_moves(nenemy, nown);
-    const raz_bb l2 = l1 ? 0ULL : bb_legal_moves(nown, nenemy);
+    const raz_bb l1 = bbv_legal_moves(nenemy, nown);
+    const raz_bb l2 = l1 ? 0ULL : bbv_legal_moves(nown, nenemy);
     if (!(l1 | l2)) {
         v = bb_popcount(nown) - bb_popcount(nenemy);
         no = ne = nm = 0ULL;
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             h->ans_score = bs;
             h->ans_kind = bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
             h->state = RAZ_SOLVE_ANSWERED;
+            atomicAdd(&E.counters[21], 1ULL);
+            atomicAdd(&E.counters[22], (unsigned long long)(st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds));
         }
         return;
     }
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     if (st == RAZ_SOLVE_REQUESTED) {
         for (int i = lane; i < (int)(sizeof(SolverTree) / 8); i += 64) ((unsigned long long*)T)[i] = ((const unsigned long long*)P)[i];
         if (lane == 0) {
+            h->rounds = 0u;
             h->k = (uint32_t)k;
             h->n2 = (uint32_t)n2;
             h->total = (uint32_t)total;
@@ -278,6 +282,10 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     if (collect) {
         const uint32_t next = st == RAZ_SOLVE_REQUESTED ? 0u : uni(h->next);
         if (next < (uint32_t)total && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
+        if (lane == 0) {
+            h->rounds = (st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds) + 1u;
+            if (st == RAZ_SOLVE_REQUESTED) atomicAdd(&E.counters[20], 1ULL);
+        }
     }
 }
 
@@ -326,9 +334,12 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     }
     bool dry = nact == 0u;
     int empty_draws = 0;
+    uint32_t st_busy = 0u, st_iters = 0u, st_done = 0u, st_skipped = 0u;   // statistics (raz_engine_solver_stats)
     for (int iter = 0; iter < budget; ++iter) {
         const unsigned long long idle = __ballot(!have);
         const int nidle = __popcll(idle);
+        st_busy += 64u - (uint32_t)nidle;
+        ++st_iters;
         if (!dry && nidle && (nidle >= 16 || (iter & 15) == 0)) {
             uint32_t base = 0u;
             if (lane == 0) base = atomicAdd(&ph->cursor, (uint32_t)nidle);
@@ -369,9 +380,12 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                             flip = 0;
                             fresh = 1;
                             have = true;
-                        } else
+                        } else {
                             T->result[t] = (signed char)v;
-                    }
+                            ++st_done;
+                        }
+                    } else
+                        ++st_skipped;
                 }
             }
             if (__ballot(got) == 0ULL) {
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 if (d == 0) {
                     solve_tree(E, g)->result[task] = (signed char)(task_sign * rs);
                     have = false;
+                    ++st_done;
                 } else {   // back to the parent
                     const int v = flip ? -rs : rs, a = pact;
                     --d;
@@ -442,6 +457,16 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     bsc = score;
                 }
             }
+        }
+    }
+    {
+        const uint32_t done = wave_sum_u32(st_done), skipped = wave_sum_u32(st_skipped);
+        if (lane == 0) {
+            atomicAdd(&E.counters[23], (unsigned long long)st_busy);
+            atomicAdd(&E.counters[24], (unsigned long long)st_iters);
+            atomicAdd(&E.counters[25], (unsigned long long)done);
+            atomicAdd(&E.counters[26], (unsigned long long)skipped);
+            atomicAdd(&E.counters[27], 1ULL);
         }
     }
     // park: the next launch goes on from here

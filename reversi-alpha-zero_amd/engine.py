@@ -233,6 +233,15 @@ class SelfPlayEngine:
             check(lib.raz_engine_leaf_cache_stats(self._h, out, _stream()), "raz_engine_leaf_cache_stats")
         return {"hits": out[0], "in_batch_duplicates": out[1], "evaluated": out[2], "no_room": out[3]}
 
+    def solver_stats(self):
+        """The end-game solver pool's counters since start() (include/raz.h raz_engine_solver_stats)."""
+        out = (ctypes.c_uint64 * 8)()
+        check(lib.raz_engine_solver_stats(self._h, out, _stream()), "raz_engine_solver_stats")
+        req, ans, rounds, busy, wave_iters, done, skipped, wave_launches = (int(x) for x in out)
+        return {"solves": req, "answers": ans, "pool_rounds_per_answer": rounds / ans if ans else None,
+                "lane_utilisation": busy / (64.0 * wave_iters) if wave_iters else None, "busy_lane_iterations": busy,
+                "wave_iterations": wave_iters, "subtrees_finished": done, "subtrees_skipped": skipped, "worker_wave_launches": wave_launches}
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:

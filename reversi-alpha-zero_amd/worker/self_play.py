@@ -627,14 +627,18 @@ class BatchedSelfPlayWorker:
 
     def _group(self):
         """True when the collectives of the path run: more than one rank, or a process group of one (the nccl path exercised on a
-        single GPU - tests/test_multirank_gpu.py, bench.py RAZ_BENCH_NCCL_WORLD1)."""
-        if self.world > 1:
-            return True
+        single GPU - tests/test_multirank_gpu.py, bench.py RAZ_BENCH_NCCL_WORLD1).  The process group must be THIS worker's group:
+        a host process that initialised torch.distributed for more ranks than the worker was built for would otherwise walk a
+        world-1 worker into collectives of a larger group (size mismatch or hang)."""
         try:
             import torch.distributed as dist
-            return dist.is_available() and dist.is_initialized()
+            up = dist.is_available() and dist.is_initialized()
         except Exception:   # noqa: BLE001
-            return False
+            up = False
+        if up and dist.get_world_size() != self.world:
+            raise RuntimeError(f"BatchedSelfPlayWorker(world={self.world}) inside a torch.distributed process group of {dist.get_world_size()} "
+                               "ranks: build the worker with that world size (rank = its rank) or destroy the group first")
+        return self.world > 1 or up
 
     def _all_ranks_state(self, state):
         """MAX of the per-rank block state over all ranks: every rank takes the same branch before the next collective, and a

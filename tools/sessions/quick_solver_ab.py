@@ -1,0 +1,22 @@
+"""GPU A/B of the solver pool's knobs on mini.yml as shipped (configs[1] batch): one process, several (budget, waves, fused) settings.
+usage: python tools/sessions/quick_solver_ab.py "budget,waves,fused;budget,waves,fused;..." """
+import json
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import torch  # noqa: E402
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+dev = torch.device("cuda:0")
+args = types.SimpleNamespace(no_spotcheck=True)
+for spec in (sys.argv[1] if len(sys.argv) > 1 else "0,0,0").split(";"):
+    b, w, f = (int(x) for x in spec.split(","))
+    os.environ["RAZ_BENCH_SOLVER_BUDGET"], os.environ["RAZ_BENCH_SOLVER_WAVES"] = str(b), str(w)
+    out = bench.config1_leg(dev, args, 4, fused=bool(f), shipped=True)[0]
+    print(json.dumps({"budget": b, "waves": w, "fused": f, "sims_per_s": out["value"], "steps": out["steps"], "ms_per_step": out["ms_per_step"],
+                      "k_tree_avg_ms": out.get("k_tree_avg_ms"), "solver_pool": out["solver_pool"]}), flush=True)
