@@ -869,7 +869,8 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
     blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
     net = DeviceNet(blob, dev, kernel=net_kernel)
     eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=fused,
-                         solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")))
+                         solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")),
+                         parts=int(os.environ.get("RAZ_BENCH_PARTS", "0")))
     eng.start(0, sims)
     eng.step(50)
     eng.stats()

@@ -337,11 +337,13 @@ int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32
                               raz_stream_t stream);
 int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_stream_t stream);
 /* Statistics of the end-game solver's pool since raz_engine_start (csrc/raz_solver_pool.h; no reference counterpart - the reference
- * solves one position at a time, lib/alt/reversi_solver_cython.pyx:40-61).  out8: [0] solves whose task tree was built, [1] answers
+ * solves one position at a time, lib/alt/reversi_solver_cython.pyx:40-61).  out15: [0..2] clock ticks the worker waves spent in their slow phases / folding finished nodes / in all, then [3] solves whose task tree was built, [1] answers
  * published, [2] rounds of the pool those solves were listed in before their answer, [3] lane-iterations in which a worker lane
  * searched a subtree, [4] wave-iterations executed (x 64 = lane slots), [5] subtrees finished, [6] subtrees drawn but not searched
- * (their node was decided already), [7] worker-wave launches that found work.  Synchronises `stream`. */
-int raz_engine_solver_stats(raz_engine* e, uint64_t* out8, raz_stream_t stream);
+ * (their node was decided already), [7] worker-wave launches that found work, [8] requests posted by all game slots, [9] most by
+ * one slot, [10] rounds all slots' solves were listed in, [11] most of one slot (the batch's critical path in rounds of the pool).
+ * Synchronises `stream`. */
+int raz_engine_solver_stats(raz_engine* e, uint64_t* out15, raz_stream_t stream);
 /* config.play.resign_threshold is mutated while the worker runs (worker/self_play.py:250-260: +-0.01 per 100
  * no-resign test games); moves decided from the next raz_engine_step on use the new value.  Trees, records and
  * random streams are untouched. */

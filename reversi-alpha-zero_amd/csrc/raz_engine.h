@@ -71,19 +71,19 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
     int32_t ans_move, ans_score;
     uint32_t ans_kind;           // RAZ_SOLVE_DONE / RAZ_SOLVE_NONE
     uint32_t rounds;             // rounds of the pool the solve has been listed in (statistics)
-    uint32_t pad[1];
+    uint32_t rounds_total;       // ... and all solves of this game slot since raz_engine_start
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_solve_hdr) == 64, "raz_solve_hdr layout");
 #endif
-#define RAZ_SOLVER_TREE_BYTES 10240   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there)
+#define RAZ_SOLVER_TREE_BYTES 12288   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there)
 #define RAZ_SOLVER_WS_BYTES (64 + RAZ_SOLVER_TREE_BYTES)
 // a worker wave of the pool: 8 words of lane state and 14 frames of 32 B per lane
 #define RAZ_SOLVER_WORKER_STATE_BYTES (8 * 64 * 8)
 #define RAZ_SOLVER_WORKER_FRAME_BYTES (14 * 64 * 32)
 struct raz_solver_pool_hdr {     // one per slice of the batch (64 bytes)
     uint32_t n_active;           // solves with tasks left to hand out, listed in `active`
-    uint32_t cursor;             // round-robin draw over them (workers: atomicAdd)
+    uint32_t unused;
     uint32_t pad[14];
 };
 #define RAZ_PHASE_NEW_MOVE 0

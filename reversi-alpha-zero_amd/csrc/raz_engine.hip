@@ -48,6 +48,10 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_d
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
+    if (SOLVER && solve_in_flight(E, g)) {
+        if (lane == 0) E.nn_active[g] = 0;
+        return;
+    }
     // ONE round trip: control block, path, the net's answer for the leaf of the previous launch
     uint32_t* gw = (uint32_t*)(E.game + g);
     Regs R;
@@ -139,6 +143,10 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
     const int lane = threadIdx.x;
     if (g >= E.B) return;
     const uint32_t K = E.K;
+    if (SOLVER && solve_in_flight(E, g)) {   // (leaves queued before the solve was posted have been evaluated: their flags go down)
+        if (lane < (int)K) E.nn_active[(size_t)g * K + lane] = 0;
+        return;
+    }
     const unsigned long long kmask = (1ULL << K) - 1ULL;  // K <= 16
     uint32_t* gw = (uint32_t*)(E.game + g);
     Regs R;
@@ -1562,10 +1570,11 @@ extern "C" int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_st
     return RAZ_OK;
 }
 
-extern "C" int raz_engine_solver_stats(raz_engine* e, uint64_t* out8, raz_stream_t stream) {
-    if (!e || !out8) return raz_fail(RAZ_EINVAL, "raz_engine_solver_stats: NULL argument");
+extern "C" int raz_engine_solver_stats(raz_engine* e, uint64_t* out12, raz_stream_t stream) {
+    if (!e || !out12) return raz_fail(RAZ_EINVAL, "raz_engine_solver_stats: NULL argument");
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
-    RAZ_HIP_TRY(hipMemcpyAsync(out8, e->dev.counters + 20, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_solver_stats: copy");
+    if (e->dev.W) hipLaunchKernelGGL(k_solver_game_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, e->dev);
+    RAZ_HIP_TRY(hipMemcpyAsync(out12, e->dev.counters + 17, 15 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "raz_engine_solver_stats: copy");
     RAZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream), "raz_engine_solver_stats: sync");
     return RAZ_OK;
 }

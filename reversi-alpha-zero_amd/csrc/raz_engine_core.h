@@ -480,7 +480,7 @@ __device__ __forceinline__ float masked_normalised_prior(float pol, raz_bb legal
 //   * a per-game memo in HBM (positions with >= 4 empties; it only saves time, exactly as the reference's dict does) is shared by
 //     all of them.
 // f is a function of the position, so WHEN an answer arrives changes nothing but a game's wall time.
-struct SolverLDS {   // the scalar search's frames (depth <= RAZ_SOLVER_SCALAR_EMPTIES + passes < 16)
+struct SolverLDS {   // the scalar search's frames (depth <= RAZ_SOLVER_SCALAR_EMPTIES + passes; positions of > RAZ_SOLVER_MAX_DEPTH empties never get here: validate())
     unsigned long long own[16], enemy[16], left[16];
     int best_move[16], best_score[16], paction[16], flip[16], fresh[16];
 };
@@ -550,17 +550,22 @@ __device__ void memo_put(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb
 __device__ bool memo_find_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int& move, int& score) {
     const raz_slot* tab = E.memo + (size_t)g * E.M;
     const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
-    for (uint32_t r = 0; r < 2; ++r) {
-        const raz_slot* s = tab + ((h + r) & mask);
-        const uint32_t it = s->idx_tag;
-        if (!(it >> 31)) return false;
-        if (s->black == own && s->white == enemy && ((it >> 30) & 1u) == exact) {
-            move = (int)((it >> 8) & 0xffu) - 1;
-            score = (int)(it & 0xffu) - 128;
-            return true;
-        }
-    }
-    return false;
+    // both slots' fields are requested together: ONE round trip into the game's table (the 64 searches of a worker wave advance in
+    // lockstep, so a dependent second request would be paid by all of them)
+    const raz_slot *s0 = tab + (h & mask), *s1 = tab + ((h + 1u) & mask);
+    const uint32_t it0 = s0->idx_tag, it1 = s1->idx_tag;
+    const raz_bb b0 = s0->black, w0 = s0->white, b1 = s1->black, w1 = s1->white;
+    uint32_t it;
+    if (!(it0 >> 31)) return false;
+    if (b0 == own && w0 == enemy && ((it0 >> 30) & 1u) == exact)
+        it = it0;
+    else if ((it1 >> 31) && b1 == own && w1 == enemy && ((it1 >> 30) & 1u) == exact)
+        it = it1;
+    else
+        return false;
+    move = (int)((it >> 8) & 0xffu) - 1;
+    score = (int)(it & 0xffu) - 128;
+    return true;
 }
 __device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb enemy, uint32_t exact, int move, int score) {
     raz_slot* tab = E.memo + (size_t)g * E.M;
@@ -645,7 +650,7 @@ __device__ bool solver_solve_scalar(const raz_engine_dev& E, uint32_t g, int lan
     }
 }
 
-#define RAZ_SOLVER_SCALAR_EMPTIES 6
+#define RAZ_SOLVER_SCALAR_EMPTIES 4   // (round 4: 6 - a wave-uniform search of 720 leaf paths with a memo probe per node was the tree kernel's straggler, up to 3 ms)
 #define RAZ_SOLVER_MAX_DEPTH 14
 #define RAZ_SOLVE_NONE 0
 #define RAZ_SOLVE_DONE 1
@@ -660,6 +665,12 @@ __device__ bool solver_solve_scalar(const raz_engine_dev& E, uint32_t g, int lan
 
 __device__ __forceinline__ raz_solve_hdr* solve_hdr(const raz_engine_dev& E, uint32_t g) {
     return (raz_solve_hdr*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES);
+}
+// A game whose request is still with the pool has nothing to do in this launch: one word tells (the tree kernels look at it before
+// they load anything else - in a solver-bound batch most games of a launch are in that state).
+__device__ __forceinline__ bool solve_in_flight(const raz_engine_dev& E, uint32_t g) {
+    const uint32_t st = uni(solve_hdr(E, g)->state);
+    return st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING;
 }
 
 // f_mode(own0, enemy0) for the game's wave: RAZ_SOLVE_DONE (out_move / out_score), RAZ_SOLVE_NONE (the reference's (None, None)) or

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
+    if (SOLVER && solve_in_flight(E, g)) return;   // the request is still with the solver pool: nothing to do in this launch
     uint32_t* gw = (uint32_t*)(E.game + g);
     Regs R;
     R.cw = gw[lane];
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
     const uint32_t g = g0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (g >= E.B) return;
+    if (SOLVER && solve_in_flight(E, g)) return;   // the request is still with the solver pool: nothing to do in this launch
     const uint32_t K = E.K;
     const unsigned long long kmask = (1ULL << K) - 1ULL;  // K <= 16
     uint32_t* gw = (uint32_t*)(E.game + g);

@@ -41,7 +41,7 @@ struct SolverTree {   // in the game's block of E.solver_ws behind the header; k
     unsigned char g_kind[RAZ_SOLVER_MAX_L2];         // node n, likewise (seen from the child's mover)
     unsigned char c_a[RAZ_SOLVER_MAX_DEPTH];         // the square of the root's i-th move
     unsigned char g_child[RAZ_SOLVER_MAX_L2];        // node n's child
-    unsigned char task_node[RAZ_SOLVER_MAX_TASKS];   // task t's level-2 node
+    unsigned short task_entry[RAZ_SOLVER_MAX_TASKS]; // task t: its level-2 node | that node's child << 8 (one request tells a worker both)
 };
 static_assert(sizeof(SolverTree) <= RAZ_SOLVER_TREE_BYTES, "SolverTree must fit the game's solver block");
 static_assert(sizeof(SolverTree) % 8 == 0, "SolverTree is copied in 8-byte words");
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         total = (int)uni((uint32_t)P->g_first[n2]);
         for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
         for (int n = lane; n < n2; n += 64)
-            for (int t = P->g_first[n]; t < (int)P->g_first[n + 1]; ++t) P->task_node[t] = (unsigned char)n;
+            for (int t = P->g_first[n]; t < (int)P->g_first[n + 1]; ++t) P->task_entry[t] = (unsigned short)(n | ((int)P->g_child[n] << 8));
     } else {
         k = (int)uni(h->k);
         n2 = (int)uni(h->n2);
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         if (next < (uint32_t)total && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
         if (lane == 0) {
             h->rounds = (st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds) + 1u;
+            h->rounds_total += 1u;
             if (st == RAZ_SOLVE_REQUESTED) atomicAdd(&E.counters[20], 1ULL);
         }
     }
@@ -294,9 +295,11 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 // 4 game slot | request generation << 32, 5 task | level-2 node << 16 | child << 24 - and frames in E.pool_frames[w][level][lane].
 // The lanes consult the memo only at nodes with at least RAZ_SOLVER_LANE_MEMO_EMPTIES empties: the 64 searches advance in lockstep,
 // so ONE lane's probe (dependent HBM round trips into a 2 MB table) is paid by all of them; subtrees below that size are searched
-// outright (<= 720 leaf paths).  A wave looks for new tasks when a quarter of its lanes are idle, or every 16th iteration: the draw
-// is five dependent round trips for the whole wave.
+// outright (<= 720 leaf paths) - and even those probes are batched (the slow phase, below).
 #define RAZ_SOLVER_LANE_MEMO_EMPTIES 6
+#ifndef RAZ_SOLVER_SLOW_EVERY
+#define RAZ_SOLVER_SLOW_EVERY 8   // (a power of two)
+#endif
 #ifndef RAZ_SOLVER_POOL_BUDGET
 #define RAZ_SOLVER_POOL_BUDGET 384
 #endif
@@ -310,7 +313,11 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     const int lane = threadIdx.x;
     const uint32_t w = w0 + blockIdx.x;
     unsigned long long* lw = E.pool_state + (size_t)w * 512;                  // lw[word * 64 + lane]
-    unsigned long long* fr = E.pool_frames + ((size_t)w * RAZ_SOLVER_MAX_DEPTH * 64 + (size_t)lane) * 4;   // this lane's frame at level d: fr[d * 256 + {0 own, 1 enemy, 2 left, 3 meta}]
+    // the lanes' frames live in LDS while the wave runs (a push or a pop is four conflict-free 8-byte accesses - word j of level d at
+    // [(d * 4 + j) * 64 + lane] - instead of an HBM round trip in the middle of every node) and in E.pool_frames between launches
+    __shared__ unsigned long long frames_lds[RAZ_SOLVER_MAX_DEPTH * 4 * 64];
+    unsigned long long* fr = frames_lds + lane;                                                            // word j of level d: fr[(d * 4 + j) * 64]
+    unsigned long long* fr_hbm = E.pool_frames + (size_t)w * RAZ_SOLVER_MAX_DEPTH * 4 * 64 + (size_t)lane;   // the same layout
     raz_solver_pool_hdr* ph = E.pool_hdr + part;
     const uint32_t nact = uni(ph->n_active);
     const uint32_t* active = E.pool_active + a0;
@@ -332,117 +339,203 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
             if (T->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || T->g_v[task_n] != RAZ_SOLVER_UNKNOWN) have = false;
         }
     }
+    if (have)   // (a lane reads and writes its own column only: no barrier)
+        for (int i = 0; i < d * 4; ++i) fr[i * 64] = fr_hbm[i * 64];
     bool dry = nact == 0u;
     int empty_draws = 0;
     uint32_t st_busy = 0u, st_iters = 0u, st_done = 0u, st_skipped = 0u;   // statistics (raz_engine_solver_stats)
+    unsigned long long tk_slow = 0, tk_pop = 0;
+    const unsigned long long tk_begin = prof_now();
+    // A lane's memo traffic waits for the wave's next SLOW PHASE (every RAZ_SOLVER_SLOW_EVERY-th iteration): the 64 searches run in
+    // lockstep, so a probe made the moment one lane reaches a node of >= 6 empties - some lane does in nearly every iteration -
+    // stalled ALL of them for an HBM round trip per iteration (first hardware runs: 5 us per iteration, 0.75 us of it arithmetic).
+    // In the slow phase the wanted probes and the claims of finished nodes are issued first, the idle lanes' task draws (five
+    // dependent round trips) run on top of them, and the probes' answers are looked at last.  A lane that wants a probe idles until
+    // then (a few iterations at a node that has ~1 chance in 30 of being such a node).
+    bool wait_find = ((m1 >> 5) & 1ULL) != 0;
+    const uint32_t lane_id = blockIdx.x * 64u + (uint32_t)lane, lanes_of_slice = wcount * 64u;
+    uint32_t draws = 0u, next_solve = nact ? active[lane_id % nact] : 0u;
+    bool put_pending = false;
+    raz_bb put_own = 0, put_enemy = 0;
+    uint32_t put_tag = 0u, put_g = 0u;
     for (int iter = 0; iter < budget; ++iter) {
         const unsigned long long idle = __ballot(!have);
         const int nidle = __popcll(idle);
         st_busy += 64u - (uint32_t)nidle;
         ++st_iters;
-        if (!dry && nidle && (nidle >= 16 || (iter & 15) == 0)) {
-            uint32_t base = 0u;
-            if (lane == 0) base = atomicAdd(&ph->cursor, (uint32_t)nidle);
-            base = uni(base);
-            bool got = false;
-            if (!have) {
-                const uint32_t c = base + (uint32_t)__popcll(idle & ((1ULL << lane) - 1ULL));
-                const uint32_t gg = active[c % nact];
-                raz_solve_hdr* hh = solve_hdr(E, gg);
-                const uint32_t t = atomicAdd(&hh->next, 1u);
-                if (t < hh->total) {
-                    got = true;
-                    SolverTree* T = solve_tree(E, gg);
-                    const uint32_t ex = hh->exact;
-                    const int n = T->task_node[t], ci = T->g_child[n];
-                    // (a task that has its result: dispatch restarted after the pool was re-partitioned; a node that is decided: moot)
-                    if (T->result[t] == RAZ_SOLVER_UNKNOWN && (ex || (T->c_v[ci] == RAZ_SOLVER_UNKNOWN && T->g_v[n] == RAZ_SOLVER_UNKNOWN))) {
-                        raz_bb m = T->g_moves[n];
-                        for (int j = (int)T->g_first[n]; j < (int)t; ++j) m &= m - 1;
-                        raz_bb no, ne, nm;
-                        int v;
-                        const int kind = solver_play(__ffsll((long long)m) - 1, T->g_own[n], T->g_enemy[n], no, ne, nm, v);
-                        if (kind) {
-                            g = gg;
-                            gen = hh->gen;
-                            exact = ex;
-                            task = (int)t;
-                            task_n = n;
-                            task_ci = ci;
-                            task_sign = kind == 1 ? -1 : 1;
-                            d = 0;
-                            own = no;
-                            enemy = ne;
-                            left = nm;
-                            bmv = -1;
-                            bsc = -100;
-                            pact = -1;
-                            flip = 0;
-                            fresh = 1;
-                            have = true;
-                        } else {
-                            T->result[t] = (signed char)v;
-                            ++st_done;
-                        }
-                    } else
-                        ++st_skipped;
+        bool hit = false;
+        int hit_m = 0, hit_s = 0;
+        const unsigned long long tk0 = prof_now();
+        if ((iter & (RAZ_SOLVER_SLOW_EVERY - 1)) == 0) {
+            // ---- 1. memo traffic goes out
+            const bool finding = have && wait_find;
+            uint32_t it0 = 0u, it1 = 0u, claimed = 1u;
+            raz_bb b0 = 0, w0 = 0, b1 = 0, w1 = 0;
+            raz_slot* pslot = nullptr;
+            if (finding) {
+                const raz_slot* tab = E.memo + (size_t)g * E.M;
+                const uint32_t h = key_hash(own, enemy, 8u + exact);
+                const raz_slot *s0 = tab + (h & (E.M - 1)), *s1 = tab + ((h + 1u) & (E.M - 1));
+                it0 = s0->idx_tag; it1 = s1->idx_tag;
+                b0 = s0->black; w0 = s0->white; b1 = s1->black; w1 = s1->white;
+            }
+            if (put_pending) {
+                pslot = E.memo + (size_t)put_g * E.M + (key_hash(put_own, put_enemy, 8u + ((put_tag >> 30) & 1u)) & (E.M - 1));
+                claimed = atomicCAS(&pslot->idx_tag, 0u, RAZ_MEMO_CLAIMED);
+            }
+            // ---- 2. idle lanes draw tasks.  No shared cursor (one address takes ~88 atomics per microsecond on this chip: a cursor drawn
+            // by every wave every few iterations was the pool's ceiling): lane L of wave w walks its own sequence over the active list,
+            // solve (w * 64 + L + q * lanes of the slice) mod nact at its q-th draw - all lanes together sweep the list evenly, and a solve's
+            // tasks still leave in scan order (its `next` counter).  The list entry of a lane's next draw is requested one phase ahead
+            if (!dry && nidle) {
+                bool got = false;
+                if (!have) {
+                    const uint32_t gg = next_solve;
+                    ++draws;
+                    next_solve = active[(lane_id + draws * lanes_of_slice) % nact];
+                    raz_solve_hdr* hh = solve_hdr(E, gg);
+                    const uint32_t t = atomicAdd(&hh->next, 1u);
+                    const uint32_t total = hh->total, ex = hh->exact, hgen = hh->gen;   // (fixed while the pool runs: requested beside the draw)
+                    if (t < total) {
+                        got = true;
+                        SolverTree* T = solve_tree(E, gg);
+                        const int te = T->task_entry[t], n = te & 0xff, ci = te >> 8;
+                        // (a task that has its result: dispatch restarted after the pool was re-partitioned; a node that is decided: moot)
+                        if (T->result[t] == RAZ_SOLVER_UNKNOWN && (ex || (T->c_v[ci] == RAZ_SOLVER_UNKNOWN && T->g_v[n] == RAZ_SOLVER_UNKNOWN))) {
+                            raz_bb m = T->g_moves[n];
+                            for (int j = (int)T->g_first[n]; j < (int)t; ++j) m &= m - 1;
+                            raz_bb no, ne, nm;
+                            int v;
+                            const int kind = solver_play(__ffsll((long long)m) - 1, T->g_own[n], T->g_enemy[n], no, ne, nm, v);
+                            if (kind) {
+                                g = gg;
+                                gen = hgen;
+                                exact = ex;
+                                task = (int)t;
+                                task_n = n;
+                                task_ci = ci;
+                                task_sign = kind == 1 ? -1 : 1;
+                                d = 0;
+                                own = no;
+                                enemy = ne;
+                                left = nm;
+                                bmv = -1;
+                                bsc = -100;
+                                pact = -1;
+                                flip = 0;
+                                fresh = 1;
+                                wait_find = false;
+                                have = true;
+                            } else {
+                                T->result[t] = (signed char)v;
+                                ++st_done;
+                            }
+                        } else
+                            ++st_skipped;
+                    }
+                }
+                if (__ballot(got) == 0ULL) {
+                    if (++empty_draws >= 2) dry = true;   // the listed solves have handed out everything (this launch)
+                } else
+                    empty_draws = 0;
+            }
+            // ---- 3. the memo's answers
+            if (finding) {
+                wait_find = false;
+                fresh = 0;   // (probed: a miss goes on with the node's moves)
+                uint32_t it = 0u;
+                if ((it0 >> 31) && b0 == own && w0 == enemy && ((it0 >> 30) & 1u) == exact) it = it0;
+                else if ((it0 >> 31) && (it1 >> 31) && b1 == own && w1 == enemy && ((it1 >> 30) & 1u) == exact) it = it1;
+                if (it) {
+                    hit = true;
+                    hit_m = (int)((it >> 8) & 0xffu) - 1;
+                    hit_s = (int)(it & 0xffu) - 128;
                 }
             }
-            if (__ballot(got) == 0ULL) {
-                if (++empty_draws >= 2) dry = true;   // the listed solves have handed out everything (this launch)
-            } else
-                empty_draws = 0;
+            if (put_pending) {   // (the home slot only: a finished node whose slot is taken is simply not remembered)
+                if (claimed == 0u) {
+                    pslot->black = put_own;
+                    pslot->white = put_enemy;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __hip_atomic_store(&pslot->idx_tag, put_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                put_pending = false;
+            }
         }
+        const unsigned long long tk1 = prof_now();
+        tk_slow += tk1 - tk0;
         if (__ballot(have) == 0ULL) {
             if (dry) break;
             continue;
         }
-        if (have) {   // one node of this lane's search: solver_solve_scalar's loop body
-            const bool big = bb_popcount(~(own | enemy)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES;
-            int rm = 0, rs = 0;
-            bool done = false;
-            if (fresh) {
-                fresh = 0;
-                if (big && memo_find_lane(E, g, own, enemy, exact, rm, rs)) done = true;
-            }
-            if (!done && (left == 0 || (!exact && bsc > 0))) {
-                if (big) memo_put_lane(E, g, own, enemy, exact, bmv, bsc);
-                rm = bmv;
-                rs = bsc;
-                done = true;
-            }
-            if (done) {
+        if (have && !wait_find) {
+            // ---- one MOVE of this lane's search per iteration (solver_solve_scalar's loop, its "node is finished" steps folded in):
+            // first every node that is finished hands its value to its parent - cheap LDS pops, usually none or one - then the node the
+            // search stands on plays its next move.  (A separate iteration per finished node made 45 % of the iterations pops, each at
+            // the full price of the lockstep wave's expand path.)
+            for (;;) {
+                const bool big = bb_popcount(~(own | enemy)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES;
+                int rm = 0, rs = 0;
+                bool done = false;
+                if (hit) {
+                    rm = hit_m;
+                    rs = hit_s;
+                    done = true;
+                    hit = false;
+                    fresh = 0;
+                } else if (fresh && big) {
+                    wait_find = true;   // the probe goes out with the next slow phase
+                    break;
+                } else {
+                    fresh = 0;
+                    if (left == 0 || (!exact && bsc > 0)) {
+                        if (big) {   // remembered at the next slow phase (one finished node per lane at a time)
+                            put_pending = true;
+                            put_own = own;
+                            put_enemy = enemy;
+                            put_g = g;
+                            put_tag = 0x80000000u | (exact << 30) | ((uint32_t)(bmv + 1) << 8) | (uint32_t)(bsc + 128);
+                        }
+                        rm = bmv;
+                        rs = bsc;
+                        done = true;
+                    }
+                }
+                if (!done) break;
                 if (d == 0) {
                     solve_tree(E, g)->result[task] = (signed char)(task_sign * rs);
                     have = false;
                     ++st_done;
-                } else {   // back to the parent
-                    const int v = flip ? -rs : rs, a = pact;
-                    --d;
-                    own = fr[d * 256 + 0];
-                    enemy = fr[d * 256 + 1];
-                    left = fr[d * 256 + 2];
-                    const uint32_t meta = (uint32_t)fr[d * 256 + 3];
-                    bmv = (int)(meta & 0xffu) - 1;
-                    bsc = (int)((meta >> 8) & 0xffu) - 128;
-                    pact = (int)((meta >> 16) & 0xffu) - 1;
-                    flip = (int)((meta >> 24) & 1u);
-                    if (bsc < v) {
-                        bmv = a;
-                        bsc = v;
-                    }
+                    break;
                 }
-            } else {
+                // back to the parent
+                const int v = flip ? -rs : rs, a = pact;
+                --d;
+                own = fr[(d * 4 + 0) * 64];
+                enemy = fr[(d * 4 + 1) * 64];
+                left = fr[(d * 4 + 2) * 64];
+                const uint32_t meta = (uint32_t)fr[(d * 4 + 3) * 64];
+                bmv = (int)(meta & 0xffu) - 1;
+                bsc = (int)((meta >> 8) & 0xffu) - 128;
+                pact = (int)((meta >> 16) & 0xffu) - 1;
+                flip = (int)((meta >> 24) & 1u);
+                if (bsc < v) {
+                    bmv = a;
+                    bsc = v;
+                }
+            }
+            tk_pop += prof_now() - tk1;
+            if (have && !wait_find) {
                 const int a = __ffsll((long long)left) - 1;
                 left &= left - 1;
                 raz_bb no, ne, nm;
                 int score;
                 const int kind = solver_play(a, own, enemy, no, ne, nm, score);
                 if (kind) {   // down a ply
-                    fr[d * 256 + 0] = own;
-                    fr[d * 256 + 1] = enemy;
-                    fr[d * 256 + 2] = left;
-                    fr[d * 256 + 3] = (unsigned long long)((uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24));
+                    fr[(d * 4 + 0) * 64] = own;
+                    fr[(d * 4 + 1) * 64] = enemy;
+                    fr[(d * 4 + 2) * 64] = left;
+                    fr[(d * 4 + 3) * 64] = (unsigned long long)((uint32_t)(bmv + 1) | ((uint32_t)(bsc + 128) << 8) | ((uint32_t)(pact + 1) << 16) | ((uint32_t)flip << 24));
                     ++d;
                     own = no;
                     enemy = ne;
@@ -467,17 +560,44 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
             atomicAdd(&E.counters[25], (unsigned long long)done);
             atomicAdd(&E.counters[26], (unsigned long long)skipped);
             atomicAdd(&E.counters[27], 1ULL);
+            atomicAdd(&E.counters[17], tk_slow);                    // shader-clock ticks: slow phases,
+            atomicAdd(&E.counters[18], tk_pop);                     // the pops of finished nodes,
+            atomicAdd(&E.counters[19], prof_now() - tk_begin);      // the whole loop
         }
     }
     // park: the next launch goes on from here
+    if (have)
+        for (int i = 0; i < d * 4; ++i) fr_hbm[i * 64] = fr[i * 64];
     lw[0 * 64 + lane] = own;
     lw[1 * 64 + lane] = enemy;
     lw[2 * 64 + lane] = left;
     lw[3 * 64 + lane] = (have ? 1ULL : 0ULL) | ((unsigned long long)(fresh & 1) << 1) | ((unsigned long long)(flip & 1) << 2) | ((task_sign < 0 ? 1ULL : 0ULL) << 3) |
-                        ((unsigned long long)(exact & 1u) << 4) | ((unsigned long long)(d & 0xff) << 8) | ((unsigned long long)((bmv + 1) & 0xff) << 16) |
+                        ((unsigned long long)(exact & 1u) << 4) | ((wait_find ? 1ULL : 0ULL) << 5) | ((unsigned long long)(d & 0xff) << 8) | ((unsigned long long)((bmv + 1) & 0xff) << 16) |
                         ((unsigned long long)((bsc + 128) & 0xff) << 24) | ((unsigned long long)((pact + 1) & 0xff) << 32);
     lw[4 * 64 + lane] = (unsigned long long)g | ((unsigned long long)gen << 32);
     lw[5 * 64 + lane] = (unsigned long long)(task & 0xffff) | ((unsigned long long)(task_n & 0xff) << 16) | ((unsigned long long)(task_ci & 0xff) << 24);
+}
+
+// per-game totals for raz_engine_solver_stats: counters[28] solves of all games, [29] most solves of one game, [30] rounds all games'
+// solves were listed in, [31] most of one game (its critical path in rounds of the pool)
+__global__ __launch_bounds__(256) void k_solver_game_stats(raz_engine_dev E) {
+    __shared__ unsigned long long sh[4][256];
+    unsigned long long a = 0, b = 0, c = 0, d = 0;
+    for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
+        const raz_solve_hdr* h = solve_hdr(E, g);
+        const unsigned long long n = h->gen, r = h->rounds_total;
+        a += n;
+        b = n > b ? n : b;
+        c += r;
+        d = r > d ? r : d;
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c; sh[3][threadIdx.x] = d;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long x = 0;
+        for (int i = 0; i < 256; ++i) x = (threadIdx.x & 1) ? (sh[threadIdx.x][i] > x ? sh[threadIdx.x][i] : x) : x + sh[threadIdx.x][i];
+        E.counters[28 + threadIdx.x] = x;
+    }
 }
 
 // after the batch was re-partitioned into a different number of slices (raz_engine_set_parts): parked searches may sit in another

@@ -235,10 +235,16 @@ class SelfPlayEngine:
 
     def solver_stats(self):
         """The end-game solver pool's counters since start() (include/raz.h raz_engine_solver_stats)."""
-        out = (ctypes.c_uint64 * 8)()
+        out = (ctypes.c_uint64 * 15)()
         check(lib.raz_engine_solver_stats(self._h, out, _stream()), "raz_engine_solver_stats")
-        req, ans, rounds, busy, wave_iters, done, skipped, wave_launches = (int(x) for x in out)
-        return {"solves": req, "answers": ans, "pool_rounds_per_answer": rounds / ans if ans else None,
+        tk_slow, tk_pop, tk_all = (int(x) for x in out[:3])
+        out = out[3:]
+        self._solver_ticks = {"slow_phase_share_of_worker_time": tk_slow / tk_all if tk_all else None, "pops_share": tk_pop / tk_all if tk_all else None,
+                              "ticks_per_wave_iteration": None}
+        req, ans, rounds, busy, wave_iters, done, skipped, wave_launches, posted, posted_max, listed, listed_max = (int(x) for x in out)
+        self._solver_ticks["ticks_per_wave_iteration"] = tk_all / wave_iters if wave_iters else None
+        return {"ticks": self._solver_ticks, "requests_posted": posted, "most_requests_of_one_game": posted_max, "rounds_listed_all_games": listed, "most_rounds_listed_of_one_game": listed_max,
+                "solves": req, "answers": ans, "pool_rounds_per_answer": rounds / ans if ans else None,
                 "lane_utilisation": busy / (64.0 * wave_iters) if wave_iters else None, "busy_lane_iterations": busy,
                 "wave_iterations": wave_iters, "subtrees_finished": done, "subtrees_skipped": skipped, "worker_wave_launches": wave_launches}
 

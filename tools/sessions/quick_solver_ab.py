@@ -15,8 +15,8 @@ g.build()
 dev = torch.device("cuda:0")
 args = types.SimpleNamespace(no_spotcheck=True)
 for spec in (sys.argv[1] if len(sys.argv) > 1 else "0,0,0").split(";"):
-    b, w, f = (int(x) for x in spec.split(","))
-    os.environ["RAZ_BENCH_SOLVER_BUDGET"], os.environ["RAZ_BENCH_SOLVER_WAVES"] = str(b), str(w)
+    b, w, f, parts = (list(int(x) for x in spec.split(",")) + [0])[:4]
+    os.environ["RAZ_BENCH_SOLVER_BUDGET"], os.environ["RAZ_BENCH_SOLVER_WAVES"], os.environ["RAZ_BENCH_PARTS"] = str(b), str(w), str(parts)
     out = bench.config1_leg(dev, args, 4, fused=bool(f), shipped=True)[0]
-    print(json.dumps({"budget": b, "waves": w, "fused": f, "sims_per_s": out["value"], "steps": out["steps"], "ms_per_step": out["ms_per_step"],
+    print(json.dumps({"budget": b, "waves": w, "fused": f, "parts": parts, "sims_per_s": out["value"], "steps": out["steps"], "ms_per_step": out["ms_per_step"],
                       "k_tree_avg_ms": out.get("k_tree_avg_ms"), "solver_pool": out["solver_pool"]}), flush=True)
