@@ -311,18 +311,46 @@ def calibrate_ply_weights(eng, n, sims, seed, dev, first_id, steps=12):
     return (1.0 / r), r
 
 
-def conv_traffic():
-    """HBM bytes per net forward from the committed PMC passes (separate rocprofv3 --pmc runs of this command:
-    tools/run_profiles.sh -> tools/pmc_summary.py); None when no pass is committed for this build."""
-    path = os.path.join(ROOT, "profiles", "r4_pmc", "headline_config3_traffic.json")
+def kernel_sources_sha256():
+    """sha256 over the kernel sources of libraz (csrc/*.hip, csrc/*.h, include/raz.h, in name order): what a committed counter pass
+    records (tools/pmc_summary.py) and what this run compares it with - a traffic figure measured on other sources is not reported."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "reversi-alpha-zero_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(ROOT, "include", "raz.h")]:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+PMC_DIR = "r5_pmc"   # the counter passes of this round's final build (profiles/README.md)
+
+
+def committed_traffic(name):
+    """A committed counter-traffic file of profiles/<PMC_DIR>/ with its provenance checked: (json, source note) - or (None, why not)
+    when the file is missing, is half a measurement, or was measured on kernel sources other than the ones this run was built from."""
+    rel = f"profiles/{PMC_DIR}/{name}"
+    path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
-        return None, None
+        return None, f"{rel}: no counter pass committed for this build"
     with open(path) as f:
         t = json.load(f)
     if not t.get("fetch_pass_present") or not t.get("write_pass_present"):   # never report half a measurement
-        return None, None
-    return t.get("net_forward_hbm_bytes_per_launch"), ("profiles/r4_pmc/headline_config3_traffic.json (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes "
-                                                       "of this command, summed over the launches of one net forward; FETCH doubled as MI355X_MICROARCH.md prescribes)")
+        return None, f"{rel}: FETCH_SIZE or WRITE_SIZE pass missing"
+    prov = t.get("provenance") or {}
+    if prov.get("kernel_sources_sha256") != kernel_sources_sha256():
+        return None, f"{rel}: measured {prov.get('measured_utc', 'at an unknown time')} on OTHER kernel sources than this build's - not reported"
+    return t, (f"{rel}, measured {prov.get('measured_utc')} UTC on these kernel sources (sha256 {prov.get('kernel_sources_sha256', '')[:12]}): separate rocprofv3 --pmc "
+               "FETCH_SIZE and WRITE_SIZE passes of this command (tools/run_profiles.sh), FETCH doubled as MI355X_MICROARCH.md prescribes")
+
+
+def conv_traffic():
+    """HBM bytes per net forward from the committed PMC passes of THIS build (separate rocprofv3 --pmc runs of this command:
+    tools/run_profiles.sh -> tools/pmc_summary.py); (None, reason) otherwise."""
+    t, note = committed_traffic("headline_config3_traffic.json")
+    return (t.get("net_forward_hbm_bytes_per_launch") if t else None), note
 
 
 def sweep_traffic():
@@ -510,12 +538,15 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
     k["note"] = "latency-bound (one wave per game, dependent round trips): the HBM fraction is nominal"
     # counter traffic of the tree kernel: profiles/r4_pmc/headline_ktree_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this
     # command; "games_per_launch" says how many games the profiled launches covered - traffic per game is what is compared)
-    tpath = os.path.join(ROOT, "profiles", "r4_pmc", ("headline_ktree" if args.net == "ch5" else "config1") + "_traffic.json")
+    tname = ("headline" if args.net == "ch5" else "config1") + "_traffic.json"
+    tj, tnote = committed_traffic(tname)
+    tpath = os.path.join(ROOT, "profiles", PMC_DIR, tname)
     tgames = None
-    if os.path.exists(tpath):   # counter traffic of the same command (tools/run_profiles.sh): FETCH_SIZE / WRITE_SIZE passes
-        with open(tpath) as f:
-            tj = json.load(f)
-        kt, tgames = tj.get("kernels", {}).get("k_tree"), tj.get("games_per_launch")
+    if tj is None:
+        k["traffic"], k["traffic_source"] = None, tnote
+    else:   # counter traffic of the same command (tools/run_profiles.sh): FETCH_SIZE / WRITE_SIZE passes
+        k["traffic_source"] = tnote
+        kt, tgames = tj.get("kernels", {}).get("k_tree"), (tj.get("games_per_launch") or ((tj.get("kernels", {}).get("k_tree") or {}).get("grid_threads") or 0) // 64 or None)
         if kt and k["algorithmic_bytes_per_launch"]:
             scale = (args.games / parts / tgames) if tgames else 1.0   # the profiled launches covered tgames games each
             kt = dict(kt, fetch_bytes_raw=kt["fetch_bytes_raw"] * scale, write_bytes=kt["write_bytes"] * scale)
@@ -890,7 +921,7 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
             eng.gc(min(eng.cfg.nodes_per_game // 4, st["max_pool_used"] // 2))
         if st["finished_games"] >= games:
             break
-        if steps > (80 * sims * 4 + 4000) * (40 if shipped else 1):   # (a game whose solve is suspended ends its launch: more launches, not more work)
+        if steps > (int(os.environ.get("RAZ_BENCH_MAX_STEPS", "0")) or (80 * sims * 4 + 4000) * (40 if shipped else 1)):   # (a game whose solve is suspended ends its launch: more launches, not more work)
             raise RuntimeError("engine did not finish")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -906,8 +937,8 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
            "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims}
     if shipped:
-        out["solver_pool"] = dict(eng.solver_stats(), worker_waves=int(eng.cfg.solver_pool_waves) or min(2048, (games + 1) // 2),
-                                  iterations_per_round=(int(eng.cfg.reserved) >> 16 & 0xff) * 64 or 384,
+        out["solver_pool"] = dict(eng.solver_stats(), worker_waves=int(eng.cfg.solver_pool_waves) or min(1280, (games + 3) // 4),
+                                  iterations_per_round=(int(eng.cfg.reserved) >> 16 & 0xff) * 64 or 128,
                                   what="the end-game solver's pool of worker lanes (csrc/raz_solver_pool.h) over the whole leg: solves, rounds of the pool per answer, "
                                        "share of the worker lanes' iterations spent searching a subtree")
     if fused:
@@ -939,8 +970,97 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
     return out, blob, cfg
 
 
-def continuous_leg(dev, args, rounds=3):
-    """configs[1] with continuous batching (raz_engine_harvest: a finished slot restarts on the next game id at once,
+def worker_end_to_end_leg(dev, args, seconds=60.0):
+    """BatchedSelfPlayWorker.run() itself - what `run.py self` runs - on BASELINE configs[1] (4096 slots, mini net, 200 sims/move) for a
+    fixed window: continuous batching inside blocks of 16384 game ids, the block's packed records gathered under an RCCL process group of
+    ONE rank (the N > 1 code path), resignation bookkeeping, the native row emitter on host threads and the background writer putting
+    play_*.json files on tmpfs (the reference's loop plays, buffers AND writes inside the timed game: worker/self_play.py:139-217,
+    lib/data_helper.py:23-25).  games/hour here INCLUDES emission; the engine-level figure of the same blocks is beside it."""
+    import glob
+    import shutil
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from reversi_alpha_zero_amd.agent.model import ReversiNet
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker, rows_of_game
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    root = tempfile.mkdtemp(prefix="raz_e2e_", dir=base)
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sims = 200
+        mc = mini_config(sims, 1)
+        cfg = Config()
+        for k, v in vars(mc.play).items():
+            setattr(cfg.play, k, v)
+        cfg.play.schedule_of_simulation_num_per_move = [[0, sims]]
+        cfg.play_data.update(dict(nb_game_in_file=64, nb_game_in_ggf_file=1 << 30, enable_ggf_data=False, max_file_num=24,
+                                  save_policy_of_tau_1=bool(mc.play_data.save_policy_of_tau_1), drop_draw_game_rate=0.0))
+        rc = cfg.resource
+        rc.data_dir, rc.play_data_dir, rc.self_play_ggf_data_dir = root, os.path.join(root, "play"), os.path.join(root, "ggf")
+        rc.self_play_game_idx_file = os.path.join(root, ".self-play-game-idx")
+        rc.force_simulation_num_file = os.path.join(root, ".force-sim")
+        rc.create_directories = lambda: [os.makedirs(d, exist_ok=True) for d in (rc.play_data_dir, rc.self_play_ggf_data_dir)]
+        blob = ReversiNet(*NETS["mini"]).keras_init_(0).to_blob()
+        slots, block = 4096, 16384
+        w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=slots, block_games=block, seed=0, device=str(dev), rank=0, world=1)
+        # the first file of the run, for the oracle check below (max_file_num prunes it later)
+        keep = {}
+        orig_remove = w.remove_play_data
+
+        def remove_and_keep_first(files):
+            if files and "first" not in keep:
+                keep["first"] = open(files[0], "rb").read()
+            return orig_remove(files)
+        w.remove_play_data = remove_and_keep_first
+        import time as _t
+        torch.cuda.synchronize()
+        t0 = _t.monotonic()
+        w.run(total_games=None, background_emit=True, until=t0 + seconds)
+        torch.cuda.synchronize()
+        dt = _t.monotonic() - t0
+        games = int(open(rc.self_play_game_idx_file).read())
+        st = w.last_stats
+        out = {"workload": f"BatchedSelfPlayWorker.run() on BASELINE configs[1]: {slots} slots, blocks of {block} game ids with continuous batching, mini net, {sims} sims/move, "
+                           "mini.yml play settings (thinking_loop 1, solver off, parallel_search_num 1), RCCL group of one rank for the record gather, native row emitter "
+                           f"on {w._emit_executor_threads} host threads + background writer, play_*.json files of 64 games on tmpfs (max_file_num 24)",
+               "seconds": dt, "games_written": games, "games_per_hour_including_emission": games / dt * 3600.0,
+               "sims_per_s_including_emission": games * st["total_sims"] / max(1, st["finished_games"]) / dt,
+               "bytes_written": int(getattr(w, "bytes_written", 0)), "gb_per_s_of_json_text": getattr(w, "bytes_written", 0) / dt / 1e9,
+               "writer_busy_share_of_the_run": w.last_writer_busy_seconds / dt, "blocks": w.last_writer_batches,
+               "gather_backend": getattr(w, "last_gather_backend", None), "gather_bytes_last_block": getattr(w, "last_gather_bytes", None),
+               "host_threads": os.cpu_count()}
+        # two games of the first file against the oracle's rows for the same ids
+        first = json.loads(keep.get("first") or open(sorted(glob.glob(os.path.join(rc.play_data_dir, "*.json")))[0], "rb").read())
+        ocfg = O.play_cfg_from_config(mc)
+        at, checked = 0, []
+        for gid in (0, 1):
+            plies, summ = O.selfplay_game(ocfg, blob, 0, gid, sims)
+            rows = json.loads(json.dumps(rows_of_game(plies, summ["winner"])))
+            ok = first[at:at + len(rows)] == rows
+            checked.append({"game_id": gid, "rows": len(rows), "ok": bool(ok)})
+            at += len(rows)
+            if not ok:
+                raise AssertionError(f"worker_end_to_end: the rows of game {gid} in the first play_*.json differ from the oracle's")
+        out["parity_check_files"] = {"result": "ok", "what": "the rows of game ids 0 and 1 in the run's first play_*.json == the rows of the games the CPU oracle plays for those ids", "games": checked}
+        w._drop_engine(net_too=True)
+        return out
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def continuous_leg(dev, args, rounds=3, shipped=False):
+    """shipped: mini.yml's play section as shipped (thinking_loop 2, parallel_search_num 4, solver from turn 50) - the steady state of
+    the solver-bound configuration: slots are at every stage of a game at once, so the solver pool's lanes are shared between the
+    few games that are solving instead of waiting for the slowest game of a lock-step batch.
+    configs[1] with continuous batching (raz_engine_harvest: a finished slot restarts on the next game id at once,
     worker/self_play.py:95-137): 4096 slots, rounds x 4096 game ids, whole games.  games/hour and sims/s here are measured
     on complete games in a (mostly) steady state, not extrapolated; leaf_slot_occupancy = nn leaves / (steps x slots)."""
     import numpy as np
@@ -948,9 +1068,12 @@ def continuous_leg(dev, args, rounds=3):
     from reversi_alpha_zero_amd.agent.model import ReversiNet
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine, raw_from_packed
     games, sims = 4096, 200
-    cfg = mini_config(sims, 1)
+    cfg = mini_config(sims, 4 if shipped else 1)
+    if shipped:
+        cfg.play.thinking_loop, cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = 2, 50, 50
     blob = ReversiNet(*NETS["mini"]).keras_init_(0).to_blob()
-    eng = SelfPlayEngine(cfg, DeviceNet(blob, dev), n_games=games, seed=0, sims_hint=sims)
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, dev), n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=False,
+                         solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")))
     eng.start(0, sims)
     eng.step(50)
     eng.stats()
@@ -961,7 +1084,8 @@ def continuous_leg(dev, args, rounds=3):
     # leg, the start of the batch and the allocation of the id-ordered outbox are outside the timed region
     dt = sum(st["seconds"].values())
     out = {"workload": f"BASELINE configs[1] with continuous batching: {games} slots, {rounds * games} game ids (whole games), mini net, {sims} sims/move, "
-                       "mini.yml play settings, thinking_loop=1, solver off, parallel_search_num=1",
+                       + ("mini.yml play section AS SHIPPED (thinking_loop 2, parallel_search_num 4, end-game solver from turn 50), two-kernel pipeline + solver pool"
+                          if shipped else "mini.yml play settings, thinking_loop=1, solver off, parallel_search_num=1"),
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "finished_games": st["finished_games"], "steps": st["steps"], "ms_per_step": 1e3 * dt / st["steps"],
            "leaf_slot_occupancy": st["leaf_slot_occupancy"], "gc_runs": st["gc_runs"], "seconds": st["seconds"],
@@ -972,7 +1096,9 @@ def continuous_leg(dev, args, rounds=3):
         ids = [int(x) for x in np.linspace(0, rounds * games - 1, 8).astype(int)]
         rows = torch.tensor(ids, device=dev)
         raw = raw_from_packed(*(outbox[k][rows].cpu().numpy() for k in ("headers", "root_n", "summary")))
-        ocfg = O.play_cfg_from_config(cfg, parallel_search_num=1)
+        ocfg = O.play_cfg_from_config(cfg, parallel_search_num=4 if shipped else 1)
+        if shipped:
+            out["solver_pool"] = eng.solver_stats()
         with cf.ThreadPoolExecutor(max_workers=8) as ex:
             ref = list(ex.map(lambda gid: O.selfplay_game(ocfg, blob, 0, gid, sims), ids))
         for r, (gid, (plies, summ)) in enumerate(zip(ids, ref)):
@@ -1235,6 +1361,8 @@ def main():
                     ("config1_two_kernel_pipeline", lambda: config1_leg(dev, args, 1, fused=False)[0]),
                     ("config1_two_kernel_pipeline_parallel_search_num_4", lambda: config1_leg(dev, args, 4, fused=False)[0]),
                     ("config1_continuous_batching", lambda: continuous_leg(dev, args)),
+                    ("config1_mini_yml_as_shipped_continuous_batching", lambda: continuous_leg(dev, args, rounds=3, shipped=True)),
+                    ("worker_end_to_end_config1", lambda: worker_end_to_end_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             only = set(args.legs.split(",")) if args.legs else None
             for key, leg in legs:

@@ -170,7 +170,7 @@ typedef struct {
                                                  slices/streams (0 = 3); bits 12-15: max simulations per game per tree launch
                                                  (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num);
                                                  bits 16-23: x 64 = iterations a worker lane of the end-game solver's pool runs between two
-                                                 tree launches (0 = 384); a game whose solve - the root's or one inside a simulation - is
+                                                 tree launches (0 = 128); a game whose solve - the root's or one inside a simulation - is
                                                  not answered yet stays suspended: results do not depend on the value.
                                                  Every other bit must be 0 (RAZ_EINVAL) */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
@@ -187,7 +187,7 @@ typedef struct {
                                                  0 = nodes_per_game x 232 + 64 x 704; at most 256 MB */
     uint32_t solver_pool_waves;               /* worker wavefronts of the end-game solver's pool (csrc/raz_solver_pool.h): positions of 7..14
                                                  empties are solved by a pool of lanes shared by all games, one subtree per lane, instead
-                                                 of inside the game's own wave.  0 = one per two games, at most 2048 (two per SIMD); 32 KB
+                                                 of inside the game's own wave.  0 = one per four games, at most 1280 (what the chip's LDS holds at once); 36 KB
                                                  of workspace each.  Results do not depend on the value.  No reference counterpart
                                                  (lib/alt/reversi_solver_cython.pyx runs one position at a time) */
     uint32_t reserved2;                       /* must be 0 */
@@ -344,6 +344,10 @@ int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_stream_t stre
  * one slot, [10] rounds all slots' solves were listed in, [11] most of one slot (the batch's critical path in rounds of the pool).
  * Synchronises `stream`. */
 int raz_engine_solver_stats(raz_engine* e, uint64_t* out15, raz_stream_t stream);
+/* Diagnostics (no reference counterpart): `bytes` at `offset` of one of the engine's device arrays (raz_engine_device_ptr's numbering:
+ * 3 the games' control blocks, 6 the solver blocks, 7 / 8 / 9 the solver pool's lane state / headers / active list) copied to host
+ * memory.  Synchronises the device. */
+int raz_engine_debug_read(raz_engine* e, int which, size_t offset, size_t bytes, void* host_out);
 /* config.play.resign_threshold is mutated while the worker runs (worker/self_play.py:250-260: +-0.01 per 100
  * no-resign test games); moves decided from the next raz_engine_step on use the new value.  Trees, records and
  * random streams are untouched. */

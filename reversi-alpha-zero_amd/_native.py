@@ -123,6 +123,7 @@ SIGNATURES.update({
     "raz_engine_set_leaf_cache": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]),
     "raz_engine_leaf_cache_stats": (c_int, [c_void_p, c_void_p, c_void_p]),
     "raz_engine_solver_stats": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "raz_engine_debug_read": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
     "raz_engine_set_resign_threshold": (c_int, [c_void_p, c_int, ctypes.c_double]),
 })
 

@@ -66,7 +66,7 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
     uint32_t state, gen;
     unsigned long long own0, enemy0;
     uint32_t exact;
-    uint32_t k, n2, total;       // root moves, level-2 nodes, tasks
+    uint32_t k_n2, tasks, total; // root moves | level-2 nodes << 8; level-3 nodes; subtrees the workers search (the tasks)
     uint32_t next;               // next task to hand out (workers: atomicAdd)
     int32_t ans_move, ans_score;
     uint32_t ans_kind;           // RAZ_SOLVE_DONE / RAZ_SOLVE_NONE
@@ -76,10 +76,11 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
 #ifdef __cplusplus
 static_assert(sizeof(raz_solve_hdr) == 64, "raz_solve_hdr layout");
 #endif
-#define RAZ_SOLVER_TREE_BYTES 12288   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there)
-#define RAZ_SOLVER_WS_BYTES (64 + RAZ_SOLVER_TREE_BYTES)
-// a worker wave of the pool: 8 words of lane state and 14 frames of 32 B per lane
-#define RAZ_SOLVER_WORKER_STATE_BYTES (8 * 64 * 8)
+#define RAZ_SOLVER_TREE_BYTES 12288   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there): the top three plies, folded in LDS
+#define RAZ_SOLVER_DEEP_BYTES 131072  // >= sizeof(SolverDeep): the positions three plies down and, below the larger ones, a fourth ply of tasks
+#define RAZ_SOLVER_WS_BYTES (64 + RAZ_SOLVER_TREE_BYTES + RAZ_SOLVER_DEEP_BYTES)
+// a worker wave of the pool: 16 words of lane state (the search in hand and the task drawn ahead) and 14 frames of 32 B per lane
+#define RAZ_SOLVER_WORKER_STATE_BYTES (16 * 64 * 8)
 #define RAZ_SOLVER_WORKER_FRAME_BYTES (14 * 64 * 32)
 struct raz_solver_pool_hdr {     // one per slice of the batch (64 bytes)
     uint32_t n_active;           // solves with tasks left to hand out, listed in `active`

@@ -587,13 +587,14 @@ inline size_t slots_of(const raz_engine_config& cfg) { return cfg.parallel_searc
 // k_tree_par drives the games when more than one simulation is in flight (or when reserved bit 3 asks for it)
 inline bool uses_slot_kernel(const raz_engine_config& cfg) { return slots_of(cfg) > 1 || (cfg.reserved & 8u); }
 
-// Worker waves of the solver pool: the caller's figure, or one per two games up to two per SIMD of the chip (1024 SIMDs) - enough
-// lanes for every running solve's next tasks, few enough that lanes looking for work do not crowd out the ones that have it.
+// Worker waves of the solver pool: the caller's figure, or one per four games, at most 1280 - five waves per CU is what a CU's LDS holds
+// of their 28 KB of frames, so 1280 are resident at once.  Measured on mini.yml as shipped (4096 games, profiles/r5/solver_pool_*):
+// with the fourth ply of tasks 1024 waves are the best size, 512 and 1280 within 4 %; beyond 1280 the launch runs in two rounds.
 // At least kPoolParts, so that every slice of the batch has a wave.
 constexpr uint32_t kPoolParts = 8;   // == kMaxParts below
 inline uint32_t pool_waves_of(const raz_engine_config& cfg) {
-    uint32_t w = cfg.solver_pool_waves ? cfg.solver_pool_waves : (cfg.n_games + 1) / 2;
-    if (w > 2048u && !cfg.solver_pool_waves) w = 2048u;
+    uint32_t w = cfg.solver_pool_waves ? cfg.solver_pool_waves : (cfg.n_games + 3) / 4;
+    if (w > 1280u && !cfg.solver_pool_waves) w = 1280u;
     if (w > 16384u) w = 16384u;
     return w < kPoolParts ? kPoolParts : w;
 }
@@ -1586,6 +1587,9 @@ extern "C" int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold,
     return RAZ_OK;
 }
 
+// diagnostics: `bytes` at `offset` of one of raz_engine_device_ptr's arrays, copied to the host (synchronises the device)
+extern "C" int raz_engine_debug_read(raz_engine* e, int which, size_t offset, size_t bytes, void* host_out);
+
 extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) {
     if (!e) return nullptr;
     switch (which) {
@@ -1594,6 +1598,18 @@ extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) {
         case 2: return e->dev.rec_w;
         case 3: return e->dev.game;
         case 5: return e->dev.prof;
+        case 6: return e->dev.solver_ws;     // diagnostics of the solver pool (tools/sessions/debug_solver_stall.py)
+        case 7: return e->dev.pool_state;
+        case 8: return e->dev.pool_hdr;
+        case 9: return e->dev.pool_active;
         default: return nullptr;
     }
+}
+
+extern "C" int raz_engine_debug_read(raz_engine* e, int which, size_t offset, size_t bytes, void* host_out) {
+    unsigned char* p = (unsigned char*)raz_engine_device_ptr(e, which);
+    if (!p || !host_out) return raz_fail(RAZ_EINVAL, "raz_engine_debug_read: no such array");
+    RAZ_HIP_TRY(hipDeviceSynchronize(), "raz_engine_debug_read: sync");
+    RAZ_HIP_TRY(hipMemcpy(host_out, p + offset, bytes, hipMemcpyDeviceToHost), "raz_engine_debug_read: copy");
+    return RAZ_OK;
 }

@@ -34,20 +34,38 @@ struct SolverTree {   // in the game's block of E.solver_ws behind the header; k
     unsigned long long g_own[RAZ_SOLVER_MAX_L2], g_enemy[RAZ_SOLVER_MAX_L2], g_moves[RAZ_SOLVER_MAX_L2];           // level-2 node n, likewise
     unsigned short g_first[RAZ_SOLVER_MAX_L2 + 2];   // node n's first task
     unsigned char c_first[RAZ_SOLVER_MAX_DEPTH + 2]; // child i's first level-2 node
-    signed char result[RAZ_SOLVER_MAX_TASKS];        // task t: the value of that move for the level-2 node's mover (RAZ_SOLVER_UNKNOWN: not there yet)
+    signed char result[RAZ_SOLVER_MAX_TASKS];        // level-3 node t: the value of the move that leads to it, for the level-2 node's mover (RAZ_SOLVER_UNKNOWN: not there yet)
     signed char c_v[RAZ_SOLVER_MAX_DEPTH];           // child i: the value of the root's i-th move once known, for the ROOT's mover (else RAZ_SOLVER_UNKNOWN)
     signed char g_v[RAZ_SOLVER_MAX_L2];              // node n: the value of the reply that leads to it once known, for the CHILD's mover
     unsigned char c_kind[RAZ_SOLVER_MAX_DEPTH];      // child i: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo)
     unsigned char g_kind[RAZ_SOLVER_MAX_L2];         // node n, likewise (seen from the child's mover)
     unsigned char c_a[RAZ_SOLVER_MAX_DEPTH];         // the square of the root's i-th move
     unsigned char g_child[RAZ_SOLVER_MAX_L2];        // node n's child
-    unsigned short task_entry[RAZ_SOLVER_MAX_TASKS]; // task t: its level-2 node | that node's child << 8 (one request tells a worker both)
+    unsigned short task_entry[RAZ_SOLVER_MAX_TASKS]; // level-3 node t: its level-2 node | that node's child << 8 (one request tells a worker both)
 };
+// Below the three plies of SolverTree: level-3 node t = the position after level-2 node n's j-th move (what round 4 and the first
+// pool handed to a lane whole).  One subtree of a 10-empties solve is then up to 5040 leaf paths, and a solve is as slow as the
+// longest subtree its scan needs - which set the pace of the whole lock-step batch (profiles/r5: the slowest game listed for 1492
+// rounds of the pool, 3.7 per solve, whatever the number of lanes).  So a level-3 node with >= RAZ_SOLVER_SPLIT_EMPTIES empties is
+// split once more: its moves are the tasks (a FOURTH ply), folded by k_solve_scan with the same scan; smaller ones are one task.
+#define RAZ_SOLVER_SPLIT_EMPTIES 7
+#define RAZ_SOLVER_MAX_SUB (RAZ_SOLVER_MAX_TASKS * (RAZ_SOLVER_MAX_DEPTH - 3))   // 24024
+struct SolverDeep {   // HBM only (behind the SolverTree in the game's block)
+    unsigned long long h_own[RAZ_SOLVER_MAX_TASKS], h_enemy[RAZ_SOLVER_MAX_TASKS], h_moves[RAZ_SOLVER_MAX_TASKS];   // level-3 node t (its mover's view), its moves
+    unsigned short sub_first[RAZ_SOLVER_MAX_TASKS + 4];   // node t's first task
+    unsigned char h_kind[RAZ_SOLVER_MAX_TASKS];           // node t: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo; +8: not split - ONE task, the node itself)
+    signed char sub_result[RAZ_SOLVER_MAX_SUB];           // task u: the value of that move for node t's mover (an unsplit node: f of the node)
+    unsigned short sub_task[RAZ_SOLVER_MAX_SUB];          // task u's level-3 node
+};
+static_assert(sizeof(SolverDeep) <= RAZ_SOLVER_DEEP_BYTES, "SolverDeep must fit the game's solver block");
 static_assert(sizeof(SolverTree) <= RAZ_SOLVER_TREE_BYTES, "SolverTree must fit the game's solver block");
 static_assert(sizeof(SolverTree) % 8 == 0, "SolverTree is copied in 8-byte words");
 
 __device__ __forceinline__ SolverTree* solve_tree(const raz_engine_dev& E, uint32_t g) {
     return (SolverTree*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES + sizeof(raz_solve_hdr));
+}
+__device__ __forceinline__ SolverDeep* solve_deep(const raz_engine_dev& E, uint32_t g) {
+    return (SolverDeep*)(E.solver_ws + (size_t)g * RAZ_SOLVER_WS_BYTES + sizeof(raz_solve_hdr) + RAZ_SOLVER_TREE_BYTES);
 }
 
 // the reference's loop over a node's moves, on values that are already there: `vals` in ascending move order, RAZ_SOLVER_UNKNOWN =
@@ -104,9 +122,10 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     __shared__ SolverTree tree_lds;
     SolverTree* P = &tree_lds;
     SolverTree* T = solve_tree(E, g);
+    SolverDeep* D = solve_deep(E, g);
     const raz_bb own0 = uni((raz_bb)h->own0), enemy0 = uni((raz_bb)h->enemy0);
     const uint32_t exact = uni(h->exact);
-    int k = 0, n2 = 0, total = 0;
+    int k = 0, n2 = 0, total = 0, subs = 0;   // root moves, level-2 nodes, level-3 nodes, tasks
     if (st == RAZ_SOLVE_REQUESTED) {
         const raz_bb legal0 = bb_legal_moves(own0, enemy0);
         k = bb_popcount(legal0);
@@ -197,11 +216,88 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         for (int t = lane; t < total; t += 64) P->result[t] = (signed char)RAZ_SOLVER_UNKNOWN;
         for (int n = lane; n < n2; n += 64)
             for (int t = P->g_first[n]; t < (int)P->g_first[n + 1]; ++t) P->task_entry[t] = (unsigned short)(n | ((int)P->g_child[n] << 8));
+        wave_sync_lanes();
+        // ---- ply 3: level-3 node t = the position after level-2 node n's j-th move (lane l takes a contiguous run of them, so that
+        // the tasks' numbering follows the scan order).  The game may end there, the memo may know it; else it is one task, or - with
+        // >= RAZ_SOLVER_SPLIT_EMPTIES empties - as many as it has moves
+        {
+            const int per = (total + 63) / 64;
+            const int t0 = lane * per < total ? lane * per : total, t1 = t0 + per < total ? t0 + per : total;
+            int mine = 0;
+            for (int t = t0; t < t1; ++t) {
+                const int n = P->task_entry[t] & 0xff;
+                raz_bb m = P->g_moves[n];
+                for (int j = (int)P->g_first[n]; j < t; ++j) m &= m - 1;
+                raz_bb no, ne, nm;
+                int v, cnt = 0;
+                int kind = solver_play(__ffsll((long long)m) - 1, P->g_own[n], P->g_enemy[n], no, ne, nm, v);
+                if (!kind)
+                    P->result[t] = (signed char)v;
+                else {
+                    int rm, rs;
+                    const int emp = bb_popcount(~(no | ne));
+                    if (emp >= 4 && memo_find_lane(E, g, no, ne, exact, rm, rs)) {
+                        kind |= 4;
+                        P->result[t] = (signed char)((kind & 1) ? -rs : rs);
+                    } else if (emp >= RAZ_SOLVER_SPLIT_EMPTIES)
+                        cnt = bb_popcount(nm);
+                    else {
+                        kind |= 8;
+                        cnt = 1;
+                    }
+                }
+                D->h_own[t] = no;
+                D->h_enemy[t] = ne;
+                D->h_moves[t] = nm;
+                D->h_kind[t] = (unsigned char)kind;
+                D->sub_first[t] = (unsigned short)cnt;   // (a count for now)
+                mine += cnt;
+            }
+            int before = 0;
+            for (int i = 0; i < 64; ++i) {
+                const int x = (int)lane_u32((uint32_t)mine, i);
+                if (i < lane) before += x;
+                subs += x;
+            }
+            for (int t = t0; t < t1; ++t) {
+                const int c = D->sub_first[t];
+                D->sub_first[t] = (unsigned short)before;
+                for (int u = before; u < before + c; ++u) {
+                    D->sub_task[u] = (unsigned short)t;
+                    D->sub_result[u] = (signed char)RAZ_SOLVER_UNKNOWN;
+                }
+                before += c;
+            }
+            if (lane == 0) D->sub_first[total] = (unsigned short)subs;
+        }
     } else {
-        k = (int)uni(h->k);
-        n2 = (int)uni(h->n2);
-        total = (int)uni(h->total);
+        k = (int)(uni(h->k_n2) & 0xffu);
+        n2 = (int)(uni(h->k_n2) >> 8);
+        total = (int)uni(h->tasks);
+        subs = (int)uni(h->total);
         for (int i = lane; i < (int)(sizeof(SolverTree) / 8); i += 64) ((unsigned long long*)P)[i] = ((const unsigned long long*)T)[i];
+        wave_sync_lanes();
+        // ---- level-3 nodes: the tasks' values fold into result[] (the reference's loop over the node's moves again)
+        for (int t = lane; t < total; t += 64) {
+            if (P->result[t] != RAZ_SOLVER_UNKNOWN) continue;
+            const int kind = D->h_kind[t], s0 = D->sub_first[t], s1 = D->sub_first[t + 1];
+            int bm = -1, bs = 0;
+            bool ok;
+            if (kind & 8) {   // (its one task searched the node itself and remembered it)
+                bs = D->sub_result[s0];
+                ok = bs != RAZ_SOLVER_UNKNOWN;
+            } else
+                ok = solver_scan(D->sub_result + s0, s1 - s0, D->h_moves[t], exact != 0, bm, bs);
+            if (ok) {
+                if (!(kind & 8)) {
+                    const raz_bb ho = D->h_own[t], he = D->h_enemy[t];
+                    if (bb_popcount(~(ho | he)) >= 4) memo_put_lane(E, g, ho, he, exact, bm, bs);
+                }
+                const signed char r = (signed char)((kind & 1) ? -bs : bs);
+                P->result[t] = r;
+                T->result[t] = r;   // (the workers look at it before they start or go on with a task of this node)
+            }
+        }
     }
     wave_sync_lanes();
     // ---- level-2 nodes: the reference's loop over the node's moves, on the results that are there.  A value is f of that position
@@ -269,9 +365,9 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         for (int i = lane; i < (int)(sizeof(SolverTree) / 8); i += 64) ((unsigned long long*)T)[i] = ((const unsigned long long*)P)[i];
         if (lane == 0) {
             h->rounds = 0u;
-            h->k = (uint32_t)k;
-            h->n2 = (uint32_t)n2;
-            h->total = (uint32_t)total;
+            h->k_n2 = (uint32_t)k | ((uint32_t)n2 << 8);
+            h->tasks = (uint32_t)total;
+            h->total = (uint32_t)subs;
             h->next = 0u;
             h->state = RAZ_SOLVE_RUNNING;
         }
@@ -281,7 +377,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     }
     if (collect) {
         const uint32_t next = st == RAZ_SOLVE_REQUESTED ? 0u : uni(h->next);
-        if (next < (uint32_t)total && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
+        if (next < (uint32_t)subs && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
         if (lane == 0) {
             h->rounds = (st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds) + 1u;
             h->rounds_total += 1u;
@@ -297,11 +393,14 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 // so ONE lane's probe (dependent HBM round trips into a 2 MB table) is paid by all of them; subtrees below that size are searched
 // outright (<= 720 leaf paths) - and even those probes are batched (the slow phase, below).
 #define RAZ_SOLVER_LANE_MEMO_EMPTIES 6
+#ifndef RAZ_SOLVER_PROBE_AT_DRAW
+#define RAZ_SOLVER_PROBE_AT_DRAW 0
+#endif
 #ifndef RAZ_SOLVER_SLOW_EVERY
 #define RAZ_SOLVER_SLOW_EVERY 8   // (a power of two)
 #endif
 #ifndef RAZ_SOLVER_POOL_BUDGET
-#define RAZ_SOLVER_POOL_BUDGET 384
+#define RAZ_SOLVER_POOL_BUDGET 128
 #endif
 #ifdef RAZ_WAVE_EMU
 #define RAZ_POOL_WAVES
@@ -312,7 +411,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     if (blockIdx.x >= wcount) return;
     const int lane = threadIdx.x;
     const uint32_t w = w0 + blockIdx.x;
-    unsigned long long* lw = E.pool_state + (size_t)w * 512;                  // lw[word * 64 + lane]
+    unsigned long long* lw = E.pool_state + (size_t)w * 1024;                  // lw[word * 64 + lane]
     // the lanes' frames live in LDS while the wave runs (a push or a pop is four conflict-free 8-byte accesses - word j of level d at
     // [(d * 4 + j) * 64 + lane] - instead of an HBM round trip in the middle of every node) and in E.pool_frames between launches
     __shared__ unsigned long long frames_lds[RAZ_SOLVER_MAX_DEPTH * 4 * 64];
@@ -330,13 +429,13 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     int d = (int)((m1 >> 8) & 0xffULL), bmv = (int)((m1 >> 16) & 0xffULL) - 1, bsc = (int)((m1 >> 24) & 0xffULL) - 128, pact = (int)((m1 >> 32) & 0xffULL) - 1;
     uint32_t g = (uint32_t)lw[4 * 64 + lane], gen = (uint32_t)(lw[4 * 64 + lane] >> 32);
     const unsigned long long m2 = lw[5 * 64 + lane];
-    int task = (int)(m2 & 0xffffULL), task_n = (int)((m2 >> 16) & 0xffULL), task_ci = (int)((m2 >> 24) & 0xffULL);
+    int task = (int)(m2 & 0xffffULL), task_n = (int)((m2 >> 16) & 0xffULL), task_ci = (int)((m2 >> 24) & 0xffULL), task_t = (int)((m2 >> 32) & 0xffffULL);
     if (have) {   // is the parked search still wanted?  Its request may have been answered (a decided scan) or replaced, its node decided
         const raz_solve_hdr* hh = solve_hdr(E, g);
         if (hh->gen != gen || hh->state != RAZ_SOLVE_RUNNING) have = false;
         else if (!exact) {
             const SolverTree* T = solve_tree(E, g);
-            if (T->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || T->g_v[task_n] != RAZ_SOLVER_UNKNOWN) have = false;
+            if (T->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || T->g_v[task_n] != RAZ_SOLVER_UNKNOWN || T->result[task_t] != RAZ_SOLVER_UNKNOWN) have = false;
         }
     }
     if (have)   // (a lane reads and writes its own column only: no barrier)
@@ -399,19 +498,32 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     if (t < total) {
                         got = true;
                         SolverTree* T = solve_tree(E, gg);
-                        const int te = T->task_entry[t], n = te & 0xff, ci = te >> 8;
+                        SolverDeep* D = solve_deep(E, gg);
+                        const int nt = D->sub_task[t];   // the task's level-3 node
+                        const int te = T->task_entry[nt], n = te & 0xff, ci = te >> 8, hk = D->h_kind[nt], s0 = D->sub_first[nt];
+                        const raz_bb ho = D->h_own[nt], he = D->h_enemy[nt], hm = D->h_moves[nt];
                         // (a task that has its result: dispatch restarted after the pool was re-partitioned; a node that is decided: moot)
-                        if (T->result[t] == RAZ_SOLVER_UNKNOWN && (ex || (T->c_v[ci] == RAZ_SOLVER_UNKNOWN && T->g_v[n] == RAZ_SOLVER_UNKNOWN))) {
-                            raz_bb m = T->g_moves[n];
-                            for (int j = (int)T->g_first[n]; j < (int)t; ++j) m &= m - 1;
-                            raz_bb no, ne, nm;
-                            int v;
-                            const int kind = solver_play(__ffsll((long long)m) - 1, T->g_own[n], T->g_enemy[n], no, ne, nm, v);
-                            if (kind) {
+                        if (D->sub_result[t] == RAZ_SOLVER_UNKNOWN && T->result[nt] == RAZ_SOLVER_UNKNOWN &&
+                            (ex || (T->c_v[ci] == RAZ_SOLVER_UNKNOWN && T->g_v[n] == RAZ_SOLVER_UNKNOWN))) {
+                            raz_bb no = ho, ne = he, nm = hm;
+                            int v = 0, kind = 2;   // an unsplit node: the search starts at the node itself (same mover: sign +)
+                            if (!(hk & 8)) {
+                                raz_bb m = hm;
+                                for (int j = s0; j < (int)t; ++j) m &= m - 1;
+                                kind = solver_play(__ffsll((long long)m) - 1, ho, he, no, ne, nm, v);
+                            }
+                            int pm = 0, ps = 0;
+                            if (RAZ_SOLVER_PROBE_AT_DRAW && kind && bb_popcount(~(no | ne)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES && memo_find_lane(E, gg, no, ne, ex, pm, ps)) {
+                                // the memo knows the subtree's root (a transposition another lane searched): the probe a search starts with,
+                                // made here, where the wave is waiting on memory anyway
+                                D->sub_result[t] = (signed char)((kind == 1 ? -1 : 1) * ps);
+                                ++st_done;
+                            } else if (kind) {
                                 g = gg;
                                 gen = hgen;
                                 exact = ex;
                                 task = (int)t;
+                                task_t = nt;
                                 task_n = n;
                                 task_ci = ci;
                                 task_sign = kind == 1 ? -1 : 1;
@@ -423,11 +535,11 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                                 bsc = -100;
                                 pact = -1;
                                 flip = 0;
-                                fresh = 1;
+                                fresh = RAZ_SOLVER_PROBE_AT_DRAW ? 0 : 1;   // (its root was looked up in the memo just now)
                                 wait_find = false;
                                 have = true;
                             } else {
-                                T->result[t] = (signed char)v;
+                                D->sub_result[t] = (signed char)v;
                                 ++st_done;
                             }
                         } else
@@ -503,7 +615,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 }
                 if (!done) break;
                 if (d == 0) {
-                    solve_tree(E, g)->result[task] = (signed char)(task_sign * rs);
+                    solve_deep(E, g)->sub_result[task] = (signed char)(task_sign * rs);
                     have = false;
                     ++st_done;
                     break;
@@ -575,7 +687,8 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                         ((unsigned long long)(exact & 1u) << 4) | ((wait_find ? 1ULL : 0ULL) << 5) | ((unsigned long long)(d & 0xff) << 8) | ((unsigned long long)((bmv + 1) & 0xff) << 16) |
                         ((unsigned long long)((bsc + 128) & 0xff) << 24) | ((unsigned long long)((pact + 1) & 0xff) << 32);
     lw[4 * 64 + lane] = (unsigned long long)g | ((unsigned long long)gen << 32);
-    lw[5 * 64 + lane] = (unsigned long long)(task & 0xffff) | ((unsigned long long)(task_n & 0xff) << 16) | ((unsigned long long)(task_ci & 0xff) << 24);
+    lw[5 * 64 + lane] = (unsigned long long)(task & 0xffff) | ((unsigned long long)(task_n & 0xff) << 16) | ((unsigned long long)(task_ci & 0xff) << 24) |
+                        ((unsigned long long)(task_t & 0xffff) << 32);
 }
 
 // per-game totals for raz_engine_solver_stats: counters[28] solves of all games, [29] most solves of one game, [30] rounds all games'
@@ -605,7 +718,10 @@ __global__ __launch_bounds__(256) void k_solver_game_stats(raz_engine_dev E) {
 // result are skipped at the draw).  One thread per worker lane / per game.
 __global__ __launch_bounds__(256) void k_solve_pool_reset(raz_engine_dev E) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < (size_t)E.W * 64) E.pool_state[(i / 64) * 512 + 3 * 64 + (i % 64)] = 0ULL;
+    if (i < (size_t)E.W * 64) {
+        E.pool_state[(i / 64) * 1024 + 3 * 64 + (i % 64)] = 0ULL;
+        E.pool_state[(i / 64) * 1024 + 9 * 64 + (i % 64)] = 0ULL;
+    }
     if (i < E.B) {
         raz_solve_hdr* h = solve_hdr(E, (uint32_t)i);
         if (h->state == RAZ_SOLVE_RUNNING) {

@@ -102,8 +102,8 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
     that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par).
-    solver_budget: iterations a worker lane of the end-game solver's pool runs between two tree launches (rounded up to 64; 0 = 384);
-    solver_pool_waves: worker wavefronts of that pool (0 = one per two games, at most 2048).  Neither changes a result."""
+    solver_budget: iterations a worker lane of the end-game solver's pool runs between two tree launches (rounded up to 64; 0 = 128);
+    solver_pool_waves: worker wavefronts of that pool (0 = one per four games, at most 1280).  Neither changes a result."""
     p = config.play
     par = int(getattr(p, "parallel_search_num", 1) or 1)
     if not 1 <= par <= 16:

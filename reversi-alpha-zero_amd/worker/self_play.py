@@ -491,6 +491,7 @@ class BatchedSelfPlayWorker:
                             f.write(b", ")
                         f.write(t)
                     f.write(b"]")
+                    self.bytes_written = getattr(self, "bytes_written", 0) + f.tell()
                 self.buffer_json = []
                 paths.append(path)
                 if known_files is None:
@@ -675,8 +676,9 @@ class BatchedSelfPlayWorker:
         dist.broadcast(t, src=0)
         return blob if self.rank == 0 else t.cpu().numpy().tobytes()
 
-    def run(self, total_games=None, reload_model=None, background_emit=True):
-        """_start (self_play.py:95-137): play batches until total_games (None = forever).
+    def run(self, total_games=None, reload_model=None, background_emit=True, until=None):
+        """_start (self_play.py:95-137): play batches until total_games (None = forever) - or, with `until` (a time.monotonic()
+        deadline; rank 0's clock decides for all ranks), until the block during which the deadline passes has been written.
         Per batch: every rank plays its id range; the finished games' records are packed in HBM and gathered on
         rank 0 (the path's single collective), which does the resignation bookkeeping, broadcasts what every rank needs
         for the next batch - the game index and the resign threshold (so that all ranks keep playing under the same
@@ -698,6 +700,13 @@ class BatchedSelfPlayWorker:
         writer = _BackgroundWriter(self) if (background_emit and self.rank == 0) else None
         try:
             while total_games is None or local_idx <= total_games:
+                if until is not None:
+                    import time as _time
+                    stop = [_time.monotonic() >= until]
+                    if self._group():
+                        dist.broadcast_object_list(stop, src=0)
+                    if stop[0]:
+                        break
                 packed, per_rank, state = self._play_block_checked(game_idx)
                 while self._all_ranks_state(state) == self.BLOCK_RANGE:
                     if self._f32_fallback or self._series_length() > 1:
@@ -739,7 +748,10 @@ class BatchedSelfPlayWorker:
                         self.set_net_blob(blob)
         finally:
             if writer is not None:
-                writer.close()
+                try:
+                    writer.close()
+                finally:
+                    self.last_writer_busy_seconds, self.last_writer_batches = writer.busy_seconds, writer.batches
 
     def _write_game_idx(self, game_idx):
         with open(self.config.resource.self_play_game_idx_file, "wt") as f:
@@ -766,6 +778,8 @@ class _BackgroundWriter:
         import queue
         import threading
         self.worker, self.error = worker, None
+        self.busy_seconds = 0.0        # time the thread spent writing batches (bench: the writer's share of the run)
+        self.batches = 0
         self.failed = False            # written by the writer thread only, never cleared
         self._reported = False         # the caller has been handed the exception
         self._lock = threading.Lock()  # guards `error` (handed from the thread to the caller exactly once)
@@ -782,8 +796,12 @@ class _BackgroundWriter:
                 continue   # keep draining so that submit() never blocks forever
             raw, local_idx, game_idx = item
             try:
+                import time as _time
+                t0 = _time.monotonic()
                 self.worker.write_raw(raw, local_idx)
                 self.worker._write_game_idx(game_idx)
+                self.busy_seconds += _time.monotonic() - t0
+                self.batches += 1
             except BaseException as e:   # noqa: B902 - reported to the caller
                 with self._lock:
                     self.error = e

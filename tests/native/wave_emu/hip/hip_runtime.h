@@ -81,6 +81,8 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = (hipStream_t)(uintptr_t)1; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)(uintptr_t)1; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = (hipEvent_t)(uintptr_t)1; return hipSuccess; }

@@ -46,18 +46,33 @@ def test_pmc_summary_needs_both_traffic_passes(tmp_path):
     assert _run(tmp_path / "ragged", tmp_path / "out_ragged" / "s").returncode == 2
 
 
-def test_bench_reports_no_traffic_without_both_passes(tmp_path, monkeypatch):
-    """bench.conv_traffic: a committed summary that lacks a pass yields None, never a partial sum."""
+def test_bench_reports_no_traffic_without_both_passes_or_from_other_sources(tmp_path, monkeypatch):
+    """bench.conv_traffic: a committed summary that lacks a pass yields None, never a partial sum - and so does one that was measured
+    on other kernel sources than the ones this run is built from (the file records their sha256; VERDICT r4 next #6)."""
     sys.path.insert(0, ROOT)
     import bench
-    d = tmp_path / "profiles" / "r4_pmc"
+    d = tmp_path / "profiles" / bench.PMC_DIR
     d.mkdir(parents=True)
+    csrc = tmp_path / "reversi-alpha-zero_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (csrc / "k.hip").write_text("kernel v1")
+    (tmp_path / "include" / "raz.h").write_text("abi")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.conv_traffic() == (None, None)
-    json.dump({"net_forward_hbm_bytes_per_launch": 1.0, "fetch_pass_present": False, "write_pass_present": True}, open(d / "headline_config3_traffic.json", "w"))
-    assert bench.conv_traffic() == (None, None)
+    v, why = bench.conv_traffic()
+    assert v is None and "no counter pass" in why
+    sha = bench.kernel_sources_sha256()
+    prov = {"kernel_sources_sha256": sha, "measured_utc": "2026-09-25 20:00:00"}
+    json.dump({"net_forward_hbm_bytes_per_launch": 1.0, "fetch_pass_present": False, "write_pass_present": True, "provenance": prov}, open(d / "headline_config3_traffic.json", "w"))
+    assert bench.conv_traffic()[0] is None
+    json.dump({"net_forward_hbm_bytes_per_launch": 2.5e10, "fetch_pass_present": True, "write_pass_present": True, "provenance": prov}, open(d / "headline_config3_traffic.json", "w"))
+    v, src = bench.conv_traffic()
+    assert v == 2.5e10 and "2026-09-25 20:00:00" in src and sha[:12] in src
+    (csrc / "k.hip").write_text("kernel v2")   # the kernels changed after the counter pass: the figure is withheld, and the line says why
+    v, why = bench.conv_traffic()
+    assert v is None and "OTHER kernel sources" in why
     json.dump({"net_forward_hbm_bytes_per_launch": 2.5e10, "fetch_pass_present": True, "write_pass_present": True}, open(d / "headline_config3_traffic.json", "w"))
-    assert bench.conv_traffic()[0] == 2.5e10
+    assert bench.conv_traffic()[0] is None   # no provenance at all (a file of an earlier round)
 
 
 def test_pmc_summary_tells_the_fused_kernels_from_the_classic_ones():

@@ -19,6 +19,19 @@ import sys
 SHORT = ["k_tree_par_net", "k_tree_net", "k_tree_par", "k_tree", "k_net_mfma", "k_conv3x3_wide", "k_heads_wide", "k_conv0_wide", "k_conv3x3_f16x3", "k_conv0_split",
          "k_heads_split", "k_stats", "k_start", "k_gc", "k_step", "k_legal_moves", "k_leaf_claim", "k_leaf_resolve", "k_leaf_fill"]
 TRAFFIC = ("FETCH_SIZE", "WRITE_SIZE")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def provenance():
+    """What the traffic files say about the build they were measured on: sha256 over the kernel sources (bench.py recomputes it and
+    drops a figure whose sources have changed since) and the time of the pass."""
+    import hashlib
+    import time
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_sha256
+    return {"kernel_sources_sha256": kernel_sources_sha256(), "measured_utc": time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime()),
+            "measured_by": "tools/pmc_summary.py on the GPU box, from the rocprofv3 --pmc passes of tools/run_profiles.sh"}
+
 
 
 def short(name):
@@ -83,12 +96,13 @@ def main():
     traffic = {k: {"fetch_bytes_raw": v["FETCH_SIZE"] * 1024.0, "write_bytes": v["WRITE_SIZE"] * 1024.0,
                    # FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 B on gfx950 (MI355X_MICROARCH.md): doubled
                    "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
-                   "hbm_bytes_per_launch_uncorrected": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "dispatches_averaged": v["dispatches"] if not a.last else min(a.last, v["dispatches"])}
+                   "hbm_bytes_per_launch_uncorrected": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "dispatches_averaged": v["dispatches"] if not a.last else min(a.last, v["dispatches"]),
+                   "grid_threads": int(v["grid"]) if str(v.get("grid", "")).isdigit() else None}
                for k, v in res.items() if "@" not in k and all(t in v for t in TRAFFIC)}
     with open(a.out + "_traffic.json", "w") as f:
         json.dump({"source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/run_profiles.sh), KiB -> bytes, average per dispatch; "
                              "hbm_bytes_per_launch = 2 x FETCH + WRITE (FETCH_SIZE under-reports wide coalesced reads by 2 on gfx950, MI355X_MICROARCH.md)",
-                   "fetch_pass_present": True, "write_pass_present": True, "kernels": traffic}, f, indent=1, sort_keys=True)
+                   "fetch_pass_present": True, "write_pass_present": True, "kernels": traffic, "provenance": provenance()}, f, indent=1, sort_keys=True)
     # one net forward of the wide nets = conv0 + 2R conv launches + heads: HBM bytes per forward for bench.py's roofline.traffic
     for conv, c0, hd in (("k_conv3x3_f16x3", "k_conv0_split", "k_heads_split"), ("k_conv3x3_wide", "k_conv0_wide", "k_heads_wide")):
         if conv in traffic and c0 in traffic and hd in traffic and res[c0]["dispatches"]:
@@ -96,7 +110,7 @@ def main():
             with open(a.out + "_config3_traffic.json", "w") as f:
                 json.dump({"source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the headline bench command (tools/run_profiles.sh); FETCH doubled "
                                      "(MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads on gfx950)",
-                           "fetch_pass_present": True, "write_pass_present": True,
+                           "fetch_pass_present": True, "write_pass_present": True, "provenance": provenance(),
                            "conv_kernel": conv, "conv_launches_per_forward": per_fwd,
                            "conv_fetch_bytes_per_launch_raw": traffic[conv]["fetch_bytes_raw"], "conv_write_bytes_per_launch": traffic[conv]["write_bytes"],
                            "net_forward_hbm_bytes_per_launch": traffic[c0]["hbm_bytes_per_launch"] + per_fwd * traffic[conv]["hbm_bytes_per_launch"]
