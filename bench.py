@@ -623,6 +623,27 @@ def steady_window_leg(args, dev, blob, cfg, weights, slots=8192, seconds=120.0, 
     outbox = eng.new_outbox(0, slots + spare)
     eng.step(args.tree_warm)
     nxt, done, steps, cap, gc_runs = slots, 0, 0, int(eng.cfg.nodes_per_game), 0
+    # the worker's file emission INSIDE the window (worker/self_play.py:139-217 writes play_*.json inside the timed game): every game the
+    # harvest finds finished goes - records packed in HBM, copied out, resignation bookkeeping - to BatchedSelfPlayWorker's background
+    # writer (native row emitter on host threads, files on tmpfs), while the slots play on
+    import shutil
+    import tempfile
+    from reversi_alpha_zero_amd.config import Config
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker, _BackgroundWriter
+    wroot = tempfile.mkdtemp(prefix="raz_window_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    wcfg = Config()
+    for k_, v_ in vars(cfg.play).items():
+        setattr(wcfg.play, k_, v_)
+    wcfg.play_data.update(dict(nb_game_in_file=8, enable_ggf_data=False, max_file_num=100000, drop_draw_game_rate=0.0,
+                               save_policy_of_tau_1=bool(cfg.play_data.save_policy_of_tau_1)))
+    wrc = wcfg.resource
+    wrc.data_dir, wrc.play_data_dir, wrc.self_play_ggf_data_dir = wroot, os.path.join(wroot, "play"), os.path.join(wroot, "ggf")
+    wrc.self_play_game_idx_file = os.path.join(wroot, ".self-play-game-idx")
+    os.makedirs(wrc.play_data_dir, exist_ok=True)
+    ww = BatchedSelfPlayWorker(wcfg, blob, games_in_flight=slots, seed=0, device=str(dev))
+    bw = _BackgroundWriter(ww)
+    emitted = torch.zeros(slots + spare, dtype=torch.bool, device=dev)
+    written, local_idx = 0, 1
     st0 = eng.stats()
     c0 = eng.leaf_cache_stats()
     torch.cuda.synchronize()
@@ -638,8 +659,31 @@ def steady_window_leg(args, dev, blob, cfg, weights, slots=8192, seconds=120.0, 
         h, r, skipped, playing = eng.harvest(outbox, nxt, [args.sims] * k)
         nxt += r
         done += h
+        if h:
+            new = torch.nonzero(outbox["done"].bool() & ~emitted).flatten()
+            if len(new):
+                emitted[new] = True
+                fresh = raw_from_packed(*(outbox[k2][new].cpu().numpy() for k2 in ("headers", "root_n", "summary")))
+                ww.bookkeep_raw(fresh)
+                bw.submit(fresh, local_idx, written + len(new))
+                local_idx += len(new)
+                written += len(new)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    bw.close()
+    dt_drained = time.perf_counter() - t0
+    files = sorted(os.listdir(wrc.play_data_dir))
+    emission = {"what": "every game that finished inside the window was written as play_*.json by the worker's background writer (native row emitter, files of 8 games "
+                        "on tmpfs) while the window ran; games/hour including emission = games / (window + the writer's drain after it)",
+                "games_written": written, "files": len(files), "bytes_written": int(getattr(ww, "bytes_written", 0)),
+                "writer_busy_seconds": bw.busy_seconds, "writer_busy_share_of_the_window": bw.busy_seconds / dt,
+                "drain_after_the_window_seconds": dt_drained - dt, "games_per_hour_including_emission": written / dt_drained * 3600.0}
+    if files:   # the last file holds rows: 8 symmetric rows per recorded ply, [[own, enemy], policy x 64, z]
+        rows = json.load(open(os.path.join(wrc.play_data_dir, files[-1])))
+        emission["last_file_rows"] = len(rows)
+        if not rows or len(rows) % 8 or len(rows[0]) != 3 or len(rows[0][1]) != 64:
+            raise AssertionError("steady window: the worker's play_*.json does not have the reference's row format")
+    shutil.rmtree(wroot, ignore_errors=True)
     st = eng.stats()
     c1 = eng.leaf_cache_stats()
     sims, leaves = st["total_sims"] - st0["total_sims"], st["nn_leaves"] - st0["nn_leaves"]
@@ -666,6 +710,7 @@ def steady_window_leg(args, dev, blob, cfg, weights, slots=8192, seconds=120.0, 
            "leaf_slot_occupancy": leaves / max(1, steps * slots), "games_finished_in_the_window": int(done), "slots_restarted_from_the_opening": int(nxt - slots),
            "games_per_hour": done / dt * 3600.0,
            "games_per_hour_note": "games whose last move fell inside the window / window length: in the steady state that is the completion rate of whole games",
+           "emission": emission,
            "gc_runs": gc_runs, "range_ok": net.range_ok(),
            "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table": int(served),
                            "share_of_leaf_requests": served / max(1, leaves)} if cache_log2 else None),
@@ -1208,8 +1253,12 @@ def compact_line(full):
                                                      "sims_per_net_evaluation", "ms_per_step")),
                                             slots=full.get("config", {}).get("games_per_gpu"), parity=parity(w.get("parity_check_complete_games")))
         line["whole_games_measured"]["sims_per_s"] = w.get("value")
+        if isinstance(w.get("emission"), dict):   # the worker's files written inside the window
+            line["whole_games_measured"]["emission"] = pick(w["emission"], ("games_written", "bytes_written", "writer_busy_share_of_the_window",
+                                                                             "games_per_hour_including_emission", "drain_after_the_window_seconds"))
     for key in ("headline_on_exact_f32_kernels", "ch5_yml_as_shipped", "config5_8192x3200_agz", "config1_4096x200_mini", "config1_mini_yml_parallel_search_num_4", "config1_mini_yml_as_shipped", "config1_mini_yml_as_shipped_two_kernel_pipeline",
-                "config1_two_kernel_pipeline", "config1_two_kernel_pipeline_parallel_search_num_4", "config1_continuous_batching"):
+                "config1_two_kernel_pipeline", "config1_two_kernel_pipeline_parallel_search_num_4", "config1_continuous_batching",
+                "config1_mini_yml_as_shipped_continuous_batching"):
         d = full.get(key)
         if isinstance(d, dict):
             e = pick(d, ("value", "unit", "games_per_hour", "ms_per_step", "error", "fused_tree_net_kernel"))
@@ -1226,7 +1275,15 @@ def compact_line(full):
                     e["played_on_steps"], e["played_on_sims_per_s"] = po.get("steps"), po.get("sims_per_s")
             if "parity_check_complete_games" in d:
                 e["parity"] = parity(d["parity_check_complete_games"])
+            if isinstance(d.get("solver_pool"), dict):
+                e["solver_pool"] = pick(d["solver_pool"], ("solves", "pool_rounds_per_answer", "lane_utilisation", "most_rounds_listed_of_one_game", "worker_waves"))
             line[key] = e
+    d = full.get("worker_end_to_end_config1")
+    if isinstance(d, dict):
+        line["worker_end_to_end_config1"] = pick(d, ("games_written", "seconds", "games_per_hour_including_emission", "sims_per_s_including_emission", "bytes_written",
+                                                     "writer_busy_share_of_the_run", "gather_backend", "error"))
+        if "parity_check_files" in d:
+            line["worker_end_to_end_config1"]["parity"] = parity(d["parity_check_files"])
     sw = full.get("bitboard_sweep")
     if isinstance(sw, dict) and "k_step" in sw:
         line["bitboard_sweep"] = {k: pick(sw[k], ("achieved", "peak", "unit", "frac", "traffic_over_algorithmic")) for k in ("k_step", "k_legal_moves")}

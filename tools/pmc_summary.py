@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-SHORT = ["k_tree_par_net", "k_tree_net", "k_tree_par", "k_tree", "k_net_mfma", "k_conv3x3_wide", "k_heads_wide", "k_conv0_wide", "k_conv3x3_f16x3", "k_conv0_split",
+SHORT = ["k_solve_run", "k_solve_scan", "k_tree_par_net", "k_tree_net", "k_tree_par", "k_tree", "k_net_mfma", "k_conv3x3_wide", "k_heads_wide", "k_conv0_wide", "k_conv3x3_f16x3", "k_conv0_split",
          "k_heads_split", "k_stats", "k_start", "k_gc", "k_step", "k_legal_moves", "k_leaf_claim", "k_leaf_resolve", "k_leaf_fill"]
 TRAFFIC = ("FETCH_SIZE", "WRITE_SIZE")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -82,7 +82,7 @@ def main():
     with open(a.out + "_pmc_per_dispatch.json", "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print(json.dumps({k: {c: (round(v, 1) if isinstance(v, float) else v) for c, v in res[k].items()}
-                      for k in ("k_tree", "k_tree_par", "k_tree_net", "k_tree_par_net", "k_net_mfma", "k_conv3x3_f16x3", "k_conv3x3_wide", "k_step", "k_legal_moves") if k in res}, indent=1))
+                      for k in ("k_solve_run", "k_tree", "k_tree_par", "k_tree_net", "k_tree_par_net", "k_net_mfma", "k_conv3x3_f16x3", "k_conv3x3_wide", "k_step", "k_legal_moves") if k in res}, indent=1))
 
     have = [c for c in TRAFFIC if c in passes]
     if not have:
