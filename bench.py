@@ -507,8 +507,9 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
         "mean_selections_per_sim": selections / max(total_sims, 1.0),
         "roofline": {"bound": "mfma", "kernel_name": ("k_conv3x3_f16x3" if v2 else "k_conv3x3_wide") if args.net == "ch5" else "k_net_mfma",
                      "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
-                     "power_limited": ("the conv kernel runs 1.27-1.34x faster on zero operands (same instruction stream; 1.88 GHz under random operands by "
-                                       "GRBM_GUI_ACTIVE, 77 % matrix-pipe busy): profiles/r4/conv_f16x3_probe_session1.jsonl, profiles/r4_pmc/") if v2 else None,
+                     "power_limited": ("socket power telemetry of this kernel (amdsmi at 10 Hz, profiles/r5/conv_f16x3_power_telemetry_*.jsonl): 1380 W of a 1400 W cap "
+                                       "with the PPT violation active in every sample and the gfx clock at 2.00 GHz on random operands; 1004 W and 2.40 GHz on zero "
+                                       "operands (same instruction stream, 1.26x faster); 77 % matrix-pipe busy (profiles/r4_pmc/)") if v2 else None,
                      "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                      # activations are 4 B per element in both kernel families: per conv layer one read + one write of
@@ -1033,6 +1034,12 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     root = tempfile.mkdtemp(prefix="raz_e2e_", dir=base)
     own_group = not dist.is_initialized()
+    # RCCL prints a version banner on the C library's stdout when a communicator is created; this program's stdout carries ONE JSON line,
+    # so file descriptor 1 points at stderr while the leg runs (and the C buffers are flushed before it is put back)
+    import ctypes
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -1078,6 +1085,9 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
                "sims_per_s_including_emission": games * st["total_sims"] / max(1, st["finished_games"]) / dt,
                "bytes_written": int(getattr(w, "bytes_written", 0)), "gb_per_s_of_json_text": getattr(w, "bytes_written", 0) / dt / 1e9,
                "writer_busy_share_of_the_run": w.last_writer_busy_seconds / dt, "blocks": w.last_writer_batches,
+               "main_thread_seconds": dict(getattr(w, "run_seconds", {}) or {}),
+               "engine_level_of_the_last_block": {"sims_per_s": st["total_sims"] / max(1e-9, sum(st["seconds"].values())) if isinstance(st.get("seconds"), dict) else None,
+                                                  "games_per_hour": st["finished_games"] / max(1e-9, sum(st["seconds"].values())) * 3600.0 if isinstance(st.get("seconds"), dict) else None},
                "gather_backend": getattr(w, "last_gather_backend", None), "gather_bytes_last_block": getattr(w, "last_gather_bytes", None),
                "host_threads": os.cpu_count()}
         # two games of the first file against the oracle's rows for the same ids
@@ -1099,6 +1109,12 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
         if own_group:
             dist.destroy_process_group()
         shutil.rmtree(root, ignore_errors=True)
+        try:
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
 
 def continuous_leg(dev, args, rounds=3, shipped=False):
@@ -1281,7 +1297,7 @@ def compact_line(full):
     d = full.get("worker_end_to_end_config1")
     if isinstance(d, dict):
         line["worker_end_to_end_config1"] = pick(d, ("games_written", "seconds", "games_per_hour_including_emission", "sims_per_s_including_emission", "bytes_written",
-                                                     "writer_busy_share_of_the_run", "gather_backend", "error"))
+                                                     "writer_busy_share_of_the_run", "gather_backend", "main_thread_seconds", "engine_level_of_the_last_block", "error"))
         if "parity_check_files" in d:
             line["worker_end_to_end_config1"]["parity"] = parity(d["parity_check_files"])
     sw = full.get("bitboard_sweep")

@@ -337,11 +337,16 @@ int raz_engine_set_leaf_cache(raz_engine* e, void* d_cache, size_t bytes, uint32
                               raz_stream_t stream);
 int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_stream_t stream);
 /* Statistics of the end-game solver's pool since raz_engine_start (csrc/raz_solver_pool.h; no reference counterpart - the reference
- * solves one position at a time, lib/alt/reversi_solver_cython.pyx:40-61).  out15: [0..2] clock ticks the worker waves spent in their slow phases / folding finished nodes / in all, then [3] solves whose task tree was built, [1] answers
- * published, [2] rounds of the pool those solves were listed in before their answer, [3] lane-iterations in which a worker lane
- * searched a subtree, [4] wave-iterations executed (x 64 = lane slots), [5] subtrees finished, [6] subtrees drawn but not searched
- * (their node was decided already), [7] worker-wave launches that found work, [8] requests posted by all game slots, [9] most by
- * one slot, [10] rounds all slots' solves were listed in, [11] most of one slot (the batch's critical path in rounds of the pool).
+ * solves one position at a time, lib/alt/reversi_solver_cython.pyx:40-61).  out15:
+ *   [0] [1] [2] shader-clock ticks the worker waves spent in their slow phases (memo traffic + task draws) / folding finished nodes into
+ *               their parents / in their loops altogether
+ *   [3] solves whose task tree was built            [4] answers published
+ *   [5] rounds of the pool those solves were listed in before their answer
+ *   [6] lane-iterations in which a worker lane searched a subtree      [7] wave-iterations executed (x 64 = lane slots)
+ *   [8] subtrees finished      [9] subtrees drawn but not searched (their node was decided already)
+ *   [10] worker-wave launches that found work
+ *   [11] requests posted by all game slots, [12] most by one slot
+ *   [13] rounds all slots' solves were listed in, [14] most of one slot (the batch's critical path in rounds of the pool).
  * Synchronises `stream`. */
 int raz_engine_solver_stats(raz_engine* e, uint64_t* out15, raz_stream_t stream);
 /* Diagnostics (no reference counterpart): `bytes` at `offset` of one of the engine's device arrays (raz_engine_device_ptr's numbering:

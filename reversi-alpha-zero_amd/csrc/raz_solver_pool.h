@@ -389,15 +389,18 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 // ------------------------------------------------------------------ k_solve_run
 // Worker wave w of the pool: lane state in E.pool_state[w][word][lane] - 0 own, 1 enemy, 2 moves left, 3 the search's small fields,
 // 4 game slot | request generation << 32, 5 task | level-2 node << 16 | child << 24 - and frames in E.pool_frames[w][level][lane].
-// The lanes consult the memo only at nodes with at least RAZ_SOLVER_LANE_MEMO_EMPTIES empties: the 64 searches advance in lockstep,
+// The lanes consult the memo only at nodes with at least RAZ_SOLVER_LANE_MEMO_EMPTIES empties (with the fourth ply of tasks a 10-empties
+// solve's subtrees start at 6: its workers do not touch the memo at all, its scans do): the 64 searches advance in lockstep,
 // so ONE lane's probe (dependent HBM round trips into a 2 MB table) is paid by all of them; subtrees below that size are searched
 // outright (<= 720 leaf paths) - and even those probes are batched (the slow phase, below).
-#define RAZ_SOLVER_LANE_MEMO_EMPTIES 6
+#ifndef RAZ_SOLVER_LANE_MEMO_EMPTIES
+#define RAZ_SOLVER_LANE_MEMO_EMPTIES 7   // (6: 23.3 M sims/s on mini.yml as shipped, 7: 24.5 M - profiles/r5/solver_worker_loop_compile_time_knobs_ab.jsonl)
+#endif
 #ifndef RAZ_SOLVER_PROBE_AT_DRAW
 #define RAZ_SOLVER_PROBE_AT_DRAW 0
 #endif
 #ifndef RAZ_SOLVER_SLOW_EVERY
-#define RAZ_SOLVER_SLOW_EVERY 8   // (a power of two)
+#define RAZ_SOLVER_SLOW_EVERY 16   // (a power of two; 4 / 8 / 16: 22.6 / 23.3 / 23.1 M at memo 6, 24.8 M at 16 with memo 7)
 #endif
 #ifndef RAZ_SOLVER_POOL_BUDGET
 #define RAZ_SOLVER_POOL_BUDGET 128

@@ -724,7 +724,10 @@ class BatchedSelfPlayWorker:
                         dist.broadcast_object_list(stop, src=0)
                     if stop[0]:
                         break
+                import time as _tm
+                _t0 = _tm.monotonic()
                 packed, per_rank, state = self._play_block_checked(game_idx)
+                _t1 = _tm.monotonic()
                 while self._all_ranks_state(state) == self.BLOCK_RANGE:
                     if self._f32_fallback or self._series_length() > 1:
                         raise RuntimeError("the net left its numeric range on the exact-f32 kernels too" if self._f32_fallback else
@@ -744,14 +747,21 @@ class BatchedSelfPlayWorker:
                     allraw = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
                     del pk
                 del packed   # (holds the engine / the outbox: nothing of this block may pin device memory past this point)
+                _t2 = _tm.monotonic()
                 if self.rank == 0:
                     self.bookkeep_raw(allraw)
+                    _t3 = _tm.monotonic()
                     game_idx += len(allraw["n_plies"])
                     if writer is not None:
                         writer.submit(allraw, local_idx, game_idx)
                     else:
                         self.write_raw(allraw, local_idx)
                         self._write_game_idx(game_idx)
+                    # where a block's wall time went on this rank (bench.py worker_end_to_end_config1): playing, the gather + the
+                    # records' copy to the host, the resignation bookkeeping, waiting for the writer to take the block
+                    acc = self.run_seconds = getattr(self, "run_seconds", None) or {"play": 0.0, "gather_and_copy": 0.0, "bookkeeping": 0.0, "handing_to_the_writer": 0.0}
+                    for k_, v_ in (("play", _t1 - _t0), ("gather_and_copy", _t2 - _t1), ("bookkeeping", _t3 - _t2), ("handing_to_the_writer", _tm.monotonic() - _t3)):
+                        acc[k_] += v_
                 if self._group():
                     t = [game_idx, self.config.play.resign_threshold]
                     dist.broadcast_object_list(t, src=0)
