@@ -614,9 +614,10 @@ def steady_window_leg(args, dev, blob, cfg, weights, slots=8192, seconds=120.0, 
     import torch
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine, raw_from_packed
     net = DeviceNet(blob, dev, kernel=args.net_kernel)
-    cache_log2 = None if args.no_leaf_cache else 26
+    cache_log2 = None if args.no_leaf_cache else int(os.environ.get("RAZ_BENCH_CACHE_LOG2", "26"))
+    cache_discs = int(os.environ.get("RAZ_BENCH_CACHE_DISCS", "24"))   # (A/B of the evaluation cache's admission rule; the worker's defaults: 26, 24)
     eng = SelfPlayEngine(cfg, net, n_games=slots, seed=0, sims_hint=args.sims, nodes_per_game=args.nodes_per_game or 16 * args.sims, parts=1,
-                         leaf_cache_log2=cache_log2, leaf_cache_max_discs=24)
+                         leaf_cache_log2=cache_log2, leaf_cache_max_discs=cache_discs)
     spare = slots   # ids for the refills of the window (a slot restarts at most a few times in two minutes)
     eng.start(0, args.sims)
     ply = stagger(eng, slots, args.sims, 2024, dev, weights)
@@ -713,7 +714,7 @@ def steady_window_leg(args, dev, blob, cfg, weights, slots=8192, seconds=120.0, 
            "games_per_hour_note": "games whose last move fell inside the window / window length: in the steady state that is the completion rate of whole games",
            "emission": emission,
            "gc_runs": gc_runs, "range_ok": net.range_ok(),
-           "leaf_cache": ({"entries_log2": cache_log2, "max_discs": 24, "served_from_the_table": int(served),
+           "leaf_cache": ({"entries_log2": cache_log2, "max_discs": cache_discs, "served_from_the_table": int(served),
                            "share_of_leaf_requests": served / max(1, leaves)} if cache_log2 else None),
            "pool_bytes": int(eng.workspace_bytes)}
     del eng, net, outbox

@@ -77,7 +77,7 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
 static_assert(sizeof(raz_solve_hdr) == 64, "raz_solve_hdr layout");
 #endif
 #define RAZ_SOLVER_TREE_BYTES 12288   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there): the top three plies, folded in LDS
-#define RAZ_SOLVER_DEEP_BYTES 131072  // >= sizeof(SolverDeep): the positions three plies down and, below the larger ones, a fourth ply of tasks
+#define RAZ_SOLVER_DEEP_BYTES 135168  // >= sizeof(SolverDeep): the positions three plies down and, below the larger ones, a fourth ply of tasks
 #define RAZ_SOLVER_WS_BYTES (64 + RAZ_SOLVER_TREE_BYTES + RAZ_SOLVER_DEEP_BYTES)
 // a worker wave of the pool: 16 words of lane state (the search in hand and the task drawn ahead) and 14 frames of 32 B per lane
 #define RAZ_SOLVER_WORKER_STATE_BYTES (16 * 64 * 8)

@@ -53,6 +53,7 @@ struct SolverTree {   // in the game's block of E.solver_ws behind the header; k
 struct SolverDeep {   // HBM only (behind the SolverTree in the game's block)
     unsigned long long h_own[RAZ_SOLVER_MAX_TASKS], h_enemy[RAZ_SOLVER_MAX_TASKS], h_moves[RAZ_SOLVER_MAX_TASKS];   // level-3 node t (its mover's view), its moves
     unsigned short sub_first[RAZ_SOLVER_MAX_TASKS + 4];   // node t's first task
+    unsigned char h_dead[RAZ_SOLVER_MAX_TASKS];           // node t: its value is known or no longer needed (a scan above it is decided): its tasks are moot
     unsigned char h_kind[RAZ_SOLVER_MAX_TASKS];           // node t: 0 the game ends there, 1 the opponent moves, 2 the opponent passes (+4: from the memo; +8: not split - ONE task, the node itself)
     signed char sub_result[RAZ_SOLVER_MAX_SUB];           // task u: the value of that move for node t's mover (an unsplit node: f of the node)
     unsigned short sub_task[RAZ_SOLVER_MAX_SUB];          // task u's level-3 node
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
                 D->h_enemy[t] = ne;
                 D->h_moves[t] = nm;
                 D->h_kind[t] = (unsigned char)kind;
+                D->h_dead[t] = 0;
                 D->sub_first[t] = (unsigned short)cnt;   // (a count for now)
                 mine += cnt;
             }
@@ -375,6 +377,12 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         for (int n = lane; n < n2; n += 64) T->g_v[n] = P->g_v[n];
         if (lane < k) T->c_v[lane] = P->c_v[lane];
     }
+    // what a worker asks before it starts (or goes on with) a task of level-3 node t - ONE byte instead of three dependent looks
+    for (int t = lane; t < total; t += 64) {
+        const int te = P->task_entry[t];
+        const bool dead = P->result[t] != RAZ_SOLVER_UNKNOWN || (!exact && (P->g_v[te & 0xff] != RAZ_SOLVER_UNKNOWN || P->c_v[te >> 8] != RAZ_SOLVER_UNKNOWN));
+        if (dead) D->h_dead[t] = 1;
+    }
     if (collect) {
         const uint32_t next = st == RAZ_SOLVE_REQUESTED ? 0u : uni(h->next);
         if (next < (uint32_t)subs && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
@@ -395,6 +403,9 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 // outright (<= 720 leaf paths) - and even those probes are batched (the slow phase, below).
 #ifndef RAZ_SOLVER_LANE_MEMO_EMPTIES
 #define RAZ_SOLVER_LANE_MEMO_EMPTIES 7   // (6: 23.3 M sims/s on mini.yml as shipped, 7: 24.5 M - profiles/r5/solver_worker_loop_compile_time_knobs_ab.jsonl)
+#endif
+#ifndef RAZ_SOLVER_MAX_RETURNS
+#define RAZ_SOLVER_MAX_RETURNS 2
 #endif
 #ifndef RAZ_SOLVER_PROBE_AT_DRAW
 #define RAZ_SOLVER_PROBE_AT_DRAW 0
@@ -436,10 +447,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     if (have) {   // is the parked search still wanted?  Its request may have been answered (a decided scan) or replaced, its node decided
         const raz_solve_hdr* hh = solve_hdr(E, g);
         if (hh->gen != gen || hh->state != RAZ_SOLVE_RUNNING) have = false;
-        else if (!exact) {
-            const SolverTree* T = solve_tree(E, g);
-            if (T->c_v[task_ci] != RAZ_SOLVER_UNKNOWN || T->g_v[task_n] != RAZ_SOLVER_UNKNOWN || T->result[task_t] != RAZ_SOLVER_UNKNOWN) have = false;
-        }
+        else if (solve_deep(E, g)->h_dead[task_t]) have = false;
     }
     if (have)   // (a lane reads and writes its own column only: no barrier)
         for (int i = 0; i < d * 4; ++i) fr[i * 64] = fr_hbm[i * 64];
@@ -506,8 +514,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                         const int te = T->task_entry[nt], n = te & 0xff, ci = te >> 8, hk = D->h_kind[nt], s0 = D->sub_first[nt];
                         const raz_bb ho = D->h_own[nt], he = D->h_enemy[nt], hm = D->h_moves[nt];
                         // (a task that has its result: dispatch restarted after the pool was re-partitioned; a node that is decided: moot)
-                        if (D->sub_result[t] == RAZ_SOLVER_UNKNOWN && T->result[nt] == RAZ_SOLVER_UNKNOWN &&
-                            (ex || (T->c_v[ci] == RAZ_SOLVER_UNKNOWN && T->g_v[n] == RAZ_SOLVER_UNKNOWN))) {
+                        if (D->sub_result[t] == RAZ_SOLVER_UNKNOWN && !D->h_dead[nt]) {
                             raz_bb no = ho, ne = he, nm = hm;
                             int v = 0, kind = 2;   // an unsplit node: the search starts at the node itself (same mover: sign +)
                             if (!(hk & 8)) {
@@ -588,7 +595,11 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
             // first every node that is finished hands its value to its parent - cheap LDS pops, usually none or one - then the node the
             // search stands on plays its next move.  (A separate iteration per finished node made 45 % of the iterations pops, each at
             // the full price of the lockstep wave's expand path.)
-            for (;;) {
+            // At most RAZ_SOLVER_MAX_RETURNS returns per iteration: the wave runs as many rounds of this loop as its DEEPEST unwinding
+            // lane needs (unbounded: 4-5 rounds, 28 % of the wave's time by the tick counters); a lane that has more to unwind goes on
+            // at the next iteration without playing a move in this one (about one lane-iteration in 25).
+            bool may_move = false;
+            for (int returns = 0; returns <= RAZ_SOLVER_MAX_RETURNS; ++returns) {
                 const bool big = bb_popcount(~(own | enemy)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES;
                 int rm = 0, rs = 0;
                 bool done = false;
@@ -616,7 +627,11 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                         done = true;
                     }
                 }
-                if (!done) break;
+                if (!done) {
+                    may_move = true;
+                    break;
+                }
+                if (returns == RAZ_SOLVER_MAX_RETURNS) break;   // (finished, but its return waits for the next iteration)
                 if (d == 0) {
                     solve_deep(E, g)->sub_result[task] = (signed char)(task_sign * rs);
                     have = false;
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 }
             }
             tk_pop += prof_now() - tk1;
-            if (have && !wait_find) {
+            if (have && !wait_find && may_move) {
                 const int a = __ffsll((long long)left) - 1;
                 left &= left - 1;
                 raz_bb no, ne, nm;

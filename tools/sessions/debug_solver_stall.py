@@ -31,7 +31,7 @@ eng.start(0, sims)
 eng.step(50)
 eng.stats()
 eng.start(0, sims)
-WS = 64 + 12288 + 131072
+WS = 64 + 12288 + 135168
 last, still, steps = -1, 0, 0
 while steps < 40000:
     eng.step(200)
@@ -64,12 +64,12 @@ for i in run[:6]:
     h = hdrs[i]
     d = dict(zip(ks, [int(x) for x in h]))
     tree = read(6, int(i) * WS + 64, 12288)
-    deep = read(6, int(i) * WS + 64 + 12288, 131072)
+    deep = read(6, int(i) * WS + 64 + 12288, 135168)
     T = d["tasks"]
     res_off = 3 * 8 * 14 + 3 * 8 * 182 + 2 * 184 + 16
     result = tree[res_off:res_off + T].view(np.int8)
     sub_first = deep[3 * 8 * 2184:3 * 8 * 2184 + 2 * (T + 1)].view(np.uint16)
-    kind_off = 3 * 8 * 2184 + 2 * 2188
+    kind_off = 3 * 8 * 2184 + 2 * 2188 + 2184   # (h_dead lies before h_kind)
     h_kind = deep[kind_off:kind_off + T]
     sr_off = kind_off + 2184
     sub_result = deep[sr_off:sr_off + d["total"]].view(np.int8)
