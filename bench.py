@@ -1311,8 +1311,12 @@ def compact_line(full):
     for key in ("record_gather", "config4_acceptance"):
         if key in full:
             line[key] = pick(full[key], ("collective", "bytes", "games", "seconds", "payload_check", "result", "gathered_bytes"))
+    line["bench_wall_seconds"] = full.get("bench_wall_seconds")
     line["full_document"] = full.get("_full_path")
     return line
+
+
+T_MAIN = time.perf_counter()
 
 
 def main():
@@ -1450,6 +1454,7 @@ def main():
                     raise
                 except Exception as ex:   # never lose the main line over an extra leg
                     out[key] = {"error": repr(ex)}
+        out["bench_wall_seconds"] = time.perf_counter() - T_MAIN
         path = args.full_out or os.path.join(ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "bench_full.json")
         try:
             with open(path, "w") as f:

@@ -418,7 +418,11 @@ class BatchedSelfPlayWorker:
                 cache[gid] = decide_simulation_num_per_move(self.config, gid)
             return cache[gid]
         eng = self._get_engine(max(sims_of(base + i) for i in range(blk)))
-        outbox, self.last_stats = eng.play_continuous(base, blk, sims_of)
+        # steps between two polls of the device (statistics + harvest, a host synchronisation each): a step of a 16-filter net is ~40 us,
+        # so 64 steps between polls left the host in the loop a sixth of the time (bench worker_end_to_end_config1: the worker's engine at
+        # 19.2 M games/h where the same engine reaches 25 M polled every 200 steps); a wide net's step is ~25 ms and 64 is a poll every 1.6 s
+        chunk = 64 if (self._net is not None and getattr(self._net, "filters", 256) >= 128) else 256
+        outbox, self.last_stats = eng.play_continuous(base, blk, sims_of, chunk=chunk)
 
         def packed(plies):
             if plies is None:   # n_plies is the u32 at byte 20 of a raz_game_summary

@@ -507,6 +507,31 @@ def test_engine_solves_suspended_on_the_smallest_budget_equal_the_oracle(golden,
     assert nsolved > 0
 
 
+@pytest.mark.parametrize("par,waves,budget", [(2, 8, 64), (3, 24, 64), (4, 2048, 128)])
+def test_engine_solver_pool_of_any_size_equals_the_oracle(golden, blob, par, waves, budget):
+    """The end-game solver's pool (csrc/raz_solver_pool.h) on the device: 16 games post their solves into ONE pool of `waves` worker
+    waves - 8 (each slice's single wave serves every game: every search is parked again and again), 24, 2048 (more lanes than tasks:
+    the launch runs in two rounds of resident waves) - at parallel_search_num 2, 3 and 4 (2 and 3 with the solver on were not covered
+    before round 5).  Records == the oracle's; the pool's counters say that it did the solving."""
+    from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
+    g0 = next(g for g in golden["games"] if g["variant"] == "mini_solver_noresign")
+    cfg = config_of(g0)
+    cfg.play.parallel_search_num = par
+    n, sims = 16, 12
+    eng = SelfPlayEngine(cfg, DeviceNet(blob, DEV), n_games=n, seed=43, sims_hint=sims, record_root_w=True, solver_budget=budget, solver_pool_waves=waves)
+    eng.start(first_game_id=900, sims_per_move=sims)
+    eng.run(chunk=48)
+    recs = eng.records(save_policy_of_tau_1=True)
+    ocfg = O.play_cfg_from_config(cfg, parallel_search_num=par)
+    nsolved = 0
+    for i in range(0, n, 4):
+        plies, summ = O.selfplay_game(ocfg, blob, 43, 900 + i, sims)
+        _compare_game(f"pool{waves}/par{par}/{900 + i}", recs[i][0], recs[i][1], plies, summ["winner"])
+        nsolved += sum(p["solved"] for p in plies)
+    st = eng.solver_stats()
+    assert nsolved > 0 and st["answers"] > 0 and st["subtrees_finished"] > 0 and st["requests_posted"] >= st["answers"]
+
+
 @pytest.mark.parametrize("par", [1, 4])
 def test_engine_solves_of_11_to_13_empties_equal_the_oracle(golden, blob, par):
     """The lane-parallel solver on LARGE task trees (three plies below positions of 11-13 empties: up to ~150 level-2 nodes and
