@@ -948,7 +948,7 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
     net = DeviceNet(blob, dev, kernel=net_kernel)
     eng = SelfPlayEngine(cfg, net, n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=fused,
                          solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")),
-                         parts=int(os.environ.get("RAZ_BENCH_PARTS", "0")))
+                         solver_pool_every=int(os.environ.get("RAZ_BENCH_POOL_EVERY", "0")), parts=int(os.environ.get("RAZ_BENCH_PARTS", "0")))
     eng.start(0, sims)
     eng.step(50)
     eng.stats()
@@ -1135,7 +1135,8 @@ def continuous_leg(dev, args, rounds=3, shipped=False):
         cfg.play.thinking_loop, cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = 2, 50, 50
     blob = ReversiNet(*NETS["mini"]).keras_init_(0).to_blob()
     eng = SelfPlayEngine(cfg, DeviceNet(blob, dev), n_games=games, seed=0, sims_hint=sims * (2 if shipped else 1), fused=False,
-                         solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")))
+                         solver_budget=int(os.environ.get("RAZ_BENCH_SOLVER_BUDGET", "0")), solver_pool_waves=int(os.environ.get("RAZ_BENCH_SOLVER_WAVES", "0")),
+                         solver_pool_every=int(os.environ.get("RAZ_BENCH_POOL_EVERY", "0")), parts=int(os.environ.get("RAZ_BENCH_PARTS", "0")))
     eng.start(0, sims)
     eng.step(50)
     eng.stats()

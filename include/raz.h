@@ -171,7 +171,11 @@ typedef struct {
                                                  (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num);
                                                  bits 16-23: x 64 = iterations a worker lane of the end-game solver's pool runs between two
                                                  tree launches (0 = 128); a game whose solve - the root's or one inside a simulation - is
-                                                 not answered yet stays suspended: results do not depend on the value.
+                                                 not answered yet stays suspended: results do not depend on the value;
+                                                 bits 24-27: tree launches per round of that pool (0 = the library's default; 1 = every
+                                                 step waits for the pool's round; n > 1 = the round runs on a stream of its own beside
+                                                 the next n - 1 steps, so that games that wait for no solve are not held up by it;
+                                                 raz_engine_step joins it before it returns).  Results do not depend on it either.
                                                  Every other bit must be 0 (RAZ_EINVAL) */
     int32_t use_solver_turn;                  /* config.py:154: 0 = off, else >= 46: exact end-game solve at the root
                                                  (agent/player.py:100-103,150-161; lib/alt/reversi_solver_cython.pyx) */
@@ -273,6 +277,12 @@ int raz_engine_gc(raz_engine* e, uint32_t threshold, raz_stream_t stream);
 /* Number of slices/streams a step is split into (1..8; 1 = one tree launch + one net launch over the
  * whole batch).  Call with the stream idle. */
 int raz_engine_set_parts(raz_engine* e, int parts);
+/* Tree launches per round of the end-game solver's pool (raz_engine_config.reserved bits 24-27 set it at creation): 0 = the library's
+ * default, 1 = every step waits for the pool's round, n in 2..15 = the round runs on a stream of its own beside the next n - 1 steps.
+ * A batch whose games all reach the solver together (lock-step whole games) is served best by 1, continuous batching - a sixth of
+ * the slots in the end game at any time - by 3 (mini.yml as shipped, 4096 slots: 22.7 M -> 30.3 M sims/s).  No result depends on it.
+ * Call between raz_engine_step calls. */
+int raz_engine_set_solver_pool_every(raz_engine* e, int n);
 /* Synchronise the stream and read the counters. */
 int raz_engine_stats_sync(raz_engine* e, raz_engine_stats* out, raz_stream_t stream);
 /* Copy finished-game records to host memory (synchronous).  headers: n_games*max_plies*48 bytes

@@ -112,6 +112,7 @@ SIGNATURES.update({
     "raz_engine_adopt_tree": (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
     "raz_engine_gc": (c_int, [c_void_p, c_uint32, c_void_p]),
     "raz_engine_set_parts": (c_int, [c_void_p, c_int]),
+    "raz_engine_set_solver_pool_every": (c_int, [c_void_p, c_int]),
     "raz_engine_stats_sync": (c_int, [c_void_p, POINTER(RazEngineStats), c_void_p]),
     "raz_engine_read_records": (c_int, [c_void_p] * 11 + [c_void_p]),
     "raz_engine_device_ptr": (c_void_p, [c_void_p, c_int]),

@@ -55,13 +55,22 @@
 #define RAZ_SIM_SOLVING 3      // its descent is suspended at an in-simulation solve (RAZ_LEAF_SOLVE_PENDING in its block)
 
 // End-game solver, POOLED across games (raz_solver_pool.h).  A tree kernel that needs f_mode(position) for a position with 7..14
-// empties POSTS a request in its game's block of E.solver_ws (header below, then the three-ply task tree) and suspends where it
+// empties POSTS a request in its game's block of E.solver_ws (header below, then the task tree: three plies + a fourth of tasks) and suspends where it
 // stands; between tree launches k_solve_scan builds the task trees of new requests and folds finished tasks into answers, and
 // k_solve_run - a fixed pool of worker waves that belongs to no game - hands ONE subtree to every LANE, whatever game it comes from.
 #define RAZ_SOLVE_IDLE 0u
 #define RAZ_SOLVE_REQUESTED 1u   // posted by a tree kernel: own0 / enemy0 / exact are valid, gen was bumped
 #define RAZ_SOLVE_RUNNING 2u     // its task tree is built; workers take tasks off `next`
-#define RAZ_SOLVE_ANSWERED 3u    // ans_* hold f(own0, enemy0): stays until another position is requested
+#define RAZ_SOLVE_ANSWERED 3u    // the state word carries f(own0, enemy0): stays until another position is requested
+// The state word: bits 0-7 the state; an ANSWERED word also holds the answer - bits 8-15 RAZ_SOLVE_DONE / RAZ_SOLVE_NONE, 16-23 move + 1,
+// 24-31 score + 128 - so that ONE 4-byte store publishes it: the pool's round may run on its own stream beside the tree kernels of the
+// following steps (raz_engine.hip, pool_every), and a tree kernel that sees ANSWERED must see the whole answer.
+#define RAZ_SOLVE_STATE(w) ((w) & 0xffu)
+#define RAZ_SOLVE_ANSWER_WORD(kind, move, score) \
+    (RAZ_SOLVE_ANSWERED | ((uint32_t)(kind) << 8) | ((uint32_t)(((move) + 1) & 0xff) << 16) | ((uint32_t)(((score) + 128) & 0xff) << 24))
+#define RAZ_SOLVE_ANSWER_KIND(w) (((w) >> 8) & 0xffu)
+#define RAZ_SOLVE_ANSWER_MOVE(w) ((int)(((w) >> 16) & 0xffu) - 1)
+#define RAZ_SOLVE_ANSWER_SCORE(w) ((int)(((w) >> 24) & 0xffu) - 128)
 struct raz_solve_hdr {           // 64 bytes at the start of a game's solver block
     uint32_t state, gen;
     unsigned long long own0, enemy0;
@@ -69,7 +78,7 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
     uint32_t k_n2, tasks, total; // root moves | level-2 nodes << 8; level-3 nodes; subtrees the workers search (the tasks)
     uint32_t next;               // next task to hand out (workers: atomicAdd)
     int32_t ans_move, ans_score;
-    uint32_t ans_kind;           // RAZ_SOLVE_DONE / RAZ_SOLVE_NONE
+    uint32_t ans_kind;           // (copies of what the state word carries: diagnostics)
     uint32_t rounds;             // rounds of the pool the solve has been listed in (statistics)
     uint32_t rounds_total;       // ... and all solves of this game slot since raz_engine_start
 };
@@ -208,7 +217,7 @@ struct raz_engine_dev {
     // reduced by k_stats: [0] finished games, [1] total sims, [2] error flags, [3] nn leaves, [4] selections, [5] max pool_used over live games, [6] idle or finished slots
     raz_slot* memo;                // [B][M] solved positions: {own, enemy, used<<31 | exact<<30 | (move+1)<<8 | score+128}
     uint32_t M;
-    unsigned char* solver_ws;      // [B][RAZ_SOLVER_WS_BYTES] per game: raz_solve_hdr + the three-ply task tree of the solve in flight
+    unsigned char* solver_ws;      // [B][RAZ_SOLVER_WS_BYTES] per game: raz_solve_hdr + the task tree of the solve in flight (SolverTree, SolverDeep)
     // the worker pool of the end-game solver (raz_solver_pool.h): W waves, split evenly over the slices of the batch
     uint32_t W;                    // worker waves
     raz_solver_pool_hdr* pool_hdr; // [kMaxParts]

@@ -671,8 +671,8 @@ int validate(const raz_engine_config* cfg) {
     if ((cfg->use_solver_turn || cfg->use_solver_turn_in_simulation) &&
         (cfg->solver_memo_slots < 1024 || (cfg->solver_memo_slots & (cfg->solver_memo_slots - 1))))
         return raz_fail(RAZ_EINVAL, "raz_engine: solver_memo_slots must be a power of two >= 1024 when the solver is on");
-    if ((cfg->reserved & ~0x00ffff1bu) || cfg->reserved2)
-        return raz_fail(RAZ_EINVAL, "raz_engine: reserved bits 2, 5-7 and 24-31 and reserved2 must be 0 (ABI 3: bit 2 - hipGraph replay - is gone)");
+    if ((cfg->reserved & ~0x0fffff1bu) || cfg->reserved2)
+        return raz_fail(RAZ_EINVAL, "raz_engine: reserved bits 2, 5-7 and 28-31 and reserved2 must be 0 (ABI 3: bit 2 - hipGraph replay - is gone)");
     if (cfg->share_mtcs_info && !cfg->mirror_updates)
         return raz_fail(RAZ_EINVAL, "raz_engine: share_mtcs_info=1 requires mirror_updates=1 (player.py:279-280)");
     return RAZ_OK;
@@ -698,15 +698,15 @@ int raz_net_forward_compact(const raz_net* net, const uint64_t* own, const uint6
 // and gone can land two of its slices on ONE queue, which serialises them (measured: the same workload 3.3x slower after
 // an engine with a different stream history had been destroyed).  A fixed pool keeps every engine on the mapping of the
 // first one.  Engines of one host thread run one at a time (include/raz.h), so sharing the streams orders nothing extra.
-static hipError_t raz_pool_stream(int h, hipStream_t* out) {
+static hipError_t raz_pool_stream(int h, hipStream_t* out) {   // h < kMaxParts: a slice's stream; kMaxParts + h: its solver pool's
     static std::mutex mu;
-    static hipStream_t pool[64][kMaxParts] = {};
+    static hipStream_t pool[64][2 * kMaxParts] = {};
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
-    if (dev < 0 || dev >= 64 || h < 0 || h >= kMaxParts) return hipErrorInvalidValue;
+    if (dev < 0 || dev >= 64 || h < 0 || h >= 2 * kMaxParts) return hipErrorInvalidValue;
     std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i <= h; ++i)   // always in index order, so that stream i of a device is the i-th created
+    for (int i = h < kMaxParts ? 0 : kMaxParts; i <= h; ++i)   // always in index order, so that stream i of a device is the i-th created of its kind
         if (!pool[dev][i]) {
             err = hipStreamCreateWithFlags(&pool[dev][i], hipStreamNonBlocking);
             if (err != hipSuccess) return err;
@@ -733,6 +733,16 @@ struct raz_engine {
     hipEvent_t ev_fork, ev_join[kMaxParts];
     bool fused;                 // cfg.reserved bit 4: k_tree_net drives the games (tree + narrow net in one kernel)
     bool pool_reset_pending;    // the batch was re-partitioned (raz_engine_set_parts): parked solver searches are re-dispatched first
+    // The solver pool's round of a slice is launched after every pool_every-th tree launch of the slice.  pool_every == 1: on the
+    // slice's stream, between the tree kernel and the net kernel (every step waits for the round).  pool_every > 1: on the slice's
+    // POOL stream, beside the net kernel and the next pool_every - 1 tree launches of the slice - games that are not waiting for the
+    // solver go on at the tree kernels' pace, the ones that are get an answer at the pool's - and joined before the launch that the
+    // next round follows; raz_engine_step joins the last one before it returns, so every other entry point finds the pool at rest.
+    int pool_every;
+    hipStream_t pool_stream[kMaxParts];
+    hipEvent_t ev_pool_go[kMaxParts], ev_pool_done[kMaxParts];
+    bool pool_open[kMaxParts];      // a round of this slice is in flight on its pool stream
+    uint32_t pool_tick[kMaxParts];  // tree launches of the slice since raz_engine_start
 };
 
 namespace {
@@ -758,8 +768,9 @@ inline int pool_budget_of(const raz_engine_dev& d) {
     return units ? units * 64 : RAZ_SOLVER_POOL_BUDGET;
 }
 
-// The solver pool's round for slice h, between two tree launches (raz_solver_pool.h): task trees for the requests the tree kernel
-// just posted, `budget` iterations of the slice's share of the worker waves, answers for the scans that are decided.
+// The solver pool's round for slice h (raz_solver_pool.h): task trees for the requests the tree kernels have posted, `budget`
+// iterations of the slice's share of the worker waves, answers for the scans that are decided.  On the slice's stream right after a
+// tree launch, or on the slice's pool stream (pool_after_tree below).
 int launch_solver_pool(raz_engine* e, int h, hipStream_t s) {
     const raz_engine_dev& d = e->dev;
     if (!d.W) return RAZ_OK;
@@ -772,13 +783,55 @@ int launch_solver_pool(raz_engine* e, int h, hipStream_t s) {
     return raz_check_launch("raz_engine_step: solver pool");
 }
 
+// pool_every > 1 (see raz_engine): before tree launch number `tick` of slice h on stream s - the round in flight is joined if this is
+// the launch the next round follows ...
+int pool_before_tree(raz_engine* e, int h, hipStream_t s) {
+    if (e->pool_every <= 1 || !e->dev.W) return RAZ_OK;
+    if (e->pool_open[h] && e->pool_tick[h] % (uint32_t)e->pool_every == 0u) {
+        RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_pool_done[h], 0), "raz_engine_step: solver pool join");
+        e->pool_open[h] = false;
+    }
+    return RAZ_OK;
+}
+// ... and after it: the round starts on the pool stream once the tree kernel has posted its requests
+int pool_after_tree(raz_engine* e, int h, hipStream_t s) {
+    if (!e->dev.W) return RAZ_OK;
+    if (e->pool_every <= 1) return launch_solver_pool(e, h, s);
+    const uint32_t tick = e->pool_tick[h]++;
+    if (tick % (uint32_t)e->pool_every != 0u) return RAZ_OK;
+    if (!e->pool_stream[h]) {
+        hipError_t err = raz_pool_stream(kMaxParts + h, &e->pool_stream[h]);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_pool_go[h], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_pool_done[h], hipEventDisableTiming);
+        if (err != hipSuccess) return raz_fail_hip(err, "raz_engine_step: solver pool stream");
+    }
+    RAZ_HIP_TRY(hipEventRecord(e->ev_pool_go[h], s), "raz_engine_step: solver pool fork");
+    RAZ_HIP_TRY(hipStreamWaitEvent(e->pool_stream[h], e->ev_pool_go[h], 0), "raz_engine_step: solver pool fork");
+    const int rc = launch_solver_pool(e, h, e->pool_stream[h]);
+    if (rc != RAZ_OK) return rc;
+    RAZ_HIP_TRY(hipEventRecord(e->ev_pool_done[h], e->pool_stream[h]), "raz_engine_step: solver pool done");
+    e->pool_open[h] = true;
+    return RAZ_OK;
+}
+// at the end of raz_engine_step: slice h's stream s waits for the round in flight
+int pool_join(raz_engine* e, int h, hipStream_t s) {
+    if (!e->pool_open[h]) return RAZ_OK;
+    RAZ_HIP_TRY(hipStreamWaitEvent(s, e->ev_pool_done[h], 0), "raz_engine_step: solver pool join");
+    e->pool_open[h] = false;
+    return RAZ_OK;
+}
+
 // one simulation step of one slice on stream s; ev (nullable) = 3 events bracketing the two kernels
 int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
     const raz_engine_dev& d = e->dev;
     const Half hf = half_of(e, h);
     if (hf.count == 0) return RAZ_OK;
-    if (ev) hipEventRecord(ev[0], s);
     const bool solver = d.cfg.use_solver_turn || d.cfg.use_solver_turn_in_simulation;
+    if (solver) {
+        const int rp = pool_before_tree(e, h, s);
+        if (rp != RAZ_OK) return rp;
+    }
+    if (ev) hipEventRecord(ev[0], s);
     if (d.par) {
         if (solver)
             hipLaunchKernelGGL(k_tree_par<true>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
@@ -790,7 +843,7 @@ int launch_half_step(raz_engine* e, int h, hipStream_t s, hipEvent_t* ev) {
         hipLaunchKernelGGL(k_tree<false>, dim3(hf.count), dim3(64), 0, s, d, hf.g0, hf.count);
     int rc = raz_check_launch("raz_engine_step: k_tree");
     if (rc != RAZ_OK) return rc;
-    if (solver && (rc = launch_solver_pool(e, h, s)) != RAZ_OK) return rc;
+    if (solver && (rc = pool_after_tree(e, h, s)) != RAZ_OK) return rc;
     if (ev) hipEventRecord(ev[1], s);
     // the slices run concurrently: each gets its own part of the net scratch (size is linear in n);
     // a game contributes one leaf-exchange row per simulation slot
@@ -826,11 +879,13 @@ int launch_fused_steps(raz_engine* e, uint32_t n_steps, hipStream_t s) {
     int rc = RAZ_OK;
     while (n_steps && rc == RAZ_OK) {
         const uint32_t it = n_steps < kFusedSolverIters ? n_steps : kFusedSolverIters;
-        rc = raz_launch_tree_net(e->dev, true, it, (const float*)e->net.d_weights, e->net.res_layers, e->net.value_fc, s);
-        if (rc == RAZ_OK) rc = launch_solver_pool(e, 0, s);
+        rc = pool_before_tree(e, 0, s);
+        if (rc == RAZ_OK) rc = raz_launch_tree_net(e->dev, true, it, (const float*)e->net.d_weights, e->net.res_layers, e->net.value_fc, s);
+        if (rc == RAZ_OK) rc = pool_after_tree(e, 0, s);
         n_steps -= it;
     }
-    return rc;
+    const int rj = pool_join(e, 0, s);
+    return rc != RAZ_OK ? rc : rj;
 }
 
 int fork_aux(raz_engine* e, hipStream_t s) {
@@ -898,9 +953,14 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
         e->parts = 1;
     }
     e->ev_fork = nullptr;
+    e->pool_every = (int)((cfg->reserved >> 24) & 0xfu) ? (int)((cfg->reserved >> 24) & 0xfu) : RAZ_SOLVER_POOL_EVERY;
     for (int h = 0; h < kMaxParts; ++h) {
         e->aux[h] = nullptr;
         e->ev_join[h] = nullptr;
+        e->pool_stream[h] = nullptr;
+        e->ev_pool_go[h] = e->ev_pool_done[h] = nullptr;
+        e->pool_open[h] = false;
+        e->pool_tick[h] = 0u;
     }
     if (parts > 1) {
         hipError_t err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
@@ -935,11 +995,20 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
     return RAZ_OK;
 }
 
+extern "C" int raz_engine_set_solver_pool_every(raz_engine* e, int n) {
+    if (!e || n < 0 || n > 15) return raz_fail(RAZ_EINVAL, "raz_engine_set_solver_pool_every: n must be 0..15");
+    e->pool_every = n ? n : RAZ_SOLVER_POOL_EVERY;   // (raz_engine_step has joined the last round: the pool is at rest)
+    for (int h = 0; h < kMaxParts; ++h) e->pool_tick[h] = 0u;
+    return RAZ_OK;
+}
+
 extern "C" void raz_engine_destroy(raz_engine* e) {
     if (!e) return;
     for (int h = 0; h < kMaxParts; ++h) {
         // (aux streams belong to the process-wide pool)
         if (e->ev_join[h]) hipEventDestroy(e->ev_join[h]);
+        if (e->ev_pool_go[h]) hipEventDestroy(e->ev_pool_go[h]);
+        if (e->ev_pool_done[h]) hipEventDestroy(e->ev_pool_done[h]);
     }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     delete e;
@@ -1010,6 +1079,10 @@ int launch_steps_direct(raz_engine* e, uint32_t n_steps, hipStream_t s) {
     int rc = fork_aux(e, s);
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
         for (int h = 0; h < e->parts && rc == RAZ_OK; ++h) rc = launch_half_step(e, h, stream_of(e, h, s), nullptr);
+    }
+    for (int h = 0; h < kMaxParts; ++h) {
+        const int rp = pool_join(e, h, stream_of(e, h, s));
+        if (rc == RAZ_OK) rc = rp;
     }
     const int rj = join_aux(e, s);
     return rc != RAZ_OK ? rc : rj;
@@ -1253,6 +1326,10 @@ extern "C" int raz_engine_step_timed(raz_engine* e, uint32_t n_steps, double* tr
     for (uint32_t i = 0; i < n_steps && rc == RAZ_OK; ++i) {
         for (int h = 0; h < H && rc == RAZ_OK; ++h)
             rc = launch_half_step(e, h, stream_of(e, h, s), &ev[3 * ((size_t)i * H + h)]);
+    }
+    for (int h = 0; h < kMaxParts; ++h) {
+        const int rp = pool_join(e, h, stream_of(e, h, s));
+        if (rc == RAZ_OK) rc = rp;
     }
     const int rj = join_aux(e, s);
     hipError_t err = hipStreamSynchronize(s);

@@ -669,7 +669,7 @@ __device__ __forceinline__ raz_solve_hdr* solve_hdr(const raz_engine_dev& E, uin
 // A game whose request is still with the pool has nothing to do in this launch: one word tells (the tree kernels look at it before
 // they load anything else - in a solver-bound batch most games of a launch are in that state).
 __device__ __forceinline__ bool solve_in_flight(const raz_engine_dev& E, uint32_t g) {
-    const uint32_t st = uni(solve_hdr(E, g)->state);
+    const uint32_t st = RAZ_SOLVE_STATE(uni(solve_hdr(E, g)->state));
     return st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING;
 }
 
@@ -692,12 +692,12 @@ __device__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_b
         }
     }
     raz_solve_hdr* h = solve_hdr(E, g);
-    const uint32_t st = uni(h->state), gen = uni(h->gen);
+    const uint32_t word = uni(h->state), st = RAZ_SOLVE_STATE(word), gen = uni(h->gen);
     const bool same = uni((uint32_t)(h->own0 == own0 && h->enemy0 == enemy0 && h->exact == exact)) != 0u;
     if (same && st == RAZ_SOLVE_ANSWERED) {   // (the block keeps the last answer: the memo may have had no room for it)
-        out_move = uni(h->ans_move);
-        out_score = uni(h->ans_score);
-        return (int)uni(h->ans_kind);
+        out_move = RAZ_SOLVE_ANSWER_MOVE(word);
+        out_score = RAZ_SOLVE_ANSWER_SCORE(word);
+        return (int)RAZ_SOLVE_ANSWER_KIND(word);
     }
     if (same && (st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING)) return RAZ_SOLVE_PENDING;
     wave_sync();

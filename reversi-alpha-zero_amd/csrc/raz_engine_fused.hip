@@ -9,9 +9,10 @@
 // simulation - `iters` of them per launch, the control block and the path staying in registers throughout.  No leaf exchange, no
 // second kernel, no slices; one launch per `iters` simulation steps of the whole batch.  4 waves per SIMD (128 VGPRs, 9.7 KB of
 // LDS per wave): 4096 games are resident at once.  Measured resources (-Rpass-analysis=kernel-resource-usage): k_tree_net<false>
-// spills 30 VGPRs (124 B of scratch per lane) around the in-wave net call, k_tree_par_net<false> 56 (216 B) - most of the kernel's
-// counter traffic (profiles/r4_pmc/config1_fused_*); the SOLVER forms are built for 2 waves per SIMD (RAZ_TREE_WAVES: 213 / 236
-// VGPRs, no spill - the lane-parallel DFS is what such a configuration spends its time in).  Every game performs exactly the
+// spills 31 VGPRs (128 B of scratch per lane) around the in-wave net call - most of the kernel's counter traffic
+// (profiles/r4_pmc/config1_fused_*), and cheaper than not spilling (below) - k_tree_par_net<false> none; the SOLVER forms are at 4 waves per SIMD too since round 5 (the end-game search
+// itself runs in the solver pool, raz_solver_pool.h: these kernels only post positions and solve <= 4 empties in place; a game whose
+// request is in flight leaves the launch, and the pool gets its round after every <= 8 fused steps).  Every game performs exactly the
 // operations it performs under k_tree + k_net_mfma, in the same order: results are bit-identical (tests/test_engine_fused_emu.py
 // on the wave emulator, tests/test_engine_gpu.py, tests/test_zz_fused_gpu.py).  raz_engine_config.reserved bit 4, without the
 // evaluation cache; the worker's default for 16-filter nets when the solver is off (105 M against 77 M sims/s on BASELINE
@@ -21,7 +22,43 @@
 #include "raz_engine_core.h"
 #include "raz_net_wave.h"   // raz_net16_forward_in_wave
 
+#ifndef RAZ_FUSED_ITERS
+#define RAZ_FUSED_ITERS 256   // most simulation steps per launch (32 -> 256: +0.9 % on configs[1], profiles/r5/fused_kernel_ab.json)
+#endif
+
 namespace {
+
+// Loop-invariant values that the compiler computes once before the step loop and keeps in VGPRs for the whole launch - the lane's
+// addresses and masks, (double)virtual_loss, 1 / dirichlet_alpha, (float)c_puct ... - are the registers it spills around the in-wave
+// net call (128 VGPRs per wave; the forward needs most of them).  Taking the lane id and those config words through an empty asm
+// once per step (or per round operation) makes it recompute them where they are used instead, and the spills go away: measured on
+// one box, configs[1] whole games (tools/sessions/r5_s17.sh, profiles/r5/fused_kernel_ab.json):
+//     k_tree_par_net<false>  56 spilled VGPRs -> 0    92.3 -> 96.3 M sims/s   (kept: RAZ_FRESH_K = 7)
+//     k_tree_net<false>      30 spilled VGPRs -> 0   105.3 -> 101.3 M sims/s  (NOT kept: RAZ_FRESH_1 = 0.  The kernel is bound by
+//         instruction issue, 4 waves x 21 % per SIMD; its spills are one batch of scratch stores before the forward and one batch of
+//         loads behind it, which cost less than the recomputation - lane id alone -2.5 %, config words alone -0.6 %)
+// bit 0: lane id per step, bit 1: config words per step, bit 2 (k_tree_par_net): lane id per round operation and per queued leaf.
+#ifndef RAZ_FRESH_1
+#define RAZ_FRESH_1 0
+#endif
+#ifndef RAZ_FRESH_K
+#define RAZ_FRESH_K 7
+#endif
+template <int ON = 1>
+__device__ __forceinline__ int fresh_lane(int lane) {
+#ifndef RAZ_WAVE_EMU
+    if (ON) asm volatile("" : "+v"(lane));
+#endif
+    return lane;
+}
+template <int ON = 1>
+__device__ __forceinline__ raz_engine_dev fresh_config(const raz_engine_dev& E) {
+    raz_engine_dev F = E;
+#ifndef RAZ_WAVE_EMU
+    if (ON) asm volatile("" : "+s"(F.cfg.virtual_loss), "+s"(F.cfg.required_visit_to_decide_action), "+s"(F.cfg.c_puct), "+s"(F.cfg.noise_eps), "+s"(F.cfg.dirichlet_alpha));
+#endif
+    return F;
+}
 
 template <bool SOLVER>
 __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engine_dev E, uint32_t g0, uint32_t count,
@@ -35,7 +72,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
     float* lds64 = netbuf + 16 * PS;
     SolverLDS* slds_p = SOLVER ? (SolverLDS*)(netbuf + 16 * PS + 64) : nullptr;
     const uint32_t g = g0 + blockIdx.x;
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
     if (g >= E.B) return;
     if (SOLVER && solve_in_flight(E, g)) return;   // the request is still with the solver pool: nothing to do in this launch
     uint32_t* gw = (uint32_t*)(E.game + g);
@@ -53,7 +90,11 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) return;
     }
     raz_net16_zero_planes(netbuf, lane);
+    const int lane0 = lane;
+    const raz_engine_dev& E0 = E;
     for (uint32_t it = 0; it < iters; ++it) {
+        const int lane = fresh_lane<(RAZ_FRESH_1 & 1)>(lane0);
+        const raz_engine_dev E = fresh_config<(RAZ_FRESH_1 >> 1) & 1>(E0);
         uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (G32(R, GW(error))) break;
@@ -92,6 +133,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
         } else if (lk != RAZ_LEAF_TERMINAL && lk != RAZ_LEAF_SOLVED)
             break;
     }
+    lane = fresh_lane<(RAZ_FRESH_1 & 1)>(lane);
     gw[lane] = R.cw;
     if (R.path_dirty) path_store(E, R, (size_t)g, lane);
     // the answer for a leaf that is still to be backed up waits where the net kernel would have left it
@@ -120,7 +162,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
     float* lds64 = netbuf + 16 * PS;
     SolverLDS* slds_p = SOLVER ? (SolverLDS*)(netbuf + 16 * PS + 64) : nullptr;
     const uint32_t g = g0 + blockIdx.x;
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
     if (g >= E.B) return;
     if (SOLVER && solve_in_flight(E, g)) return;   // the request is still with the solver pool: nothing to do in this launch
     const uint32_t K = E.K;
@@ -153,7 +195,11 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
     constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D outlives an iteration only under a suspended solve
     uint32_t stage = G32(R, GW(par_stage));
     unsigned long long dmask = stage == kStageD ? (unsigned long long)G32(R, GW(par_dmask)) : 0ULL;  // sleepers still to poll in D
+    const int lane0 = lane;
+    const raz_engine_dev& E0 = E;
     for (uint32_t it = 0; it < iters; ++it) {
+        const int lane = fresh_lane<(RAZ_FRESH_K & 1)>(lane0);
+        const raz_engine_dev E = fresh_config<(RAZ_FRESH_K >> 1) & 1>(E0);
         {
             const uint32_t phase = G32(R, GW(phase));
             if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) break;
@@ -161,6 +207,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
         uint32_t nnmask = 0u;
         int budget = (int)K + (((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax);
         for (;;) {
+            const int lane = fresh_lane<(RAZ_FRESH_K >> 2) & 1>(lane0);
             if (G32(R, GW(error))) break;
             // ---- the next operation of the round
             int j = -1;
@@ -264,6 +311,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
         // kernel would have put them; the B phase of the next iteration picks them up with slot_load)
         wave_sync();
         for (uint32_t m = nnmask; m; m &= m - 1) {
+            const int lane = fresh_lane<(RAZ_FRESH_K >> 2) & 1>(lane0);
             const uint32_t jj = (uint32_t)__ffs((int)m) - 1u;
             const size_t gi = (size_t)g * K + jj;
             const raz_bb own = uni((raz_bb)E.nn_own[gi]), enemy = uni((raz_bb)E.nn_enemy[gi]);
@@ -277,7 +325,9 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
     }
     if (SOLVER && stage == kStageD) S32(R, GW(par_dmask), (uint32_t)dmask);
     S32(R, GW(par_stage), stage);
+    lane = fresh_lane<(RAZ_FRESH_K & 1)>(lane);
     gw[lane] = R.cw;
+    myblk = E.sim + ((size_t)g * K + (uint32_t)(lane < (int)K ? lane : 0)) * 64;
     if (lane < (int)K) {
         myblk[GW(sim_state)] = T.st;
         myblk[GW(sim_seq)] = T.sq;
@@ -290,9 +340,9 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
 
 // `n_steps` simulation steps of the whole batch in ceil(n_steps / 32) launches on stream s (raz_engine_step, reserved bit 4)
 int raz_launch_tree_net(const raz_engine_dev& d, bool solver, uint32_t n_steps, const float* W, int R, int V, hipStream_t s) {
-    constexpr uint32_t kFusedIters = 32;
+    constexpr uint32_t kFusedIters = RAZ_FUSED_ITERS;
     // behind the plane buffer: the heads' scratch of a forward, shared in time with backup_leaf's 64 floats and - solver forms only - the
-    // solver's block (7.5 KB: the solver forms run 2 waves per SIMD, 8 per CU x 16.6 KB; the others 16 per CU x 9.7 KB)
+    // scalar end-game search's frames (704 B); 16 waves per CU x 9.7 KB either way
     const int between = 64 + (solver ? (int)(sizeof(SolverLDS) / sizeof(float)) : 0);
     const int head = 192 + V > between ? 192 + V : between;
     const size_t shm = ((size_t)16 * PS + head) * sizeof(float);

@@ -5,21 +5,27 @@
 // lanes ran them.  A win/loss solve needs only the few tasks the reference's early-stopping scan really visits, so on mini.yml as
 // shipped 13 of a wave's 64 lanes executed an instruction (profiles/r5_pmc/solver_bound_*three_ply_build*: 20 %; 12.7 % with two-ply
 // tasks) - and every game held a whole wave (and 248 registers of the tree kernel) for it.  Here the tree kernels only POST the
-// position (raz_engine_core.h solver_solve) and three kernels between two tree launches do the work:
-//   k_solve_scan (one wave per game that has a request)  builds the three-ply task tree of a new request in the game's block of
-//       E.solver_ws - child i, its j-th move, the m-th move after that, as before - and lists the game as ACTIVE;
-//   k_solve_run  (W worker waves that belong to no game)  every LANE takes a task - the next one of the next active solve, drawn
-//       round-robin over the active list, so each solve's tasks leave in the reference's scan order and the lanes go first to the
+// position (raz_engine_core.h solver_solve) and three launches between two tree launches do the work:
+//   k_solve_scan (one wave per game that has a request)  builds the task tree of a new request in the game's block of E.solver_ws -
+//       child i, its j-th move, the m-th move after that (three plies, folded in LDS), and below every such position that still has
+//       >= RAZ_SOLVER_SPLIT_EMPTIES empties a FOURTH ply: its moves are the tasks (SolverDeep, in HBM) - and lists the game as ACTIVE;
+//   k_solve_run  (W worker waves that belong to no game)  every LANE draws a task - lane L of wave w walks its own sequence over the
+//       active list, a solve's tasks leave in the reference's scan order by the solve's own counter, so the lanes go first to the
 //       tasks the sequential search needs - and runs the reference's depth-first search on its subtree: current node in registers,
-//       ancestors' frames in the worker's own frames in HBM, the per-game memo shared with everybody.  After `budget` iterations the
-//       lanes park their searches in the pool's state arrays; the next launch picks them up;
-//   k_solve_scan again  folds the finished tasks into level-2 values, those into the root's children, those into the root's answer -
-//       each scan the reference's loop over a node's moves in ascending order, strict improvement, win/loss mode stopping at the first
-//       value > 0 - and publishes an answer as soon as the scan is decided; tasks behind a decided node are never started, searches
-//       of them are dropped at the next launch.
+//       ancestors' frames in LDS (in the pool's arrays in HBM between launches), one move per iteration with the returns of finished
+//       nodes folded in; memo traffic and task draws only in a slow phase every RAZ_SOLVER_SLOW_EVERY-th iteration.  After `budget`
+//       iterations the lanes park their searches; the next launch picks them up;
+//   k_solve_scan again  folds the finished tasks into level-3 values, those into level-2 values, those into the root's children,
+//       those into the root's answer - each scan the reference's loop over a node's moves in ascending order, strict improvement,
+//       win/loss mode stopping at the first value > 0 - and publishes an answer as soon as the root's scan is decided; tasks behind a
+//       decided node are never started (one dead-flag byte per level-3 node), searches of them are dropped at the next launch.
+// One round = scan, run, scan.  It follows a tree launch on the slice's stream, or - raz_engine.hip, pool_every > 1 - runs on a stream of
+// its own beside the next tree launches (games that wait for no solve are not held up by it; continuous batching: 22.7 M -> 30.3 M
+// sims/s on mini.yml as shipped): an answer is ONE 4-byte store of the header's state word (raz_engine.h), a request is complete
+// before its state says so, and a memo entry whose tag is visible before its keys is a miss.
 // f is a function of (position, mode): which lane searches a subtree, in which launch, or whether a subtree the sequential scan
-// would have skipped is searched as well changes no answer.  Workers never talk to each other inside a launch (only the two atomic
-// counters of the queue and the claim of a memo slot); everything else crosses kernel boundaries.
+// would have skipped is searched as well changes no answer.  Workers never talk to each other inside a launch (only the solves' task
+// counters and the claim of a memo slot are atomic); everything else crosses kernel boundaries.  Measurements: DESIGN.md 4.7.
 #pragma once
 #include "raz_engine_core.h"
 #include "raz_bitboard_valu.h"   // the per-LANE forms of the bitboard primitives (same results for every input)
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     const uint32_t g = g0 + blockIdx.x;
     if (g >= E.B) return;
     raz_solve_hdr* h = solve_hdr(E, g);
-    const uint32_t st = uni(h->state);
+    const uint32_t st = RAZ_SOLVE_STATE(uni(h->state));
     if (st != RAZ_SOLVE_REQUESTED && st != RAZ_SOLVE_RUNNING) return;
     __shared__ SolverTree tree_lds;
     SolverTree* P = &tree_lds;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
                 h->ans_move = -1;
                 h->ans_score = -100;
                 h->ans_kind = RAZ_SOLVE_NONE;
-                h->state = RAZ_SOLVE_ANSWERED;
+                h->state = RAZ_SOLVE_ANSWER_WORD(RAZ_SOLVE_NONE, -1, -100);
             }
             return;
         }
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             h->ans_move = bm;
             h->ans_score = bs;
             h->ans_kind = bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
-            h->state = RAZ_SOLVE_ANSWERED;
+            h->state = RAZ_SOLVE_ANSWER_WORD(bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE, bm, bs);   // (the last store to the header: see raz_engine.h)
             atomicAdd(&E.counters[21], 1ULL);
             atomicAdd(&E.counters[22], (unsigned long long)(st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds));
         }
@@ -413,6 +419,9 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 #ifndef RAZ_SOLVER_SLOW_EVERY
 #define RAZ_SOLVER_SLOW_EVERY 16   // (a power of two; 4 / 8 / 16: 22.6 / 23.3 / 23.1 M at memo 6, 24.8 M at 16 with memo 7)
 #endif
+#ifndef RAZ_SOLVER_POOL_EVERY
+#define RAZ_SOLVER_POOL_EVERY 1   // tree launches per round of the pool (raz_engine.hip: > 1 = the round runs beside them on its own stream)
+#endif
 #ifndef RAZ_SOLVER_POOL_BUDGET
 #define RAZ_SOLVER_POOL_BUDGET 128
 #endif
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     int task = (int)(m2 & 0xffffULL), task_n = (int)((m2 >> 16) & 0xffULL), task_ci = (int)((m2 >> 24) & 0xffULL), task_t = (int)((m2 >> 32) & 0xffffULL);
     if (have) {   // is the parked search still wanted?  Its request may have been answered (a decided scan) or replaced, its node decided
         const raz_solve_hdr* hh = solve_hdr(E, g);
-        if (hh->gen != gen || hh->state != RAZ_SOLVE_RUNNING) have = false;
+        if (hh->gen != gen || RAZ_SOLVE_STATE(hh->state) != RAZ_SOLVE_RUNNING) have = false;
         else if (solve_deep(E, g)->h_dead[task_t]) have = false;
     }
     if (have)   // (a lane reads and writes its own column only: no barrier)
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(256) void k_solve_pool_reset(raz_engine_dev E) {
     }
     if (i < E.B) {
         raz_solve_hdr* h = solve_hdr(E, (uint32_t)i);
-        if (h->state == RAZ_SOLVE_RUNNING) {
+        if (RAZ_SOLVE_STATE(h->state) == RAZ_SOLVE_RUNNING) {
             h->gen += 1u;
             h->next = 0u;
         }

@@ -7,6 +7,7 @@ SelfPlayWorker.start_game loop (worker/self_play.py:139-175) with two ReversiPla
 keeps (ReversiPlayer.moves rows are derived from them in worker/self_play.py of this package).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -96,14 +97,19 @@ class DeviceNet:
         return policy, value
 
 
+CONTINUOUS_SOLVER_POOL_EVERY = 3   # play_continuous: tree launches per round of the solver pool (tools/sessions/r5_s19.sh: 2: 27.2, 3: 30.3, 4: 30.0, 6: 28.7 M)
+
+
 def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirror_updates=None,
                        record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0, solver_memo_slots=1 << 16,
-                       force_slot_kernel=False, pool_bytes_per_game=0, fused=False, solver_budget=0, solver_pool_waves=0):
+                       force_slot_kernel=False, pool_bytes_per_game=0, fused=False, solver_budget=0, solver_pool_waves=0, solver_pool_every=0):
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
     that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par).
     solver_budget: iterations a worker lane of the end-game solver's pool runs between two tree launches (rounded up to 64; 0 = 128);
-    solver_pool_waves: worker wavefronts of that pool (0 = one per four games, at most 1280).  Neither changes a result."""
+    solver_pool_waves: worker wavefronts of that pool (0 = one per four games, at most 1280); solver_pool_every: tree launches per round
+    of the pool (0 = the library's default, 1 = every step waits for the round, n > 1 = the round runs beside the next n - 1 steps on its
+    own stream).  None of them changes a result."""
     p = config.play
     par = int(getattr(p, "parallel_search_num", 1) or 1)
     if not 1 <= par <= 16:
@@ -133,7 +139,7 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
         reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (8 if force_slot_kernel else 0)
-        | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12) | ((min(255, (int(solver_budget) + 63) // 64) & 0xff) << 16),
+        | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12) | ((min(255, (int(solver_budget) + 63) // 64) & 0xff) << 16) | ((int(solver_pool_every or os.environ.get("RAZ_SOLVER_POOL_EVERY", "0")) & 0xf) << 24),   # (the environment variable: tuning / test runs)
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
         solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par,
         pool_bytes_per_game=int(pool_bytes_per_game or 0), solver_pool_waves=int(solver_pool_waves or 0))
@@ -144,7 +150,7 @@ class SelfPlayEngine:
     def __init__(self, config, net: DeviceNet, n_games, seed=0, nodes_per_game=None, sims_hint=None,
                  max_plies=72, mirror_updates=None, record_root_w=False, phase_profile=False, single_stream=False, parts=0, inner_max=0,
                  force_slot_kernel=False, leaf_cache_log2=None, leaf_cache_max_discs=0, pool_bytes_per_game=0, fused=False, solver_budget=0,
-                 solver_pool_waves=0):
+                 solver_pool_waves=0, solver_pool_every=0):
         """fused: 16-filter nets - tree and net in ONE kernel, every game's wave evaluating its own leaves (csrc/raz_engine_fused.hip:
         k_tree_net, k_tree_par_net for parallel_search_num > 1; the same results bit for bit, +40 % on BASELINE configs[1]; what
         BatchedSelfPlayWorker selects for 16-filter nets).  No evaluation cache in that form.
@@ -185,7 +191,7 @@ class SelfPlayEngine:
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, mirror_updates,
                                       record_root_w, phase_profile, single_stream, parts, inner_max,
                                       force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused,
-                                      solver_budget=solver_budget, solver_pool_waves=solver_pool_waves)
+                                      solver_budget=solver_budget, solver_pool_waves=solver_pool_waves, solver_pool_every=solver_pool_every)
         self.fused = bool(fused)
         self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
         self.slots = int(self.cfg.parallel_search_num) or 1   # simulation slots (leaf-exchange rows) per game
@@ -284,6 +290,13 @@ class SelfPlayEngine:
         import torch
         torch.cuda.synchronize(self.device)
         check(lib.raz_engine_set_parts(self._h, parts), "raz_engine_set_parts")
+
+    def set_solver_pool_every(self, n):
+        """Tree launches per round of the end-game solver's pool (include/raz.h raz_engine_set_solver_pool_every): 1 = every step
+        waits for the round, n > 1 = the round runs beside the next n - 1 steps, 0 = the library's default.  Between steps only."""
+        import torch
+        torch.cuda.synchronize(self.device)
+        check(lib.raz_engine_set_solver_pool_every(self._h, int(n)), "raz_engine_set_solver_pool_every")
 
     def step_timed(self, n=1):
         """step(n) with HIP events around each kernel; returns (tree_ms, net_ms) summed over n."""
@@ -428,6 +441,13 @@ class SelfPlayEngine:
         raw_from_packed(...) on the host); stats adds steps, leaf_slot_occupancy and gc_runs."""
         B = self.n_games
         n0 = min(B, total_games)
+        # with slots at every stage of a game only some of them wait for the end-game solver at any time: its pool's round runs beside
+        # three tree launches instead of holding every step up (mini.yml as shipped: 22.7 M -> 30.3 M sims/s; a value given at
+        # construction - solver_pool_every / RAZ_SOLVER_POOL_EVERY - stays)
+        solver_on = bool(self.cfg.use_solver_turn or self.cfg.use_solver_turn_in_simulation)
+        tuned = solver_on and not ((int(self.cfg.reserved) >> 24) & 0xf)
+        if tuned:
+            self.set_solver_pool_every(CONTINUOUS_SOLVER_POOL_EVERY)
         sims0 = np.array([sims_of(first_game_id + i) if i < n0 else 1 for i in range(B)], dtype=np.uint32)
         if resign_threshold_of is not None:
             self.set_resign_threshold(resign_threshold_of(first_game_id))
@@ -465,6 +485,8 @@ class SelfPlayEngine:
         st = self.stats()
         st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs,
                   seconds=host)
+        if tuned:
+            self.set_solver_pool_every(0)
         return outbox, st
 
     def gc(self, threshold=0):

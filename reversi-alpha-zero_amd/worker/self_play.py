@@ -187,14 +187,16 @@ def gather_packed(packed, rank, world):
 
 def wants_fused_tree_net(setting, filters, value_fc, net_reserved, cache_log2, play):
     """Whether the games are stepped by the fused tree + net kernel (csrc/raz_engine_fused.hip).  It applies to 16-filter nets on the
-    default net kernels (value_fc_size <= 1024); setting True = wherever it applies, False = never, "auto" = where it applies and
-    the evaluation cache (wide nets only anyway) is not attached.  With the end-game solver on the two forms are level (mini.yml as
-    shipped, solver-bound: 15.7 M sims/s fused, 15.0 M on the two-kernel pipeline), so `play` does not enter the decision."""
+    default net kernels (value_fc_size <= 1024); setting True = wherever it applies, False = never, "auto" = where it applies, the
+    evaluation cache (wide nets only anyway) is not attached and the end-game solver is off: with the solver on a game that posts a
+    position leaves its launch, and the two-kernel pipeline - whose launches are one step long - gives the solver pool its round
+    sooner (mini.yml as shipped, round 5: 25.5 M sims/s two-kernel, 21.3 M fused).  The files are the same either way."""
     if not (filters == 16 and value_fc <= 1024 and net_reserved == 0):
         return False
     if setting is True:
         return True
-    return setting == "auto" and not cache_log2
+    solver_on = bool(getattr(play, "use_solver_turn", 0) or getattr(play, "use_solver_turn_in_simulation", 0))
+    return setting == "auto" and not cache_log2 and not solver_on
 
 
 class BatchedSelfPlayWorker:

@@ -63,6 +63,7 @@ class EmuEngine:
         self.cfg = engine_config_from(config, n_games, seed, nodes_per_game, max_plies, None, record_root_w, False, True, 1, inner_max,
                                       force_slot_kernel=force_slot_kernel, pool_bytes_per_game=pool_bytes_per_game, fused=fused)
         self.pool_bytes = int(pool_bytes_per_game) or (int(nodes_per_game) * NODE_POOL_BYTES_PER_NODE + 64 * NODE_MAX_BYTES)
+        self.cfg.reserved |= (int(cfg_overrides.pop("solver_pool_every", 0)) & 0xf) << 24   # tree launches per round of the solver pool
         for k, v in cfg_overrides.items():
             setattr(self.cfg, k, v)
         self.slots = int(self.cfg.parallel_search_num) or 1

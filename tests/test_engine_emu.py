@@ -116,17 +116,18 @@ def test_emulated_slot_kernel_equals_oracle(blob, k, pool):
         _same(f"par{k}/{i}", recs[i][0], recs[i][1], plies, summ["winner"])
 
 
-@pytest.mark.parametrize("k,waves,budget", [(1, 8, 6), (2, 9, 3), (3, 64, 17)])
-def test_emulated_solver_pool_serves_several_games_from_one_set_of_worker_lanes(golden, blob, k, waves, budget, monkeypatch):
+@pytest.mark.parametrize("k,waves,budget,every", [(1, 8, 6, 1), (2, 9, 3, 3), (3, 64, 17, 2)])
+def test_emulated_solver_pool_serves_several_games_from_one_set_of_worker_lanes(golden, blob, k, waves, budget, every, monkeypatch):
     """The end-game solver's pool (csrc/raz_solver_pool.h): five games post their solves - exact at the root, win/loss inside
     simulations - into ONE pool of `waves` worker waves whose lanes take subtrees of whichever game is next in the queue and park
-    every search after `budget` iterations; each game must still be the oracle's game, whatever the pool's size or budget.
-    (parallel_search_num 2 and 3 with the solver on were not covered before round 5.)"""
+    every search after `budget` iterations; each game must still be the oracle's game, whatever the pool's size or budget, and
+    whether the pool gets its round after every tree launch or after every `every`-th one (on the GPU that round then runs beside
+    the following launches; here, in program order).  (parallel_search_num 2 and 3 with the solver on were not covered before round 5.)"""
     monkeypatch.setenv("RAZ_SOLVER_BUDGET", str(budget))
     cfg = config_of(_variant(golden, "mini_solver_noresign"))
     cfg.play.parallel_search_num = k
     cfg.play.thinking_loop = 1
-    eng = EmuEngine(cfg, blob, n_games=5, seed=43, sims_hint=10, solver_pool_waves=waves)
+    eng = EmuEngine(cfg, blob, n_games=5, seed=43, sims_hint=10, solver_pool_waves=waves, solver_pool_every=every)
     eng.start(70, 10)
     eng.run(chunk=32)
     recs = eng.records(save_policy_of_tau_1=True)

@@ -515,15 +515,15 @@ def test_threshold_update_once_per_emitted_batch(tmp_path):
 
 
 def test_the_fused_kernel_is_chosen_where_it_applies_and_pays():
-    """worker/self_play.py wants_fused_tree_net: 16-filter nets on the default net kernels; "auto" not with the evaluation cache; the
-    end-game solver does not enter the decision (the two forms are level on a solver-bound configuration)."""
+    """worker/self_play.py wants_fused_tree_net: 16-filter nets on the default net kernels; "auto" not with the evaluation cache and not with
+    the end-game solver on (round 5: the two-kernel pipeline is the faster one once solves go through the pool)."""
     import types
     from reversi_alpha_zero_amd.worker.self_play import wants_fused_tree_net
     off = types.SimpleNamespace(use_solver_turn=0, use_solver_turn_in_simulation=0)
     on = types.SimpleNamespace(use_solver_turn=50, use_solver_turn_in_simulation=50)
     insim = types.SimpleNamespace(use_solver_turn=0, use_solver_turn_in_simulation=50)
     assert wants_fused_tree_net("auto", 16, 16, 0, None, off)
-    assert wants_fused_tree_net("auto", 16, 16, 0, None, on) and wants_fused_tree_net("auto", 16, 16, 0, None, insim)
+    assert not wants_fused_tree_net("auto", 16, 16, 0, None, on) and not wants_fused_tree_net("auto", 16, 16, 0, None, insim)
     assert not wants_fused_tree_net("auto", 16, 16, 0, 20, off)            # evaluation cache attached
     assert wants_fused_tree_net(True, 16, 16, 0, 20, on)                   # forced: wherever it applies
     assert not wants_fused_tree_net(False, 16, 16, 0, None, off)
