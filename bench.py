@@ -978,7 +978,7 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
            "workload": f"BASELINE configs[1]: {games} concurrent self-play games/GPU, mini net (F16 R1 V16), {sims} sims/move, mini.yml "
                        + ("play section AS SHIPPED (thinking_loop 2, parallel_search_num 4, end-game solver from turn 50: exact at the root, win/loss inside simulations), "
                           if shipped else f"play settings, thinking_loop=1, solver off, parallel_search_num={par}, ") + "whole games (lock-step batch)"
-                       + ("; tree and net in ONE kernel (k_tree_net / k_tree_par_net: the game's wave evaluates its own leaves, 32 simulation steps per launch)" if fused else "")
+                       + ("; tree and net in ONE kernel (k_tree_net / k_tree_par_net: the game's wave evaluates its own leaves, up to 256 simulation steps per launch)" if fused else "")
                        + (f"; narrow-net kernel variant {net_kernel}" if net_kernel else ""),
            "value": st["total_sims"] / dt, "unit": "sims/s", "games_per_hour": st["finished_games"] / dt * 3600.0,
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "total_sims": st["total_sims"], "nn_leaves": st["nn_leaves"],
