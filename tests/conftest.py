@@ -19,6 +19,41 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (-m "not gpu") is eleven minutes of single-threaded work - whole games on the wave emulator, the unmodified
+    reference played against the oracle - in tests that share nothing but read-only fixtures (the two-rank gloo tests have a port
+    each): run it on worker processes (pytest-xdist) unless the caller chose a count himself or set RAZ_TESTS_SERIAL.  The GPU
+    suite stays in one process: one GPU, and the loader of the HIP library is what its run records."""
+    opt = config.option
+    # never inside a worker process: a worker that starts workers of its own is a fork bomb (xdist sets PYTEST_XDIST_WORKER in
+    # its workers; the sentinel below is inherited by everything this process starts, whatever xdist does)
+    if os.environ.get("PYTEST_XDIST_WORKER") or os.environ.get("RAZ_TESTS_PARENT") or hasattr(config, "workerinput"):
+        return None
+    if (getattr(opt, "markexpr", "") == "not gpu" and getattr(opt, "numprocesses", 0) is None and not os.environ.get("RAZ_TESTS_SERIAL")
+            and config.pluginmanager.hasplugin("xdist")):
+        os.environ["RAZ_TESTS_PARENT"] = str(os.getpid())
+        opt.numprocesses = max(1, min(6, (os.cpu_count() or 2) - 2))   # (before pytest-xdist's own hook reads it; set here too in case the order changes)
+        opt.dist, opt.tx = "load", ["popen"] * opt.numprocesses
+
+
+def _locked(name):
+    """A lock file under tests/native: the worker processes build the shared libraries one at a time."""
+    import contextlib
+    import fcntl
+
+    @contextlib.contextmanager
+    def cm():
+        os.makedirs(os.path.join(ROOT, "tests", "native"), exist_ok=True)
+        with open(os.path.join(ROOT, "tests", "native", f".{name}.lock"), "w") as f:
+            fcntl.flock(f, fcntl.LOCK_EX)
+            try:
+                yield
+            finally:
+                fcntl.flock(f, fcntl.LOCK_UN)
+    return cm()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "needs_reference: imports /root/reference (skipped if absent)")
@@ -44,7 +79,8 @@ def _built():
     """Make sure libraz.so and liboracle.so exist (the .so files travel with the snapshot to the GPU
     box; here they are rebuilt only when sources are newer)."""
     import __graft_entry__ as g
-    g.build()
+    with _locked("build"):
+        g.build()
 
 
 @pytest.fixture(scope="session")

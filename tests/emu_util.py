@@ -8,7 +8,7 @@ import subprocess
 
 import numpy as np
 
-from conftest import ROOT
+from conftest import ROOT, _locked
 
 EMU_DIR = os.path.join(ROOT, "tests", "native", "wave_emu")
 EMU_LIB = os.path.join(ROOT, "tests", "native", "libraz_emu.so")
@@ -21,7 +21,8 @@ def load(full=False):
     whole product incl. the real net kernels on emulated matrix cores (libraz_emu_full.so, a minute to build): what the fused
     tree + net kernel needs."""
     if full not in _libs:
-        r = subprocess.run(["make", "-C", EMU_DIR] + (["../libraz_emu_full.so"] if full else []), capture_output=True, text=True)
+        with _locked("emu"):
+            r = subprocess.run(["make", "-C", EMU_DIR] + (["../libraz_emu_full.so"] if full else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("wave-emulator build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
         from reversi_alpha_zero_amd import _native as N

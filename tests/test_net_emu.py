@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from conftest import ROOT
+from conftest import ROOT, _locked
 
 EMU_DIR = os.path.join(ROOT, "tests", "native", "wave_emu")
 LIB = os.path.join(ROOT, "tests", "native", "libraz_emu_net.so")
@@ -24,7 +24,8 @@ LIB = os.path.join(ROOT, "tests", "native", "libraz_emu_net.so")
 
 @pytest.fixture(scope="module")
 def lib():
-    r = subprocess.run(["make", "-C", EMU_DIR, "../libraz_emu_net.so"], capture_output=True, text=True)
+    with _locked("emu"):
+        r = subprocess.run(["make", "-C", EMU_DIR, "../libraz_emu_net.so"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     from reversi_alpha_zero_amd import _native as N
     lib = ctypes.CDLL(LIB)
