@@ -11,8 +11,10 @@ so the reference's `opt` / `eval` workers consume them unchanged.
 
 Multi-GPU: launched with torch.distributed (one rank per GPU); rank r plays global game ids
 [first + r*B, first + (r+1)*B); results do not depend on the sharding because every random draw is
-keyed by the global game id.  The only collective is a gather of finished-game records to rank 0
-(RCCL over xGMI on GPUs, gloo in the CPU tests), which then writes the files.
+keyed by the global game id.  The only collective with a payload is a gather to rank 0 (RCCL over xGMI
+on GPUs, gloo in the CPU tests): of the finished games' records when rank 0 writes every file
+(emission "rank0"), of their 32-byte summaries when a rank's id range is a whole number of files and
+every rank writes its own (emission "per_rank"; "auto" picks it where it applies).  Same files either way.
 """
 import os
 from datetime import datetime, timedelta
@@ -185,6 +187,27 @@ def gather_packed(packed, rank, world):
     return raw_from_packed(out["headers"], out["root_n"], out["summary"]), moved
 
 
+def gather_summaries(summary, rank, world):
+    """Per-rank emission (BatchedSelfPlayWorker.run, emission "per_rank"): every rank writes the files of its own id range, so
+    all that rank 0 needs from the others is what finish_game (self_play.py:219-260) reads - winner, resignation flags, whether
+    the game was a no-resign test game: the 32-byte game summaries (engine.GAME_SUMMARY), gathered in rank order = id order;
+    the records (304 B per ply) never leave their rank.  Returns (dict with bookkeep_raw's keys, bytes moved) on rank 0,
+    (None, bytes) elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from ..engine import GAME_SUMMARY
+    dev = summary.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = summary.contiguous().to(dev)
+    lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, lst, dst=0)
+    moved = t.numel() * t.element_size() * (world - 1)
+    if rank != 0:
+        return None, moved
+    sm = np.ascontiguousarray(torch.cat(lst, dim=0).cpu().numpy()).view(GAME_SUMMARY).reshape(-1)
+    return dict(n_plies=sm["n_plies"].copy(), status=sm["status"].copy(), game_id=sm["game_id"].copy(),
+                resigned=np.stack([sm["resigned_black"], sm["resigned_white"]], axis=1), enable_resign=sm["enable_resign"].copy()), moved
+
+
 def wants_fused_tree_net(setting, filters, value_fc, net_reserved, cache_log2, play):
     """Whether the games are stepped by the fused tree + net kernel (csrc/raz_engine_fused.hip).  It applies to 16-filter nets on the
     default net kernels (value_fc_size <= 1024); setting True = wherever it applies, False = never, "auto" = where it applies, the
@@ -203,7 +226,7 @@ class BatchedSelfPlayWorker:
     """SelfPlayWorker (worker/self_play.py:64-272) for a batch of concurrent games on one GPU."""
 
     def __init__(self, config, net_blob, games_in_flight=4096, seed=0, device="cuda:0", rank=0, world=1, block_games=None,
-                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24, fused_tree_net="auto"):
+                 net_kernel="auto", leaf_cache_log2="auto", leaf_cache_max_discs=24, fused_tree_net="auto", emission="auto"):
         """games_in_flight: game slots resident on the device.  block_games (per rank; default = games_in_flight): the
         number of consecutive game ids a rank plays between two gathers.  With block_games > games_in_flight the slots are
         refilled as games finish (continuous batching, SelfPlayEngine.play_continuous); the files do not depend on either
@@ -222,6 +245,13 @@ class BatchedSelfPlayWorker:
         # 16-filter nets: tree and net in ONE kernel, the game's wave evaluating its own leaves (csrc/raz_engine_fused.hip; the same
         # files bit for bit, +30 % on BASELINE configs[1]).  "auto" = wherever it applies (wants_fused_tree_net); False = the two-kernel pipeline
         self.fused_tree_net = fused_tree_net if fused_tree_net in ("auto", True, False) else bool(fused_tree_net)
+        # who writes the files of a block when world > 1 (run()): "rank0" - all records are gathered on rank 0, which writes every
+        # file; "per_rank" - every rank writes the files of its own id range and only the 32-byte game summaries are gathered (needs
+        # the ids per rank to be a multiple of nb_game_in_file - and of nb_game_in_ggf_file with GGF output - so that no file spans
+        # two ranks, and ONE file system under play_data_dir: the ranks of one node); "auto" - per_rank where that holds
+        if emission not in ("auto", "rank0", "per_rank"):
+            raise ValueError(f"emission={emission!r}: auto, rank0 or per_rank")
+        self.emission = emission
         self.seed = seed
         self.device = device
         self.rank, self.world = rank, world
@@ -461,10 +491,13 @@ class BatchedSelfPlayWorker:
             self._emit_executor, self._emit_executor_threads = cf.ThreadPoolExecutor(max_workers=want), want
         return self._emit_executor
 
-    def write_raw(self, raw, first_local_idx=1, threads=None, ahead=128):
+    def write_raw(self, raw, first_local_idx=1, threads=None, ahead=128, stamp_base=None):
         """The files of a batch of finished games (self_play.py:180-207), streamed: the JSON text of at most `ahead`
         games is in flight on the host threads while the games before them are written, so memory stays bounded by
-        nb_game_in_file + ahead games (a game's rows are ~0.7 MB of text) whatever the batch size."""
+        nb_game_in_file + ahead games (a game's rows are ~0.7 MB of text) whatever the batch size.
+        stamp_base (per-rank emission): the k-th play file and the k-th GGF file of this call are named stamp_base + k
+        microseconds instead of by this process's clock - rank 0 hands every rank of a block its own range of stamps, so the
+        directory listing sorts in game order whichever rank wrote what when."""
         from collections import deque
         pd, pc, rc = self.config.play_data, self.config.play, self.config.resource
         n = len(raw["n_plies"])
@@ -481,6 +514,13 @@ class BatchedSelfPlayWorker:
         # a finished file is WRITTEN on the host threads too (its text is 0.7 MB per game: one thread writing 64-game files kept the
         # whole worker at 1.3 GB/s on the mini net); names are stamped here, in game order, so the listing sorts as the reference's does
         writes, max_writes = deque(), 8
+        stamped = [0, 0]   # play files, GGF files named from stamp_base so far
+
+        def ggf_stamp():
+            if stamp_base is None:
+                return None
+            stamped[1] += 1
+            return stamp_base + timedelta(microseconds=stamped[1] - 1)
 
         def put(path, frags):
             with open(path, "wb") as f:
@@ -505,11 +545,15 @@ class BatchedSelfPlayWorker:
             if nrows and (not is_draw or pd.drop_draw_game_rate <= drop_draw_uniform(self.seed, int(game_ids[g]))):
                 self.buffer_json.append(text)
             if local_idx % pd.nb_game_in_file == 0 and self.buffer_json:
-                now = datetime.now()
                 last = getattr(self, "_last_file_stamp", None)
-                if last is not None and now <= last:   # (two files inside one clock tick must still sort in game order)
-                    now = last + timedelta(microseconds=1)
-                self._last_file_stamp = now
+                if stamp_base is not None:
+                    now = stamp_base + timedelta(microseconds=stamped[0])
+                    stamped[0] += 1
+                else:
+                    now = datetime.now()
+                    if last is not None and now <= last:   # (two files inside one clock tick must still sort in game order)
+                        now = last + timedelta(microseconds=1)
+                self._last_file_stamp = now if last is None else max(now, last)
                 path = os.path.join(rc.play_data_dir, rc.play_data_filename_tmpl % now.strftime("%Y%m%d-%H%M%S.%f"))
                 writes.append(ex.submit(put, path, self.buffer_json))
                 self.buffer_json = []
@@ -517,13 +561,16 @@ class BatchedSelfPlayWorker:
                 if known_files is None:
                     settle(0)   # (the listing must see this batch's first file)
                     known_files = get_game_data_filenames(rc)
-                elif not known_files or known_files[-1] != path:
+                elif not known_files or known_files[-1] < path:
                     known_files.append(path)
+                elif path not in known_files:   # (per-rank emission: files another rank wrote ahead of this one carry later stamps)
+                    import bisect
+                    bisect.insort(known_files, path)
                 settle(0 if pd.max_file_num <= max_writes else max_writes)   # never prune a file that is still being written
                 known_files = self.remove_play_data(known_files)
             if pd.enable_ggf_data:
-                self.save_ggf_data(plies_for_ggf(raw["headers"][g], raw["n_plies"][g]),
-                                   write=(local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5)
+                wr = (local_idx % pd.nb_game_in_ggf_file == 0) or local_idx <= 5
+                self.save_ggf_data(plies_for_ggf(raw["headers"][g], raw["n_plies"][g]), write=wr, stamp=ggf_stamp() if wr else None)
         settle(0)
         return paths
 
@@ -571,13 +618,13 @@ class BatchedSelfPlayWorker:
         self.buffer = []
         return path
 
-    def save_ggf_data(self, plies, write=True):
-        """self_play.py:196-207."""
+    def save_ggf_data(self, plies, write=True, stamp=None):
+        """self_play.py:196-207.  stamp: the file's name (write_raw's stamp_base) instead of this process's clock."""
         self.move_history_buffer.append(ggf_moves_of_game(plies))
         if not write:
             return None
         rc = self.config.resource
-        game_id = datetime.now().strftime("%Y%m%d-%H%M%S.%f")
+        game_id = (stamp or datetime.now()).strftime("%Y%m%d-%H%M%S.%f")
         path = os.path.join(rc.self_play_ggf_data_dir, rc.ggf_filename_tmpl % game_id)
         with open(path, "wt") as f:
             for moves in self.move_history_buffer:
@@ -664,17 +711,22 @@ class BatchedSelfPlayWorker:
                                "ranks: build the worker with that world size (rank = its rank) or destroy the group first")
         return self.world > 1 or up
 
-    def _all_ranks_state(self, state):
+    def _all_ranks_state(self, state, blocks_written=0):
         """MAX of the per-rank block state over all ranks: every rank takes the same branch before the next collective, and a
-        failure anywhere raises everywhere (the failing rank its own exception, the others a RuntimeError naming the event)."""
+        failure anywhere raises everywhere (the failing rank its own exception, the others a RuntimeError naming the event).
+        The same collective carries the MIN over ranks of `blocks_written` (per-rank emission: how many blocks' files this rank
+        has on disk) into self._blocks_written_everywhere - what rank 0 may advance data/.self-play-game-idx to."""
         worst = state
-        if self._group():
+        if not self._group():
+            self._blocks_written_everywhere = blocks_written
+        else:   # (set only from the reduced value: a collective that fails leaves the last agreed count)
             import torch
             import torch.distributed as dist
             dev = torch.device(self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
-            t = torch.tensor([state], dtype=torch.int32, device=dev)
+            t = torch.tensor([state, -int(blocks_written)], dtype=torch.int32, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            worst = int(t.item())
+            worst, least = (int(v) for v in t.tolist())
+            self._blocks_written_everywhere = -least
         if worst == self.BLOCK_FATAL:
             if self._block_error is not None:
                 raise self._block_error
@@ -699,6 +751,35 @@ class BatchedSelfPlayWorker:
         dist.broadcast(t, src=0)
         return blob if self.rank == 0 else t.cpu().numpy().tobytes()
 
+    def _ids_per_block(self):
+        """Consecutive game ids ONE rank plays between two gathers (_play_block)."""
+        continuous = self.block_games > self.games_in_flight and self._series_length() == 1
+        return self.block_games if continuous else self.games_in_flight
+
+    def _per_rank_emission(self):
+        """Whether every rank writes the files of its own id range (see __init__, `emission`).  A file holds nb_game_in_file
+        consecutive games counted from the run's first (self_play.py:186: local index % nb_game_in_file), so a rank's range is a
+        whole number of files exactly when its length is a multiple of that number; the GGF buffer likewise."""
+        if self.world <= 1 or self.emission == "rank0":
+            return False
+        pd, n = self.config.play_data, self._ids_per_block()
+        aligned = n % pd.nb_game_in_file == 0 and (not pd.enable_ggf_data or n % pd.nb_game_in_ggf_file == 0)
+        if self.emission == "per_rank" and not aligned:
+            raise ValueError(f"emission='per_rank': {n} game ids per rank and block are not a multiple of nb_game_in_file {pd.nb_game_in_file}"
+                             + (f" and nb_game_in_ggf_file {pd.nb_game_in_ggf_file}" if pd.enable_ggf_data else "") + " - a file would span two ranks")
+        return aligned
+
+    def _next_block_stamps(self, per_rank):
+        """Rank 0, per-rank emission: the first file-name stamp of a block; rank r names its files from stamp + r * (per_rank + 8)
+        microseconds on (write_raw's stamp_base; at most per_rank / nb_game_in_ggf_file + 5 files per rank), so names sort by game
+        id across ranks and blocks, and after every file an earlier block or run left."""
+        now = datetime.now()
+        for last in (getattr(self, "_block_stamps_end", None), getattr(self, "_last_file_stamp", None)):
+            if last is not None and now <= last:
+                now = last + timedelta(microseconds=1)
+        self._block_stamps_end = now + timedelta(microseconds=self.world * (per_rank + 8))
+        return now
+
     def run(self, total_games=None, reload_model=None, background_emit=True, until=None):
         """_start (self_play.py:95-137): play batches until total_games (None = forever) - or, with `until` (a time.monotonic()
         deadline; rank 0's clock decides for all ranks), until the block during which the deadline passes has been written.
@@ -709,10 +790,18 @@ class BatchedSelfPlayWorker:
         batch k are written by a host thread while batch k + 1 is played (the text of 65 536 games is ~45 GB: minutes
         of host work that would otherwise idle every GPU); data/.self-play-game-idx is advanced after a batch's files
         are on disk, and run() returns only when everything is written.
+        Per-rank emission (`emission`, _per_rank_emission): the records stay where they were played - each rank copies its own to
+        its host and writes the files of its own id range (its own PCIe link, its own host threads; rank 0 would otherwise turn
+        world x 45 GB of text per block on its own) - and the gather shrinks to the 32-byte game summaries rank 0's bookkeeping
+        reads; rank 0 adds the block's file-name stamps to the broadcast, advances data/.self-play-game-idx to a block once the
+        block-state all_reduce has shown every rank's files of it on disk, and prunes to max_file_num once more at the end (each
+        rank prunes from its own listing meanwhile, which can only leave too many files, never remove a wrong one).  The files
+        are those of the rank-0 path byte for byte (tests/test_worker_run_host.py).
         reload_model (optional): callable returning a new net blob or None, polled by RANK 0 between batches
         (api.py:117-125); its answer - and the weights - are broadcast, so every rank plays a block with the same net.
         A block during which an activation of the split-f16 trunk left the f16 range (raz_net_range_check) is discarded
         on every rank and played again on the exact-f32 kernels, which the net then stays on (include/raz.h)."""
+        import time as _tm
         import torch.distributed as dist
         from ..engine import raw_from_packed
         rc = self.config.resource
@@ -720,21 +809,52 @@ class BatchedSelfPlayWorker:
             rc.create_directories()
         game_idx = read_as_int(rc.self_play_game_idx_file) or 0
         local_idx = 1
-        writer = _BackgroundWriter(self) if (background_emit and self.rank == 0) else None
+        own_files = self._per_rank_emission()
+        writer = _BackgroundWriter(self) if (background_emit and (self.rank == 0 or own_files)) else None
+        inline = {"written": 0, "error": None}   # per-rank emission without the background thread
+        block_game_idx = []                      # rank 0, per-rank emission: the game index after each block
+
+        def written():   # blocks whose files THIS rank has on disk
+            return writer.batches if writer is not None else inline["written"]
+
+        def with_writer(state):
+            """Per-rank emission: a rank whose writer has failed says so in the block state, so that every rank stops with it (raised
+            on that rank alone, the others would wait for it in the next collective)."""
+            if own_files and state != self.BLOCK_FATAL:
+                err = inline["error"] if writer is None else (writer.take_error() if writer.failed else None)
+                if err is not None:
+                    self._block_error = err
+                    return self.BLOCK_FATAL
+            return state
+
+        def advance_game_idx():
+            done = min(self._blocks_written_everywhere, len(block_game_idx))
+            if self.rank == 0 and own_files and done > advance_game_idx.done:
+                advance_game_idx.done = done
+                self._write_game_idx(block_game_idx[done - 1])
+        advance_game_idx.done = 0
+        self._blocks_written_everywhere = 0
+
+        def agree(state):
+            """The block state all ranks share (raises on every rank if one of them failed) - and, failed or not, the game index
+            file advanced to the last block the same collective showed on disk everywhere."""
+            try:
+                return self._all_ranks_state(with_writer(state), written())
+            finally:
+                advance_game_idx()
+        finished = False
         try:
             while total_games is None or local_idx <= total_games:
                 if until is not None:
-                    import time as _time
-                    stop = [_time.monotonic() >= until]
+                    stop = [_tm.monotonic() >= until]
                     if self._group():
                         dist.broadcast_object_list(stop, src=0)
                     if stop[0]:
                         break
-                import time as _tm
                 _t0 = _tm.monotonic()
                 packed, per_rank, state = self._play_block_checked(game_idx)
                 _t1 = _tm.monotonic()
-                while self._all_ranks_state(state) == self.BLOCK_RANGE:
+                while agree(state) == self.BLOCK_RANGE:
                     if self._f32_fallback or self._series_length() > 1:
                         raise RuntimeError("the net left its numeric range on the exact-f32 kernels too" if self._f32_fallback else
                                            "an activation of the net left the f16 range of the split-operand trunk (raznet-forward-v2) "
@@ -745,7 +865,14 @@ class BatchedSelfPlayWorker:
                     self._f32_fallback = True
                     self._drop_engine(net_too=True)
                     packed, per_rank, state = self._play_block_checked(game_idx)
-                if self._group():
+                mine = None
+                if own_files:
+                    pk = packed(None)   # cut to THIS rank's longest game: nothing has to agree in shape but the summaries
+                    mine = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
+                    allraw, self.last_gather_bytes = gather_summaries(pk["summary"], self.rank, self.world)
+                    self.last_gather_backend = dist.get_backend()
+                    del pk
+                elif self._group():
                     allraw, self.last_gather_bytes = gather_packed(packed, self.rank, self.world)
                     self.last_gather_backend = dist.get_backend()
                 else:
@@ -754,11 +881,15 @@ class BatchedSelfPlayWorker:
                     del pk
                 del packed   # (holds the engine / the outbox: nothing of this block may pin device memory past this point)
                 _t2 = _tm.monotonic()
+                stamps = None
                 if self.rank == 0:
                     self.bookkeep_raw(allraw)
                     _t3 = _tm.monotonic()
                     game_idx += len(allraw["n_plies"])
-                    if writer is not None:
+                    if own_files:
+                        stamps = self._next_block_stamps(per_rank)
+                        block_game_idx.append(game_idx)
+                    elif writer is not None:
                         writer.submit(allraw, local_idx, game_idx)
                     else:
                         self.write_raw(allraw, local_idx)
@@ -769,9 +900,21 @@ class BatchedSelfPlayWorker:
                     for k_, v_ in (("play", _t1 - _t0), ("gather_and_copy", _t2 - _t1), ("bookkeeping", _t3 - _t2), ("handing_to_the_writer", _tm.monotonic() - _t3)):
                         acc[k_] += v_
                 if self._group():
-                    t = [game_idx, self.config.play.resign_threshold]
+                    t = [game_idx, self.config.play.resign_threshold, stamps]
                     dist.broadcast_object_list(t, src=0)
-                    game_idx, self.config.play.resign_threshold = t
+                    game_idx, self.config.play.resign_threshold, stamps = t
+                if own_files:
+                    first_local = local_idx + self.rank * per_rank
+                    base = stamps + timedelta(microseconds=self.rank * (per_rank + 8))
+                    if writer is not None:
+                        writer.submit(mine, first_local, None, quiet=True, stamp_base=base)
+                    elif inline["error"] is None:
+                        try:
+                            self.write_raw(mine, first_local, stamp_base=base)
+                            inline["written"] += 1
+                        except Exception as ex:   # noqa: BLE001 - agreed on by all ranks in the next block state
+                            inline["error"] = RuntimeError(f"writing play data failed: {ex!r}")
+                    del mine
                 local_idx += per_rank * self.world
                 if reload_model is not None:
                     blob = reload_model() if self.rank == 0 else None   # rank 0 decides; the digest of ITS read is what counts
@@ -779,12 +922,18 @@ class BatchedSelfPlayWorker:
                         blob = self._broadcast_blob(blob)
                     if blob is not None:
                         self.set_net_blob(blob)
+            finished = True
         finally:
             if writer is not None:
                 try:
-                    writer.close()
+                    writer.close(quiet=own_files)
                 finally:
                     self.last_writer_busy_seconds, self.last_writer_batches = writer.busy_seconds, writer.batches
+        if own_files and finished:
+            # every rank's writer is closed: agree that all files are on disk (or fail together), then rank 0 finishes the run
+            agree(self.BLOCK_OK)
+            if self.rank == 0:
+                self.remove_play_data()
 
     def _write_game_idx(self, game_idx):
         with open(self.config.resource.self_play_game_idx_file, "wt") as f:
@@ -827,12 +976,13 @@ class _BackgroundWriter:
                 return
             if self.failed:
                 continue   # keep draining so that submit() never blocks forever
-            raw, local_idx, game_idx = item
+            raw, local_idx, game_idx, kw = item
             try:
                 import time as _time
                 t0 = _time.monotonic()
-                self.worker.write_raw(raw, local_idx)
-                self.worker._write_game_idx(game_idx)
+                self.worker.write_raw(raw, local_idx, **kw)
+                if game_idx is not None:   # (per-rank emission: rank 0 advances the index once EVERY rank has written the block)
+                    self.worker._write_game_idx(game_idx)
                 self.busy_seconds += _time.monotonic() - t0
                 self.batches += 1
             except BaseException as e:   # noqa: B902 - reported to the caller
@@ -849,14 +999,26 @@ class _BackgroundWriter:
         if self.failed and not (closing and self._reported):   # (close() after the error was raised: nothing new to say)
             raise RuntimeError("writing play data failed earlier: the writer is stopped")
 
-    def submit(self, raw, local_idx, game_idx):
-        self._check()
-        self.queue.put((raw, local_idx, game_idx))
+    def submit(self, raw, local_idx, game_idx, quiet=False, **write_raw_kw):
+        """quiet (ranks of a process group): a failure is not raised here, on this rank alone - the caller folds `failed` into the
+        block state every rank agrees on (take_error) - and a batch submitted to a failed writer is dropped like any other."""
+        if not quiet:
+            self._check()
+        self.queue.put((raw, local_idx, game_idx, write_raw_kw))
 
-    def close(self):
+    def take_error(self):
+        """The thread's exception as the RuntimeError _check would raise (None if the writer is healthy), without raising."""
+        try:
+            self._check()
+        except RuntimeError as ex:
+            return ex
+        return None
+
+    def close(self, quiet=False):
         self.queue.put(None)
         self.thread.join()
-        self._check(closing=True)
+        if not quiet:
+            self._check(closing=True)
 
 
 # ---- the single collective: finished-game records -> rank 0 ------------------------------------------
@@ -975,9 +1137,21 @@ def try_reload_model(config, model):
         return False
 
 
-def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None, fused_tree_net="auto"):
+def whole_files_block(config, block_games):
+    """block_games rounded up to a whole number of play files and GGF files (nb_game_in_file, nb_game_in_ggf_file), so that under
+    several ranks every rank writes the files of its own id range (BatchedSelfPlayWorker._per_rank_emission)."""
+    import math
+    pd = config.play_data
+    unit = max(1, int(pd.nb_game_in_file))
+    if pd.enable_ggf_data:
+        unit = math.lcm(unit, max(1, int(pd.nb_game_in_ggf_file)))
+    return -(-int(block_games) // unit) * unit
+
+
+def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None, fused_tree_net="auto", emission="auto"):
     """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU.  fused_tree_net: see
-    BatchedSelfPlayWorker (16-filter nets: tree and net in one kernel; opt-in)."""
+    BatchedSelfPlayWorker (16-filter nets: tree and net in one kernel; opt-in).  block_games (ids per rank between two gathers):
+    default 4 games per slot, under several ranks rounded up to whole files (whole_files_block) so that each rank writes its own."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -1002,8 +1176,11 @@ def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0,
         def reload_model():
             return model.model.to_blob() if try_reload_model(config, model) else None
     B = games_in_flight or 4096
+    if not block_games:
+        block_games = 4 * B                  # continuous batching: 4 games per slot between two gathers
+        if world > 1 and emission != "rank0":
+            block_games = whole_files_block(config, block_games)
     w = BatchedSelfPlayWorker(config, net_blob, B, seed=seed, device=f"cuda:{local}", rank=rank, world=world,
-                              block_games=block_games or 4 * B,   # continuous batching: 4 games per slot between two gathers
-                              fused_tree_net=fused_tree_net)
+                              block_games=block_games, fused_tree_net=fused_tree_net, emission=emission)
     w.run(total_games, reload_model=reload_model)
     return w

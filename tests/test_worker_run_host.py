@@ -77,6 +77,12 @@ def make_stub_worker(cfg, games_in_flight, rank=0, world=1, seed=4):
     return StubWorker(cfg, b"", games_in_flight=games_in_flight, seed=seed, device="cpu", rank=rank, world=world)
 
 
+def say(*words):
+    """One line of a rank's report as ONE write (two ranks share the launcher's stdout; print() writes its pieces separately)."""
+    sys.stdout.write(" ".join(str(w) for w in words) + "\n")
+    sys.stdout.flush()
+
+
 def make_config(root):
     from reversi_alpha_zero_amd.config import Config
     cfg = Config()
@@ -252,7 +258,7 @@ _RUN2_SCRIPT = r'''
 import os, sys, pathlib
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
 import torch.distributed as dist
-from test_worker_run_host import make_config, make_stub_worker
+from test_worker_run_host import make_config, make_stub_worker, say
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = make_config(pathlib.Path({out!r}))
@@ -265,7 +271,7 @@ def reload_model():   # only rank 0 may be asked; what it answers is what BOTH r
     return bytes(range(256)) * 40 if len(polls) == 2 else None
 w.run(total_games=200, reload_model=reload_model)
 assert loaded == [bytes(range(256)) * 40], (rank, len(loaded))
-print("RANK", rank, "THRESHOLDS", w.thresholds_seen, cfg.play.resign_threshold)
+say("RANK", rank, "THRESHOLDS", w.thresholds_seen, cfg.play.resign_threshold)
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -296,7 +302,7 @@ _FATAL_SCRIPT = r'''
 import os, sys, pathlib
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
 import torch.distributed as dist
-from test_worker_run_host import make_config, make_stub_worker
+from test_worker_run_host import make_config, make_stub_worker, say
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = make_config(pathlib.Path({out!r}))
@@ -309,9 +315,9 @@ def play(first_game_idx=0, device_records=False):
 w.play_batch_raw = play
 try:
     w.run(total_games=60)
-    print("RANK", rank, "RETURNED")
+    say("RANK", rank, "RETURNED")
 except RuntimeError as ex:
-    print("RANK", rank, "RAISED", str(ex)[:60])
+    say("RANK", rank, "RAISED", str(ex)[:60])
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -336,3 +342,134 @@ def test_a_fatal_error_on_one_rank_raises_on_every_rank(tmp_path):
     w.play_batch_raw = boom
     with pytest.raises(RuntimeError, match="records full"):
         w.run(total_games=10)
+
+
+# ---- per-rank emission: every rank writes the files of its own id range -------------------------------------------------------
+_PER_RANK_SCRIPT = r'''
+import os, sys, pathlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch.distributed as dist
+from test_worker_run_host import make_config, make_stub_worker, say
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = make_config(pathlib.Path({out!r}))
+cfg.play_data.update(dict(nb_game_in_file=5, nb_game_in_ggf_file=5, max_file_num={max_files}))
+w = make_stub_worker(cfg, games_in_flight=25, rank=rank, world=world)
+w.emission = {emission!r}
+fail_at = {fail_at}
+if fail_at and rank == 1:
+    real, calls = w.write_raw, []
+    def failing(raw, first_local_idx=1, threads=None, ahead=128, stamp_base=None):
+        calls.append(first_local_idx)
+        if len(calls) == fail_at:
+            import time; time.sleep(1.5)    # (rank 0's writer has the first block on disk by now: what the index may advance to)
+            raise OSError("disk full")
+        return real(raw, first_local_idx, threads, ahead, stamp_base)
+    w.write_raw = failing
+try:
+    w.run(total_games=200, background_emit={background})
+    say("RANK", rank, "RETURNED")
+except RuntimeError as ex:
+    say("RANK", rank, "RAISED", str(ex)[:70].replace("\n", " "))
+say("RANK", rank, "OWNFILES", int(w._per_rank_emission()), "BYTES", getattr(w, "bytes_written", 0), "GATHER", getattr(w, "last_gather_bytes", None))
+say("RANK", rank, "THRESHOLDS", w.thresholds_seen, cfg.play.resign_threshold)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _per_rank_run(tmp_path, tag, port, emission="auto", background=True, max_files=1000, fail_at=0):
+    script = tmp_path / f"{tag}.py"
+    script.write_text(_PER_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path / tag), emission=emission, background=background, max_files=max_files, fail_at=fail_at))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def _one_rank_reference(tmp_path, max_files=1000):
+    cfg = make_config(tmp_path / "one")
+    cfg.play_data.update(dict(nb_game_in_file=5, nb_game_in_ggf_file=5, max_file_num=max_files))
+    w = make_stub_worker(cfg, games_in_flight=50)
+    w.run(total_games=200)
+    return outputs(cfg), f"{w.thresholds_seen} {cfg.play.resign_threshold}"
+
+
+@pytest.mark.parametrize("background", [True, False])
+def test_per_rank_emission_writes_the_files_of_the_rank0_path(tmp_path, background):
+    """2 ranks x 25 ids per block with 5 games per file: "auto" lets every rank write the files of its own id range (only the
+    32-byte summaries are gathered); the directory - play files and GGF files in name order, the game index - is what 1 rank x
+    50 ids writes and what the same two ranks write with everything gathered on rank 0, byte for byte; both ranks play every
+    block under the same broadcast threshold."""
+    out = _per_rank_run(tmp_path, "two", 29561 + int(background), background=background)
+    assert "RANK 0 RETURNED" in out and "RANK 1 RETURNED" in out, out[-1500:]
+    own = dict(re.findall(r"RANK (\d) OWNFILES (\d) BYTES \d+ GATHER \d+", out))
+    assert own == {"0": "1", "1": "1"}, out[-1500:]
+    written = {k: int(v) for k, v in re.findall(r"RANK (\d) OWNFILES \d BYTES (\d+)", out)}
+    assert written["0"] > 10000 and written["1"] > 10000                     # both ranks wrote files
+    moved = {int(v) for v in re.findall(r"GATHER (\d+)", out)}
+    assert moved == {25 * 32}                                                 # 32 B per game crossed, nothing else
+    thr = dict(re.findall(r"RANK (\d) THRESHOLDS (\[[^\]]*\] \S+)", out))
+    one, thr_one = _one_rank_reference(tmp_path)
+    two = outputs(make_config(tmp_path / "two"))
+    assert one[2] == two[2] == "200" and len(one[0]) >= 30 and len(one[1]) >= 40
+    assert [hashlib.sha256(b).hexdigest() for b in one[0]] == [hashlib.sha256(b).hexdigest() for b in two[0]] and one[1] == two[1]
+    assert thr["0"] == thr["1"] == thr_one
+    if background:   # and the rank-0 path on the same two ranks
+        out0 = _per_rank_run(tmp_path, "rank0", 29565, emission="rank0")
+        assert dict(re.findall(r"RANK (\d) OWNFILES (\d)", out0)) == {"0": "0", "1": "0"}
+        r0 = outputs(make_config(tmp_path / "rank0"))
+        assert r0[0] == two[0] and r0[1] == two[1] and r0[2] == "200"
+
+
+def test_per_rank_emission_keeps_the_newest_max_file_num_files(tmp_path):
+    """max_file_num with two ranks pruning from their own listings: what is left at the end is exactly the newest files of the
+    one-rank run (same contents, same order)."""
+    out = _per_rank_run(tmp_path, "two", 29567, max_files=9)
+    assert "RANK 0 RETURNED" in out and "RANK 1 RETURNED" in out, out[-1500:]
+    one, _ = _one_rank_reference(tmp_path, max_files=9)
+    two = outputs(make_config(tmp_path / "two"))
+    assert len(two[0]) == 9 and two[0] == one[0]
+
+
+def test_per_rank_emission_a_failed_writer_stops_every_rank(tmp_path):
+    """Rank 1's writer fails on its second block: the failure travels in the next block-state all_reduce, BOTH ranks raise (no
+    rank is left waiting in a collective), and data/.self-play-game-idx stays at the last block every rank has on disk (the first:
+    rank 0 has written more by then, rank 1 never will)."""
+    out = _per_rank_run(tmp_path, "fail", 29569, fail_at=2)
+    assert "RANK 1 RAISED writing play data failed" in out and "disk full" in out, out[-1500:]
+    assert "RANK 0 RAISED rank 0: another rank failed" in out, out[-1500:]
+    idx = open(make_config(tmp_path / "fail").resource.self_play_game_idx_file).read()
+    assert idx == "50", idx
+
+
+def test_per_rank_emission_needs_whole_files_per_rank(tmp_path):
+    """A rank's id range must be a whole number of files: "auto" falls back to the rank-0 path, "per_rank" says why it cannot."""
+    cfg = make_config(tmp_path / "x")                     # 3 games per file, 4 per GGF file
+    w = make_stub_worker(cfg, games_in_flight=25, rank=0, world=2)
+    assert w._per_rank_emission() is False
+    w.emission = "per_rank"
+    with pytest.raises(ValueError, match="would span two ranks"):
+        w._per_rank_emission()
+    w = make_stub_worker(cfg, games_in_flight=24, rank=0, world=2)
+    assert w._per_rank_emission() is True
+    assert make_stub_worker(cfg, games_in_flight=24, rank=0, world=1)._per_rank_emission() is False
+    from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+    with pytest.raises(ValueError, match="emission"):
+        BatchedSelfPlayWorker(cfg, b"", emission="everyone")
+
+
+def test_whole_files_block_rounds_up_to_the_file_sizes(tmp_path):
+    """start()'s default block under several ranks: a whole number of play files AND GGF files (ch5.yml: 1 and the default 100;
+    mini.yml: 2 and 2), so that every rank writes its own files."""
+    from reversi_alpha_zero_amd.worker.self_play import whole_files_block
+    cfg = make_config(tmp_path / "x")
+    cfg.play_data.update(dict(nb_game_in_file=1, nb_game_in_ggf_file=100, enable_ggf_data=True))
+    assert whole_files_block(cfg, 16384) == 16400 and whole_files_block(cfg, 16400) == 16400
+    cfg.play_data.enable_ggf_data = False
+    assert whole_files_block(cfg, 16384) == 16384
+    cfg.play_data.update(dict(nb_game_in_file=6, nb_game_in_ggf_file=4, enable_ggf_data=True))
+    assert whole_files_block(cfg, 25) == 36
+    w = make_stub_worker(cfg, games_in_flight=36, rank=1, world=2)
+    assert w._per_rank_emission() is True
