@@ -1,0 +1,112 @@
+"""CPU: BatchedSelfPlayWorker.run() - the product's worker, unchanged - over the tree kernels on the WAVE EMULATOR (real games:
+real records, resignations, no-resign test games, draws), with continuous batching, under one rank and under two gloo ranks in
+both emission modes.  The stub-engine tests (tests/test_worker_run_host.py) cover the control flow on prepared records; this runs
+what the engine really hands over - the id-ordered outbox of raz_engine_harvest, cut to each rank's longest game - through
+gather / bookkeeping / broadcast / native row emitter, and compares the directories byte for byte.  The GPU tests of record:
+tests/test_multirank_gpu.py (rank-0 emission; per-rank emission has not run on hardware)."""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch, torch.distributed as dist
+from emu_util import EmuEngine
+from oracle_util import load_mcts_golden, golden_net_blob
+from reversi_alpha_zero_amd.config import Config
+from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+gold = load_mcts_golden()
+g0 = next(g for g in gold["games"] if g["variant"] == "agz_resign")
+cfg = Config()
+cfg.play.update(g0["resolved_play"])
+cfg.play_data.update(g0["resolved_play_data"])
+cfg.play.schedule_of_simulation_num_per_move = [(0, 6)]
+cfg.play.resign_threshold, cfg.play.disable_resignation_rate = -0.2, 0.5     # resignations AND test games in a small block
+cfg.play.resign_threshold_delta, cfg.play.false_positive_threshold = 0.05, 0.0
+cfg.play_data.update(dict(nb_game_in_file=2, nb_game_in_ggf_file=2, enable_ggf_data=True, drop_draw_game_rate=0.5, max_file_num=1000))
+rc, out = cfg.resource, {out!r}
+rc.data_dir = out; rc.play_data_dir = os.path.join(out, "play_data"); rc.self_play_ggf_data_dir = os.path.join(out, "ggf")
+rc.force_simulation_num_file = os.path.join(out, ".force-sim"); rc.self_play_game_idx_file = os.path.join(out, ".self-play-game-idx")
+rc.create_directories = lambda: [os.makedirs(d, exist_ok=True) for d in (rc.play_data_dir, rc.self_play_ggf_data_dir)]
+
+class Net:
+    filters = 16
+    def range_ok(self):
+        return True
+
+class Engine:
+    """What play_block_continuous needs of SelfPlayEngine, on the emulated kernels (a new engine per block: built from the config,
+    it plays under the threshold the block was started with, as raz_engine_set_resign_threshold makes the device engine do)."""
+    def __init__(self, worker, sims):
+        self.e = EmuEngine(worker.config, worker.net_blob, worker.games_in_flight, seed=worker.seed, sims_hint=sims, record_root_w=False)
+    def play_continuous(self, first, total, sims_of, chunk=64):
+        ob = self.e.play_continuous(first, total, sims_of(first), chunk=8)
+        assert ob["done"].all()
+        return {{k: torch.from_numpy(ob[k]) for k in ("headers", "root_n", "summary")}}, {{"gc_runs": self.e.gc_runs}}
+
+class EmuWorker(BatchedSelfPlayWorker):
+    def _get_engine(self, max_sims):
+        self._net = Net()
+        return Engine(self, max_sims)
+
+w = EmuWorker(cfg, golden_net_blob(gold["net"]), games_in_flight=2, seed=21, device="cpu", rank=rank, world=world,
+              block_games={block}, emission={emission!r})
+orig = w.check_and_update_resignation_threshold
+def check():   # make every block step the threshold (>= 100 test games in the reference; scaled down for the test)
+    if w.resign_test_game_count >= 2:
+        w.resign_test_game_count += 100
+        orig()
+w.check_and_update_resignation_threshold = check
+w.run(total_games={total})
+sys.stdout.write(f"RANK {{rank}} OWNFILES {{int(w._per_rank_emission())}} BYTES {{getattr(w, 'bytes_written', 0)}} THRESHOLD {{cfg.play.resign_threshold!r}}\n")
+if dist.is_initialized():
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run(tmp_path, tag, world, block, total, emission="auto", port=29571):
+    out = tmp_path / tag
+    out.mkdir()
+    script = tmp_path / f"{tag}.py"
+    script.write_text(_SCRIPT.format(root=ROOT, out=str(out), block=block, total=total, emission=emission))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(script)] if world == 1 else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+        "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    play = [open(out / "play_data" / f, "rb").read() for f in sorted(os.listdir(out / "play_data"))]
+    ggf = [re.sub(r"DT\[[^\]]*\]", "DT[]", open(out / "ggf" / f).read()) for f in sorted(os.listdir(out / "ggf"))]
+    info = {m[0]: m[1:] for m in re.findall(r"RANK (\d) OWNFILES (\d) BYTES (\d+) THRESHOLD (\S+)", r.stdout)}
+    return play, ggf, open(out / ".self-play-game-idx").read(), info
+
+
+def test_worker_on_emulated_kernels_two_ranks_both_emission_modes_equal_one_rank(tmp_path):
+    """2 blocks of 8 game ids, 6 sims/move, 2 slots per rank with continuous batching (4 or 8 ids through 2 slots): one rank; two
+    ranks with every rank writing its own files (auto: 4 ids = 2 files per rank and block); two ranks with rank 0 writing all.
+    play_*.json, GGF files (date aside), game index and the final threshold - stepped after the first block, so the second block's
+    games depend on the broadcast - are identical."""
+    one = _run(tmp_path, "one", 1, 8, 16)
+    own = _run(tmp_path, "own", 2, 4, 16, port=29571)
+    r0 = _run(tmp_path, "rank0", 2, 4, 16, emission="rank0", port=29573)
+    assert {k: v[0] for k, v in own[3].items()} == {"0": "1", "1": "1"} and {k: v[0] for k, v in r0[3].items()} == {"0": "0", "1": "0"}
+    assert int(own[3]["1"][1]) > 10000 and int(r0[3]["1"][1]) == 0          # rank 1 wrote files only in the first mode
+    assert len(one[0]) >= 6 and len(one[1]) >= 8
+    sha = lambda files: [hashlib.sha256(b).hexdigest() for b in files]
+    assert sha(one[0]) == sha(own[0]) == sha(r0[0])
+    assert one[1] == own[1] == r0[1]
+    assert one[2] == own[2] == r0[2] == "16"
+    thr = {v[2] for run in (one, own, r0) for v in run[3].values()}
+    assert len(thr) == 1 and thr != {repr(-0.2)}, thr                         # everyone ended under the same, moved, threshold
