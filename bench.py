@@ -1341,6 +1341,10 @@ def main():
     ap.add_argument("--no-whole-games", action="store_true", help="skip the fixed-window leg on the headline configuration (~2.5 min)")
     ap.add_argument("--window-seconds", type=float, default=120.0, help="length of the fixed window the headline configuration is played for")
     ap.add_argument("--legs", default=None, help="comma-separated keys: run only these extra legs (e.g. ch5_yml_as_shipped,config1_4096x200_mini)")
+    ap.add_argument("--time-budget", type=float, default=600.0,
+                    help="seconds: an extra leg is not STARTED when the run's elapsed time plus the leg's nominal duration would pass this "
+                         "(the default run takes ~7 min on an MI355X box; on a slower box legs are dropped from the end, each with a note, "
+                         "instead of the line arriving late or not at all)")
     ap.add_argument("--full-out", default=None, help="where the full document goes (default: gpurun_out/bench_full.json if gpurun_out/ exists, else ./bench_full.json)")
     args = ap.parse_args()
 
@@ -1444,8 +1448,15 @@ def main():
                     ("worker_end_to_end_config1", lambda: worker_end_to_end_leg(dev, args)),
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             only = set(args.legs.split(",")) if args.legs else None
+            # nominal seconds of a leg on an MI355X box (profiles/r5/bench_r5_default_run_*: engine construction included)
+            nominal = {"worker_end_to_end_config1": 75.0, "config5_8192x3200_agz": 35.0, "ch5_yml_as_shipped": 30.0, "headline_on_exact_f32_kernels": 20.0,
+                       "config1_mini_yml_as_shipped_continuous_batching": 20.0}
             for key, leg in legs:
                 if only is not None and key not in only:
+                    continue
+                elapsed = time.perf_counter() - T_MAIN
+                if only is None and elapsed + nominal.get(key, 10.0) > args.time_budget:
+                    out[key] = {"error": f"not run: {elapsed:.0f} s into the run, --time-budget {args.time_budget:.0f} s"}
                     continue
                 gc.collect()
                 torch.cuda.empty_cache()
