@@ -3,7 +3,7 @@ real records, resignations, no-resign test games, draws), with continuous batchi
 both emission modes.  The stub-engine tests (tests/test_worker_run_host.py) cover the control flow on prepared records; this runs
 what the engine really hands over - the id-ordered outbox of raz_engine_harvest, cut to each rank's longest game - through
 gather / bookkeeping / broadcast / native row emitter, and compares the directories byte for byte.  The GPU tests of record:
-tests/test_multirank_gpu.py (rank-0 emission; per-rank emission has not run on hardware)."""
+tests/test_multirank_gpu.py (rank-0 emission) and tests/test_zzz_per_rank_emission_gpu.py (per-rank emission)."""
 import hashlib
 import os
 import re

@@ -1,8 +1,9 @@
 """GPU: per-rank emission (BatchedSelfPlayWorker.run, emission "auto" with a rank's id range a whole number of files) on the real
 engine - two ranks share cuda:0 and rendezvous over gloo, each copies its OWN packed records from HBM and writes its own files,
-only the 32-byte summaries are gathered.  This path has never run on hardware in the build container (no GPU there; covered by
-tests/test_worker_emu.py on the wave emulator and tests/test_worker_run_host.py on a stub engine): the file sorts last so that
-the tests of record before it run whatever happens here."""
+only the 32-byte summaries are gathered.  (Written when no GPU minutes seemed left, hence sorted last - so that the tests of
+record before it would run whatever happened here; it has since passed on an MI355X:
+profiles/r5/pytest_gpu_per_rank_emission_two_ranks_on_one_gpu.log.  CPU coverage of the same path: tests/test_worker_emu.py on
+the wave emulator, tests/test_worker_run_host.py on a stub engine.)"""
 import re
 
 import pytest
