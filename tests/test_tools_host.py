@@ -126,3 +126,19 @@ def test_bench_line_is_compact_and_keeps_the_contract():
     assert line["config5_8192x3200_agz"] == {"error": "RuntimeError('x')"} and line["bitboard_sweep"]["k_step"]["frac"] == 0.63
     assert line["full_document"] == "gpurun_out/bench_full.json"
 
+
+
+def test_train_then_check_v2_runs_end_to_end_on_a_small_net(tmp_path):
+    """tools/train_then_check_v2.py (the evidence file profiles/r5/net_v2_on_a_cpu_trained_256x10_net_wave_emulator.json) at a size
+    a test can afford: oracle self-play rows, a few SGD steps of a 128-filter net, then the product's v1 and v2 kernel sources on
+    the wave emulator against fp32 torch - within the path's tolerance, range flag clear, weights really moved."""
+    out = tmp_path / "acc.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_then_check_v2.py"), "--games", "24", "--sims", "8", "--steps", "12",
+                        "--net", "128,1,32", "--emu-positions", "3", "--torch-positions", "64", "--threads", "2", "--out", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.load(open(out))
+    e = d["emulated_kernels"]
+    assert d["within_tolerance"] is True and e["v2_range_flag"] is False and e["positions"] == 3
+    assert max(e["v1_vs_fp32_torch"]["policy"]["max"], e["v1_vs_fp32_torch"]["value"]["max"]) <= 1e-5
+    assert d["what_training_changed"]["weights_moved_from_init_rel_l2"] > 0 and d["training"]["rows"] > 200
