@@ -72,8 +72,11 @@ def planes_of(own, enemy):
 
 
 def emu_lib():
+    import fcntl
     emu_dir = os.path.join(ROOT, "tests", "native", "wave_emu")
-    r = subprocess.run(["make", "-C", emu_dir, "../libraz_emu_net.so"], capture_output=True, text=True)
+    with open(os.path.join(ROOT, "tests", "native", ".emu.lock"), "w") as lock:   # (the tests' lock: one build of the emulator libraries at a time)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-C", emu_dir, "../libraz_emu_net.so"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stdout[-2000:] + r.stderr[-2000:])
     from reversi_alpha_zero_amd import _native as N
