@@ -448,45 +448,47 @@ class SelfPlayEngine:
         tuned = solver_on and not ((int(self.cfg.reserved) >> 24) & 0xf)
         if tuned:
             self.set_solver_pool_every(CONTINUOUS_SOLVER_POOL_EVERY)
-        sims0 = np.array([sims_of(first_game_id + i) if i < n0 else 1 for i in range(B)], dtype=np.uint32)
-        if resign_threshold_of is not None:
-            self.set_resign_threshold(resign_threshold_of(first_game_id))
-        self.start(first_game_id, sims0, n_active=n0)
-        if resign_threshold_of is not None and len({resign_threshold_of(first_game_id + i) for i in range(n0)}) > 1:
-            raise ValueError("the first batch of ids must share one resign threshold (raz_engine_start takes the engine's run-time value)")
-        outbox = self.new_outbox(first_game_id, total_games)
-        nxt, done, steps, cap = first_game_id + n0, 0, 0, int(self.cfg.nodes_per_game)
-        end = first_game_id + total_games
-        self.gc_runs = 0
-        import time
-        host = {"steps_and_stats": 0.0, "harvest": 0.0}
-        while done < total_games:
-            t0 = time.perf_counter()
-            self.step(chunk)
-            steps += chunk
+        try:
+            sims0 = np.array([sims_of(first_game_id + i) if i < n0 else 1 for i in range(B)], dtype=np.uint32)
+            if resign_threshold_of is not None:
+                self.set_resign_threshold(resign_threshold_of(first_game_id))
+            self.start(first_game_id, sims0, n_active=n0)
+            if resign_threshold_of is not None and len({resign_threshold_of(first_game_id + i) for i in range(n0)}) > 1:
+                raise ValueError("the first batch of ids must share one resign threshold (raz_engine_start takes the engine's run-time value)")
+            outbox = self.new_outbox(first_game_id, total_games)
+            nxt, done, steps, cap = first_game_id + n0, 0, 0, int(self.cfg.nodes_per_game)
+            end = first_game_id + total_games
+            self.gc_runs = 0
+            import time
+            host = {"steps_and_stats": 0.0, "harvest": 0.0}
+            while done < total_games:
+                t0 = time.perf_counter()
+                self.step(chunk)
+                steps += chunk
+                st = self.stats()
+                if self.pool_nearly_full(st, chunk):
+                    self.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
+                    self.gc_runs += 1
+                t1 = time.perf_counter()
+                k = min(B, end - nxt)
+                ids = range(nxt, nxt + k)
+                h, r, skipped, playing = self.harvest(outbox, nxt, [sims_of(i) for i in ids],
+                                                      [resign_threshold_of(i) for i in ids] if resign_threshold_of else None)
+                assert skipped == 0
+                nxt += r
+                done += h
+                host["steps_and_stats"] += t1 - t0
+                host["harvest"] += time.perf_counter() - t1
+                if on_chunk is not None:
+                    on_chunk(steps, done, st)
+                if steps >= max_steps:
+                    raise RuntimeError("engine did not finish within max_steps")
             st = self.stats()
-            if self.pool_nearly_full(st, chunk):
-                self.gc(threshold=min(cap // 4, st["max_pool_used"] // 2))
-                self.gc_runs += 1
-            t1 = time.perf_counter()
-            k = min(B, end - nxt)
-            ids = range(nxt, nxt + k)
-            h, r, skipped, playing = self.harvest(outbox, nxt, [sims_of(i) for i in ids],
-                                                  [resign_threshold_of(i) for i in ids] if resign_threshold_of else None)
-            assert skipped == 0
-            nxt += r
-            done += h
-            host["steps_and_stats"] += t1 - t0
-            host["harvest"] += time.perf_counter() - t1
-            if on_chunk is not None:
-                on_chunk(steps, done, st)
-            if steps >= max_steps:
-                raise RuntimeError("engine did not finish within max_steps")
-        st = self.stats()
-        st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs,
-                  seconds=host)
-        if tuned:
-            self.set_solver_pool_every(0)
+            st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs,
+                      seconds=host)
+        finally:
+            if tuned:   # (also when a step raised: the engine may be used again by the caller)
+                self.set_solver_pool_every(0)
         return outbox, st
 
     def gc(self, threshold=0):
