@@ -141,3 +141,19 @@ def test_valu_shaped_bitboard_ops_equal_the_reference_shaped_ones(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe, "1500000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "BBV_OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md's table of entry points covers the whole header (names may be abbreviated as `raz_engine_create/start/...`)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "raz.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(raz_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 50
+    slashed = set()
+    for m in re.finditer(r"`(raz_[a-z0-9_]+?)_([a-z0-9_]+(?:\s*/\s*_?[a-z0-9_]+)+)`", doc):   # `raz_engine_create/start/step` or `raz_engine_create / _start / _step`
+        prefix = m.group(1)
+        for part in re.split(r"\s*/\s*", m.group(2)):
+            slashed.add(prefix + "_" + part.lstrip("_"))
+    missing = [n for n in names if n not in doc and n not in slashed]
+    assert not missing, missing
