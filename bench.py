@@ -40,6 +40,10 @@ byte-identical (SURVEY 8(d) Config 4's acceptance).
 `config1_mini_yml_as_shipped*`: mini.yml's play section with no declared override (thinking_loop 2, 4 simulations in flight, solver
 from turn 50) on both kernel forms - the solver-bound regime.
 
+`worker_end_to_end_config1`: BatchedSelfPlayWorker.run() itself for 60 s (files written, RCCL group of one rank).  The default run
+takes ~7 min on an MI355X box; --time-budget (600 s) keeps a slower box from delivering the line late: an extra leg whose nominal
+duration no longer fits is not started and says so.
+
 Environment (test rigs and profiling runs only; the driver's form uses none): RAZ_BENCH_SHARED_GPU=1 (N ranks on the visible GPUs over
 gloo), RAZ_BENCH_NCCL_WORLD1=1 (the N > 1 path on an RCCL group of one rank), RAZ_BENCH_SOLVER_BUDGET=<iterations> (ch5_yml_as_shipped:
 the per-launch solver budget), RAZ_BENCH_MINI_SHIPPED=1 (--net mini: the headline leg on mini.yml's play section as shipped).
