@@ -367,6 +367,46 @@ def sweep_traffic():
         return json.load(f)
 
 
+def net_check_timed_leaves(eng, net, module, blob, dev, n_f64=256):
+    """the net's VALUES on the timed batch.  The parity spot checks feed the oracle with the device net's outputs, so
+    they pin the search given the net, not the net.  Here every row of the leaf exchange that the LAST timed step's forward evaluated
+    (include/raz.h raz_engine_device_ptr 10-14) - the answers the timed tree kernels consumed, produced by the timed kernel (the
+    split-f16 trunk, raznet-forward-v2) - is evaluated again by the exact-f32 kernels (raznet-forward-v1: bitwise the CPU oracle's
+    chains) on the same positions; a sample of n_f64 of them also by the fp32 torch graph and by the graph in f64 (tools/trained_net.py
+    F64Graph).  Raises when v2 is further than the north star's 1e-5 from v1 on any policy entry or value.  Untimed."""
+    import torch
+    from reversi_alpha_zero_amd.engine import DeviceNet
+    from trained_net import F64Graph, planes_of
+    t0 = time.perf_counter()
+    ex = eng.leaf_exchange()
+    idx = ex["active"].nonzero()[:, 0]
+    own, enemy = ex["own"][idx].contiguous(), ex["enemy"][idx].contiguous()
+    p_run, v_run = ex["policy"][idx].clone(), ex["value"][idx].clone()
+    exact = DeviceNet(blob, dev, kernel="f32")
+    p1, v1 = exact.predict_bitboards(own, enemy)
+    dp, dv = float((p_run - p1).abs().max()), float((v_run - v1).abs().max())
+    pick = torch.linspace(0, idx.numel() - 1, min(n_f64, idx.numel()), device=dev).long()
+    planes = planes_of(own[pick], enemy[pick])
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    with torch.no_grad():
+        pt, vt = module.to(dev).eval()(planes)
+    p64, v64 = F64Graph(module, dev)(planes)
+    module.cpu()
+    worst = lambda p, v: {"policy": float((p.double() - p64).abs().max()), "value": float((v.double() - v64).abs().max())}
+    out = {"n": int(idx.numel()), "max_abs_dp": dp, "max_abs_dv": dv, "tolerance": 1e-5,
+           "what": "every leaf the last TIMED step's forward evaluated: the answers in the leaf exchange (timed kernel: " + str(net.kernel_name) +
+                   ") against the exact-f32 kernels (raznet-forward-v1) on the same positions, max |d policy| and max |d value|",
+           "sample_vs_the_graph_in_f64": {"n": int(pick.numel()), "timed_kernel": worst(p_run[pick], v_run[pick]), "exact_f32_kernels": worst(p1[pick], v1[pick]),
+                                          "torch_fp32_on_this_gpu": worst(pt, vt[:, 0])},
+           "seconds": time.perf_counter() - t0}
+    del exact
+    if not (dp <= 1e-5 and dv <= 1e-5):
+        raise AssertionError(f"net_check: the timed net kernel is {dp:.3g} (policy) / {dv:.3g} (value) from the exact-f32 kernels on the timed leaves (> 1e-5)")
+    out["result"] = "ok"
+    return out
+
+
 def headline_leg(args, dev, rank, world, cdev, group=False):
     import numpy as np
     import torch
@@ -374,7 +414,8 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
     from reversi_alpha_zero_amd.agent.model import ReversiNet, macs_per_position
     from reversi_alpha_zero_amd.engine import DeviceNet, SelfPlayEngine
     F, R, V = NETS[args.net]
-    blob = ReversiNet(F, R, V).keras_init_(0).to_blob()
+    module = ReversiNet(F, R, V).keras_init_(0)
+    blob = module.to_blob()
     cfg = ch5_config(args.sims) if args.net == "ch5" else mini_config(args.sims)
     if args.net == "mini" and os.environ.get("RAZ_BENCH_MINI_SHIPPED") == "1":   # profiling runs of the solver-bound regime (tools/sessions/r4_s22.sh)
         cfg.play.parallel_search_num, cfg.play.thinking_loop, cfg.play.use_solver_turn, cfg.play.use_solver_turn_in_simulation = 4, 2, 50, 50
@@ -429,6 +470,9 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
     elapsed = time.perf_counter() - t0
     st = eng.stats()
     c1 = eng.leaf_cache_stats()
+    net_check = None
+    if rank == 0 and not args.no_spotcheck and "f16x3" in (net.kernel_name or "") and not args.fused:
+        net_check = net_check_timed_leaves(eng, net, module, blob, dev)
     d = {k: float(st[k] - st0[k]) for k in ("total_sims", "nn_leaves", "selections")}
     served = float((c1["hits"] - c0["hits"]) + (c1["in_batch_duplicates"] - c0["in_batch_duplicates"]))
     tot = torch.tensor([d["total_sims"], d["nn_leaves"], d["selections"], elapsed, float(st["finished_games"])],
@@ -522,7 +566,8 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
                      "peak_note": ("f16 MFMA dense peak - the pipe the trunk runs on; every algorithmic (f32-accurate) flop costs 3 f16 MFMA "
                                    "flops, so this fraction cannot exceed 1/3" if v2 else "f32 MFMA dense peak"),
                      "executed_mfma_tflops": ach * (3.0 if v2 else 1.0), "executed_mfma_frac_of_pipe_peak": ach * (3.0 if v2 else 1.0) / peak,
-                     "achieved_over_f32_mfma_peak": ach / FP32_PEAK_TFLOPS},
+                     # SURVEY 8(d) names the f32 MFMA peak as the denominator of the conv batch: the same achieved figure over it
+                     "frac_of_f32_mfma_peak": ach / FP32_PEAK_TFLOPS},
         "kernels": {"k_tree": {"bound": "hbm", "avg_ms": tree_avg_ms,
                                "algorithmic_bytes_per_launch": (TREE_BYTES_PER_SELECTION * selections + TREE_BYTES_PER_SIM * total_sims) / world / launches}},
         "node_pools": {"nodes_per_game": int(eng.cfg.nodes_per_game), "bytes_per_game": int(eng.pool_bytes), "total_bytes": int(eng.pool_bytes) * args.games,
@@ -535,6 +580,7 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
                        if cache_log2 else None),
         "record_gather": gather, "parity_spotcheck": spot if spot else "skipped",
         "parity_spotcheck_timed_batch": spot_timed if spot_timed else "skipped",
+        "net_check": net_check if net_check else "skipped (the timed net kernel is the exact-f32 one)" if "f16x3" not in (net.kernel_name or "") else "skipped",
     })
     k = out["kernels"]["k_tree"]
     k["achieved"] = k["algorithmic_bytes_per_launch"] / (tree_avg_ms * 1e-3) / 1e9 if tree_avg_ms else None
@@ -1258,7 +1304,7 @@ def compact_line(full):
     line["config"] = pick(full.get("config", {}), ("workload", "games_per_gpu", "sims_per_move", "net", "test_rig", "collective_backend"))
     r = full.get("roofline", {})
     line["roofline"] = pick(r, ("bound", "kernel_name", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "algorithmic_flops_per_launch",
-                                "algorithmic_hbm_bytes_per_launch", "executed_mfma_tflops", "executed_mfma_frac_of_pipe_peak", "achieved_over_f32_mfma_peak",
+                                "algorithmic_hbm_bytes_per_launch", "executed_mfma_tflops", "executed_mfma_frac_of_pipe_peak", "frac_of_f32_mfma_peak",
                                 "power_limited"))
     c = full.get("cpu_baseline")
     if isinstance(c, dict):
@@ -1269,6 +1315,9 @@ def compact_line(full):
     line["leaves_per_sec"] = full.get("leaves_per_sec")
     line["parity_spotcheck"] = parity(full.get("parity_spotcheck"))
     line["parity_spotcheck_timed_batch"] = parity(full.get("parity_spotcheck_timed_batch"))
+    nc = full.get("net_check")
+    line["net_check"] = (dict(pick(nc, ("n", "max_abs_dp", "max_abs_dv", "tolerance", "result")), vs_f64_sample=nc.get("sample_vs_the_graph_in_f64"))
+                         if isinstance(nc, dict) else nc)
     w = full.get("whole_games_measured")
     if isinstance(w, dict):
         line["whole_games_measured"] = dict(pick(w, ("value", "unit", "seconds", "games_per_hour", "games_finished_in_the_window", "leaf_slot_occupancy",
@@ -1376,7 +1425,13 @@ def main():
     cdev = torch.device("cpu") if shared_gpu else dev   # where the collectives' tensors live
     if world > 1 or nccl_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:   # (a launcher always sets it; ranks started by hand cannot agree on a port nobody named)
+                raise SystemExit("bench.py: WORLD_SIZE > 1 needs MASTER_PORT (torch.distributed.run sets it; `python bench.py --gpus N` picks a free one)")
+            import socket
+            with socket.socket() as sock:   # a group of one rank: any free port (29511 may belong to another run on a shared box)
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

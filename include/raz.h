@@ -361,7 +361,7 @@ int raz_engine_leaf_cache_stats(raz_engine* e, uint64_t* out4, raz_stream_t stre
 int raz_engine_solver_stats(raz_engine* e, uint64_t* out15, raz_stream_t stream);
 /* Diagnostics (no reference counterpart): `bytes` at `offset` of one of the engine's device arrays (raz_engine_device_ptr's numbering:
  * 3 the games' control blocks, 6 the solver blocks, 7 / 8 / 9 the solver pool's lane state / headers / active list) copied to host
- * memory.  Synchronises the device. */
+ * memory.  RAZ_EINVAL when offset + bytes reaches beyond the array.  Synchronises the device. */
 int raz_engine_debug_read(raz_engine* e, int which, size_t offset, size_t bytes, void* host_out);
 /* config.play.resign_threshold is mutated while the worker runs (worker/self_play.py:250-260: +-0.01 per 100
  * no-resign test games); moves decided from the next raz_engine_step on use the new value.  Trees, records and
@@ -380,8 +380,12 @@ long long raz_emit_game_rows_json(const void* headers, const uint32_t* root_n, i
                                   int* n_rows);
 /* float.__repr__(x) (the number format of json.dump) into out32 (>= 32 bytes, NUL-terminated); returns its length. */
 int raz_format_float_repr(double x, char* out32);
-/* Device pointers of the record arrays, for a caller that gathers them itself (e.g. RCCL):
- * which = 0 headers, 1 root_n, 2 root_w, 3 n_plies, 4 status. */
+/* Device pointers of the engine's arrays, for a caller that gathers / inspects them itself (e.g. RCCL): which = 0 ply headers, 1 root_n,
+ * 2 root_w (NULL unless record_root_w), 3 the games' control blocks, 5 the phase profile, 6-9 the solver pool (diagnostics);
+ * 10-14 the LEAF EXCHANGE with the net - the role of the reference's prediction queue (agent/player.py:329-346, agent/api.py:30-45):
+ * one row per simulation slot (row = game * parallel_search_num + slot): 10 active u8 (1 = the last step's net forward evaluated the
+ * row; rows served by the evaluation cache read 0), 11 own u64, 12 enemy u64 (the position as shown to the net, D4 transform
+ * applied), 13 policy f32[64], 14 value f32 - what the net answered.  NULL for any other number. */
 void* raz_engine_device_ptr(raz_engine* e, int which);
 
 #ifdef __cplusplus

@@ -1667,25 +1667,44 @@ extern "C" int raz_engine_set_resign_threshold(raz_engine* e, int has_threshold,
 // diagnostics: `bytes` at `offset` of one of raz_engine_device_ptr's arrays, copied to the host (synchronises the device)
 extern "C" int raz_engine_debug_read(raz_engine* e, int which, size_t offset, size_t bytes, void* host_out);
 
-extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) {
-    if (!e) return nullptr;
-    switch (which) {
-        case 0: return e->dev.rec;
-        case 1: return e->dev.rec_n;
-        case 2: return e->dev.rec_w;
-        case 3: return e->dev.game;
-        case 5: return e->dev.prof;
-        case 6: return e->dev.solver_ws;     // diagnostics of the solver pool (tools/sessions/debug_solver_stall.py)
-        case 7: return e->dev.pool_state;
-        case 8: return e->dev.pool_hdr;
-        case 9: return e->dev.pool_active;
-        default: return nullptr;
+// One of the engine's device arrays and its size in bytes (0: no such array in this engine).
+static unsigned char* device_array(raz_engine* e, int which, size_t* bytes) {
+    size_t n = 0;
+    void* p = nullptr;
+    if (e) {
+        const raz_engine_dev& d = e->dev;
+        const size_t B = d.B, MP = d.max_plies, BK = (size_t)d.B * d.K;
+        switch (which) {
+            case 0: p = d.rec; n = B * MP * sizeof(raz_ply_header); break;
+            case 1: p = d.rec_n; n = B * MP * 64 * 4; break;
+            case 2: p = d.rec_w; n = d.rec_w ? B * MP * 64 * 8 : 0; break;
+            case 3: p = d.game; n = B * sizeof(raz_game); break;
+            case 5: p = d.prof; n = B * 8 * 8; break;
+            case 6: p = d.solver_ws; n = d.solver_ws ? B * (size_t)RAZ_SOLVER_WS_BYTES : 0; break;   // diagnostics of the solver pool (tools/sessions/debug_solver_stall.py)
+            case 7: p = d.pool_state; n = (size_t)d.W * RAZ_SOLVER_WORKER_STATE_BYTES; break;
+            case 8: p = d.pool_hdr; n = d.W ? kMaxParts * sizeof(raz_solver_pool_hdr) : 0; break;
+            case 9: p = d.pool_active; n = d.W ? B * 4 : 0; break;
+            // the leaf exchange between the tree kernels and the net (one row per simulation slot, row = game * K + slot): what the
+            // LAST step asked the net and what it answered (bench.py's net_check reads the timed batch's rows)
+            case 10: p = d.nn_active; n = BK; break;
+            case 11: p = d.nn_own; n = BK * 8; break;
+            case 12: p = d.nn_enemy; n = BK * 8; break;
+            case 13: p = d.nn_policy; n = BK * 64 * 4; break;
+            case 14: p = d.nn_value; n = BK * 4; break;
+            default: break;
+        }
     }
+    if (bytes) *bytes = p ? n : 0;
+    return n ? (unsigned char*)p : nullptr;
 }
 
+extern "C" void* raz_engine_device_ptr(raz_engine* e, int which) { return device_array(e, which, nullptr); }
+
 extern "C" int raz_engine_debug_read(raz_engine* e, int which, size_t offset, size_t bytes, void* host_out) {
-    unsigned char* p = (unsigned char*)raz_engine_device_ptr(e, which);
+    size_t size = 0;
+    unsigned char* p = device_array(e, which, &size);
     if (!p || !host_out) return raz_fail(RAZ_EINVAL, "raz_engine_debug_read: no such array");
+    if (offset > size || bytes > size - offset) return raz_fail(RAZ_EINVAL, "raz_engine_debug_read: offset + bytes beyond the array");
     RAZ_HIP_TRY(hipDeviceSynchronize(), "raz_engine_debug_read: sync");
     RAZ_HIP_TRY(hipMemcpy(host_out, p + offset, bytes, hipMemcpyDeviceToHost), "raz_engine_debug_read: copy");
     return RAZ_OK;

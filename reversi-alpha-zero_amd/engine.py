@@ -318,6 +318,20 @@ class SelfPlayEngine:
                  "node_load_wait", "expand_part_of_backup"]
         return {n: int(a[:, i].sum()) for i, n in enumerate(names)}
 
+    def leaf_exchange(self):
+        """Views (no copy) of the leaf exchange between the tree kernels and the net as the LAST step left it (include/raz.h
+        raz_engine_device_ptr 10-14; the reference's prediction queue, agent/player.py:329-346): {"active" u8 [rows], "own" / "enemy"
+        i64 [rows] (as shown to the net), "policy" f32 [rows, 64], "value" f32 [rows]}, rows = n_games x parallel_search_num."""
+        import torch
+        rows = self.n_games * self.slots
+        torch.cuda.synchronize(self.device)
+
+        def view(which, nbytes, dtype):
+            off = lib.raz_engine_device_ptr(self._h, which) - self._ws.data_ptr()
+            return self._ws[off:off + nbytes].view(dtype)
+        return {"active": view(10, rows, torch.uint8), "own": view(11, rows * 8, torch.int64), "enemy": view(12, rows * 8, torch.int64),
+                "policy": view(13, rows * 256, torch.float32).view(rows, 64), "value": view(14, rows * 4, torch.float32)}
+
     def stats(self):
         import torch
         st = N.RazEngineStats()
