@@ -189,7 +189,7 @@ typedef struct {
                                                  LEGAL move of the position (the reference keeps three f64[64] per key = 1536 B,
                                                  agent/player.py:62-66), ~212 B on average over a game, 704 B at most.
                                                  0 = nodes_per_game x 232 + 64 x 704; at most 256 MB */
-    uint32_t solver_pool_waves;               /* worker wavefronts of the end-game solver's pool (csrc/raz_solver_pool.h): positions of 7..14
+    uint32_t solver_pool_waves;               /* worker wavefronts of the end-game solver's pool (csrc/raz_solver_pool.h): positions of 5..14
                                                  empties are solved by a pool of lanes shared by all games, one subtree per lane, instead
                                                  of inside the game's own wave.  0 = one per four games, at most 1280 (what the chip's LDS holds at once); 36 KB
                                                  of workspace each.  Results do not depend on the value.  No reference counterpart

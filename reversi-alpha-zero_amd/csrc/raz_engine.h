@@ -54,8 +54,8 @@
 #define RAZ_SIM_WAIT_EXPAND 2  // sleeping on now_expanding at node sim_parked
 #define RAZ_SIM_SOLVING 3      // its descent is suspended at an in-simulation solve (RAZ_LEAF_SOLVE_PENDING in its block)
 
-// End-game solver, POOLED across games (raz_solver_pool.h).  A tree kernel that needs f_mode(position) for a position with 7..14
-// empties POSTS a request in its game's block of E.solver_ws (header below, then the task tree: three plies + a fourth of tasks) and suspends where it
+// End-game solver, POOLED across games (raz_solver_pool.h).  A tree kernel that needs f_mode(position) for a position with 5..14
+// empties (more than RAZ_SOLVER_SCALAR_EMPTIES = 4) POSTS a request in its game's block of E.solver_ws (header below, then the task tree: three plies + a fourth of tasks) and suspends where it
 // stands; between tree launches k_solve_scan builds the task trees of new requests and folds finished tasks into answers, and
 // k_solve_run - a fixed pool of worker waves that belongs to no game - hands ONE subtree to every LANE, whatever game it comes from.
 #define RAZ_SOLVE_IDLE 0u
@@ -77,13 +77,14 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
     uint32_t exact;
     uint32_t k_n2, tasks, total; // root moves | level-2 nodes << 8; level-3 nodes; subtrees the workers search (the tasks)
     uint32_t next;               // next task to hand out (workers: atomicAdd)
-    int32_t ans_move, ans_score;
-    uint32_t ans_kind;           // (copies of what the state word carries: diagnostics)
+    int32_t ans_move, ans_score; // (copies of what the state word carries: diagnostics)
+    uint32_t posted;             // requests this game slot has posted since raz_engine_start (the tree kernels' word; statistics)
     uint32_t rounds;             // rounds of the pool the solve has been listed in (statistics)
     uint32_t rounds_total;       // ... and all solves of this game slot since raz_engine_start
 };
 #ifdef __cplusplus
 static_assert(sizeof(raz_solve_hdr) == 64, "raz_solve_hdr layout");
+static_assert(__builtin_offsetof(raz_solve_hdr, state) == 0 && __builtin_offsetof(raz_solve_hdr, gen) == 4, "{state, gen} is ONE aligned 8-byte word (raz_engine_core.h solver_solve)");
 #endif
 #define RAZ_SOLVER_TREE_BYTES 12288   // >= sizeof(SolverTree) (raz_solver_pool.h, checked there): the top three plies, folded in LDS
 #define RAZ_SOLVER_DEEP_BYTES 135168  // >= sizeof(SolverDeep): the positions three plies down and, below the larger ones, a fourth ply of tasks

@@ -37,7 +37,7 @@ namespace {
 
 // ------------------------------------------------------------------ the tree kernel
 // SOLVER = false compiles the end-game solver's call sites (and the scalar search's LDS frames) out: the common case, and the
-// bench configuration.  With the solver in, the kernel only solves the smallest positions itself (<= 6 empties, wave-uniform);
+// bench configuration.  With the solver in, the kernel only solves the smallest positions itself (<= RAZ_SOLVER_SCALAR_EMPTIES = 4 empties, wave-uniform);
 // larger ones are posted to the solver pool (raz_solver_pool.h) and the game suspends until the answer is there.
 template <bool SOLVER>
 __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_dev E, uint32_t g0, uint32_t count) {

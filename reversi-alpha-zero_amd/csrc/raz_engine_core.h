@@ -33,6 +33,25 @@ __device__ __forceinline__ void wave_sync_lanes() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ------------------------------------------------------------------ words that cross between CONCURRENT kernels
+// The solver pool's round may run on its own stream beside the tree launches (raz_engine.hip, pool_every > 1), so tree kernels and pool
+// kernels exchange a few words with no kernel boundary in between: a game's request header (raz_solve_hdr: position + state), the
+// answer word, memo entries.  On MI355X the per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another
+// CU's stores (MI355X_MICROARCH.md "inter-workgroup visibility"): such words are written AND read with agent-scope atomics only
+// (sc1: stores write through, loads bypass L1) - the guide's "8-byte agent atomics on both sides" form - and a word that publishes
+// others (a memo slot's tag, a request's state) is stored after the publisher's `s_waitcnt vmcnt(0)` (xk_drain: the asm form, which the
+// compiler cannot drop).  tools/litmus_slot_handoff.hip is the hardware check of exactly this against the plain-store / plain-load form
+// of rounds 1-5 (profiles/r6/litmus_slot_handoff.json).  No cache-wide fence (buffer_wbl2 / buffer_inv) is needed or issued.
+__device__ __forceinline__ void xk_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xk_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long xk_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t xk_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xk_drain() {
+#ifndef RAZ_WAVE_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // Values every lane holds identically (game state, keys, node indices) are moved to SGPRs so the
 // 64-bit board arithmetic and the address math run on the scalar unit.
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -491,12 +510,15 @@ static_assert(sizeof(SolverLDS) == RAZ_SOLVER_LDS_BYTES, "SolverLDS layout");
 // of several lanes - of this wave or of any worker wave of the pool - exactly one wins), stores the key, then publishes the tag
 // (bit 31).  Readers take a slot whose bit 31 is clear for empty, so a claimed slot is a miss, never a torn entry.
 #define RAZ_MEMO_CLAIMED 0x20000000u
+// Writers and readers may be waves of concurrent kernels on different XCDs (the pool's round beside the tree launches): key words and
+// tag are agent-scope atomics on both sides, the tag stored after the key stores have drained (xk_* above).  A reader that still gets
+// the tag before the keys compares unequal: a miss.
 __device__ __forceinline__ bool memo_claim_and_write(raz_slot* s, raz_bb own, raz_bb enemy, uint32_t tag) {
     if (atomicCAS(&s->idx_tag, 0u, RAZ_MEMO_CLAIMED) != 0u) return false;
-    s->black = own;
-    s->white = enemy;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler order; one lane's stores to one 32-byte slot reach memory in order)
-    __hip_atomic_store(&s->idx_tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xk_store64(&s->black, own);
+    xk_store64(&s->white, enemy);
+    xk_drain();
+    xk_store32(&s->idx_tag, tag);
     return true;
 }
 
@@ -507,8 +529,8 @@ __device__ bool memo_find(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_b
     const uint32_t h = key_hash(own, enemy, 8u + exact);
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const raz_slot* s = tab + ((h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask);
-        const raz_bb sb = s->black, sw = s->white;
-        const uint32_t it = s->idx_tag;
+        const uint32_t it = xk_load32(&s->idx_tag);
+        const raz_bb sb = xk_load64(&s->black), sw = xk_load64(&s->white);
         const bool used = (it >> 31) != 0;
         const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact;
         const unsigned long long mm = __ballot(match) & 0xffffULL;
@@ -532,7 +554,7 @@ __device__ void memo_put(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb
     const uint32_t tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
-        unsigned long long em = __ballot(tab[si].idx_tag == 0u) & 0xffffULL;
+        unsigned long long em = __ballot(xk_load32(&tab[si].idx_tag) == 0u) & 0xffffULL;
         while (em) {   // (wave-uniform) the first free slot of the group - or the next one, if a worker wave of the pool claimed it meanwhile
             const int j = __ffsll((long long)em) - 1;
             em &= em - 1;
@@ -553,8 +575,8 @@ __device__ bool memo_find_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, 
     // both slots' fields are requested together: ONE round trip into the game's table (the 64 searches of a worker wave advance in
     // lockstep, so a dependent second request would be paid by all of them)
     const raz_slot *s0 = tab + (h & mask), *s1 = tab + ((h + 1u) & mask);
-    const uint32_t it0 = s0->idx_tag, it1 = s1->idx_tag;
-    const raz_bb b0 = s0->black, w0 = s0->white, b1 = s1->black, w1 = s1->white;
+    const uint32_t it0 = xk_load32(&s0->idx_tag), it1 = xk_load32(&s1->idx_tag);
+    const raz_bb b0 = xk_load64(&s0->black), w0 = xk_load64(&s0->white), b1 = xk_load64(&s1->black), w1 = xk_load64(&s1->white);
     uint32_t it;
     if (!(it0 >> 31)) return false;
     if (b0 == own && w0 == enemy && ((it0 >> 30) & 1u) == exact)
@@ -669,7 +691,7 @@ __device__ __forceinline__ raz_solve_hdr* solve_hdr(const raz_engine_dev& E, uin
 // A game whose request is still with the pool has nothing to do in this launch: one word tells (the tree kernels look at it before
 // they load anything else - in a solver-bound batch most games of a launch are in that state).
 __device__ __forceinline__ bool solve_in_flight(const raz_engine_dev& E, uint32_t g) {
-    const uint32_t st = RAZ_SOLVE_STATE(uni(solve_hdr(E, g)->state));
+    const uint32_t st = RAZ_SOLVE_STATE(uni(xk_load32(&solve_hdr(E, g)->state)));   // (the pool may publish the answer while this kernel runs)
     return st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING;
 }
 
@@ -692,8 +714,11 @@ __device__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_b
         }
     }
     raz_solve_hdr* h = solve_hdr(E, g);
-    const uint32_t word = uni(h->state), st = RAZ_SOLVE_STATE(word), gen = uni(h->gen);
-    const bool same = uni((uint32_t)(h->own0 == own0 && h->enemy0 == enemy0 && h->exact == exact)) != 0u;
+    // every word of the header that the other side reads or writes while this kernel runs goes through xk_* (state and gen share one
+    // aligned 8-byte word: the pool's kernels see a request's generation and state together)
+    const unsigned long long sg = uni((raz_bb)xk_load64((const unsigned long long*)h));
+    const uint32_t word = (uint32_t)sg, st = RAZ_SOLVE_STATE(word), gen = (uint32_t)(sg >> 32);
+    const bool same = uni((uint32_t)(xk_load64(&h->own0) == own0 && xk_load64(&h->enemy0) == enemy0 && xk_load32(&h->exact) == exact)) != 0u;
     if (same && st == RAZ_SOLVE_ANSWERED) {   // (the block keeps the last answer: the memo may have had no room for it)
         out_move = RAZ_SOLVE_ANSWER_MOVE(word);
         out_score = RAZ_SOLVE_ANSWER_SCORE(word);
@@ -702,11 +727,14 @@ __device__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_b
     if (same && (st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING)) return RAZ_SOLVE_PENDING;
     wave_sync();
     if (lane == 0) {   // a new request (an abandoned one - another position - is overwritten: its workers see the new gen and drop their tasks)
-        h->own0 = own0;
-        h->enemy0 = enemy0;
-        h->exact = exact;
-        h->gen = gen + 1u;
-        h->state = RAZ_SOLVE_REQUESTED;
+        // the position first, drained; then {state, gen} in ONE 8-byte store: a scan that sees REQUESTED sees this request's position
+        // (five plain stores could be merged or reordered by the compiler, and sat in this XCD's L2 until the kernel ended)
+        xk_store64(&h->own0, own0);
+        xk_store64(&h->enemy0, enemy0);
+        xk_store32(&h->exact, exact);
+        xk_drain();
+        xk_store64((unsigned long long*)h, (unsigned long long)RAZ_SOLVE_REQUESTED | ((unsigned long long)(gen + 1u) << 32));
+        h->posted += 1u;   // (this side's word: nobody else touches it while a kernel runs)
     }
     wave_sync();
     return RAZ_SOLVE_PENDING;

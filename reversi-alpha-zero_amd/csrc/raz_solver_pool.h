@@ -124,14 +124,16 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     const uint32_t g = g0 + blockIdx.x;
     if (g >= E.B) return;
     raz_solve_hdr* h = solve_hdr(E, g);
-    const uint32_t st = RAZ_SOLVE_STATE(uni(h->state));
+    // (the tree kernels may be running beside this launch: a request's words are read the way they are published, raz_engine_core.h xk_*;
+    // the position is requested after the state has arrived - a REQUESTED state is stored after its position has drained)
+    const uint32_t st = RAZ_SOLVE_STATE(uni(xk_load32(&h->state)));
     if (st != RAZ_SOLVE_REQUESTED && st != RAZ_SOLVE_RUNNING) return;
     __shared__ SolverTree tree_lds;
     SolverTree* P = &tree_lds;
     SolverTree* T = solve_tree(E, g);
     SolverDeep* D = solve_deep(E, g);
-    const raz_bb own0 = uni((raz_bb)h->own0), enemy0 = uni((raz_bb)h->enemy0);
-    const uint32_t exact = uni(h->exact);
+    const raz_bb own0 = uni((raz_bb)xk_load64(&h->own0)), enemy0 = uni((raz_bb)xk_load64(&h->enemy0));
+    const uint32_t exact = uni(xk_load32(&h->exact));
     int k = 0, n2 = 0, total = 0, subs = 0;   // root moves, level-2 nodes, level-3 nodes, tasks
     if (st == RAZ_SOLVE_REQUESTED) {
         const raz_bb legal0 = bb_legal_moves(own0, enemy0);
@@ -140,8 +142,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             if (lane == 0) {
                 h->ans_move = -1;
                 h->ans_score = -100;
-                h->ans_kind = RAZ_SOLVE_NONE;
-                h->state = RAZ_SOLVE_ANSWER_WORD(RAZ_SOLVE_NONE, -1, -100);
+                xk_store32(&h->state, RAZ_SOLVE_ANSWER_WORD(RAZ_SOLVE_NONE, -1, -100));
             }
             return;
         }
@@ -361,8 +362,9 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         if (lane == 0) {
             h->ans_move = bm;
             h->ans_score = bs;
-            h->ans_kind = bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE;
-            h->state = RAZ_SOLVE_ANSWER_WORD(bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE, bm, bs);   // (the last store to the header: see raz_engine.h)
+            // ONE agent-scope 4-byte store (write-through): a tree kernel running beside this launch on another XCD finds the answer at
+            // its next look instead of at the next kernel boundary (a plain store stayed in this XCD's L2 until the launch ended)
+            xk_store32(&h->state, RAZ_SOLVE_ANSWER_WORD(bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE, bm, bs));
             atomicAdd(&E.counters[21], 1ULL);
             atomicAdd(&E.counters[22], (unsigned long long)(st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds));
         }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             h->tasks = (uint32_t)total;
             h->total = (uint32_t)subs;
             h->next = 0u;
-            h->state = RAZ_SOLVE_RUNNING;
+            xk_store32(&h->state, RAZ_SOLVE_RUNNING);   // (the tree kernels treat REQUESTED and RUNNING alike: nothing of the task tree is theirs to read)
         }
     } else {
         for (int n = lane; n < n2; n += 64) T->g_v[n] = P->g_v[n];
@@ -455,7 +457,8 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     int task = (int)(m2 & 0xffffULL), task_n = (int)((m2 >> 16) & 0xffULL), task_ci = (int)((m2 >> 24) & 0xffULL), task_t = (int)((m2 >> 32) & 0xffffULL);
     if (have) {   // is the parked search still wanted?  Its request may have been answered (a decided scan) or replaced, its node decided
         const raz_solve_hdr* hh = solve_hdr(E, g);
-        if (hh->gen != gen || RAZ_SOLVE_STATE(hh->state) != RAZ_SOLVE_RUNNING) have = false;
+        const unsigned long long sg = xk_load64((const unsigned long long*)hh);   // {state, gen}: one word, as the tree kernels publish it
+        if ((uint32_t)(sg >> 32) != gen || RAZ_SOLVE_STATE((uint32_t)sg) != RAZ_SOLVE_RUNNING) have = false;
         else if (solve_deep(E, g)->h_dead[task_t]) have = false;
     }
     if (have)   // (a lane reads and writes its own column only: no barrier)
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 const raz_slot* tab = E.memo + (size_t)g * E.M;
                 const uint32_t h = key_hash(own, enemy, 8u + exact);
                 const raz_slot *s0 = tab + (h & (E.M - 1)), *s1 = tab + ((h + 1u) & (E.M - 1));
-                it0 = s0->idx_tag; it1 = s1->idx_tag;
-                b0 = s0->black; w0 = s0->white; b1 = s1->black; w1 = s1->white;
+                it0 = xk_load32(&s0->idx_tag); it1 = xk_load32(&s1->idx_tag);   // (memo entries cross between concurrent kernels: raz_engine_core.h xk_*)
+                b0 = xk_load64(&s0->black); w0 = xk_load64(&s0->white); b1 = xk_load64(&s1->black); w1 = xk_load64(&s1->white);
             }
             if (put_pending) {
                 pslot = E.memo + (size_t)put_g * E.M + (key_hash(put_own, put_enemy, 8u + ((put_tag >> 30) & 1u)) & (E.M - 1));
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     next_solve = active[(lane_id + draws * lanes_of_slice) % nact];
                     raz_solve_hdr* hh = solve_hdr(E, gg);
                     const uint32_t t = atomicAdd(&hh->next, 1u);
-                    const uint32_t total = hh->total, ex = hh->exact, hgen = hh->gen;   // (fixed while the pool runs: requested beside the draw)
+                    const uint32_t total = hh->total, ex = xk_load32(&hh->exact), hgen = xk_load32(&hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
                     if (t < total) {
                         got = true;
                         SolverTree* T = solve_tree(E, gg);
@@ -583,15 +586,16 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     hit_s = (int)(it & 0xffu) - 128;
                 }
             }
-            if (put_pending) {   // (the home slot only: a finished node whose slot is taken is simply not remembered)
-                if (claimed == 0u) {
-                    pslot->black = put_own;
-                    pslot->white = put_enemy;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __hip_atomic_store(&pslot->idx_tag, put_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                put_pending = false;
+            // (the home slot only: a finished node whose slot is taken is simply not remembered.)  memo_claim_and_write's second half:
+            // keys, drained, then the tag - all agent-scope words; the wait is the wave's, not a lane's, so it stands outside the branch
+            const bool putting = put_pending && claimed == 0u;
+            if (putting) {
+                xk_store64(&pslot->black, put_own);
+                xk_store64(&pslot->white, put_enemy);
             }
+            xk_drain();
+            if (putting) xk_store32(&pslot->idx_tag, put_tag);
+            put_pending = false;
         }
         const unsigned long long tk1 = prof_now();
         tk_slow += tk1 - tk0;
@@ -725,7 +729,7 @@ __global__ __launch_bounds__(256) void k_solver_game_stats(raz_engine_dev E) {
     unsigned long long a = 0, b = 0, c = 0, d = 0;
     for (uint32_t g = threadIdx.x; g < E.B; g += 256) {
         const raz_solve_hdr* h = solve_hdr(E, g);
-        const unsigned long long n = h->gen, r = h->rounds_total;
+        const unsigned long long n = h->posted, r = h->rounds_total;   // (not gen: k_solve_pool_reset bumps that too)
         a += n;
         b = n > b ? n : b;
         c += r;

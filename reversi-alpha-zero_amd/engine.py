@@ -97,6 +97,12 @@ class DeviceNet:
         return policy, value
 
 
+def _tuning_env(name):
+    """A tuning knob from the environment - honoured ONLY under RAZ_TUNING=1 (GPU tuning sessions, tools/sessions/): a stray variable in a
+    production environment must not reach an engine's configuration."""
+    return int(os.environ.get(name, "0") or 0) if os.environ.get("RAZ_TUNING") == "1" else 0
+
+
 CONTINUOUS_SOLVER_POOL_EVERY = 3   # play_continuous: tree launches per round of the solver pool (tools/sessions/r5_s19.sh: 2: 27.2, 3: 30.3, 4: 30.0, 6: 28.7 M)
 
 
@@ -139,7 +145,7 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
         disable_resignation_rate=float(p.disable_resignation_rate), n_games=n_games,
         nodes_per_game=nodes_per_game, table_slots=slots, max_plies=max_plies, seed=seed,
         reserved=(1 if phase_profile else 0) | (2 if single_stream else 0) | (8 if force_slot_kernel else 0)
-        | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12) | ((min(255, (int(solver_budget) + 63) // 64) & 0xff) << 16) | ((int(solver_pool_every or os.environ.get("RAZ_SOLVER_POOL_EVERY", "0")) & 0xf) << 24),   # (the environment variable: tuning / test runs)
+        | (16 if fused else 0) | ((parts & 0xf) << 8) | ((inner_max & 0xf) << 12) | ((min(255, (int(solver_budget) + 63) // 64) & 0xff) << 16) | ((int(solver_pool_every or _tuning_env("RAZ_SOLVER_POOL_EVERY")) & 0xf) << 24),
         use_solver_turn=ust, use_solver_turn_in_simulation=usts,
         solver_memo_slots=(solver_memo_slots if (ust or usts) else 0), parallel_search_num=par,
         pool_bytes_per_game=int(pool_bytes_per_game or 0), solver_pool_waves=int(solver_pool_waves or 0))
@@ -457,7 +463,7 @@ class SelfPlayEngine:
         n0 = min(B, total_games)
         # with slots at every stage of a game only some of them wait for the end-game solver at any time: its pool's round runs beside
         # three tree launches instead of holding every step up (mini.yml as shipped: 22.7 M -> 30.3 M sims/s; a value given at
-        # construction - solver_pool_every / RAZ_SOLVER_POOL_EVERY - stays)
+        # construction - solver_pool_every, or RAZ_SOLVER_POOL_EVERY under RAZ_TUNING=1 - stays)
         solver_on = bool(self.cfg.use_solver_turn or self.cfg.use_solver_turn_in_simulation)
         tuned = solver_on and not ((int(self.cfg.reserved) >> 24) & 0xf)
         if tuned:

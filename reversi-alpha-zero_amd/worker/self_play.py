@@ -454,6 +454,11 @@ class BatchedSelfPlayWorker:
         # so 64 steps between polls left the host in the loop a sixth of the time (bench worker_end_to_end_config1: the worker's engine at
         # 19.2 M games/h where the same engine reaches 25 M polled every 200 steps); a wide net's step is ~25 ms and 64 is a poll every 1.6 s
         chunk = 64 if (self._net is not None and getattr(self._net, "filters", 256) >= 128) else 256
+        # ... but pools are only pruned at polls: a pool that was capped by the HBM budget (as small as 12 x sims nodes) must not be able
+        # to fill up inside one chunk - keep what a chunk can add (nodes_per_step per step) under a quarter of the pool
+        pool, per_step = getattr(getattr(eng, "cfg", None), "nodes_per_game", 0), getattr(eng, "nodes_per_step", 0)
+        if pool and per_step:
+            chunk = max(16, min(chunk, int(pool) // (4 * int(per_step))))
         outbox, self.last_stats = eng.play_continuous(base, blk, sims_of, chunk=chunk)
 
         def packed(plies):
@@ -762,12 +767,27 @@ class BatchedSelfPlayWorker:
         whole number of files exactly when its length is a multiple of that number; the GGF buffer likewise."""
         if self.world <= 1 or self.emission == "rank0":
             return False
+        if self.emission == "auto" and not self._ranks_share_one_host():
+            # ranks on several nodes: each would write into its OWN node's play_data_dir while rank 0's game index and pruning count
+            # every file as local, and the optimizer on node 0 would train on 1 / nodes of the games (ADVICE r5).  Gather everything on
+            # rank 0 instead; emission="per_rank" stays available to a caller who knows play_data_dir is one shared file system
+            if not getattr(self, "_said_rank0", False):
+                self._said_rank0 = True
+                logger.info("emission='auto': the ranks span several hosts (LOCAL_WORLD_SIZE < WORLD_SIZE) - every record is gathered on rank 0, which writes all "
+                            "files; pass emission='per_rank' if play_data_dir is one file system shared by all nodes")
+            return False
         pd, n = self.config.play_data, self._ids_per_block()
         aligned = n % pd.nb_game_in_file == 0 and (not pd.enable_ggf_data or n % pd.nb_game_in_ggf_file == 0)
         if self.emission == "per_rank" and not aligned:
             raise ValueError(f"emission='per_rank': {n} game ids per rank and block are not a multiple of nb_game_in_file {pd.nb_game_in_file}"
                              + (f" and nb_game_in_ggf_file {pd.nb_game_in_ggf_file}" if pd.enable_ggf_data else "") + " - a file would span two ranks")
         return aligned
+
+    def _ranks_share_one_host(self):
+        """True when all ranks of the job run on this host - the launcher's LOCAL_WORLD_SIZE equals the world size (torchrun sets both;
+        without a launcher's environment the ranks were started by hand on one machine: tests, bench rigs)."""
+        lws = os.environ.get("LOCAL_WORLD_SIZE")
+        return lws is None or int(lws) >= self.world
 
     def _next_block_stamps(self, per_rank):
         """Rank 0, per-rank emission: the first file-name stamp of a block; rank r names its files from stamp + r * (per_rank + 8)

@@ -59,7 +59,7 @@ class EmuWorker(BatchedSelfPlayWorker):
         self._net = Net()
         return Engine(self, max_sims)
 
-w = EmuWorker(cfg, golden_net_blob(gold["net"]), games_in_flight=2, seed=21, device="cpu", rank=rank, world=world,
+w = EmuWorker(cfg, golden_net_blob(gold["net"]), games_in_flight={slots}, seed=21, device="cpu", rank=rank, world=world,
               block_games={block}, emission={emission!r})
 orig = w.check_and_update_resignation_threshold
 def check():   # make every block step the threshold (>= 100 test games in the reference; scaled down for the test)
@@ -74,12 +74,12 @@ if dist.is_initialized():
 '''
 
 
-def _run(tmp_path, tag, world, block, total, emission="auto", port=29571):
+def _run(tmp_path, tag, world, block, total, emission="auto", port=29571, slots=2):
     out = tmp_path / tag
     out.mkdir()
     script = tmp_path / f"{tag}.py"
-    script.write_text(_SCRIPT.format(root=ROOT, out=str(out), block=block, total=total, emission=emission))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    script.write_text(_SCRIPT.format(root=ROOT, out=str(out), block=block, total=total, emission=emission, slots=slots))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, str(script)] if world == 1 else [
@@ -90,6 +90,7 @@ def _run(tmp_path, tag, world, block, total, emission="auto", port=29571):
     play = [open(out / "play_data" / f, "rb").read() for f in sorted(os.listdir(out / "play_data"))]
     ggf = [re.sub(r"DT\[[^\]]*\]", "DT[]", open(out / "ggf" / f).read()) for f in sorted(os.listdir(out / "ggf"))]
     info = {m[0]: m[1:] for m in re.findall(r"RANK (\d) OWNFILES (\d) BYTES (\d+) THRESHOLD (\S+)", r.stdout)}
+    assert len(info) == world, r.stdout[-2000:]
     return play, ggf, open(out / ".self-play-game-idx").read(), info
 
 
@@ -110,3 +111,20 @@ def test_worker_on_emulated_kernels_two_ranks_both_emission_modes_equal_one_rank
     assert one[2] == own[2] == r0[2] == "16"
     thr = {v[2] for run in (one, own, r0) for v in run[3].values()}
     assert len(thr) == 1 and thr != {repr(-0.2)}, thr                         # everyone ended under the same, moved, threshold
+
+
+def test_worker_on_emulated_kernels_eight_ranks_equal_one_rank(tmp_path):
+    """The rank count of the node the path is built for: 2 blocks of 16 game ids - 8 ranks x 2 ids (one file each) per block, every
+    rank writing its own file, and the same with rank 0 writing all - against one rank playing the 16 ids of a block through its 2
+    slots.  Real games on the emulated kernels: the second block is played under the threshold rank 0 stepped and broadcast."""
+    one = _run(tmp_path, "one", 1, 16, 32)
+    own = _run(tmp_path, "own", 8, 2, 32, port=29575, slots=1)      # (one slot per rank: 2 ids through 1 slot = continuous batching)
+    r0 = _run(tmp_path, "rank0", 8, 2, 32, emission="rank0", port=29577, slots=1)
+    assert {k: v[0] for k, v in own[3].items()} == {str(r): "1" for r in range(8)}
+    assert {k: v[0] for k, v in r0[3].items()} == {str(r): "0" for r in range(8)}
+    assert all(int(own[3][str(r)][1]) > 3000 for r in range(8)) and all(int(r0[3][str(r)][1]) == 0 for r in range(1, 8))
+    sha = lambda files: [hashlib.sha256(b).hexdigest() for b in files]
+    assert len(one[0]) >= 12 and sha(one[0]) == sha(own[0]) == sha(r0[0])
+    assert one[1] == own[1] == r0[1] and one[2] == own[2] == r0[2] == "32"
+    thr = {v[2] for run in (one, own, r0) for v in run[3].values()}
+    assert len(thr) == 1 and thr != {repr(-0.2)}, thr

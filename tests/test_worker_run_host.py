@@ -354,10 +354,10 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = make_config(pathlib.Path({out!r}))
 cfg.play_data.update(dict(nb_game_in_file=5, nb_game_in_ggf_file=5, max_file_num={max_files}))
-w = make_stub_worker(cfg, games_in_flight=25, rank=rank, world=world)
+w = make_stub_worker(cfg, games_in_flight={in_flight}, rank=rank, world=world)
 w.emission = {emission!r}
 fail_at = {fail_at}
-if fail_at and rank == 1:
+if fail_at and rank == {fail_rank}:
     real, calls = w.write_raw, []
     def failing(raw, first_local_idx=1, threads=None, ahead=128, stamp_base=None):
         calls.append(first_local_idx)
@@ -367,7 +367,7 @@ if fail_at and rank == 1:
         return real(raw, first_local_idx, threads, ahead, stamp_base)
     w.write_raw = failing
 try:
-    w.run(total_games=200, background_emit={background})
+    w.run(total_games={total}, background_emit={background})
     say("RANK", rank, "RETURNED")
 except RuntimeError as ex:
     say("RANK", rank, "RAISED", str(ex)[:70].replace("\n", " "))
@@ -377,22 +377,23 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def _per_rank_run(tmp_path, tag, port, emission="auto", background=True, max_files=1000, fail_at=0):
+def _per_rank_run(tmp_path, tag, port, emission="auto", background=True, max_files=1000, fail_at=0, nproc=2, in_flight=25, total=200, fail_rank=1):
     script = tmp_path / f"{tag}.py"
-    script.write_text(_PER_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path / tag), emission=emission, background=background, max_files=max_files, fail_at=fail_at))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    script.write_text(_PER_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path / tag), emission=emission, background=background, max_files=max_files, fail_at=fail_at,
+                                              in_flight=in_flight, total=total, fail_rank=fail_rank))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                       capture_output=True, text=True, env=env, timeout=600)
+                       capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
 
-def _one_rank_reference(tmp_path, max_files=1000):
+def _one_rank_reference(tmp_path, max_files=1000, in_flight=50, total=200):
     cfg = make_config(tmp_path / "one")
     cfg.play_data.update(dict(nb_game_in_file=5, nb_game_in_ggf_file=5, max_file_num=max_files))
-    w = make_stub_worker(cfg, games_in_flight=50)
-    w.run(total_games=200)
+    w = make_stub_worker(cfg, games_in_flight=in_flight)
+    w.run(total_games=total)
     return outputs(cfg), f"{w.thresholds_seen} {cfg.play.resign_threshold}"
 
 
@@ -473,3 +474,92 @@ def test_whole_files_block_rounds_up_to_the_file_sizes(tmp_path):
     assert whole_files_block(cfg, 25) == 36
     w = make_stub_worker(cfg, games_in_flight=36, rank=1, world=2)
     assert w._per_rank_emission() is True
+
+
+# ---- world 8: the rank count of the node the path is built for (BASELINE configs[3]: 65 536 games over 8 GPUs) ----------------------
+def _sha(files):
+    return [hashlib.sha256(b).hexdigest() for b in files]
+
+
+def test_eight_ranks_rank0_emission_equals_one_rank(tmp_path):
+    """8 ranks x 7 ids per block (7 is no whole number of 5-game files: "auto" gathers every record on rank 0, the path's one data
+    collective at its full fan-in; 200 requested games are no whole number of 56-id blocks either: the run plays 4 blocks = 224 ids, as
+    one rank x 56 does): the directory, the game index and the threshold trajectory are those of one rank."""
+    out = _per_rank_run(tmp_path, "eight", 29571, nproc=8, in_flight=7)
+    assert all(f"RANK {r} RETURNED" in out for r in range(8)), out[-2000:]
+    assert dict(re.findall(r"RANK (\d) OWNFILES (\d)", out)) == {str(r): "0" for r in range(8)}
+    written = {k: int(v) for k, v in re.findall(r"RANK (\d) OWNFILES \d BYTES (\d+)", out)}
+    assert written["0"] > 10000 and all(written[str(r)] == 0 for r in range(1, 8))      # rank 0 alone wrote
+    thr = dict(re.findall(r"RANK (\d) THRESHOLDS (\[[^\]]*\] \S+)", out))
+    one, thr_one = _one_rank_reference(tmp_path, in_flight=56)
+    eight = outputs(make_config(tmp_path / "eight"))
+    assert one[2] == eight[2] == "224" and len(one[0]) >= 35
+    assert _sha(one[0]) == _sha(eight[0]) and one[1] == eight[1]
+    assert len(set(thr.values())) == 1 and thr["0"] == thr_one and len(thr) == 8
+
+
+def test_eight_ranks_per_rank_emission_equals_one_rank(tmp_path):
+    """8 ranks x 10 ids per block, 5 games per file: every rank writes the two files (and the GGF files) of its own id range, 32 B per
+    game are gathered; 240 games = 3 blocks.  Byte-identical to one rank x 80, and max_file_num pruned from eight listings leaves the
+    newest files of the one-rank run."""
+    out = _per_rank_run(tmp_path, "eight", 29573, nproc=8, in_flight=10, total=240)
+    assert all(f"RANK {r} RETURNED" in out for r in range(8)), out[-2000:]
+    assert dict(re.findall(r"RANK (\d) OWNFILES (\d)", out)) == {str(r): "1" for r in range(8)}
+    written = {k: int(v) for k, v in re.findall(r"RANK (\d) OWNFILES \d BYTES (\d+)", out)}
+    assert all(written[str(r)] > 3000 for r in range(8)), written
+    assert {int(v) for v in re.findall(r"GATHER (\d+)", out)} == {7 * 10 * 32}    # 32 B per game of the seven other ranks: nothing else crossed
+    thr = dict(re.findall(r"RANK (\d) THRESHOLDS (\[[^\]]*\] \S+)", out))
+    one, thr_one = _one_rank_reference(tmp_path, in_flight=80, total=240)
+    eight = outputs(make_config(tmp_path / "eight"))
+    assert one[2] == eight[2] == "240" and len(one[0]) >= 35
+    assert _sha(one[0]) == _sha(eight[0]) and one[1] == eight[1]
+    assert len(set(thr.values())) == 1 and thr["0"] == thr_one
+    # pruning
+    out = _per_rank_run(tmp_path, "pruned", 29575, nproc=8, in_flight=10, total=240, max_files=11)
+    assert all(f"RANK {r} RETURNED" in out for r in range(8)), out[-2000:]
+    cfgp = make_config(tmp_path / "one_pruned")
+    cfgp.play_data.update(dict(nb_game_in_file=5, nb_game_in_ggf_file=5, max_file_num=11))
+    make_stub_worker(cfgp, games_in_flight=80).run(total_games=240)
+    pruned = outputs(make_config(tmp_path / "pruned"))
+    assert len(pruned[0]) == 11 and _sha(pruned[0]) == _sha(outputs(cfgp)[0])
+
+
+def test_eight_ranks_a_failed_writer_on_rank_5_stops_every_rank(tmp_path):
+    """Rank 5's writer fails on its second block: all eight ranks raise within the run (nobody waits in a collective), rank 5 its own
+    exception, and the game index stays at the one block every rank has on disk."""
+    out = _per_rank_run(tmp_path, "fail", 29577, nproc=8, in_flight=10, total=240, fail_at=2, fail_rank=5)
+    assert "RANK 5 RAISED writing play data failed" in out and "disk full" in out, out[-2000:]
+    for r in (0, 1, 2, 3, 4, 6, 7):
+        assert f"RANK {r} RAISED rank {r}: another rank failed" in out, out[-2000:]
+    assert open(make_config(tmp_path / "fail").resource.self_play_game_idx_file).read() == "80"
+
+
+def test_auto_emission_across_hosts_gathers_on_rank0(tmp_path, monkeypatch):
+    """emission="auto" picks per-rank files only when all ranks run on ONE host (the launcher's LOCAL_WORLD_SIZE == the world size):
+    on several nodes each rank would write into its own node's directory.  "per_rank" stays the caller's explicit choice."""
+    cfg = make_config(tmp_path / "x")
+    cfg.play_data.update(dict(nb_game_in_file=5, nb_game_in_ggf_file=5))
+    w = make_stub_worker(cfg, games_in_flight=10, rank=3, world=16)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert w._per_rank_emission() is False
+    w.emission = "per_rank"
+    assert w._per_rank_emission() is True
+    w.emission = "auto"
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
+    assert w._per_rank_emission() is True
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert w._per_rank_emission() is True
+
+
+def test_start_block_of_ch5_yml_on_eight_ranks_is_whole_files(tmp_path):
+    """start()'s default block under 8 ranks with ch5.yml's file sizes (1 game per play file, 100 per GGF file): 4 x 4096 = 16 384 ids
+    per rank is rounded up to 16 400, so that every one of the 8 ranks owns whole files and writes them itself."""
+    from reversi_alpha_zero_amd.worker.self_play import whole_files_block
+    cfg = make_config(tmp_path / "x")
+    cfg.play_data.update(dict(nb_game_in_file=1, nb_game_in_ggf_file=100, enable_ggf_data=True))
+    blk = whole_files_block(cfg, 4 * 4096)
+    assert blk == 16400
+    for rank in range(8):
+        w = make_stub_worker(cfg, games_in_flight=4096, rank=rank, world=8)
+        w.block_games = blk
+        assert w._ids_per_block() == blk and w._per_rank_emission() is True

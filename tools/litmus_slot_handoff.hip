@@ -39,6 +39,25 @@ __device__ __forceinline__ unsigned long long key_of(uint32_t b, uint32_t r, uin
     return x | 1ULL;
 }
 
+// PLAIN loads as the product's `s->idx_tag` compiles to (global_load_dword / dwordx2, no sc bits: served by this CU's L1 and this XCD's
+// L2).  Inline asm because a C++ `volatile` load is emitted with sc0 sc1 on gfx950 (it bypasses both caches - the first version of this
+// litmus used volatile and therefore saw no staleness at all) and a non-volatile one in a loop is hoisted.
+__device__ __forceinline__ unsigned long long plain64(const void* p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t plain32(const void* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// the three words of a slot requested together (one wait), as memo_find_lane does
+__device__ __forceinline__ void plain_slot(const void* s, unsigned long long& kb, unsigned long long& kw, uint32_t& tag) {
+    asm volatile("global_load_dword %2, %3, off offset:16\n\tglobal_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(kb), "=&v"(kw), "=&v"(tag) : "v"(s) : "memory");
+}
+
 struct Ctl { uint32_t warm[128]; uint32_t done[128]; };   // per publisher block: the reader is warm / the publisher has finished
 
 template <int FORM>
@@ -79,8 +98,8 @@ __global__ __launch_bounds__(64) void k_read(Slot* slots, Ctl* ctl, uint32_t R, 
     if (threadIdx.x != 0) return;
     unsigned long long sink = 0;
     for (uint32_t r = 0; r < R; ++r) {   // warm: this CU's L1 and this XCD's L2 hold the slots as they are BEFORE they are published
-        const volatile Slot* s = slots + (size_t)b * R + r;
-        sink += s->black + s->white + s->tag;
+        const Slot* s = slots + (size_t)b * R + r;
+        sink += plain64(&s->black) + plain64(&s->white) + plain32(&s->tag);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&ctl->warm[b], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -101,8 +120,8 @@ __global__ __launch_bounds__(64) void k_read(Slot* slots, Ctl* ctl, uint32_t R, 
             kw = __hip_atomic_load(&s->white, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (READ == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            kb = *(volatile unsigned long long*)&s->black;
-            kw = *(volatile unsigned long long*)&s->white;
+            kb = plain64(&s->black);
+            kw = plain64(&s->white);
         }
         const unsigned long long k = key_of(b, r, epoch);
         if (kb != k || kw != ~k) ++stale;
@@ -122,8 +141,8 @@ __global__ __launch_bounds__(64) void k_look(Slot* slots, Ctl* ctl, uint32_t R, 
     if (threadIdx.x != 0) return;
     unsigned long long sink = 0;
     for (uint32_t r = 0; r < R; ++r) {
-        const volatile Slot* s = slots + (size_t)b * R + r;
-        sink += s->black + s->white + s->tag;
+        const Slot* s = slots + (size_t)b * R + r;
+        sink += plain64(&s->black) + plain64(&s->white) + plain32(&s->tag);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&ctl->warm[b], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -140,9 +159,7 @@ __global__ __launch_bounds__(64) void k_look(Slot* slots, Ctl* ctl, uint32_t R, 
             kb = __hip_atomic_load(&s->black, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             kw = __hip_atomic_load(&s->white, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            tag = *(volatile uint32_t*)&s->tag;
-            kb = *(volatile unsigned long long*)&s->black;
-            kw = *(volatile unsigned long long*)&s->white;
+            plain_slot(s, kb, kw, tag);
         }
         const unsigned long long k = key_of(b, r, epoch);
         if (tag != (0x80000000u | (epoch << 16) | (r & 0xffffu))) ++unseen;
