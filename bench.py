@@ -1069,7 +1069,7 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
 
 def worker_end_to_end_leg(dev, args, seconds=60.0):
     """BatchedSelfPlayWorker.run() itself - what `run.py self` runs - on BASELINE configs[1] (4096 slots, mini net, 200 sims/move) for a
-    fixed window: continuous batching inside blocks of 16384 game ids, the block's packed records gathered under an RCCL process group of
+    fixed window: continuous batching inside blocks of 65 536 game ids (worker.start()'s default for a 16-filter net), the block's packed records gathered under an RCCL process group of
     ONE rank (the N > 1 code path), resignation bookkeeping, the native row emitter on host threads and the background writer putting
     play_*.json files on tmpfs (the reference's loop plays, buffers AND writes inside the timed game: worker/self_play.py:139-217,
     lib/data_helper.py:23-25).  games/hour here INCLUDES emission; the engine-level figure of the same blocks is beside it."""
@@ -1110,7 +1110,9 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
         rc.force_simulation_num_file = os.path.join(root, ".force-sim")
         rc.create_directories = lambda: [os.makedirs(d, exist_ok=True) for d in (rc.play_data_dir, rc.self_play_ggf_data_dir)]
         blob = ReversiNet(*NETS["mini"]).keras_init_(0).to_blob()
-        slots, block = 4096, 16384
+        from reversi_alpha_zero_amd.worker.self_play import default_block_games
+        slots = 4096
+        block = default_block_games(blob, slots)   # what worker.start() picks: 16 games per slot for a 16-filter net (65 536 ids, ~9 s per block)
         w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=slots, block_games=block, seed=0, device=str(dev), rank=0, world=1)
         # the first file of the run, for the oracle check below (max_file_num prunes it later)
         keep = {}
@@ -1508,7 +1510,7 @@ def main():
                     ("bitboard_sweep", lambda: sweep_leg(dev)))
             only = set(args.legs.split(",")) if args.legs else None
             # nominal seconds of a leg on an MI355X box (profiles/r5/bench_r5_default_run_*: engine construction included)
-            nominal = {"worker_end_to_end_config1": 75.0, "config5_8192x3200_agz": 35.0, "ch5_yml_as_shipped": 30.0, "headline_on_exact_f32_kernels": 20.0,
+            nominal = {"worker_end_to_end_config1": 85.0, "config5_8192x3200_agz": 35.0, "ch5_yml_as_shipped": 30.0, "headline_on_exact_f32_kernels": 20.0,
                        "config1_mini_yml_as_shipped_continuous_batching": 20.0}
             for key, leg in legs:
                 if only is not None and key not in only:

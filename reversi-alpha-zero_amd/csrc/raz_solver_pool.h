@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 xk_store64(&pslot->black, put_own);
                 xk_store64(&pslot->white, put_enemy);
             }
-            xk_drain();
+            if (__ballot(putting)) xk_drain();   // (only a wave that stores keys waits: the wait also covers the loads requested a phase ahead)
             if (putting) xk_store32(&pslot->idx_tag, put_tag);
             put_pending = false;
         }

@@ -1168,10 +1168,23 @@ def whole_files_block(config, block_games):
     return -(-int(block_games) // unit) * unit
 
 
+def default_block_games(net_blob, games_in_flight):
+    """Game ids per rank between two gathers when the caller names none.  A block ends with a ramp-down - its last games finish while
+    the slots they leave stay empty - worth about half a game per slot, plus fixed host work (outbox, gather, bookkeeping): at g games
+    per slot a block runs at ~ g / (g + 0.5) of the steady state.  Wide nets (a 256x10 game takes ~13 minutes of an 8192-slot batch):
+    4 games per slot, so that files and the optimizer's new weights (polled between blocks) turn around within the hour.  Narrow nets
+    (a 16-filter block of 4 x 4096 ids lasts 2.4 s): 16 games per slot - 9 s per block, ramp-down and per-block work a quarter of what
+    they were (bench.py worker_end_to_end_config1: end to end 91-93 % of the engine-level rate at 4 games per slot)."""
+    import struct
+    filters = struct.unpack_from("<5i", net_blob, 0)[2] if net_blob and len(net_blob) >= 20 else 256
+    return (4 if filters >= 128 else 16) * int(games_in_flight)
+
+
 def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0, block_games=None, fused_tree_net="auto", emission="auto"):
     """Reference entry point (worker/self_play.py:28).  Under torchrun uses one rank per GPU.  fused_tree_net: see
     BatchedSelfPlayWorker (16-filter nets: tree and net in one kernel; opt-in).  block_games (ids per rank between two gathers):
-    default 4 games per slot, under several ranks rounded up to whole files (whole_files_block) so that each rank writes its own."""
+    default_block_games - 4 games per slot (16 for narrow nets) -, under several ranks rounded up to whole files (whole_files_block) so
+    that each rank writes its own."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -1197,7 +1210,7 @@ def start(config, net_blob=None, games_in_flight=None, total_games=None, seed=0,
             return model.model.to_blob() if try_reload_model(config, model) else None
     B = games_in_flight or 4096
     if not block_games:
-        block_games = 4 * B                  # continuous batching: 4 games per slot between two gathers
+        block_games = default_block_games(net_blob, B)   # continuous batching: several games per slot between two gathers
         if world > 1 and emission != "rank0":
             block_games = whole_files_block(config, block_games)
     w = BatchedSelfPlayWorker(config, net_blob, B, seed=seed, device=f"cuda:{local}", rank=rank, world=world,
