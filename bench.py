@@ -1131,6 +1131,13 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
         dt = _t.monotonic() - t0
         games = int(open(rc.self_play_game_idx_file).read())
         st = w.last_stats
+        blocks = list(getattr(w, "block_stats", []))
+
+        def engine_level(seconds, games_, sims_):   # the engine's own loop: steps + statistics + harvests (host time around them included)
+            if not isinstance(seconds, dict):
+                return None
+            t = max(1e-9, float(seconds.get("steps_and_stats", 0.0)) + float(seconds.get("harvest", 0.0)))
+            return {"sims_per_s": sims_ / t, "games_per_hour": games_ / t * 3600.0, "seconds": t}
         out = {"workload": f"BatchedSelfPlayWorker.run() on BASELINE configs[1]: {slots} slots, blocks of {block} game ids with continuous batching, mini net, {sims} sims/move, "
                            "mini.yml play settings (thinking_loop 1, solver off, parallel_search_num 1), RCCL group of one rank for the record gather, native row emitter "
                            f"on {w._emit_executor_threads} host threads + background writer, play_*.json files of 64 games on tmpfs (max_file_num 24)",
@@ -1139,8 +1146,10 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
                "bytes_written": int(getattr(w, "bytes_written", 0)), "gb_per_s_of_json_text": getattr(w, "bytes_written", 0) / dt / 1e9,
                "writer_busy_share_of_the_run": w.last_writer_busy_seconds / dt, "blocks": w.last_writer_batches,
                "main_thread_seconds": dict(getattr(w, "run_seconds", {}) or {}),
-               "engine_level_of_the_last_block": {"sims_per_s": st["total_sims"] / max(1e-9, sum(st["seconds"].values())) if isinstance(st.get("seconds"), dict) else None,
-                                                  "games_per_hour": st["finished_games"] / max(1e-9, sum(st["seconds"].values())) * 3600.0 if isinstance(st.get("seconds"), dict) else None},
+               "engine_level_of_the_last_block": engine_level(st.get("seconds"), st["finished_games"], st["total_sims"]),
+               "engine_level_of_all_blocks": engine_level({k: sum(b.get(k, 0.0) for b in blocks) for k in ("steps_and_stats", "harvest")},
+                                                          sum(b["games"] for b in blocks), sum(b["sims"] for b in blocks)),
+               "blocks_detail": blocks[:3] + blocks[-2:],
                "gather_backend": getattr(w, "last_gather_backend", None), "gather_bytes_last_block": getattr(w, "last_gather_bytes", None),
                "host_threads": os.cpu_count()}
         # two games of the first file against the oracle's rows for the same ids
@@ -1197,7 +1206,7 @@ def continuous_leg(dev, args, rounds=3, shipped=False):
     torch.cuda.synchronize()
     # the stepping loop (steps + per-chunk stats + harvests, host clock, every chunk ends synchronised) - like the lock-step
     # leg, the start of the batch and the allocation of the id-ordered outbox are outside the timed region
-    dt = sum(st["seconds"].values())
+    dt = st["seconds"]["steps_and_stats"] + st["seconds"]["harvest"]
     out = {"workload": f"BASELINE configs[1] with continuous batching: {games} slots, {rounds * games} game ids (whole games), mini net, {sims} sims/move, "
                        + ("mini.yml play section AS SHIPPED (thinking_loop 2, parallel_search_num 4, end-game solver from turn 50), two-kernel pipeline + solver pool"
                           if shipped else "mini.yml play settings, thinking_loop=1, solver off, parallel_search_num=1"),
@@ -1354,7 +1363,7 @@ def compact_line(full):
     d = full.get("worker_end_to_end_config1")
     if isinstance(d, dict):
         line["worker_end_to_end_config1"] = pick(d, ("games_written", "seconds", "games_per_hour_including_emission", "sims_per_s_including_emission", "bytes_written",
-                                                     "writer_busy_share_of_the_run", "gather_backend", "main_thread_seconds", "engine_level_of_the_last_block", "error"))
+                                                     "writer_busy_share_of_the_run", "gather_backend", "main_thread_seconds", "engine_level_of_the_last_block", "engine_level_of_all_blocks", "error"))
         if "parity_check_files" in d:
             line["worker_end_to_end_config1"]["parity"] = parity(d["parity_check_files"])
     sw = full.get("bitboard_sweep")

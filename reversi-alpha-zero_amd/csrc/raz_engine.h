@@ -196,6 +196,8 @@ struct raz_engine_dev {
     raz_engine_config cfg;
     uint32_t B, C, H, max_plies;   // C: node COUNT capacity per game (directory / table sizing)
     unsigned long long pool_bytes; // bytes of one game's node pool (multiple of 8, <= 8 x RAZ_LINK_MAX_UNITS)
+    uint32_t xk;                   // 1: the solver pool's round runs on its own stream BESIDE tree launches (pool_every > 1): the words the two sides
+                                   // exchange are agent-scope (raz_engine_core.h xk_*).  0: every hand-off crosses a kernel boundary - plain accesses
     uint32_t K;                    // simulation slots per game: parallel_search_num (1 for the classic one-in-flight kernel)
     uint32_t par;                  // 1: k_tree_par drives the games (per-slot state in `sim`), 0: k_tree
     uint32_t* sim;                 // [B][K][64] slot blocks (raz_game layout), par only

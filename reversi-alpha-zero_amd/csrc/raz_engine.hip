@@ -954,6 +954,7 @@ extern "C" int raz_engine_create(const raz_engine_config* cfg, const raz_net* ne
     }
     e->ev_fork = nullptr;
     e->pool_every = (int)((cfg->reserved >> 24) & 0xfu) ? (int)((cfg->reserved >> 24) & 0xfu) : RAZ_SOLVER_POOL_EVERY;
+    e->dev.xk = e->pool_every > 1 ? 1u : 0u;   // tree and pool kernels run concurrently: their hand-off words are agent-scope (raz_engine_core.h xk_*)
     for (int h = 0; h < kMaxParts; ++h) {
         e->aux[h] = nullptr;
         e->ev_join[h] = nullptr;
@@ -998,6 +999,7 @@ extern "C" int raz_engine_set_parts(raz_engine* e, int parts) {
 extern "C" int raz_engine_set_solver_pool_every(raz_engine* e, int n) {
     if (!e || n < 0 || n > 15) return raz_fail(RAZ_EINVAL, "raz_engine_set_solver_pool_every: n must be 0..15");
     e->pool_every = n ? n : RAZ_SOLVER_POOL_EVERY;   // (raz_engine_step has joined the last round: the pool is at rest)
+    e->dev.xk = e->pool_every > 1 ? 1u : 0u;
     for (int h = 0; h < kMaxParts; ++h) e->pool_tick[h] = 0u;
     return RAZ_OK;
 }

@@ -42,13 +42,40 @@ __device__ __forceinline__ void wave_sync_lanes() {
 // others (a memo slot's tag, a request's state) is stored after the publisher's `s_waitcnt vmcnt(0)` (xk_drain: the asm form, which the
 // compiler cannot drop).  tools/litmus_slot_handoff.hip is the hardware check of exactly this against the plain-store / plain-load form
 // of rounds 1-5 (profiles/r6/litmus_slot_handoff.json).  No cache-wide fence (buffer_wbl2 / buffer_inv) is needed or issued.
-__device__ __forceinline__ void xk_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void xk_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long xk_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t xk_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void xk_drain() {
+// The TREE kernels' side of the exchange always uses the agent-scope forms (a look at a request header per launch, the memo probe
+// before a request, the request's four stores: nothing that is timed).  The POOL kernels choose at run time:
+// `conc` (raz_engine_dev.xk) is 0 when the pool's round runs between the tree launches on their own stream (pool_every == 1, whole-game
+// batches): every hand-off then crosses a kernel boundary and plain accesses are what they always were - lines stay in L1 / L2, which
+// is worth 4-5 % on mini.yml as shipped (profiles/r6/handoff_*_ab*.jsonl: agent-scope stores drop the line from the XCD's L2, and the
+// one look a suspended game takes at its request header then comes from memory).
+// (The "plain" forms are wavefront-scope relaxed atomics: the same instructions as an ordinary load / store - no sc bits, served by
+// L1 / L2 - but always VECTOR memory instructions: with a real plain load of a uniform address in one arm the compiler builds a
+// scalar load there, a vector load in the other, and fails on the merge in the fused kernels - "illegal VGPR to SGPR copy".)
+__device__ __forceinline__ void xk_store64(bool conc, unsigned long long* p, unsigned long long v) {
+    if (conc) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void xk_store32(bool conc, uint32_t* p, uint32_t v) {
+    if (conc) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ unsigned long long xk_load64(bool conc, const unsigned long long* p) {
+    unsigned long long v = conc ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #ifndef RAZ_WAVE_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(v));   // (the merged value stays a vector register: see above)
+#endif
+    return v;
+}
+__device__ __forceinline__ uint32_t xk_load32(bool conc, const uint32_t* p) {
+    uint32_t v = conc ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifndef RAZ_WAVE_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+__device__ __forceinline__ void xk_drain(bool conc) {
+#ifndef RAZ_WAVE_EMU
+    if (conc) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
@@ -513,12 +540,13 @@ static_assert(sizeof(SolverLDS) == RAZ_SOLVER_LDS_BYTES, "SolverLDS layout");
 // Writers and readers may be waves of concurrent kernels on different XCDs (the pool's round beside the tree launches): key words and
 // tag are agent-scope atomics on both sides, the tag stored after the key stores have drained (xk_* above).  A reader that still gets
 // the tag before the keys compares unequal: a miss.
-__device__ __forceinline__ bool memo_claim_and_write(raz_slot* s, raz_bb own, raz_bb enemy, uint32_t tag) {
+__device__ __forceinline__ bool memo_claim_and_write(bool conc, raz_slot* s, raz_bb own, raz_bb enemy, uint32_t tag) {
     if (atomicCAS(&s->idx_tag, 0u, RAZ_MEMO_CLAIMED) != 0u) return false;
-    xk_store64(&s->black, own);
-    xk_store64(&s->white, enemy);
-    xk_drain();
-    xk_store32(&s->idx_tag, tag);
+    xk_store64(conc, &s->black, own);
+    xk_store64(conc, &s->white, enemy);
+    if (conc) xk_drain(true);
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler order only)
+    __hip_atomic_store(&s->idx_tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
@@ -529,8 +557,9 @@ __device__ bool memo_find(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_b
     const uint32_t h = key_hash(own, enemy, 8u + exact);
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const raz_slot* s = tab + ((h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask);
-        const uint32_t it = xk_load32(&s->idx_tag);
-        const raz_bb sb = xk_load64(&s->black), sw = xk_load64(&s->white);
+        constexpr bool conc = true;   // (tree side: always the agent-scope forms, see xk_* above)
+        const uint32_t it = xk_load32(conc, &s->idx_tag);
+        const raz_bb sb = xk_load64(conc, &s->black), sw = xk_load64(conc, &s->white);
         const bool used = (it >> 31) != 0;
         const bool match = used && sb == own && sw == enemy && ((it >> 30) & 1u) == exact;
         const unsigned long long mm = __ballot(match) & 0xffffULL;
@@ -554,12 +583,12 @@ __device__ void memo_put(const raz_engine_dev& E, uint32_t g, raz_bb own, raz_bb
     const uint32_t tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
     for (uint32_t r = 0; r < 64; r += RAZ_PROBE) {
         const uint32_t si = (h + r + (uint32_t)(lane & (RAZ_PROBE - 1))) & mask;
-        unsigned long long em = __ballot(xk_load32(&tab[si].idx_tag) == 0u) & 0xffffULL;
+        unsigned long long em = __ballot(xk_load32(true, &tab[si].idx_tag) == 0u) & 0xffffULL;
         while (em) {   // (wave-uniform) the first free slot of the group - or the next one, if a worker wave of the pool claimed it meanwhile
             const int j = __ffsll((long long)em) - 1;
             em &= em - 1;
             uint32_t ok = 0u;
-            if (lane == 0) ok = memo_claim_and_write(tab + ((h + r + (uint32_t)j) & mask), own, enemy, tag) ? 1u : 0u;
+            if (lane == 0) ok = memo_claim_and_write(true, tab + ((h + r + (uint32_t)j) & mask), own, enemy, tag) ? 1u : 0u;
             if (uni(ok)) {
                 wave_sync();
                 return;
@@ -575,8 +604,9 @@ __device__ bool memo_find_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, 
     // both slots' fields are requested together: ONE round trip into the game's table (the 64 searches of a worker wave advance in
     // lockstep, so a dependent second request would be paid by all of them)
     const raz_slot *s0 = tab + (h & mask), *s1 = tab + ((h + 1u) & mask);
-    const uint32_t it0 = xk_load32(&s0->idx_tag), it1 = xk_load32(&s1->idx_tag);
-    const raz_bb b0 = xk_load64(&s0->black), w0 = xk_load64(&s0->white), b1 = xk_load64(&s1->black), w1 = xk_load64(&s1->white);
+    const bool conc = E.xk != 0u;
+    const uint32_t it0 = xk_load32(conc, &s0->idx_tag), it1 = xk_load32(conc, &s1->idx_tag);
+    const raz_bb b0 = xk_load64(conc, &s0->black), w0 = xk_load64(conc, &s0->white), b1 = xk_load64(conc, &s1->black), w1 = xk_load64(conc, &s1->white);
     uint32_t it;
     if (!(it0 >> 31)) return false;
     if (b0 == own && w0 == enemy && ((it0 >> 30) & 1u) == exact)
@@ -594,7 +624,7 @@ __device__ void memo_put_lane(const raz_engine_dev& E, uint32_t g, raz_bb own, r
     const uint32_t mask = E.M - 1, h = key_hash(own, enemy, 8u + exact);
     const uint32_t tag = 0x80000000u | (exact << 30) | ((uint32_t)(move + 1) << 8) | (uint32_t)(score + 128);
     for (uint32_t r = 0; r < 2; ++r)
-        if (memo_claim_and_write(tab + ((h + r) & mask), own, enemy, tag)) return;
+        if (memo_claim_and_write(E.xk != 0u, tab + ((h + r) & mask), own, enemy, tag)) return;
     // both slots taken: skipping the insert only costs time
 }
 
@@ -691,7 +721,7 @@ __device__ __forceinline__ raz_solve_hdr* solve_hdr(const raz_engine_dev& E, uin
 // A game whose request is still with the pool has nothing to do in this launch: one word tells (the tree kernels look at it before
 // they load anything else - in a solver-bound batch most games of a launch are in that state).
 __device__ __forceinline__ bool solve_in_flight(const raz_engine_dev& E, uint32_t g) {
-    const uint32_t st = RAZ_SOLVE_STATE(uni(xk_load32(&solve_hdr(E, g)->state)));   // (the pool may publish the answer while this kernel runs)
+    const uint32_t st = RAZ_SOLVE_STATE(uni(xk_load32(true, &solve_hdr(E, g)->state)));   // (the pool may publish the answer while this kernel runs)
     return st == RAZ_SOLVE_REQUESTED || st == RAZ_SOLVE_RUNNING;
 }
 
@@ -716,9 +746,10 @@ __device__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_b
     raz_solve_hdr* h = solve_hdr(E, g);
     // every word of the header that the other side reads or writes while this kernel runs goes through xk_* (state and gen share one
     // aligned 8-byte word: the pool's kernels see a request's generation and state together)
-    const unsigned long long sg = uni((raz_bb)xk_load64((const unsigned long long*)h));
+    constexpr bool conc = true;   // (tree side: always the agent-scope forms)
+    const unsigned long long sg = uni((raz_bb)xk_load64(conc, (const unsigned long long*)h));
     const uint32_t word = (uint32_t)sg, st = RAZ_SOLVE_STATE(word), gen = (uint32_t)(sg >> 32);
-    const bool same = uni((uint32_t)(xk_load64(&h->own0) == own0 && xk_load64(&h->enemy0) == enemy0 && xk_load32(&h->exact) == exact)) != 0u;
+    const bool same = uni((uint32_t)(xk_load64(conc, &h->own0) == own0 && xk_load64(conc, &h->enemy0) == enemy0 && xk_load32(conc, &h->exact) == exact)) != 0u;
     if (same && st == RAZ_SOLVE_ANSWERED) {   // (the block keeps the last answer: the memo may have had no room for it)
         out_move = RAZ_SOLVE_ANSWER_MOVE(word);
         out_score = RAZ_SOLVE_ANSWER_SCORE(word);
@@ -729,11 +760,11 @@ __device__ int solver_solve(const raz_engine_dev& E, uint32_t g, int lane, raz_b
     if (lane == 0) {   // a new request (an abandoned one - another position - is overwritten: its workers see the new gen and drop their tasks)
         // the position first, drained; then {state, gen} in ONE 8-byte store: a scan that sees REQUESTED sees this request's position
         // (five plain stores could be merged or reordered by the compiler, and sat in this XCD's L2 until the kernel ended)
-        xk_store64(&h->own0, own0);
-        xk_store64(&h->enemy0, enemy0);
-        xk_store32(&h->exact, exact);
-        xk_drain();
-        xk_store64((unsigned long long*)h, (unsigned long long)RAZ_SOLVE_REQUESTED | ((unsigned long long)(gen + 1u) << 32));
+        xk_store64(conc, &h->own0, own0);
+        xk_store64(conc, &h->enemy0, enemy0);
+        xk_store32(conc, &h->exact, exact);
+        xk_drain(conc);
+        xk_store64(conc, (unsigned long long*)h, (unsigned long long)RAZ_SOLVE_REQUESTED | ((unsigned long long)(gen + 1u) << 32));
         h->posted += 1u;   // (this side's word: nobody else touches it while a kernel runs)
     }
     wave_sync();

@@ -126,14 +126,15 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
     raz_solve_hdr* h = solve_hdr(E, g);
     // (the tree kernels may be running beside this launch: a request's words are read the way they are published, raz_engine_core.h xk_*;
     // the position is requested after the state has arrived - a REQUESTED state is stored after its position has drained)
-    const uint32_t st = RAZ_SOLVE_STATE(uni(xk_load32(&h->state)));
+    const bool conc = E.xk != 0u;
+    const uint32_t st = RAZ_SOLVE_STATE(uni(xk_load32(conc, &h->state)));
     if (st != RAZ_SOLVE_REQUESTED && st != RAZ_SOLVE_RUNNING) return;
     __shared__ SolverTree tree_lds;
     SolverTree* P = &tree_lds;
     SolverTree* T = solve_tree(E, g);
     SolverDeep* D = solve_deep(E, g);
-    const raz_bb own0 = uni((raz_bb)xk_load64(&h->own0)), enemy0 = uni((raz_bb)xk_load64(&h->enemy0));
-    const uint32_t exact = uni(xk_load32(&h->exact));
+    const raz_bb own0 = uni((raz_bb)xk_load64(conc, &h->own0)), enemy0 = uni((raz_bb)xk_load64(conc, &h->enemy0));
+    const uint32_t exact = uni(xk_load32(conc, &h->exact));
     int k = 0, n2 = 0, total = 0, subs = 0;   // root moves, level-2 nodes, level-3 nodes, tasks
     if (st == RAZ_SOLVE_REQUESTED) {
         const raz_bb legal0 = bb_legal_moves(own0, enemy0);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             if (lane == 0) {
                 h->ans_move = -1;
                 h->ans_score = -100;
-                xk_store32(&h->state, RAZ_SOLVE_ANSWER_WORD(RAZ_SOLVE_NONE, -1, -100));
+                xk_store32(conc, &h->state, RAZ_SOLVE_ANSWER_WORD(RAZ_SOLVE_NONE, -1, -100));
             }
             return;
         }
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             h->ans_score = bs;
             // ONE agent-scope 4-byte store (write-through): a tree kernel running beside this launch on another XCD finds the answer at
             // its next look instead of at the next kernel boundary (a plain store stayed in this XCD's L2 until the launch ended)
-            xk_store32(&h->state, RAZ_SOLVE_ANSWER_WORD(bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE, bm, bs));
+            xk_store32(conc, &h->state, RAZ_SOLVE_ANSWER_WORD(bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE, bm, bs));
             atomicAdd(&E.counters[21], 1ULL);
             atomicAdd(&E.counters[22], (unsigned long long)(st == RAZ_SOLVE_REQUESTED ? 0u : h->rounds));
         }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             h->tasks = (uint32_t)total;
             h->total = (uint32_t)subs;
             h->next = 0u;
-            xk_store32(&h->state, RAZ_SOLVE_RUNNING);   // (the tree kernels treat REQUESTED and RUNNING alike: nothing of the task tree is theirs to read)
+            xk_store32(conc, &h->state, RAZ_SOLVE_RUNNING);   // (the tree kernels treat REQUESTED and RUNNING alike: nothing of the task tree is theirs to read)
         }
     } else {
         for (int n = lane; n < n2; n += 64) T->g_v[n] = P->g_v[n];
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev E, uint32_t part, uint32_t w0, uint32_t wcount, uint32_t a0, int budget) {
     if (blockIdx.x >= wcount) return;
     const int lane = threadIdx.x;
+    const bool conc = E.xk != 0u;   // the tree kernels may be running beside this launch (raz_engine_core.h xk_*)
     const uint32_t w = w0 + blockIdx.x;
     unsigned long long* lw = E.pool_state + (size_t)w * 1024;                  // lw[word * 64 + lane]
     // the lanes' frames live in LDS while the wave runs (a push or a pop is four conflict-free 8-byte accesses - word j of level d at
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     int task = (int)(m2 & 0xffffULL), task_n = (int)((m2 >> 16) & 0xffULL), task_ci = (int)((m2 >> 24) & 0xffULL), task_t = (int)((m2 >> 32) & 0xffffULL);
     if (have) {   // is the parked search still wanted?  Its request may have been answered (a decided scan) or replaced, its node decided
         const raz_solve_hdr* hh = solve_hdr(E, g);
-        const unsigned long long sg = xk_load64((const unsigned long long*)hh);   // {state, gen}: one word, as the tree kernels publish it
+        const unsigned long long sg = xk_load64(conc, (const unsigned long long*)hh);   // {state, gen}: one word, as the tree kernels publish it
         if ((uint32_t)(sg >> 32) != gen || RAZ_SOLVE_STATE((uint32_t)sg) != RAZ_SOLVE_RUNNING) have = false;
         else if (solve_deep(E, g)->h_dead[task_t]) have = false;
     }
@@ -498,8 +500,8 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 const raz_slot* tab = E.memo + (size_t)g * E.M;
                 const uint32_t h = key_hash(own, enemy, 8u + exact);
                 const raz_slot *s0 = tab + (h & (E.M - 1)), *s1 = tab + ((h + 1u) & (E.M - 1));
-                it0 = xk_load32(&s0->idx_tag); it1 = xk_load32(&s1->idx_tag);   // (memo entries cross between concurrent kernels: raz_engine_core.h xk_*)
-                b0 = xk_load64(&s0->black); w0 = xk_load64(&s0->white); b1 = xk_load64(&s1->black); w1 = xk_load64(&s1->white);
+                it0 = xk_load32(conc, &s0->idx_tag); it1 = xk_load32(conc, &s1->idx_tag);   // (memo entries cross between concurrent kernels: raz_engine_core.h xk_*)
+                b0 = xk_load64(conc, &s0->black); w0 = xk_load64(conc, &s0->white); b1 = xk_load64(conc, &s1->black); w1 = xk_load64(conc, &s1->white);
             }
             if (put_pending) {
                 pslot = E.memo + (size_t)put_g * E.M + (key_hash(put_own, put_enemy, 8u + ((put_tag >> 30) & 1u)) & (E.M - 1));
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     next_solve = active[(lane_id + draws * lanes_of_slice) % nact];
                     raz_solve_hdr* hh = solve_hdr(E, gg);
                     const uint32_t t = atomicAdd(&hh->next, 1u);
-                    const uint32_t total = hh->total, ex = xk_load32(&hh->exact), hgen = xk_load32(&hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
+                    const uint32_t total = hh->total, ex = xk_load32(conc, &hh->exact), hgen = xk_load32(conc, &hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
                     if (t < total) {
                         got = true;
                         SolverTree* T = solve_tree(E, gg);
@@ -590,11 +592,12 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
             // keys, drained, then the tag - all agent-scope words; the wait is the wave's, not a lane's, so it stands outside the branch
             const bool putting = put_pending && claimed == 0u;
             if (putting) {
-                xk_store64(&pslot->black, put_own);
-                xk_store64(&pslot->white, put_enemy);
+                xk_store64(conc, &pslot->black, put_own);
+                xk_store64(conc, &pslot->white, put_enemy);
             }
-            if (__ballot(putting)) xk_drain();   // (only a wave that stores keys waits: the wait also covers the loads requested a phase ahead)
-            if (putting) xk_store32(&pslot->idx_tag, put_tag);
+            if (__ballot(putting)) xk_drain(conc);   // (only a wave that stores keys waits: the wait also covers the loads requested a phase ahead)
+            if (!conc) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler order)
+            if (putting) __hip_atomic_store(&pslot->idx_tag, put_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             put_pending = false;
         }
         const unsigned long long tk1 = prof_now();

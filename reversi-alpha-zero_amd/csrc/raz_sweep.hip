@@ -16,8 +16,10 @@
 //     software prefetch (the hardware dispatcher overlaps the next workgroup's loads with the current one's arithmetic).
 //     Consecutive workgroups land on consecutive XCDs and there is no inter-block sharing, so no XCD remap is needed.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "raz_bitboard.h"
 #include "raz_bitboard_valu.h"
+#include "raz_sweep_sliced.h"
 #include "raz_internal.h"
 
 namespace {
@@ -70,6 +72,23 @@ __global__ __launch_bounds__(kBlock) void k_legal_moves(const ulonglong2* __rest
     // ragged tail: the boards after the last full block
     for (size_t t = (nblocks << 8) + (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock)
         legal[t] = bbv_legal_moves(own[t], enemy[t]);
+}
+
+// find_correct_moves in bit-sliced form (raz_sweep_sliced.h): one single-wave workgroup per superblock of 2048 boards, 32 boards per
+// lane.  ~70 vector instructions per board (three transposes + the walks) instead of 134: the kernel is HBM-bound.
+__global__ __launch_bounds__(64) void k_legal_moves_sliced(const ulonglong2* __restrict__ own2, const ulonglong2* __restrict__ enemy2,
+                                                           ulonglong2* __restrict__ legal2, size_t nsb) {
+    for (size_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        const size_t at = sb * 1024 + threadIdx.x;
+        uint32_t o[64], e[64], L[64];
+        sl::load_boards(own2, at, o);
+        sl::load_boards(enemy2, at, e);
+        sl::transpose_boards(o);
+        sl::transpose_boards(e);
+        sl::mobility(o, e, L);
+        sl::transpose_boards(L);
+        sl::store_boards(legal2, at, L);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_calc_flip(const uint8_t* __restrict__ pos,
@@ -208,6 +227,87 @@ __global__ __launch_bounds__(kBlock) void k_step(raz_bb* __restrict__ black,
     }
 }
 
+// ReversiEnv.step in bit-sliced form (raz_sweep_sliced.h step_boards): one single-wave workgroup per superblock of 2048 boards.
+__global__ __launch_bounds__(64) void k_step_sliced(ulonglong2* __restrict__ black2, ulonglong2* __restrict__ white2, uchar2* __restrict__ player2,
+                                                    uchar2* __restrict__ status2, ulonglong2* __restrict__ legal2, const uchar2* __restrict__ action2,
+                                                    size_t nsb) {
+    for (size_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        const size_t at = sb * 1024 + threadIdx.x;
+        uint32_t b[64], w[64], L[64], pw[8], sw[8], aw[8];
+        sl::load_boards(black2, at, b);
+        sl::load_boards(white2, at, w);
+        sl::sfor<8>([&](auto q_) __attribute__((always_inline)) {   // rows 2q, 2q + 1 = the lane's boards 4q .. 4q + 3
+            constexpr int q = decltype(q_)::value;
+            const uchar2 p0 = player2[at + (size_t)(2 * q) * 64], p1 = player2[at + (size_t)(2 * q + 1) * 64];
+            const uchar2 s0 = status2[at + (size_t)(2 * q) * 64], s1 = status2[at + (size_t)(2 * q + 1) * 64];
+            const uchar2 a0 = action2[at + (size_t)(2 * q) * 64], a1 = action2[at + (size_t)(2 * q + 1) * 64];
+            pw[q] = (uint32_t)p0.x | ((uint32_t)p0.y << 8) | ((uint32_t)p1.x << 16) | ((uint32_t)p1.y << 24);
+            sw[q] = (uint32_t)s0.x | ((uint32_t)s0.y << 8) | ((uint32_t)s1.x << 16) | ((uint32_t)s1.y << 24);
+            aw[q] = (uint32_t)a0.x | ((uint32_t)a0.y << 8) | ((uint32_t)a1.x << 16) | ((uint32_t)a1.y << 24);
+        });
+        sl::transpose_boards(b);
+        sl::transpose_boards(w);
+        const sl::StepMasks m = sl::step_boards(b, w, L, pw, sw, aw);
+        if (m.overlap) {
+            // one of this lane's boards has a square that is black AND white - no position of the game, and the one input on which the
+            // reference's ray arithmetic is not a walk along the board's lines (raz_sweep_sliced.h StepMasks): this lane's 32 boards are
+            // stepped one by one with the reference-shaped primitives instead, from memory (nothing of them has been stored yet)
+            raz_bb* bl = (raz_bb*)black2;
+            raz_bb* wh = (raz_bb*)white2;
+            raz_bb* lg = (raz_bb*)legal2;
+            uint8_t* pl = (uint8_t*)player2;
+            uint8_t* st = (uint8_t*)status2;
+            const uint8_t* ac = (const uint8_t*)action2;
+            for (int k = 0; k < 32; ++k) {
+                const size_t t = 2 * (at + (size_t)(k >> 1) * 64) + (size_t)(k & 1);
+                raz_bb bb_ = bl[t], ww_ = wh[t], ll_;
+                uint8_t pp_ = pl[t], ss_ = st[t];
+                step_one(bb_, ww_, pp_, ss_, ll_, ac[t]);
+                bl[t] = bb_; wh[t] = ww_; lg[t] = ll_; pl[t] = pp_; st[t] = ss_;
+            }
+            continue;
+        }
+        sl::transpose_boards(b);
+        sl::transpose_boards(w);
+        sl::transpose_boards(L);
+        sl::store_boards(black2, at, b);
+        sl::store_boards(white2, at, w);
+        sl::store_boards(legal2, at, L);
+        // player / status of every board (bb_env_step's cases; the boards are in memory layout again: b[k] / b[32 + k] = the halves of board k)
+        uint32_t npw[8], nsw[8];
+        sl::sfor<8>([&](auto q_) __attribute__((always_inline)) {
+            constexpr int q = decltype(q_)::value;
+            uint32_t np = 0, ns = 0;
+            sl::sfor<4>([&](auto i_) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_)::value, k = 4 * q + i;
+                const uint32_t p = (pw[q] >> (8 * i)) & 0xffu, st = (sw[q] >> (8 * i)) & 0xffu, a = (aw[q] >> (8 * i)) & 0xffu;
+                const uint32_t other_wins = p == RAZ_PLAYER_BLACK ? RAZ_WIN_WHITE : RAZ_WIN_BLACK;
+                const bool moved = (m.moved >> k) & 1u, nz1 = (m.nz1 >> k) & 1u, nz2 = (m.nz2 >> k) & 1u;
+                uint32_t p2 = p, s2 = st;
+                if (st == 0) {
+                    if (a == RAZ_ACTION_RESIGN) s2 = other_wins | RAZ_STATUS_RESIGNED;
+                    else if (!moved) s2 = other_wins | RAZ_STATUS_ILLEGAL;
+                    else if (nz1) p2 = (3u - p) & 0xffu;
+                    else if (!nz2) {
+                        const int nb = __builtin_popcount(b[k]) + __builtin_popcount(b[32 + k]), nw = __builtin_popcount(w[k]) + __builtin_popcount(w[32 + k]);
+                        s2 = nb > nw ? RAZ_WIN_BLACK : (nb < nw ? RAZ_WIN_WHITE : RAZ_WIN_DRAW);
+                    }
+                }
+                np |= p2 << (8 * i);
+                ns |= s2 << (8 * i);
+            });
+            npw[q] = np;
+            nsw[q] = ns;
+        });
+        sl::sfor<16>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const uint32_t hp = npw[r >> 1] >> (16 * (r & 1)), hs = nsw[r >> 1] >> (16 * (r & 1));
+            player2[at + (size_t)r * 64] = make_uchar2((unsigned char)(hp & 0xff), (unsigned char)((hp >> 8) & 0xff));
+            status2[at + (size_t)r * 64] = make_uchar2((unsigned char)(hs & 0xff), (unsigned char)((hs >> 8) & 0xff));
+        });
+    }
+}
+
 __device__ __forceinline__ void score_one(raz_bb b, raz_bb w, uint8_t& win, int8_t& diff) {
     int nb = bb_popcount(b), nw = bb_popcount(w);
     win = (uint8_t)(nb > nw ? RAZ_WIN_BLACK : (nb < nw ? RAZ_WIN_WHITE : RAZ_WIN_DRAW));
@@ -292,6 +392,17 @@ __global__ __launch_bounds__(kBlock) void k_pick_kth(const raz_bb* __restrict__ 
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Batches of at least this many boards run their whole superblocks on the bit-sliced kernels (a superblock is one wave's work: 2^21
+// boards are 1024 waves, one per SIMD of the chip; smaller batches fill the chip better with a board per lane).  RAZ_SWEEP_SLICED_MIN
+// overrides it (tests: 2048 runs every superblock sliced; a huge value switches the sliced kernels off).
+inline size_t sliced_min_boards() {
+    static const size_t v = [] {
+        const char* s = getenv("RAZ_SWEEP_SLICED_MIN");
+        return s && *s ? (size_t)strtoull(s, nullptr, 10) : (size_t)1 << 21;
+    }();
+    return v < 2048 ? 2048 : v;
+}
+
 }  // namespace
 
 #define RAZ_REQUIRE(cond, msg)                \
@@ -305,9 +416,15 @@ extern "C" int raz_legal_moves_batch(const uint64_t* own, const uint64_t* enemy,
     RAZ_REQUIRE(own && enemy && legal, "raz_legal_moves_batch: NULL array");
     RAZ_REQUIRE(aligned16(own) && aligned16(enemy) && aligned16(legal),
                 "raz_legal_moves_batch: arrays must be 16-byte aligned");
-    hipLaunchKernelGGL(k_legal_moves, dim3(grid_for(n / 4 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (const ulonglong2*)own, (const ulonglong2*)enemy, (ulonglong2*)legal,
-                       (const raz_bb*)own, (const raz_bb*)enemy, (raz_bb*)legal, n);
+    // large batches: whole superblocks of 2048 boards on the bit-sliced kernel, the rest on the board-per-lane kernel
+    const size_t nsb = n >= sliced_min_boards() ? n / 2048 : 0, done = nsb * 2048;
+    if (nsb)
+        hipLaunchKernelGGL(k_legal_moves_sliced, dim3((unsigned)(nsb > (size_t)kMaxGrid ? (size_t)kMaxGrid : nsb)), dim3(64), 0, (hipStream_t)stream,
+                           (const ulonglong2*)own, (const ulonglong2*)enemy, (ulonglong2*)legal, nsb);
+    if (n > done)
+        hipLaunchKernelGGL(k_legal_moves, dim3(grid_for((n - done) / 4 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const ulonglong2*)(own + done), (const ulonglong2*)(enemy + done), (ulonglong2*)(legal + done),
+                           (const raz_bb*)(own + done), (const raz_bb*)(enemy + done), (raz_bb*)(legal + done), n - done);
     return raz_check_launch("raz_legal_moves_batch");
 }
 
@@ -331,8 +448,13 @@ extern "C" int raz_step_batch(uint64_t* black, uint64_t* white, uint8_t* player,
                 "raz_step_batch: u64 arrays must be 16-byte aligned");
     RAZ_REQUIRE((((uintptr_t)player | (uintptr_t)status | (uintptr_t)action) & 3) == 0,
                 "raz_step_batch: u8 arrays must be 4-byte aligned");
-    hipLaunchKernelGGL(k_step, dim3(grid_for(n / 4 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (raz_bb*)black, (raz_bb*)white, player, status, (raz_bb*)legal, action, n);
+    const size_t nsb = n >= sliced_min_boards() ? n / 2048 : 0, done = nsb * 2048;
+    if (nsb)
+        hipLaunchKernelGGL(k_step_sliced, dim3((unsigned)(nsb > (size_t)kMaxGrid ? (size_t)kMaxGrid : nsb)), dim3(64), 0, (hipStream_t)stream,
+                           (ulonglong2*)black, (ulonglong2*)white, (uchar2*)player, (uchar2*)status, (ulonglong2*)legal, (const uchar2*)action, nsb);
+    if (n > done)
+        hipLaunchKernelGGL(k_step, dim3(grid_for((n - done) / 4 + 1)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (raz_bb*)black + done, (raz_bb*)white + done, player + done, status + done, (raz_bb*)legal + done, action + done, n - done);
     return raz_check_launch("raz_step_batch");
 }
 

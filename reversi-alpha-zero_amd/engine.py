@@ -468,6 +468,8 @@ class SelfPlayEngine:
         tuned = solver_on and not ((int(self.cfg.reserved) >> 24) & 0xf)
         if tuned:
             self.set_solver_pool_every(CONTINUOUS_SOLVER_POOL_EVERY)
+        import time
+        t_begin = time.perf_counter()
         try:
             sims0 = np.array([sims_of(first_game_id + i) if i < n0 else 1 for i in range(B)], dtype=np.uint32)
             if resign_threshold_of is not None:
@@ -479,8 +481,7 @@ class SelfPlayEngine:
             nxt, done, steps, cap = first_game_id + n0, 0, 0, int(self.cfg.nodes_per_game)
             end = first_game_id + total_games
             self.gc_runs = 0
-            import time
-            host = {"steps_and_stats": 0.0, "harvest": 0.0}
+            host = {"steps_and_stats": 0.0, "harvest": 0.0, "before_the_first_step": time.perf_counter() - t_begin}
             while done < total_games:
                 t0 = time.perf_counter()
                 self.step(chunk)
@@ -504,6 +505,7 @@ class SelfPlayEngine:
                 if steps >= max_steps:
                     raise RuntimeError("engine did not finish within max_steps")
             st = self.stats()
+            host["whole_call"] = time.perf_counter() - t_begin
             st.update(steps=steps, leaf_slot_occupancy=st["nn_leaves"] / max(1, steps * B * self.slots), gc_runs=self.gc_runs,
                       seconds=host)
         finally:

@@ -460,6 +460,10 @@ class BatchedSelfPlayWorker:
         if pool and per_step:
             chunk = max(16, min(chunk, int(pool) // (4 * int(per_step))))
         outbox, self.last_stats = eng.play_continuous(base, blk, sims_of, chunk=chunk)
+        # per block: what the engine's loop took (bench.py worker_end_to_end_config1 reports the run's blocks, not only the last one)
+        self.block_stats = getattr(self, "block_stats", [])
+        self.block_stats.append({"games": int(self.last_stats["finished_games"]), "sims": int(self.last_stats["total_sims"]), "steps": int(self.last_stats["steps"]),
+                                 **{k: float(v) for k, v in (self.last_stats.get("seconds") or {}).items()}})
 
         def packed(plies):
             if plies is None:   # n_plies is the u32 at byte 20 of a raz_game_summary

@@ -135,6 +135,7 @@ template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 #define __ATOMIC_EMU_SCOPE 0
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 

@@ -4,6 +4,9 @@ record) check on the device, here for the kernels' LOGIC - the 256-board wave bl
 for boards whose opponent cannot move, finished games left untouched - on sizes a CPU finishes in seconds.  The host build takes
 the plain-C++ branch of the VALU-shaped primitives (their device forms are checked by tests/native/bbv_check.cpp + the GPU tests)."""
 import ctypes
+import os
+
+os.environ.setdefault("RAZ_SWEEP_SLICED_MIN", "2048")   # (read once by the library: every whole superblock of 2048 boards runs on the bit-sliced kernels)
 
 import numpy as np
 import pytest
@@ -43,8 +46,9 @@ def _playout_positions(n, seed):
     return black, white, player, action
 
 
-@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 1030])
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 1030, 2048, 4096 + 333])
 def test_emulated_legal_moves_and_flips_equal_oracle(n):
+    """(n >= 2048: the whole superblocks on the bit-sliced kernel of csrc/raz_sweep_sliced.h, the rest a board per lane.)"""
     lib = load()
     rng = np.random.default_rng(n + 5)
     own = rng.integers(0, 2**64, size=n, dtype=np.uint64)
@@ -60,8 +64,9 @@ def test_emulated_legal_moves_and_flips_equal_oracle(n):
     assert np.array_equal(flip, ref)
 
 
-@pytest.mark.parametrize("n", [5, 256, 777])
+@pytest.mark.parametrize("n", [5, 256, 777, 2048 + 300])
 def test_emulated_step_equals_oracle_incl_passes_and_finished_games(n):
+    """(n >= 2048: the first superblock on the bit-sliced kernel.)"""
     lib = load()
     black, white, player, action = _playout_positions(n, n)
     status = np.zeros(n, np.uint8)
@@ -106,3 +111,29 @@ def test_emulated_score_d4_and_pick_equal_host_primitives():
     for i in range(n):
         bits = [s for s in range(64) if int(legal[i]) >> s & 1]
         assert act[i] == bits[int(rnd[i]) % len(bits)]
+
+
+def test_emulated_sliced_step_on_garbage_boards_and_every_kind_of_action():
+    """The bit-sliced step kernel (csrc/raz_sweep_sliced.h) on 2048 + 2048 boards of overlapping own / enemy garbage, actions on occupied
+    squares, no-flip moves, resignations, actions outside the board (64..254: treated as a move that flips nothing), finished games:
+    == the board-per-lane kernel's primitives, i.e. the oracle's step."""
+    lib = load()
+    n = 4096
+    rng = np.random.default_rng(77)
+    black = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    white = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    white[: n // 2] &= ~black[: n // 2]
+    thin = rng.integers(0, 2**64, size=n, dtype=np.uint64) & rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    black[n // 4: n // 2] &= thin[n // 4: n // 2]                # sparse boards: moves that flip something, passes, empty squares
+    player = rng.integers(1, 3, size=n, dtype=np.uint8)
+    status = np.where(rng.random(n) < 0.1, rng.integers(1, 4, size=n), 0).astype(np.uint8)
+    action = rng.integers(0, 64, size=n, dtype=np.uint8)
+    action[rng.random(n) < 0.05] = 255
+    b, w, p, s = black.copy(), white.copy(), player.copy(), status.copy()
+    legal = np.zeros(n, np.uint64)
+    assert lib.raz_step_batch(_ptr(b), _ptr(w), _ptr(p), _ptr(s), _ptr(legal), _ptr(action), n, None) == 0
+    ob, ow, op, os_, ol = O.np_step(black, white, player, status, action)
+    for name, got, want in (("black", b, ob), ("white", w, ow), ("player", p, op), ("status", s, os_), ("legal", legal, ol)):
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (name, bad[:5], [hex(int(x)) for x in got[bad[:3]]], [hex(int(x)) for x in want[bad[:3]]])
+    assert (os_ & 0x10).any() and (os_ & 0x20).any() and ((os_ == 0) & (status == 0)).sum() > n // 4
