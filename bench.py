@@ -1144,7 +1144,8 @@ def worker_end_to_end_leg(dev, args, seconds=60.0):
                "seconds": dt, "games_written": games, "games_per_hour_including_emission": games / dt * 3600.0,
                "sims_per_s_including_emission": games * st["total_sims"] / max(1, st["finished_games"]) / dt,
                "bytes_written": int(getattr(w, "bytes_written", 0)), "gb_per_s_of_json_text": getattr(w, "bytes_written", 0) / dt / 1e9,
-               "writer_busy_share_of_the_run": w.last_writer_busy_seconds / dt, "blocks": w.last_writer_batches,
+               "writer_busy_share_of_the_run": w.last_writer_busy_seconds / dt, "blocks": len(blocks), "pieces_handed_to_the_writer": w.last_writer_batches,
+               "streamed_emission": "the finished prefix of a block goes to the writer while the block is played (worker.run: one rank, exact-f32 net)",
                "main_thread_seconds": dict(getattr(w, "run_seconds", {}) or {}),
                "engine_level_of_the_last_block": engine_level(st.get("seconds"), st["finished_games"], st["total_sims"]),
                "engine_level_of_all_blocks": engine_level({k: sum(b.get(k, 0.0) for b in blocks) for k in ("steps_and_stats", "harvest")},

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(64) void k_step_sliced(ulonglong2* __restrict__ bla
         });
         sl::transpose_boards(b);
         sl::transpose_boards(w);
+        RAZ_SL_PHASE();
         const sl::StepMasks m = sl::step_boards(b, w, L, pw, sw, aw);
+        RAZ_SL_PHASE();
         if (m.overlap) {
             // one of this lane's boards has a square that is black AND white - no position of the game, and the one input on which the
             // reference's ray arithmetic is not a walk along the board's lines (raz_sweep_sliced.h StepMasks): this lane's 32 boards are

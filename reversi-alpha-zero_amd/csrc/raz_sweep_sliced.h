@@ -26,6 +26,13 @@
 namespace sl {
 
 #define RAZ_SL __device__ __forceinline__
+// keeps the instruction scheduler from mixing two phases of a kernel (it would otherwise start the next phase's independent work early
+// and hold both phases' registers at once)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RAZ_SL_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RAZ_SL_PHASE() ((void)0)
+#endif
 
 template <class F, int... I>
 RAZ_SL void sfor_(F&& f, std::integer_sequence<int, I...>) {
@@ -393,7 +400,9 @@ RAZ_SL StepMasks step_boards(uint32_t (&b)[64], uint32_t (&w)[64], uint32_t (&L)
         colsel[i] = op3<(1 << i)>(plane[2], plane[1], plane[0]);
         rowsel[i] = op3<(1 << i)>(plane[5], plane[4], plane[3]) & plays;
     });
+    RAZ_SL_PHASE();
     flips(b, w, rowsel, colsel, F);
+    RAZ_SL_PHASE();
     F[0] = F[7] = F[56] = F[63] = 0;   // (the corners: never flipped)
     StepMasks m;
     m.overlap = both;
@@ -409,6 +418,7 @@ RAZ_SL StepMasks step_boards(uint32_t (&b)[64], uint32_t (&w)[64], uint32_t (&L)
         }
     });
     // the opponent's moves (:66) ...
+    RAZ_SL_PHASE();
     mobility_raw(w, b, L);
     sfor<64>([&](auto s_) __attribute__((always_inline)) {
         constexpr int s = decltype(s_)::value;
@@ -417,7 +427,9 @@ RAZ_SL StepMasks step_boards(uint32_t (&b)[64], uint32_t (&w)[64], uint32_t (&L)
     m.nz1 = any_square(L) & m.moved;
     // ... and where it has none the mover's own (:68), OR-ed in on those boards only (their L is empty so far)
     const uint32_t second = m.moved & ~m.nz1;
+    RAZ_SL_PHASE();
     mobility_raw_into(b, w, L, second);
+    RAZ_SL_PHASE();
     sfor<64>([&](auto s_) __attribute__((always_inline)) {
         constexpr int s = decltype(s_)::value;
         L[s] = op3<kAndNor>(L[s] & m.moved, b[s], w[s]);   // blank squares, of boards that moved (blank twice is blank)

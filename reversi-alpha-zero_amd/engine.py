@@ -454,9 +454,12 @@ class SelfPlayEngine:
         """Play global game ids first_game_id .. first_game_id + total_games - 1 with continuous batching: the batch's
         slots are refilled with the next unplayed id as games finish (worker/self_play.py:95-137: a reference worker
         starts its next game the moment one ends), finished games land in an id-ordered device outbox.
-        sims_of(id) -> simulations per move of that game (the reference's per-game-index schedule, self_play.py:145).
+        sims_of(id) -> simulations per move of that game (the reference's per-game-index schedule, self_play.py:145); or an array
+        with one entry per id of the call (entry i = id first_game_id + i): what the worker passes - a Python call per id and poll was
+        3 M calls per 65 536-id block.
         resign_threshold_of(id) (optional) -> the threshold that game is played under.
-        on_chunk(steps, games_done, stats) (optional) is called after every chunk's harvest (progress reporting).
+        on_chunk(steps, games_done, stats, outbox) (optional) is called after every chunk's harvest (progress reporting; the worker
+        ships the finished prefix of the outbox to its file writer from it).
         Returns (outbox, stats): outbox = device tensors in id order (pack/gather them as they are, or
         raw_from_packed(...) on the host); stats adds steps, leaf_slot_occupancy and gc_runs."""
         B = self.n_games
@@ -471,7 +474,14 @@ class SelfPlayEngine:
         import time
         t_begin = time.perf_counter()
         try:
-            sims0 = np.array([sims_of(first_game_id + i) if i < n0 else 1 for i in range(B)], dtype=np.uint32)
+            if not callable(sims_of):
+                table = np.ascontiguousarray(sims_of, dtype=np.uint32)
+                assert table.size == total_games
+                sims_at = lambda lo, n: table[lo - first_game_id: lo - first_game_id + n]
+            else:
+                sims_at = lambda lo, n: np.array([sims_of(i) for i in range(lo, lo + n)], dtype=np.uint32)
+            sims0 = np.ones(B, dtype=np.uint32)
+            sims0[:n0] = sims_at(first_game_id, n0)
             if resign_threshold_of is not None:
                 self.set_resign_threshold(resign_threshold_of(first_game_id))
             self.start(first_game_id, sims0, n_active=n0)
@@ -493,7 +503,7 @@ class SelfPlayEngine:
                 t1 = time.perf_counter()
                 k = min(B, end - nxt)
                 ids = range(nxt, nxt + k)
-                h, r, skipped, playing = self.harvest(outbox, nxt, [sims_of(i) for i in ids],
+                h, r, skipped, playing = self.harvest(outbox, nxt, sims_at(nxt, k),
                                                       [resign_threshold_of(i) for i in ids] if resign_threshold_of else None)
                 assert skipped == 0
                 nxt += r
@@ -501,7 +511,7 @@ class SelfPlayEngine:
                 host["steps_and_stats"] += t1 - t0
                 host["harvest"] += time.perf_counter() - t1
                 if on_chunk is not None:
-                    on_chunk(steps, done, st)
+                    on_chunk(steps, done, st, outbox)
                 if steps >= max_steps:
                     raise RuntimeError("engine did not finish within max_steps")
             st = self.stats()

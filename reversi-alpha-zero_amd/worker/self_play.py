@@ -51,6 +51,26 @@ def decide_simulation_num_per_move(config, idx):
     return ret
 
 
+def simulation_nums_of_ids(config, first_idx, n):
+    """decide_simulation_num_per_move for the ids first_idx .. first_idx + n - 1 as one array.  data/.force-sim is read ONCE for the
+    block (the reference looks at it at every game's start: a game here starts when a slot frees up inside a block that is played in
+    seconds to minutes, so a changed file takes effect with the next block - and 65 536 stat() calls per block were a quarter of the
+    worker's wall time on a 16-filter net)."""
+    forced = read_as_int(config.resource.force_simulation_num_file)
+    if forced:
+        return np.full(n, forced, dtype=np.uint32)
+    ids = np.arange(first_idx, first_idx + n, dtype=np.int64)
+    out = np.zeros(n, dtype=np.int64)
+    seen = np.zeros(n, dtype=bool)
+    for min_idx, num in config.play.schedule_of_simulation_num_per_move:   # (the last matching entry wins, as in the reference's loop)
+        hit = ids >= min_idx
+        out[hit] = num
+        seen |= hit
+    if not seen.all():
+        raise ValueError("schedule_of_simulation_num_per_move has no entry for game index %d" % int(ids[~seen][0]))
+    return out.astype(np.uint32)
+
+
 def symmetric_rows(own, enemy, policy):
     """add_data_to_move_buffer_with_8_symmetries (agent/player.py:166-179): the 8 rows
     [(own, enemy), policy64] of one searched ply, flip in {F,T} x rot_right in 0..3."""
@@ -443,13 +463,8 @@ class BatchedSelfPlayWorker:
         callable for gather_packed (cut to the block's longest game, or to the extent the ranks agreed on)."""
         blk = self.block_games
         base = first_game_idx + self.rank * blk
-        cache = {}
-
-        def sims_of(gid):
-            if gid not in cache:
-                cache[gid] = decide_simulation_num_per_move(self.config, gid)
-            return cache[gid]
-        eng = self._get_engine(max(sims_of(base + i) for i in range(blk)))
+        sims = simulation_nums_of_ids(self.config, base, blk)
+        eng = self._get_engine(int(sims.max()))
         # steps between two polls of the device (statistics + harvest, a host synchronisation each): a step of a 16-filter net is ~40 us,
         # so 64 steps between polls left the host in the loop a sixth of the time (bench worker_end_to_end_config1: the worker's engine at
         # 19.2 M games/h where the same engine reaches 25 M polled every 200 steps); a wide net's step is ~25 ms and 64 is a poll every 1.6 s
@@ -459,18 +474,42 @@ class BatchedSelfPlayWorker:
         pool, per_step = getattr(getattr(eng, "cfg", None), "nodes_per_game", 0), getattr(eng, "nodes_per_step", 0)
         if pool and per_step:
             chunk = max(16, min(chunk, int(pool) // (4 * int(per_step))))
-        outbox, self.last_stats = eng.play_continuous(base, blk, sims_of, chunk=chunk)
+        # a single-rank worker ships the block's finished PREFIX to the file writer while the block is still played (streamed emission,
+        # run()): rows [0, p) of the id-ordered outbox are done, p advancing with the polls; pieces are whole files (no file is cut)
+        sink, self._streamed_rows = getattr(self, "_stream_sink", None), 0
+        unit = whole_files_block(self.config, 1)
+        piece = max(unit, (int(getattr(self, "stream_piece_games", 0) or max(1024, self.games_in_flight // 4)) // unit) * unit)
+
+        def ship(steps, done_games, st, ob):
+            import torch
+            from ..engine import raw_from_packed
+            at = self._streamed_rows
+            if done_games - at < piece:
+                return
+            open_rows = (ob["done"][at:] == 0).nonzero()
+            p = at + (int(open_rows[0].item()) if open_rows.numel() else blk - at)
+            n = ((p - at) // piece) * piece
+            if n <= 0:
+                return
+            plies = max(1, int(ob["summary"][at:at + n, 20:24].contiguous().view(torch.int32).max().item()))
+            sink(raw_from_packed(*(t.cpu().numpy() for t in (ob["headers"][at:at + n, :plies].contiguous(), ob["root_n"][at:at + n, :plies].contiguous(),
+                                                             ob["summary"][at:at + n]))), at)
+            self._streamed_rows = at + n
+        outbox, self.last_stats = eng.play_continuous(base, blk, sims, chunk=chunk, on_chunk=ship if sink is not None else None)
         # per block: what the engine's loop took (bench.py worker_end_to_end_config1 reports the run's blocks, not only the last one)
         self.block_stats = getattr(self, "block_stats", [])
-        self.block_stats.append({"games": int(self.last_stats["finished_games"]), "sims": int(self.last_stats["total_sims"]), "steps": int(self.last_stats["steps"]),
-                                 **{k: float(v) for k, v in (self.last_stats.get("seconds") or {}).items()}})
+        st = self.last_stats
+        self.block_stats.append({"games": int(st.get("finished_games", blk)), "sims": int(st.get("total_sims", 0)), "steps": int(st.get("steps", 0)),
+                                 **{k: float(v) for k, v in (st.get("seconds") or {}).items()}})
+        del self.block_stats[:-64]   # (a worker runs for days)
 
-        def packed(plies):
+        def packed(plies, first_row=0):
+            """Rows [first_row, block) of the outbox, cut to `plies` (None: their longest game)."""
             if plies is None:   # n_plies is the u32 at byte 20 of a raz_game_summary
                 import torch
-                plies = max(1, int(outbox["summary"][:, 20:24].contiguous().view(torch.int32).max().item()))
-            return {"headers": outbox["headers"][:, :plies].contiguous(), "root_n": outbox["root_n"][:, :plies].contiguous(),
-                    "summary": outbox["summary"]}
+                plies = max(1, int(outbox["summary"][first_row:, 20:24].contiguous().view(torch.int32).max().item())) if first_row < blk else 1
+            return {"headers": outbox["headers"][first_row:, :plies].contiguous(), "root_n": outbox["root_n"][first_row:, :plies].contiguous(),
+                    "summary": outbox["summary"][first_row:]}
         return packed
 
     def emit_raw(self, raw, first_local_idx=1, threads=None):
@@ -760,6 +799,15 @@ class BatchedSelfPlayWorker:
         dist.broadcast(t, src=0)
         return blob if self.rank == 0 else t.cpu().numpy().tobytes()
 
+    def _may_replay_block(self):
+        """True when a block may be discarded and played again - the net's trunk runs on the split-f16 kernels, whose range flag is
+        looked at after the block (run()): nothing of such a block may reach the disk before it is complete."""
+        if self._f32_fallback or self.net_kernel == "f32":
+            return False
+        import struct
+        filters = struct.unpack_from("<5i", self.net_blob, 0)[2] if self.net_blob and len(self.net_blob) >= 20 else 256
+        return self.net_kernel in ("auto", "f16x3") and filters >= 128 and filters % 128 == 0
+
     def _ids_per_block(self):
         """Consecutive game ids ONE rank plays between two gathers (_play_block)."""
         continuous = self.block_games > self.games_in_flight and self._series_length() == 1
@@ -834,7 +882,14 @@ class BatchedSelfPlayWorker:
         game_idx = read_as_int(rc.self_play_game_idx_file) or 0
         local_idx = 1
         own_files = self._per_rank_emission()
-        writer = _BackgroundWriter(self) if (background_emit and (self.rank == 0 or own_files)) else None
+        # Streamed emission (one rank, background writer, continuous blocks, a net on the exact-f32 kernels - a block of the split-f16
+        # trunk may still be discarded and replayed, below): the finished prefix of a block goes to the writer in pieces of whole files
+        # WHILE the block is played, so the writer works evenly through the block and what is left to write when the last game ends is
+        # one piece, not the block (65 536 games of a 16-filter net are 14 GB of text: 7 s of a 9 s block behind its end).
+        stream = (background_emit and self.world == 1 and not own_files and self._ids_per_block() > self.games_in_flight
+                  and not self._may_replay_block())
+        # (pieces of <= a quarter of the slots: the play loop must not wait for the writer - 16 may queue up)
+        writer = _BackgroundWriter(self, depth=16 if stream else 1) if (background_emit and (self.rank == 0 or own_files)) else None
         inline = {"written": 0, "error": None}   # per-rank emission without the background thread
         block_game_idx = []                      # rank 0, per-rank emission: the game index after each block
 
@@ -866,6 +921,13 @@ class BatchedSelfPlayWorker:
                 return self._all_ranks_state(with_writer(state), written())
             finally:
                 advance_game_idx()
+        # The writer thread runs Python between its native calls; the play loop gets the interpreter back only when that thread gives
+        # it up - by default every 5 ms, which is half a poll interval of a 16-filter net (bench worker_end_to_end_config1: a block played
+        # beside a busy writer took 9.4 s, the first block, with nothing to write yet, 7.5 s).  Hand over every 0.2 ms while run() lasts.
+        import sys as _sys
+        _switch = _sys.getswitchinterval()
+        if writer is not None:
+            _sys.setswitchinterval(min(_switch, 2e-4))
         finished = False
         try:
             while total_games is None or local_idx <= total_games:
@@ -876,6 +938,7 @@ class BatchedSelfPlayWorker:
                     if stop[0]:
                         break
                 _t0 = _tm.monotonic()
+                self._stream_sink = (lambda raw, row, _l=local_idx: writer.submit(raw, _l + row, None)) if stream else None
                 packed, per_rank, state = self._play_block_checked(game_idx)
                 _t1 = _tm.monotonic()
                 while agree(state) == self.BLOCK_RANGE:
@@ -896,6 +959,20 @@ class BatchedSelfPlayWorker:
                     allraw, self.last_gather_bytes = gather_summaries(pk["summary"], self.rank, self.world)
                     self.last_gather_backend = dist.get_backend()
                     del pk
+                elif stream and state == self.BLOCK_OK:
+                    # the rest of the block (what was not shipped while it was played) + every game's summary for the bookkeeping
+                    shipped = int(getattr(self, "_streamed_rows", 0))
+                    pk = packed(None, shipped)
+                    rest = raw_from_packed(*(pk[k].cpu().numpy() for k in ("headers", "root_n", "summary")))
+                    if self._group():   # (a process group of one rank: the summaries take the collective's path, 32 B per game)
+                        allraw, self.last_gather_bytes = gather_summaries(packed(1)["summary"], self.rank, self.world)
+                        self.last_gather_backend = dist.get_backend()
+                    else:
+                        from ..engine import GAME_SUMMARY
+                        sm = np.ascontiguousarray(packed(1)["summary"].cpu().numpy()).view(GAME_SUMMARY).reshape(-1)
+                        allraw = dict(n_plies=sm["n_plies"].copy(), status=sm["status"].copy(), game_id=sm["game_id"].copy(),
+                                      resigned=np.stack([sm["resigned_black"], sm["resigned_white"]], axis=1), enable_resign=sm["enable_resign"].copy())
+                    del pk
                 elif self._group():
                     allraw, self.last_gather_bytes = gather_packed(packed, self.rank, self.world)
                     self.last_gather_backend = dist.get_backend()
@@ -913,6 +990,9 @@ class BatchedSelfPlayWorker:
                     if own_files:
                         stamps = self._next_block_stamps(per_rank)
                         block_game_idx.append(game_idx)
+                    elif stream:
+                        writer.submit(rest, local_idx + shipped, game_idx)   # (the index file moves once the block's last file is written)
+                        del rest
                     elif writer is not None:
                         writer.submit(allraw, local_idx, game_idx)
                     else:
@@ -948,6 +1028,7 @@ class BatchedSelfPlayWorker:
                         self.set_net_blob(blob)
             finished = True
         finally:
+            _sys.setswitchinterval(_switch)
             if writer is not None:
                 try:
                     writer.close(quiet=own_files)
@@ -980,7 +1061,7 @@ class _BackgroundWriter:
     `error`): every batch queued behind the failed one is dropped, so data/.self-play-game-idx can never advance past a
     batch whose files are missing."""
 
-    def __init__(self, worker):
+    def __init__(self, worker, depth=1):
         import queue
         import threading
         self.worker, self.error = worker, None
@@ -989,7 +1070,7 @@ class _BackgroundWriter:
         self.failed = False            # written by the writer thread only, never cleared
         self._reported = False         # the caller has been handed the exception
         self._lock = threading.Lock()  # guards `error` (handed from the thread to the caller exactly once)
-        self.queue = queue.Queue(maxsize=1)
+        self.queue = queue.Queue(maxsize=depth)   # (1: whole blocks; more: the pieces of streamed emission, run())
         self.thread = threading.Thread(target=self._loop, name="raz-play-data-writer", daemon=True)
         self.thread.start()
 

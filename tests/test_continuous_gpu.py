@@ -111,12 +111,13 @@ def test_continuous_batching_with_simulation_slots_solver_and_pruning(blob):
 
 def test_worker_files_do_not_depend_on_slots_or_refill(gold, blob, tmp_path):
     """The `self` worker: 36 game ids as one block on 6 slots (continuous batching: each slot plays ~6 games) and as one
-    lock-step batch of 36 slots -> byte-identical play_*.json files (games are emitted in id order either way)."""
+    lock-step batch of 36 slots -> byte-identical play_*.json files (games are emitted in id order either way); and the same with
+    the block's finished prefix handed to the file writer while the block is still played (streamed emission)."""
     from reversi_alpha_zero_amd.config import Config
     from reversi_alpha_zero_amd.worker.self_play import BatchedSelfPlayWorker
     g0 = next(g for g in gold["games"] if g["variant"] == "agz_resign")
     outs = []
-    for tag, slots, block in (("refill", 6, 36), ("lockstep", 36, 36)):
+    for tag, slots, block in (("refill", 6, 36), ("lockstep", 36, 36), ("refill_streamed", 6, 36)):
         cfg = Config()
         cfg.play.update(g0["resolved_play"])
         cfg.play.schedule_of_simulation_num_per_move = [(0, 9), (20, 14)]
@@ -127,10 +128,13 @@ def test_worker_files_do_not_depend_on_slots_or_refill(gold, blob, tmp_path):
         rc.model_dir = str(out / "model"); rc.next_generation_model_dir = str(out / "model" / "next"); rc.log_dir = str(out / "logs")
         rc.project_dir = str(out); rc.force_simulation_num_file = str(out / ".force-sim"); rc.self_play_game_idx_file = str(out / ".idx")
         w = BatchedSelfPlayWorker(cfg, blob, games_in_flight=slots, seed=8, device=DEV, block_games=block)
+        if tag == "refill_streamed":   # streamed emission (run()): the finished prefix of the block goes to the writer in pieces of one file
+            w.stream_piece_games = 7
         w.run(total_games=36)
+        assert (getattr(w, "_streamed_rows", 0) >= 14) == (tag == "refill_streamed"), (tag, getattr(w, "_streamed_rows", None))
         files = sorted((out / "play_data").iterdir())
         outs.append([f.read_text() for f in files])
         assert (out / ".idx").read_text() == "36"
         if tag == "refill":
             assert w.last_stats["steps"] > 0 and w.last_stats["finished_games"] == 36
-    assert len(outs[0]) == 5 and outs[0] == outs[1]
+    assert len(outs[0]) == 5 and outs[0] == outs[1] == outs[2]

@@ -143,6 +143,21 @@ def test_valu_shaped_bitboard_ops_equal_the_reference_shaped_ones(tmp_path):
     assert r.returncode == 0 and "BBV_OK" in r.stdout, r.stdout[-2000:]
 
 
+def test_bit_sliced_sweep_arithmetic_equals_the_reference_shaped_ops(tmp_path):
+    """csrc/raz_sweep_sliced.h (the large-batch sweep kernels' arithmetic: 32 boards per lane, one bit per board - transposes,
+    find_correct_moves as walks along the board's lines, calc_flip, the whole step with its masks) == csrc/raz_bitboard.h on the host,
+    lane by lane: playout positions, overlapping / full / sparse garbage, legal moves, occupied squares, resignations, actions outside
+    the board, finished games; boards with a square of both colours are REPORTED (the kernel steps those board by board):
+    tests/native/sliced_check.cpp, built here with g++."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "sliced_check.cpp")
+    exe = str(tmp_path / "sliced_check")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "30000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SLICED_OK" in r.stdout, r.stdout[-2000:]
+
+
 def test_integration_md_names_every_entry_point():
     """INTEGRATION.md's table of entry points covers the whole header (names may be abbreviated as `raz_engine_create/start/...`)."""
     import re

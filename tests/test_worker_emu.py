@@ -49,8 +49,8 @@ class Engine:
     it plays under the threshold the block was started with, as raz_engine_set_resign_threshold makes the device engine do)."""
     def __init__(self, worker, sims):
         self.e = EmuEngine(worker.config, worker.net_blob, worker.games_in_flight, seed=worker.seed, sims_hint=sims, record_root_w=False)
-    def play_continuous(self, first, total, sims_of, chunk=64):
-        ob = self.e.play_continuous(first, total, sims_of(first), chunk=8)
+    def play_continuous(self, first, total, sims_of, chunk=64, on_chunk=None):   # (no streamed emission here: the whole block is handed over at its end)
+        ob = self.e.play_continuous(first, total, sims_of(first) if callable(sims_of) else int(sims_of[0]), chunk=8)   # (the worker passes one entry per id)
         assert ob["done"].all()
         return {{k: torch.from_numpy(ob[k]) for k in ("headers", "root_n", "summary")}}, {{"gc_runs": self.e.gc_runs}}
 

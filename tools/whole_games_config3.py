@@ -46,7 +46,7 @@ def main():
     t0 = time.perf_counter()
     last = [0]
 
-    def progress(steps, done, stc):
+    def progress(steps, done, stc, *_):
         if a.progress and steps - last[0] >= 2048:
             last[0] = steps
             with open(a.progress, "at") as f:
