@@ -77,7 +77,9 @@ struct raz_solve_hdr {           // 64 bytes at the start of a game's solver blo
     uint32_t exact;
     uint32_t k_n2, tasks, total; // root moves | level-2 nodes << 8; level-3 nodes; subtrees the workers search (the tasks)
     uint32_t next;               // next task to hand out (workers: atomicAdd)
-    int32_t ans_move, ans_score; // (copies of what the state word carries: diagnostics)
+    int32_t ans_move;            // (a copy of what the state word carries: diagnostics)
+    uint32_t limit;              // tasks [0, limit) may be handed out in this round (k_solve_scan: every task of an exact solve; of a win/loss
+                                 // solve the tasks below the first RAZ_SOLVER_NE_WINDOW root moves that are still open)
     uint32_t posted;             // requests this game slot has posted since raz_engine_start (the tree kernels' word; statistics)
     uint32_t rounds;             // rounds of the pool the solve has been listed in (statistics)
     uint32_t rounds_total;       // ... and all solves of this game slot since raz_engine_start

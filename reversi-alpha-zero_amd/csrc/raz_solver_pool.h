@@ -112,6 +112,10 @@ __device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_
     return l1 ? 1 : 2;
 }
 
+#ifndef RAZ_SOLVER_NE_WINDOW
+#define RAZ_SOLVER_NE_WINDOW 2   // open root moves of a win/loss solve whose tasks are handed out (0: all of them at once, rounds 4-5)
+#endif
+
 // ------------------------------------------------------------------ k_solve_scan
 // collect = 1 (before k_solve_run): new requests get their task tree, every solve with tasks left is listed as active.
 // collect = 0 (after it): the workers' results are folded in; block 0 clears the list for the next round.
@@ -142,7 +146,6 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         if (k == 0) {   // the reference's (None, None): never the case for a running game
             if (lane == 0) {
                 h->ans_move = -1;
-                h->ans_score = -100;
                 xk_store32(conc, &h->state, RAZ_SOLVE_ANSWER_WORD(RAZ_SOLVE_NONE, -1, -100));
             }
             return;
@@ -362,7 +365,6 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         memo_put(E, g, own0, enemy0, exact, bm, bs, lane);
         if (lane == 0) {
             h->ans_move = bm;
-            h->ans_score = bs;
             // ONE agent-scope 4-byte store (write-through): a tree kernel running beside this launch on another XCD finds the answer at
             // its next look instead of at the next kernel boundary (a plain store stayed in this XCD's L2 until the launch ended)
             xk_store32(conc, &h->state, RAZ_SOLVE_ANSWER_WORD(bm >= 0 ? RAZ_SOLVE_DONE : RAZ_SOLVE_NONE, bm, bs));
@@ -392,6 +394,23 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         const bool dead = P->result[t] != RAZ_SOLVER_UNKNOWN || (!exact && (P->g_v[te & 0xff] != RAZ_SOLVER_UNKNOWN || P->c_v[te >> 8] != RAZ_SOLVER_UNKNOWN));
         if (dead) D->h_dead[t] = 1;
     }
+    // A win/loss solve (the reference's `not exactly`: a node's loop ends at the first move with a value > 0) needs the root's moves
+    // one after the other: the subtrees below the third open move matter only if the first two both fail.  Handing every task of
+    // every move out at once kept the pool's lanes busy with work most of which a scan then threw away (profiles/r6: 21 500
+    // lane-iterations per solve where the reference's own search visits ~1 250 nodes) - and the pool is throughput-bound.  So only the
+    // tasks below the first RAZ_SOLVER_NE_WINDOW open root moves are released; the window moves on as scans decide them.
+    // (the limit is a LEVEL-3 NODE number, read off the tree in LDS: tasks of the nodes [0, limit) are released)
+    uint32_t limit = (uint32_t)total;
+    if (!exact && RAZ_SOLVER_NE_WINDOW > 0) {
+        int open = 0, last = k - 1;
+        for (int i = 0; i < k; ++i)
+            if (P->c_v[i] == RAZ_SOLVER_UNKNOWN && ++open == RAZ_SOLVER_NE_WINDOW) {
+                last = i;
+                break;
+            }
+        limit = (uint32_t)uni((uint32_t)P->g_first[P->c_first[last + 1]]);
+    }
+    if (lane == 0) h->limit = limit;
     if (collect) {
         const uint32_t next = st == RAZ_SOLVE_REQUESTED ? 0u : uni(h->next);
         if (next < (uint32_t)subs && lane == 0) E.pool_active[g0 + atomicAdd(&ph->n_active, 1u)] = g;
@@ -519,12 +538,20 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     next_solve = active[(lane_id + draws * lanes_of_slice) % nact];
                     raz_solve_hdr* hh = solve_hdr(E, gg);
                     const uint32_t t = atomicAdd(&hh->next, 1u);
-                    const uint32_t total = hh->total, ex = xk_load32(conc, &hh->exact), hgen = xk_load32(conc, &hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
-                    if (t < total) {
+                    const uint32_t total = hh->total, window = hh->limit, ex = xk_load32(conc, &hh->exact), hgen = xk_load32(conc, &hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
+                    const int nt_ = t < total ? (int)solve_deep(E, gg)->sub_task[t] : 0;
+                    const bool beyond = t < total && (uint32_t)nt_ >= window;
+                    // A ticket outside this round's window (k_solve_scan's limit) goes back for the round that opens it - and so does one past
+                    // the end of the list: thousands of lanes draw at once, and a ticket that stayed drawn behind the window's end would be a
+                    // task nobody ever searches (first hardware run of the window: the batch did not finish; the emulator's waves draw one
+                    // after the other and never overshoot that far).  Tickets inside the window are handed out once each: the counter only
+                    // ever comes back down to the window's end (every subtraction undoes an addition that got a ticket >= that end).
+                    if (beyond || t >= total) atomicSub(&hh->next, 1u);
+                    if (t < total && !beyond) {
                         got = true;
                         SolverTree* T = solve_tree(E, gg);
                         SolverDeep* D = solve_deep(E, gg);
-                        const int nt = D->sub_task[t];   // the task's level-3 node
+                        const int nt = nt_;   // the task's level-3 node
                         const int te = T->task_entry[nt], n = te & 0xff, ci = te >> 8, hk = D->h_kind[nt], s0 = D->sub_first[nt];
                         const raz_bb ho = D->h_own[nt], he = D->h_enemy[nt], hm = D->h_moves[nt];
                         // (a task that has its result: dispatch restarted after the pool was re-partitioned; a node that is decided: moot)

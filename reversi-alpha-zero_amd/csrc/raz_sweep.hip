@@ -394,15 +394,30 @@ __global__ __launch_bounds__(kBlock) void k_pick_kth(const raz_bb* __restrict__ 
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// Batches of at least this many boards run their whole superblocks on the bit-sliced kernels (a superblock is one wave's work: 2^21
-// boards are 1024 waves, one per SIMD of the chip; smaller batches fill the chip better with a board per lane).  RAZ_SWEEP_SLICED_MIN
-// overrides it (tests: 2048 runs every superblock sliced; a huge value switches the sliced kernels off).
-inline size_t sliced_min_boards() {
-    static const size_t v = [] {
-        const char* s = getenv("RAZ_SWEEP_SLICED_MIN");
-        return s && *s ? (size_t)strtoull(s, nullptr, 10) : (size_t)1 << 21;
-    }();
+// Which batches run their whole superblocks (2048 boards = one wave's work) on the bit-sliced kernels - measured on an MI355X
+// (profiles/r6/sweep_bit_sliced_vs_board_per_lane_ab.jsonl):
+//   find_correct_moves: 66 instead of 134 vector instructions per board, two waves per SIMD.  2^26 boards: 0.279-0.291 ms against
+//     0.315-0.325 ms (5.8 against 5.0 TB/s); 2^24 boards: 0.075-0.078 against 0.070-0.072 ms - a superblock per wave leaves too few
+//     waves to overlap one wave's loads with another's arithmetic.  Default: from 2^25 boards on.
+//   ReversiEnv.step: 247 instead of 344 instructions per board, but 256 + 176 registers = ONE wave per SIMD, whose loads, arithmetic
+//     and stores do not overlap: 0.200 ms against 0.150 ms at 2^24 boards (0.71-0.75 against 0.61-0.63 at 2^26); compiled for two waves
+//     (234 registers spilled to scratch) 0.32 ms.  Default: off - the kernel is kept, parity-tested, for RAZ_SWEEP_SLICED_STEP=1.
+// RAZ_SWEEP_SLICED_MIN=<boards> overrides both thresholds (tests: 2048 runs every superblock sliced).
+inline size_t env_boards(const char* name, size_t otherwise) {
+    const char* s = getenv(name);
+    const size_t v = s && *s ? (size_t)strtoull(s, nullptr, 10) : otherwise;
     return v < 2048 ? 2048 : v;
+}
+inline size_t sliced_min_boards() {   // find_correct_moves
+    static const size_t v = env_boards("RAZ_SWEEP_SLICED_MIN", (size_t)1 << 25);
+    return v;
+}
+inline size_t sliced_step_min_boards() {
+    static const size_t v = [] {
+        const char* on = getenv("RAZ_SWEEP_SLICED_STEP");
+        return env_boards("RAZ_SWEEP_SLICED_MIN", on && *on == '1' ? (size_t)1 << 21 : ~(size_t)0);
+    }();
+    return v;
 }
 
 }  // namespace
@@ -450,7 +465,7 @@ extern "C" int raz_step_batch(uint64_t* black, uint64_t* white, uint8_t* player,
                 "raz_step_batch: u64 arrays must be 16-byte aligned");
     RAZ_REQUIRE((((uintptr_t)player | (uintptr_t)status | (uintptr_t)action) & 3) == 0,
                 "raz_step_batch: u8 arrays must be 4-byte aligned");
-    const size_t nsb = n >= sliced_min_boards() ? n / 2048 : 0, done = nsb * 2048;
+    const size_t nsb = n >= sliced_step_min_boards() ? n / 2048 : 0, done = nsb * 2048;
     if (nsb)
         hipLaunchKernelGGL(k_step_sliced, dim3((unsigned)(nsb > (size_t)kMaxGrid ? (size_t)kMaxGrid : nsb)), dim3(64), 0, (hipStream_t)stream,
                            (ulonglong2*)black, (ulonglong2*)white, (uchar2*)player, (uchar2*)status, (ulonglong2*)legal, (const uchar2*)action, nsb);

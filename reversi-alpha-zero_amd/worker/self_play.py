@@ -478,7 +478,7 @@ class BatchedSelfPlayWorker:
         # run()): rows [0, p) of the id-ordered outbox are done, p advancing with the polls; pieces are whole files (no file is cut)
         sink, self._streamed_rows = getattr(self, "_stream_sink", None), 0
         unit = whole_files_block(self.config, 1)
-        piece = max(unit, (int(getattr(self, "stream_piece_games", 0) or max(1024, self.games_in_flight // 4)) // unit) * unit)
+        piece = max(unit, (int(getattr(self, "stream_piece_games", 0) or max(1024, self.games_in_flight)) // unit) * unit)
 
         def ship(steps, done_games, st, ob):
             import torch

@@ -59,7 +59,7 @@ hdrs = np.stack([read(6, i * WS, 64).view(np.uint32) for i in range(games)])
 state = hdrs[:, 0]
 print("states", {int(k): int((state == k).sum()) for k in np.unique(state)})
 run = np.nonzero((state == 2) | (state == 1))[0]
-ks = ["state", "gen", "own_lo", "own_hi", "en_lo", "en_hi", "exact", "k_n2", "tasks", "total", "next", "ans_move", "ans_score", "posted", "rounds", "rounds_total"]
+ks = ["state", "gen", "own_lo", "own_hi", "en_lo", "en_hi", "exact", "k_n2", "tasks", "total", "next", "ans_move", "limit", "posted", "rounds", "rounds_total"]
 for i in run[:6]:
     h = hdrs[i]
     d = dict(zip(ks, [int(x) for x in h]))
