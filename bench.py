@@ -329,7 +329,7 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
-PMC_DIR = "r5_pmc"   # the counter passes of this round's final build (profiles/README.md)
+PMC_DIR = "r6_pmc"   # the counter passes of this round's final build (profiles/README.md)
 
 
 def committed_traffic(name):
@@ -360,7 +360,7 @@ def conv_traffic():
 def sweep_traffic():
     """HBM bytes per launch of k_step / k_legal_moves from the committed PMC passes of tools/bench_sweep.py
     (tools/run_profiles.sh sweep -> tools/pmc_summary.py)."""
-    path = os.path.join(ROOT, "profiles", "r3_pmc", "sweep_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_DIR, "sweep_traffic.json")
     if not os.path.exists(path):
         return {}
     with open(path) as f:
@@ -555,7 +555,7 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
         "mean_selections_per_sim": selections / max(total_sims, 1.0),
         "roofline": {"bound": "mfma", "kernel_name": ("k_conv3x3_f16x3" if v2 else "k_conv3x3_wide") if args.net == "ch5" else "k_net_mfma",
                      "kernel": net_kernel, "algorithmic_flops_per_launch": 2.0 * macs * leaves_per_launch,
-                     "power_limited": ("socket power telemetry of this kernel (amdsmi at 10 Hz, profiles/r5/conv_f16x3_power_telemetry_*.jsonl): 1380 W of a 1400 W cap "
+                     "power_limited": ("socket power telemetry of this kernel (round 5, kernel unchanged; amdsmi at 10 Hz, profiles/r5/conv_f16x3_power_telemetry_*.jsonl): 1380 W of a 1400 W cap "
                                        "with the PPT violation active in every sample and the gfx clock at 2.00 GHz on random operands; 1004 W and 2.40 GHz on zero "
                                        "operands (same instruction stream, 1.26x faster); 77 % matrix-pipe busy (profiles/r4_pmc/)") if v2 else None,
                      "avg_kernel_ms": net_avg_ms, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -1262,7 +1262,7 @@ def sweep_leg(dev):
                 k["traffic_over_algorithmic"] = k["traffic"] / k["algorithmic_bytes_per_launch"]
                 k["traffic_detail"] = {"fetch_bytes_raw": t["fetch_bytes_raw"], "fetch_doubled": doubled, "write_bytes": t["write_bytes"],
                                        "algorithmic_read_bytes": read_alg, "dispatches_averaged": t.get("dispatches_averaged")}
-                k["traffic_source"] = "profiles/r3_pmc/sweep_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/bench_sweep.py)"
+                k["traffic_source"] = f"profiles/{PMC_DIR}/sweep_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/bench_sweep.py on this round's kernels)"
         res[f"boards_2^{boards.bit_length() - 1}"] = {"workload": o["config"]["workload"], "k_step": ks, "k_legal_moves": kl, "boards_per_s": o["value"]}
     out = dict(res["boards_2^24"])
     out["beyond_the_infinity_cache_2^26_boards"] = res["boards_2^26"]

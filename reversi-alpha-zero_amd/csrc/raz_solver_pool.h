@@ -113,7 +113,7 @@ __device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_
 }
 
 #ifndef RAZ_SOLVER_NE_WINDOW
-#define RAZ_SOLVER_NE_WINDOW 2   // open root moves of a win/loss solve whose tasks are handed out (0: all of them at once, rounds 4-5)
+#define RAZ_SOLVER_NE_WINDOW 0   // open root moves of a win/loss solve whose tasks are handed out; 0: all of them at once (the default: see k_solve_scan)
 #endif
 
 // ------------------------------------------------------------------ k_solve_scan
@@ -395,10 +395,12 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
         if (dead) D->h_dead[t] = 1;
     }
     // A win/loss solve (the reference's `not exactly`: a node's loop ends at the first move with a value > 0) needs the root's moves
-    // one after the other: the subtrees below the third open move matter only if the first two both fail.  Handing every task of
-    // every move out at once kept the pool's lanes busy with work most of which a scan then threw away (profiles/r6: 21 500
-    // lane-iterations per solve where the reference's own search visits ~1 250 nodes) - and the pool is throughput-bound.  So only the
-    // tasks below the first RAZ_SOLVER_NE_WINDOW open root moves are released; the window moves on as scans decide them.
+    // one after the other: the subtrees below the third open move matter only if the first two both fail, and the pool spends 21 500
+    // lane-iterations per solve where the reference's own search visits ~1 250 nodes.  RAZ_SOLVER_NE_WINDOW = n releases only the tasks
+    // below the first n open root moves and moves the window on as scans decide them.  MEASURED, round 6 (mini.yml as shipped, one box,
+    // profiles/r6/solver_win_loss_task_window_ab.jsonl): 0 / 1 / 2 / 3 open moves = 21.8 / 13.2 / 17.3 / 19.4 M sims/s lock-step, 27.5 /
+    // 18.1 / 21.9 / 24.3 M with continuous batching - the busy lane-iterations fall by 6 % only (the discarded work sits below the
+    // replies, not below the root's later moves) while every solve needs more rounds.  Kept as a compile-time knob, off.
     // (the limit is a LEVEL-3 NODE number, read off the tree in LDS: tasks of the nodes [0, limit) are released)
     uint32_t limit = (uint32_t)total;
     if (!exact && RAZ_SOLVER_NE_WINDOW > 0) {
@@ -540,13 +542,13 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                     const uint32_t t = atomicAdd(&hh->next, 1u);
                     const uint32_t total = hh->total, window = hh->limit, ex = xk_load32(conc, &hh->exact), hgen = xk_load32(conc, &hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
                     const int nt_ = t < total ? (int)solve_deep(E, gg)->sub_task[t] : 0;
-                    const bool beyond = t < total && (uint32_t)nt_ >= window;
+                    const bool beyond = RAZ_SOLVER_NE_WINDOW > 0 && t < total && (uint32_t)nt_ >= window;
                     // A ticket outside this round's window (k_solve_scan's limit) goes back for the round that opens it - and so does one past
                     // the end of the list: thousands of lanes draw at once, and a ticket that stayed drawn behind the window's end would be a
                     // task nobody ever searches (first hardware run of the window: the batch did not finish; the emulator's waves draw one
                     // after the other and never overshoot that far).  Tickets inside the window are handed out once each: the counter only
                     // ever comes back down to the window's end (every subtraction undoes an addition that got a ticket >= that end).
-                    if (beyond || t >= total) atomicSub(&hh->next, 1u);
+                    if (RAZ_SOLVER_NE_WINDOW > 0 && (beyond || t >= total)) atomicSub(&hh->next, 1u);   // (without a window a ticket past the end just stays drawn)
                     if (t < total && !beyond) {
                         got = true;
                         SolverTree* T = solve_tree(E, gg);

@@ -141,7 +141,10 @@ def run_sweep(args, rank, world, dev):
     e1.record()
     torch.cuda.synchronize()
     lm_ms = e0.elapsed_time(e1) / 10
-    out["k_legal_moves"] = {"bound": "hbm", "kernel": "k_legal_moves", "avg_kernel_ms": lm_ms, "achieved": 24 * n / (lm_ms * 1e-3) / 1e9,
+    env_min = os.environ.get("RAZ_SWEEP_SLICED_MIN")
+    sliced = n >= (max(2048, int(env_min)) if env_min else 1 << 25)   # csrc/raz_sweep.hip sliced_min_boards()
+    out["k_legal_moves"] = {"bound": "hbm", "kernel": ("k_legal_moves_sliced (32 boards per lane, bit-sliced: csrc/raz_sweep_sliced.h; batches from 2^25 boards on)"
+                                                       if sliced else "k_legal_moves (a board per lane)"), "avg_kernel_ms": lm_ms, "achieved": 24 * n / (lm_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 24 * n,
                             "frac": 24 * n / (lm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": f"the same {16 * n >> 20} MiB of inputs every launch: " + ("Infinity-Cache (256 MiB) resident in part" if 16 * n <= (512 << 20)
