@@ -1379,7 +1379,16 @@ def compact_line(full):
             line[key] = pick(full[key], ("collective", "bytes", "games", "seconds", "payload_check", "result", "gathered_bytes"))
     line["bench_wall_seconds"] = full.get("bench_wall_seconds")
     line["full_document"] = full.get("_full_path")
-    return line
+
+    def sig(x):   # seven significant digits say everything a measurement here can (the full document keeps the doubles): ~10 % of the line
+        if isinstance(x, float) and x == x and abs(x) not in (0.0, float("inf")):
+            return float(f"{x:.7g}")
+        if isinstance(x, dict):
+            return {k: sig(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [sig(v) for v in x]
+        return x
+    return sig(line)
 
 
 T_MAIN = time.perf_counter()

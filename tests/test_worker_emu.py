@@ -14,6 +14,14 @@ import pytest
 
 from conftest import ROOT
 
+
+def _free_port(_hint=None):
+    """A port nobody listens on right now (the suite runs on several worker processes: fixed numbers collide)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
 _SCRIPT = r'''
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
@@ -75,6 +83,7 @@ if dist.is_initialized():
 
 
 def _run(tmp_path, tag, world, block, total, emission="auto", port=29571, slots=2):
+    port = _free_port(port)
     out = tmp_path / tag
     out.mkdir()
     script = tmp_path / f"{tag}.py"

@@ -15,6 +15,14 @@ import pytest
 from conftest import ROOT
 
 
+def _free_port(_hint=None):
+    """A port nobody listens on right now (the suite runs on several worker processes: fixed numbers collide)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def stub_games(first_id, n, seed=7):
     """Deterministic fake finished games keyed by GLOBAL game id (so that any sharding yields the same games)."""
     games = []
@@ -281,9 +289,10 @@ def test_run_two_ranks_gloo_equals_one_rank(tmp_path):
     games per batch writes, and both ranks play every batch under the same (broadcast) resign threshold."""
     script = tmp_path / "run2.py"
     script.write_text(_RUN2_SCRIPT.format(root=ROOT, out=str(tmp_path / "two")))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551")
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29551", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     thr = dict(re.findall(r"RANK (\d) THRESHOLDS (\[[^\]]*\] \S+)", r.stdout))
@@ -328,9 +337,10 @@ def test_a_fatal_error_on_one_rank_raises_on_every_rank(tmp_path):
     of the healthy rank waiting forever in the record gather (2 ranks over gloo; the whole run must end within the timeout)."""
     script = tmp_path / "fatal.py"
     script.write_text(_FATAL_SCRIPT.format(root=ROOT, out=str(tmp_path / "f")))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553")
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29553", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RANK 1 RAISED engine error flags 0x1" in r.stdout and "RANK 0 RAISED rank 0: another rank failed" in r.stdout, r.stdout[-1500:]
@@ -379,6 +389,7 @@ dist.barrier(); dist.destroy_process_group()
 
 def _per_rank_run(tmp_path, tag, port, emission="auto", background=True, max_files=1000, fail_at=0, nproc=2, in_flight=25, total=200, fail_rank=1):
     script = tmp_path / f"{tag}.py"
+    port = _free_port(port)
     script.write_text(_PER_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path / tag), emission=emission, background=background, max_files=max_files, fail_at=fail_at,
                                               in_flight=in_flight, total=total, fail_rank=fail_rank))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
