@@ -1,6 +1,6 @@
 """CPU: BatchedSelfPlayWorker.run() - the product's worker, unchanged - over the tree kernels on the WAVE EMULATOR (real games:
-real records, resignations, no-resign test games, draws), with continuous batching, under one rank and under two gloo ranks in
-both emission modes.  The stub-engine tests (tests/test_worker_run_host.py) cover the control flow on prepared records; this runs
+real records, resignations, no-resign test games, draws), with continuous batching, under one rank (with streamed emission: the
+finished prefix of a block handed to the file writer while the block is played) and under two and eight gloo ranks in both emission modes.  The stub-engine tests (tests/test_worker_run_host.py) cover the control flow on prepared records; this runs
 what the engine really hands over - the id-ordered outbox of raz_engine_harvest, cut to each rank's longest game - through
 gather / bookkeeping / broadcast / native row emitter, and compares the directories byte for byte.  The GPU tests of record:
 tests/test_multirank_gpu.py (rank-0 emission) and tests/test_zzz_per_rank_emission_gpu.py (per-rank emission)."""
@@ -57,10 +57,18 @@ class Engine:
     it plays under the threshold the block was started with, as raz_engine_set_resign_threshold makes the device engine do)."""
     def __init__(self, worker, sims):
         self.e = EmuEngine(worker.config, worker.net_blob, worker.games_in_flight, seed=worker.seed, sims_hint=sims, record_root_w=False)
-    def play_continuous(self, first, total, sims_of, chunk=64, on_chunk=None):   # (no streamed emission here: the whole block is handed over at its end)
+    def play_continuous(self, first, total, sims_of, chunk=64, on_chunk=None):
         ob = self.e.play_continuous(first, total, sims_of(first) if callable(sims_of) else int(sims_of[0]), chunk=8)   # (the worker passes one entry per id)
         assert ob["done"].all()
-        return {{k: torch.from_numpy(ob[k]) for k in ("headers", "root_n", "summary")}}, {{"gc_runs": self.e.gc_runs}}
+        out = {{k: torch.from_numpy(ob[k]) for k in ("headers", "root_n", "summary")}}
+        if on_chunk is not None:   # streamed emission (one rank): the worker's poll callback sees the outbox fill up - half of it, then all
+            for p in (total // 2, total):
+                done = torch.zeros(total, dtype=torch.uint8)
+                done[:p] = 1
+                if p < total:
+                    done[min(total - 1, p + 1)] = 1   # (a game beyond the first open one has finished too: it must wait)
+                on_chunk(0, int(done.sum()), {{}}, dict(out, done=done))
+        return out, {{"gc_runs": self.e.gc_runs}}
 
 class EmuWorker(BatchedSelfPlayWorker):
     def _get_engine(self, max_sims):
@@ -69,6 +77,7 @@ class EmuWorker(BatchedSelfPlayWorker):
 
 w = EmuWorker(cfg, golden_net_blob(gold["net"]), games_in_flight={slots}, seed=21, device="cpu", rank=rank, world=world,
               block_games={block}, emission={emission!r})
+w.stream_piece_games = 2   # (one rank: the finished prefix of a block goes to the writer in pieces of one file while the block is "played")
 orig = w.check_and_update_resignation_threshold
 def check():   # make every block step the threshold (>= 100 test games in the reference; scaled down for the test)
     if w.resign_test_game_count >= 2:
@@ -76,6 +85,7 @@ def check():   # make every block step the threshold (>= 100 test games in the r
         orig()
 w.check_and_update_resignation_threshold = check
 w.run(total_games={total})
+assert world > 1 or getattr(w, "_streamed_rows", 0) >= {block} // 2 - 2, getattr(w, "_streamed_rows", None)
 sys.stdout.write(f"RANK {{rank}} OWNFILES {{int(w._per_rank_emission())}} BYTES {{getattr(w, 'bytes_written', 0)}} THRESHOLD {{cfg.play.resign_threshold!r}}\n")
 if dist.is_initialized():
     dist.barrier(); dist.destroy_process_group()

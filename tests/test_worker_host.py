@@ -12,6 +12,14 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, H
+
+
+def _free_port():
+    """A port nobody listens on right now, as a string (the suite runs on several worker processes: fixed numbers collide)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
 from oracle_util import load_mcts_golden, dense
 
 
@@ -65,6 +73,20 @@ def test_schedule_and_force_sim(tmp_path):
     assert [decide_simulation_num_per_move(cfg, i) for i in (0, 299, 300, 1999, 2000, 10**6)] == [8, 8, 50, 50, 200, 200]
     (tmp_path / ".force-sim").write_text("123\n")
     assert decide_simulation_num_per_move(cfg, 0) == 123
+    # the worker's block form: one array per block, the force file read once
+    from reversi_alpha_zero_amd.worker.self_play import simulation_nums_of_ids, default_block_games
+    assert simulation_nums_of_ids(cfg, 290, 20).tolist() == [123] * 20
+    (tmp_path / ".force-sim").unlink()
+    ids = list(range(290, 310)) + [1999, 2000]
+    assert simulation_nums_of_ids(cfg, 290, 20).tolist() == [decide_simulation_num_per_move(cfg, i) for i in range(290, 310)]
+    assert simulation_nums_of_ids(cfg, 1999, 2).tolist() == [50, 200] and simulation_nums_of_ids(cfg, 0, 0).size == 0
+    cfg.play.schedule_of_simulation_num_per_move = [(5, 9)]
+    with pytest.raises(ValueError, match="no entry for game index 3"):
+        simulation_nums_of_ids(cfg, 3, 4)
+    # default block: 4 games per slot for wide nets, 16 for 16-filter nets (worker.start)
+    import struct
+    blob = lambda f: struct.pack("<8i", 0x4E5A4152, 1, f, 1, f, 3, 0, 0)
+    assert default_block_games(blob(16), 4096) == 65536 and default_block_games(blob(256), 8192) == 32768 and default_block_games(None, 100) == 400
 
 
 @pytest.mark.needs_reference
@@ -144,9 +166,10 @@ def test_gather_records_two_ranks_gloo(tmp_path):
     """The only collective of the path, at world_size 2 on CPU (gloo), ragged per-rank sizes."""
     script = tmp_path / "gather2.py"
     script.write_text(_GATHER_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    _p = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_p)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _p, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK 8" in r.stdout
@@ -344,9 +367,10 @@ def test_gather_raw_two_ranks_gloo(tmp_path):
     """The collective of the worker's raw path at world_size 2 on CPU (gloo): rank-ordered concatenation."""
     script = tmp_path / "gather_raw2.py"
     script.write_text(_GATHER_RAW_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    _p = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_p)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29543", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _p, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_RAW_OK 8" in r.stdout
@@ -398,9 +422,10 @@ def test_gather_packed_two_ranks_gloo(tmp_path):
     extents differ, one all_reduce(MAX) aligns them, rank-ordered concatenation, summaries decoded."""
     script = tmp_path / "gather_packed2.py"
     script.write_text(_GATHER_PACKED_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    _p = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_p)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _p, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_PACKED_OK 6" in r.stdout
