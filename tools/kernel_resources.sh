@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/dev/stdout}
 cd "$ROOT/reversi-alpha-zero_amd/csrc"
-for f in raz_engine.hip raz_engine_fused.hip; do
+for f in raz_engine.hip raz_engine_fused.hip raz_sweep.hip; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -c $f -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 | \
   python3 -c "
 import re, sys
