@@ -310,6 +310,142 @@ __global__ __launch_bounds__(64) void k_step_sliced(ulonglong2* __restrict__ bla
     }
 }
 
+// ReversiEnv.step, HYBRID: the move itself board by board with the reference-shaped ray arithmetic (bbv_calc_flip: exact for every input,
+// 111 instructions per board), the legal moves after it - two find_correct_moves per board in the board-per-lane kernel's worst case,
+// 134 each - bit-sliced for the lane's 32 boards at once (raz_sweep_sliced.h legal_after_move: 2 transposes in, 1 out, 41 for both
+// mobilities): 262 vector instructions per board against 344.  A wave takes a superblock of 2048 boards, a lane 32 of them (rows r = 0..15
+// of 64 lanes x 2 boards, as k_step_sliced).  What makes it fit 256 registers without scratch, so that two waves per SIMD overlap:
+//   * the boards after the move go to memory as soon as a row is made and stay in registers only as the sliced phase's input (a row's 8
+//     registers of loaded boards become 8 of own' / enemy' words);
+//   * the player / status / action bytes come in as six 16-byte loads per lane, are handed round through LDS, and what the epilogue needs
+//     of them waits in LDS (one word per row) while the sliced phase has the registers; the winners by disc count are 2 bits per board;
+//   * every stream is addressed by a scalar base per 4 KB + ONE vector register (the lane's offset);
+//   * values the optimiser would keep alive across the phases (store-to-load forwarding through LDS, the disc counts sunk to their rare
+//     use, sixteen partial masks instead of one, the lane's number) are pinned where they belong (RAZ_SL_PIN, lane_again).
+// All of a superblock's loads are issued before the first row is worked on.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_step_hybrid(
+    ulonglong2* __restrict__ black2, ulonglong2* __restrict__ white2, uchar2* __restrict__ player2, uchar2* __restrict__ status2,
+    ulonglong2* __restrict__ legal2, const uchar2* __restrict__ action2, size_t nsb) {
+    for (size_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        const unsigned lane = threadIdx.x;
+        // ALL of the superblock's loads are issued before anything is worked on (the boards' registers are free until the rows turn them
+        // into own' / enemy' words): the superblock's arrays by a scalar base per 4 rows = 4 KB of a stream, the reach of an instruction's
+        // immediate offset, + the lane's 32-bit offset - one address register for all 16 rows of all the streams
+        uint4 p0, p1, s0, s1, a0, a1;
+        ulonglong2 bq[16], wq[16];
+        {
+            const uint4 *const pp = (const uint4*)sl::uniform_ptr(player2 + sb * 1024), *const sp = (const uint4*)sl::uniform_ptr(status2 + sb * 1024),
+                        *const ap = (const uint4*)sl::uniform_ptr(action2 + sb * 1024);
+            p0 = pp[lane]; p1 = pp[64u + lane]; s0 = sp[lane]; s1 = sp[64u + lane]; a0 = ap[lane]; a1 = ap[64u + lane];
+            sl::sfor<4>([&](auto g_) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_)::value;
+                const ulonglong2 *const bg = sl::uniform_ptr(black2 + sb * 1024 + g * 256), *const wg = sl::uniform_ptr(white2 + sb * 1024 + g * 256);
+                sl::sfor<4>([&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value;
+                    bq[4 * g + i] = bg[i * 64u + lane]; wq[4 * g + i] = wg[i * 64u + lane];
+                });
+            });
+        }
+        ulonglong2 *bl[4], *wh[4], *lg[4];
+        sl::sfor<4>([&](auto g_) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value;
+            bl[g] = sl::uniform_ptr(black2 + sb * 1024 + g * 256); wh[g] = sl::uniform_ptr(white2 + sb * 1024 + g * 256);
+            lg[g] = sl::uniform_ptr(legal2 + sb * 1024 + g * 256);
+        });
+        uchar2 *const pl = sl::uniform_ptr(player2 + sb * 1024), *const st2 = sl::uniform_ptr(status2 + sb * 1024);
+        uint32_t o[64], e[64], L[64];
+        // what the epilogue needs of every board besides the masks - its player byte and the status it leaves with if nothing moved (a game
+        // already over, a resignation, an illegal action) - waits in LDS ([row][lane]: conflict-free) while the sliced phase has the
+        // registers; the winner by disc count, should the game end with this move, is two bits per board of winsw
+        __shared__ uint32_t stash[16][64];
+        uint32_t winsw[2] = {0u, 0u};
+        // the superblock's player / status / action bytes: six 16-byte loads per lane instead of 48 two-byte ones, handed round through LDS
+        __shared__ __attribute__((aligned(16))) uint8_t psa[3][2048];
+        uint32_t moved = 0u;
+        // rows are worked on one after the other as they arrive (the scheduler must not interleave the 32 boards' flips: their
+        // temporaries would not fit); a row's 8 registers of boards turn into 8 of own' / enemy' words
+        RAZ_SL_PHASE();
+        __syncthreads();   // (every lane has read the bytes of the superblock before; a one-wave workgroup: no instruction)
+        *(uint4*)&psa[0][lane * 16] = p0; *(uint4*)&psa[0][1024 + lane * 16] = p1;
+        *(uint4*)&psa[1][lane * 16] = s0; *(uint4*)&psa[1][1024 + lane * 16] = s1;
+        *(uint4*)&psa[2][lane * 16] = a0; *(uint4*)&psa[2][1024 + lane * 16] = a1;
+        __syncthreads();
+        sl::sfor<16>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const uchar2 pv = *(const uchar2*)&psa[0][(r * 64 + lane) * 2], sv = *(const uchar2*)&psa[1][(r * 64 + lane) * 2],
+                         av = *(const uchar2*)&psa[2][(r * 64 + lane) * 2];
+            RAZ_SL_PHASE();
+            const ulonglong2 bv = bq[r], wv = wq[r];
+            ulonglong2 nbv, nwv;
+            uint32_t keep = (uint32_t)pv.x | ((uint32_t)pv.y << 8);
+            sl::sfor<2>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_)::value, k = 2 * r + j;
+                const raz_bb b = j ? bv.y : bv.x, w = j ? wv.y : wv.x;
+                const uint32_t p = j ? pv.y : pv.x, st = j ? sv.y : sv.x, a = j ? av.y : av.x;
+                const bool blk = p == RAZ_PLAYER_BLACK;
+                const raz_bb own = blk ? b : w, enemy = blk ? w : b;
+                raz_bb fl = bbv_calc_flip((int)(a & 63u), own, enemy);
+                fl = (st == 0u && a < 64u) ? fl : 0ULL;   // a finished game, a resignation, an action outside the board: nothing moves
+                const bool mv = fl != 0ULL;
+                const raz_bb own2 = mv ? ((own ^ fl) | (1ULL << (a & 63u))) : own, enemy2 = enemy ^ fl;
+                const raz_bb nb = blk ? own2 : enemy2, nw = blk ? enemy2 : own2;
+                if (j) { nbv.y = nb; nwv.y = nw; } else { nbv.x = nb; nwv.x = nw; }
+                o[k] = (uint32_t)own2; o[32 + k] = (uint32_t)(own2 >> 32);
+                e[k] = (uint32_t)enemy2; e[32 + k] = (uint32_t)(enemy2 >> 32);
+                moved |= (mv ? 1u : 0u) << k;
+                const int cb = bb_popcount(nb), cw = bb_popcount(nw);
+                winsw[k >> 4] |= (uint32_t)(cb > cw ? RAZ_WIN_BLACK : (cb < cw ? RAZ_WIN_WHITE : RAZ_WIN_DRAW)) << (2 * (k & 15));
+                const uint32_t other_wins = blk ? RAZ_WIN_WHITE : RAZ_WIN_BLACK;
+                const uint32_t unmoved = st != 0u ? st : (other_wins | (a == RAZ_ACTION_RESIGN ? RAZ_STATUS_RESIGNED : RAZ_STATUS_ILLEGAL));
+                keep |= unmoved << (16 + 8 * j);
+            });
+            bl[r >> 2][(r & 3) * 64u + lane] = nbv;
+            wh[r >> 2][(r & 3) * 64u + lane] = nwv;
+            stash[r][lane] = keep;
+            RAZ_SL_PIN(winsw[r >> 3]);   // (counted HERE, while the boards are in registers - not sunk to the epilogue's rare use)
+            RAZ_SL_PIN(moved);           // (ONE word: not sixteen partial ones kept for the epilogue's bit tests)
+            RAZ_SL_PHASE();
+        });
+        RAZ_SL_PHASE();
+        sl::transpose_boards(o);
+        sl::transpose_boards(e);
+        uint32_t nz1, nz2;
+        sl::legal_after_move(o, e, L, moved, nz1, nz2);
+        sl::transpose_boards(L);
+        RAZ_SL_PHASE();
+        const unsigned lane_ = sl::lane_again();
+        sl::sfor<16>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            ulonglong2 v;
+            v.x = ((unsigned long long)L[32 + 2 * r] << 32) | L[2 * r];
+            v.y = ((unsigned long long)L[32 + 2 * r + 1] << 32) | L[2 * r + 1];
+            lg[r >> 2][(r & 3) * 64u + lane_] = v;
+        });
+        RAZ_SL_PHASE();
+        // player / status of every board (bb_env_step's cases, without branches): a board that moved hands the turn over where the
+        // opponent can move (nz1), ends with the disc count's winner where neither side can (nz2 clear), and goes on with the same
+        // player otherwise; a board that did not move leaves with the status phase 1 put by
+        asm volatile("" ::: "memory");   // (the stash is READ here: the words must not be carried over the sliced phase in registers)
+        const uint32_t turn = moved & nz1, ends = moved & ~nz1 & ~nz2;
+        sl::sfor<16>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const uint32_t keep = stash[r][lane_];
+            uint32_t hp = 0u, hs = 0u;
+            sl::sfor<2>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_)::value, k = 2 * r + j;
+                const uint32_t p = (keep >> (8 * j)) & 0xffu, unmoved = (keep >> (16 + 8 * j)) & 0xffu;
+                const uint32_t wins = (winsw[k >> 4] >> (2 * (k & 15))) & 3u;
+                const uint32_t p2 = (turn >> k) & 1u ? (3u - p) & 0xffu : p;
+                const uint32_t s2 = (moved >> k) & 1u ? ((ends >> k) & 1u ? wins : 0u) : unmoved;
+                hp |= p2 << (8 * j);
+                hs |= s2 << (8 * j);
+            });
+            pl[r * 64u + lane_] = make_uchar2((unsigned char)(hp & 0xff), (unsigned char)(hp >> 8));
+            st2[r * 64u + lane_] = make_uchar2((unsigned char)(hs & 0xff), (unsigned char)(hs >> 8));
+        });
+    }
+}
+
 __device__ __forceinline__ void score_one(raz_bb b, raz_bb w, uint8_t& win, int8_t& diff) {
     int nb = bb_popcount(b), nw = bb_popcount(w);
     win = (uint8_t)(nb > nw ? RAZ_WIN_BLACK : (nb < nw ? RAZ_WIN_WHITE : RAZ_WIN_DRAW));
@@ -395,14 +531,19 @@ __global__ __launch_bounds__(kBlock) void k_pick_kth(const raz_bb* __restrict__ 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Which batches run their whole superblocks (2048 boards = one wave's work) on the bit-sliced kernels - measured on an MI355X
-// (profiles/r6/sweep_bit_sliced_vs_board_per_lane_ab.jsonl):
+// (profiles/r6/sweep_bit_sliced_vs_board_per_lane_ab.jsonl, profiles/r6/sweep_step_hybrid_vs_board_per_lane_ab.jsonl):
 //   find_correct_moves: 66 instead of 134 vector instructions per board, two waves per SIMD.  2^26 boards: 0.279-0.291 ms against
 //     0.315-0.325 ms (5.8 against 5.0 TB/s); 2^24 boards: 0.075-0.078 against 0.070-0.072 ms - a superblock per wave leaves too few
 //     waves to overlap one wave's loads with another's arithmetic.  Default: from 2^25 boards on.
-//   ReversiEnv.step: 247 instead of 344 instructions per board, but 256 + 176 registers = ONE wave per SIMD, whose loads, arithmetic
-//     and stores do not overlap: 0.200 ms against 0.150 ms at 2^24 boards (0.71-0.75 against 0.61-0.63 at 2^26); compiled for two waves
-//     (234 registers spilled to scratch) 0.32 ms.  Default: off - the kernel is kept, parity-tested, for RAZ_SWEEP_SLICED_STEP=1.
-// RAZ_SWEEP_SLICED_MIN=<boards> overrides both thresholds (tests: 2048 runs every superblock sliced).
+//   ReversiEnv.step, the board-per-lane kernel: 344 instructions per board, at its instruction-issue floor (0.149-0.153 ms at 2^24 boards,
+//     0.61-0.64 ms at 2^26).
+//     k_step_hybrid (the move per board, the legal moves after it sliced): 262 per board, 256 registers + 10 KB LDS, no scratch, two waves
+//     per SIMD: 0.577-0.601 ms at 2^26 boards (0.63-0.655 of 8 TB/s against 0.595-0.615), 0.169-0.175 ms at 2^24 (four rounds of 2048
+//     waves that start together do not overlap as thousands of small waves do).  Default: from 2^26 boards on.
+//     k_step_sliced (everything sliced): 247 per board but 256 + 176 registers = ONE wave per SIMD, whose loads, arithmetic and stores
+//     do not overlap: 0.200 ms at 2^24, 0.70 ms at 2^26; compiled for two waves (234 registers in scratch) 0.32 ms.  Kept, parity-tested.
+// RAZ_SWEEP_SLICED_STEP: unset = as above; 0 = the board-per-lane kernel always; 1 = k_step_sliced, 2 = k_step_hybrid from 2^21 boards on.
+// RAZ_SWEEP_SLICED_MIN=<boards> overrides every threshold (tests: 2048 runs every whole superblock on the sliced kernels).
 inline size_t env_boards(const char* name, size_t otherwise) {
     const char* s = getenv(name);
     const size_t v = s && *s ? (size_t)strtoull(s, nullptr, 10) : otherwise;
@@ -412,10 +553,26 @@ inline size_t sliced_min_boards() {   // find_correct_moves
     static const size_t v = env_boards("RAZ_SWEEP_SLICED_MIN", (size_t)1 << 25);
     return v;
 }
-inline size_t sliced_step_min_boards() {
-    static const size_t v = [] {
+inline int step_form() {   // -1 = unset
+    static const int v = [] {
         const char* on = getenv("RAZ_SWEEP_SLICED_STEP");
-        return env_boards("RAZ_SWEEP_SLICED_MIN", on && *on == '1' ? (size_t)1 << 21 : ~(size_t)0);
+        return on && *on >= '0' && *on <= '2' ? *on - '0' : -1;
+    }();
+    return v;
+}
+inline size_t sliced_step_min_boards() {
+    static const size_t v = env_boards("RAZ_SWEEP_SLICED_MIN", step_form() < 0 ? (size_t)1 << 26 : (size_t)1 << 21);
+    return v;
+}
+// k_step_hybrid's grid: a wave per superblock (RAZ_SWEEP_HYBRID_WAVES=<n>: n waves walk the superblocks - tests, so that a wave takes
+// several.  Measured: 2048 resident waves walking all the superblocks, each issuing its next one's loads before the stores of the one
+// at hand, are SLOWER - 0.203 against 0.170 ms at 2^24 boards, 0.70 against 0.58 ms at 2^26 - and so is starting the two waves of a
+// SIMD half a wave's life apart)
+inline size_t hybrid_waves() {
+    static const size_t v = [] {
+        const char* w = getenv("RAZ_SWEEP_HYBRID_WAVES");
+        const size_t v = w && *w ? (size_t)strtoull(w, nullptr, 10) : (size_t)kMaxGrid;
+        return v ? v : 1;
     }();
     return v;
 }
@@ -465,8 +622,15 @@ extern "C" int raz_step_batch(uint64_t* black, uint64_t* white, uint8_t* player,
                 "raz_step_batch: u64 arrays must be 16-byte aligned");
     RAZ_REQUIRE((((uintptr_t)player | (uintptr_t)status | (uintptr_t)action) & 3) == 0,
                 "raz_step_batch: u8 arrays must be 4-byte aligned");
-    const size_t nsb = n >= sliced_step_min_boards() ? n / 2048 : 0, done = nsb * 2048;
-    if (nsb)
+    // whole superblocks on the sliced form in force (k_step_hybrid reads the byte arrays 16 bytes at a time: other alignments stay on the
+    // board-per-lane kernel), the rest a board per lane
+    int form = step_form() < 0 ? 2 : step_form();
+    if (form == 2 && !(aligned16(player) && aligned16(status) && aligned16(action))) form = 0;
+    const size_t nsb = form && n >= sliced_step_min_boards() ? n / 2048 : 0, done = nsb * 2048;
+    if (nsb && form == 2)
+        hipLaunchKernelGGL(k_step_hybrid, dim3((unsigned)(nsb > hybrid_waves() ? hybrid_waves() : nsb)), dim3(64), 0, (hipStream_t)stream,
+                           (ulonglong2*)black, (ulonglong2*)white, (uchar2*)player, (uchar2*)status, (ulonglong2*)legal, (const uchar2*)action, nsb);
+    else if (nsb)
         hipLaunchKernelGGL(k_step_sliced, dim3((unsigned)(nsb > (size_t)kMaxGrid ? (size_t)kMaxGrid : nsb)), dim3(64), 0, (hipStream_t)stream,
                            (ulonglong2*)black, (ulonglong2*)white, (uchar2*)player, (uchar2*)status, (ulonglong2*)legal, (const uchar2*)action, nsb);
     if (n > done)

@@ -28,10 +28,41 @@ namespace sl {
 #define RAZ_SL __device__ __forceinline__
 // keeps the instruction scheduler from mixing two phases of a kernel (it would otherwise start the next phase's independent work early
 // and hold both phases' registers at once)
+// a pointer every lane holds the same value of, handed to the compiler as a scalar it cannot fold the lane's offset into: accesses
+// p[lane + constant] then take ONE vector register (the lane's 32-bit offset) for all the rows of all the streams, instead of a 64-bit
+// address pair per 4 KB of every stream
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    typedef T __attribute__((address_space(1))) * global_ptr;   // (device memory, as the kernel's arguments are: global_ not flat_ accesses)
+    return (T*)(global_ptr)(((unsigned long long)hi << 32) | lo);
+#else
+    return p;
+#endif
+}
+
+// the lane's number in a ONE-WAVE workgroup, made anew (two instructions) where a phase needs it instead of held in a register
+// through the phases before
+__device__ __forceinline__ unsigned lane_again() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned l;   // (volatile: made where this stands, every time - not once before the loop and kept, which is what it is here to avoid)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+#elif defined(RAZ_WAVE_EMU)
+    return threadIdx.x;
+#else
+    return 0u;   // (plain host harnesses of the arithmetic: no lanes)
+#endif
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RAZ_SL_PHASE() __builtin_amdgcn_sched_barrier(0)
+#define RAZ_SL_PIN(x) asm volatile("" : "+v"(x))   // the value is made where this stands: the optimiser may not sink its computation to a later use
 #else
 #define RAZ_SL_PHASE() ((void)0)
+#define RAZ_SL_PIN(x) ((void)0)
 #endif
 
 template <class F, int... I>
@@ -439,6 +470,27 @@ RAZ_SL StepMasks step_boards(uint32_t (&b)[64], uint32_t (&w)[64], uint32_t (&L)
     });
     m.nz2 = any_square(L);   // (read where nz1 is clear only)
     return m;
+}
+
+// ---- the second half of a step on its own, for a kernel that has made the moves board by board (k_step_hybrid): o / e = the mover's and
+// the opponent's discs AFTER the move, sliced; moved = the boards that moved.  L: the legal moves of whoever moves next on those boards
+// (the opponent's, :66; where it has none the mover's own, :68), nothing on the others.  nz1 / nz2 as StepMasks.
+RAZ_SL void legal_after_move(const uint32_t (&o)[64], const uint32_t (&e)[64], uint32_t (&L)[64], uint32_t moved, uint32_t& nz1, uint32_t& nz2) {
+    mobility_raw(e, o, L);
+    sfor<64>([&](auto s_) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_)::value;
+        L[s] = op3<kAndNor>(L[s], o[s], e[s]);
+    });
+    nz1 = any_square(L) & moved;
+    const uint32_t second = moved & ~nz1;
+    RAZ_SL_PHASE();
+    mobility_raw_into(o, e, L, second);
+    RAZ_SL_PHASE();
+    sfor<64>([&](auto s_) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_)::value;
+        L[s] = op3<kAndNor>(L[s] & moved, o[s], e[s]);
+    });
+    nz2 = any_square(L);
 }
 
 }  // namespace sl

@@ -6,7 +6,14 @@ the plain-C++ branch of the VALU-shaped primitives (their device forms are check
 import ctypes
 import os
 
-os.environ.setdefault("RAZ_SWEEP_SLICED_MIN", "2048")   # (read once by the library: every whole superblock of 2048 boards runs on the bit-sliced kernels)
+import subprocess
+import sys
+
+# (read once by the library) every whole superblock of 2048 boards runs on the bit-sliced kernels: k_legal_moves_sliced, and for
+# ReversiEnv.step the form the library adopts for large batches, k_step_hybrid - by two waves, so that a wave takes several superblocks;
+# k_step_sliced (RAZ_SWEEP_SLICED_STEP=1) runs in a process of its own (test_emulated_everything_sliced_step_form_...)
+os.environ.setdefault("RAZ_SWEEP_HYBRID_WAVES", "2")
+os.environ.setdefault("RAZ_SWEEP_SLICED_MIN", "2048")
 
 import numpy as np
 import pytest
@@ -64,7 +71,7 @@ def test_emulated_legal_moves_and_flips_equal_oracle(n):
     assert np.array_equal(flip, ref)
 
 
-@pytest.mark.parametrize("n", [5, 256, 777, 2048 + 300])
+@pytest.mark.parametrize("n", [5, 256, 777, 2048 + 300, 3 * 2048 + 17])
 def test_emulated_step_equals_oracle_incl_passes_and_finished_games(n):
     """(n >= 2048: the first superblock on the bit-sliced kernel.)"""
     lib = load()
@@ -74,6 +81,7 @@ def test_emulated_step_equals_oracle_incl_passes_and_finished_games(n):
     action[3::17] = 255                      # resignations
     b, w, p, s = black.copy(), white.copy(), player.copy(), status.copy()
     legal = np.zeros(n, np.uint64)
+    assert (_ptr(p) | _ptr(s) | _ptr(action)) % 16 == 0   # (k_step_hybrid's condition: otherwise the board-per-lane kernel would be what is tested)
     assert lib.raz_step_batch(_ptr(b), _ptr(w), _ptr(p), _ptr(s), _ptr(legal), _ptr(action), n, None) == 0
     ob, ow, op, os_, ol = O.np_step(black, white, player, status, action)
     assert np.array_equal(b, ob) and np.array_equal(w, ow) and np.array_equal(p, op) and np.array_equal(s, os_) and np.array_equal(legal, ol)
@@ -131,9 +139,23 @@ def test_emulated_sliced_step_on_garbage_boards_and_every_kind_of_action():
     action[rng.random(n) < 0.05] = 255
     b, w, p, s = black.copy(), white.copy(), player.copy(), status.copy()
     legal = np.zeros(n, np.uint64)
+    assert (_ptr(p) | _ptr(s) | _ptr(action)) % 16 == 0
     assert lib.raz_step_batch(_ptr(b), _ptr(w), _ptr(p), _ptr(s), _ptr(legal), _ptr(action), n, None) == 0
     ob, ow, op, os_, ol = O.np_step(black, white, player, status, action)
     for name, got, want in (("black", b, ob), ("white", w, ow), ("player", p, op), ("status", s, os_), ("legal", legal, ol)):
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (name, bad[:5], [hex(int(x)) for x in got[bad[:3]]], [hex(int(x)) for x in want[bad[:3]]])
     assert (os_ & 0x10).any() and (os_ & 0x20).any() and ((os_ == 0) & (status == 0)).sum() > n // 4
+
+
+def test_emulated_everything_sliced_step_form_in_a_process_of_its_own():
+    """k_step_sliced (RAZ_SWEEP_SLICED_STEP=1: the whole step bit-sliced, one wave per SIMD - kept beside k_step_hybrid, which the tests
+    above run): the step tests with whole superblocks, in a child process (the library reads the form once)."""
+    if os.environ.get("RAZ_SWEEP_SLICED_STEP"):
+        pytest.skip("a child of this test, or a run with the form forced from outside")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-p", "no:xdist",
+                        "-k", "(step_equals_oracle and 2348) or garbage"],
+                       env={**os.environ, "RAZ_SWEEP_SLICED_STEP": "1"}, capture_output=True, text=True, timeout=1200,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+

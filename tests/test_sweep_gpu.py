@@ -1,6 +1,10 @@
 """GPU: the batched bitboard sweep kernels (through the C ABI) against the CPU oracle — bit-exact —
 on the golden vectors, on seeded random inputs, on ragged/empty sizes, and at full size through
 size-independent game properties."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -185,3 +189,20 @@ def test_d4_and_planes_vs_oracle(orc, golden_bb):
     bits = lambda a: ((a[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.float32)
     assert np.array_equal(planes[:, 0].reshape(n, 64), bits(x))
     assert np.array_equal(planes[:, 1].reshape(n, 64), bits(y))
+
+
+@pytest.mark.parametrize("env", [{}, {"RAZ_SWEEP_HYBRID_WAVES": "100"}, {"RAZ_SWEEP_SLICED_STEP": "1"}],
+                         ids=["as_adopted_for_large_batches", "hybrid_step_by_100_waves", "everything_sliced_step"])
+def test_bit_sliced_forms_of_the_sweep_kernels_in_a_process_of_their_own(env):
+    """The library runs the whole superblocks (2048 boards) of LARGE batches on the bit-sliced kernels of csrc/raz_sweep_sliced.h -
+    k_legal_moves_sliced from 2^25 boards on, k_step_hybrid from 2^26 - and reads the thresholds once per process: every test of this
+    file again in a child with RAZ_SWEEP_SLICED_MIN=2048 (every whole superblock sliced), the step kernel (a) as adopted, (b) by 100
+    waves so that each walks many superblocks, (c) in the everything-sliced form kept beside it (RAZ_SWEEP_SLICED_STEP=1)."""
+    if os.environ.get("RAZ_SWEEP_SLICED_MIN"):
+        pytest.skip("a child of this test, or a run with the thresholds forced from outside")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "not bit_sliced_forms"],
+                       env={**os.environ, "RAZ_SWEEP_SLICED_MIN": "2048", **env}, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+

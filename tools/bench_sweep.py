@@ -126,7 +126,7 @@ def run_sweep(args, rank, world, dev):
                                f"at uniform random ply (SURVEY §8(d))", "boards_per_gpu": n},
         "roofline": {"bound": "hbm", "achieved": STEP_BYTES_PER_BOARD * n / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                     "kernel": "k_step", "avg_kernel_ms": kern_ms,
+                     "kernel": step_kernel_name(n), "avg_kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": STEP_BYTES_PER_BOARD * n},
     }
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
@@ -152,6 +152,17 @@ def run_sweep(args, rank, world, dev):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_sweep(black, white, player, action, args.cpu_budget)
     return out
+
+
+def step_kernel_name(n):
+    """Which kernel raz_step_batch runs the whole superblocks of a batch of n boards on (csrc/raz_sweep.hip step_form / sliced_step_min_boards)."""
+    form = os.environ.get("RAZ_SWEEP_SLICED_STEP", "")[:1]
+    env_min = os.environ.get("RAZ_SWEEP_SLICED_MIN")
+    least = max(2048, int(env_min)) if env_min else (1 << 26 if form not in ("0", "1", "2") else 1 << 21)
+    if form == "0" or n < least:
+        return "k_step (a board per lane)"
+    return ("k_step_sliced (32 boards per lane, everything bit-sliced)" if form == "1"
+            else "k_step_hybrid (32 boards per lane: the move per board, the legal moves after it bit-sliced; batches from 2^26 boards on)")
 
 
 def main():

@@ -26,11 +26,11 @@ def kernels(path):
 def main(path):
     CLK, CUS = 2.4e9, 256
     for name, lines in kernels(path).items():
-        short = ("k_step_sliced" if "k_step_sliced" in name else "k_legal_moves_sliced" if "k_legal_moves_sliced" in name else
+        short = ("k_step_sliced" if "k_step_sliced" in name else "k_step_hybrid" if "k_step_hybrid" in name else "k_legal_moves_sliced" if "k_legal_moves_sliced" in name else
                  "k_step" if "6k_step" in name else ("k_legal_moves" if "k_legal_moves" in name else None))
         if not short:
             continue
-        if short.endswith("_sliced"):   # straight-line kernels: one superblock of 2048 boards (32 per lane) per loop iteration; AGPR copies are VALU work too
+        if short.endswith("_sliced") or short == "k_step_hybrid":   # straight-line kernels: one superblock of 2048 boards (32 per lane) per loop iteration; AGPR copies are VALU work too
             valu = [x for x in lines if re.match(r"^\tv_", x)]
             moves = [x for x in valu if "accvgpr" in x or re.match(r"^\tv_mov_b32", x)]
             print(f"{short}: {len(valu)} VALU instructions per wave iteration of 2048 boards (32 boards per lane, bit-sliced) = {len(valu) / 32.0:.1f} per board, "
