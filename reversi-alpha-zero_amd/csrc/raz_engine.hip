@@ -69,7 +69,9 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree(raz_engine_d
     }
     if (RAZ_PROF_ON(E) && lane == 0) E.prof[(size_t)g * 8 + 5] += 1;
     const int inner_max = ((E.cfg.reserved >> 12) & 0xf) ? (int)((E.cfg.reserved >> 12) & 0xf) : kInnerMax;
+    const raz_engine_dev& E0 = E;
     for (int it = 0; it < inner_max; ++it) {
+        const raz_engine_dev& E = fresh_descriptor<RAZ_FRESH_DESC>(E0);
         uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (G32(R, GW(error))) break;
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par(raz_engi
     constexpr uint32_t kStageB = 0u, kStageC = 1u, kStageC2 = 2u, kStageD = 4u;  // D outlives a launch only under a suspended solve
     uint32_t stage = G32(R, GW(par_stage));
     unsigned long long dmask = stage == kStageD ? (unsigned long long)G32(R, GW(par_dmask)) : 0ULL;  // sleepers still to poll in D
+    const raz_engine_dev& E0 = E;
     for (;;) {
+        const raz_engine_dev& E = fresh_descriptor<RAZ_FRESH_DESC>(E0);
         if (G32(R, GW(error))) break;
         // ---- the next operation of the round
         int j = -1;

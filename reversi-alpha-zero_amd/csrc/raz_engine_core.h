@@ -291,6 +291,27 @@ __device__ __forceinline__ void node_read_squares(unsigned char* p, int L, raz_b
     Ni = on ? node_N(p, L)[rk] : 0u;
 }
 
+// The engine's descriptor (raz_engine_dev: ~90 scalar registers of pointers and configuration words) as a kernel ARGUMENT is loaded once
+// at the kernel's entry and then lives in scalar registers for the whole launch - more than a wave has, so the compiler parks them in the
+// lanes of spare vector registers (v_writelane / v_readlane: vector-ALU work in an issue-bound kernel).  Handing the step loop the
+// kernel-argument segment's address through an empty asm once per step makes every use a scalar load from the (cached) segment
+// where it is needed instead.  k_tree_net / k_tree_par_net: bit 3 of RAZ_FRESH_1 / RAZ_FRESH_K; k_tree / k_tree_par: RAZ_FRESH_DESC.
+#ifndef RAZ_FRESH_DESC
+#define RAZ_FRESH_DESC 1
+#endif
+template <int ON>
+__device__ __forceinline__ const raz_engine_dev& fresh_descriptor(const raz_engine_dev& E) {
+#ifndef RAZ_WAVE_EMU
+    if (ON) {
+        typedef const raz_engine_dev __attribute__((address_space(4))) * kernarg_ptr;
+        kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();   // (the descriptor is the kernels' FIRST argument)
+        asm volatile("" : "+s"(p));
+        return *(const raz_engine_dev*)p;
+    }
+#endif
+    return E;
+}
+
 // ------------------------------------------------------------------ the game's control block in registers
 // raz_game (raz_engine.h) is 64 dwords.  k_tree loads it with ONE coalesced request (lane i = dword
 // i) together with the in-flight path and the net's answer, keeps it in a single VGPR for the whole

@@ -38,11 +38,16 @@ namespace {
 //         instruction issue, 4 waves x 21 % per SIMD; its spills are one batch of scratch stores before the forward and one batch of
 //         loads behind it, which cost less than the recomputation - lane id alone -2.5 %, config words alone -0.6 %)
 // bit 0: lane id per step, bit 1: config words per step, bit 2 (k_tree_par_net): lane id per round operation and per queued leaf.
+// bit 3 (round 6): the engine's descriptor read from the kernel-argument segment where it is used (fresh_descriptor, raz_engine_core.h)
+// instead of the config words' asm (bit 1 is then without effect): k_tree_net<false> 206 -> 121 spilled scalar registers, 31 -> 21
+// spilled vector registers, 3985 -> 3670 vector instructions in the kernel; k_tree_par_net<false> 256 -> 193, 4547 -> 4020.
+// configs[1] whole games, two runs each on one box (tools/sessions/r6_s15.sh, profiles/r6/fused_kernels_descriptor_from_the_kernarg_segment_ab.json):
+//     k_tree_net<false>      105.3-105.8 -> 107.0-107.4 M sims/s;  k_tree_par_net<false>  96.8 -> 98.7-99.0 M;  mini.yml as shipped 21.6 -> 22.0-22.2 M
 #ifndef RAZ_FRESH_1
-#define RAZ_FRESH_1 0
+#define RAZ_FRESH_1 8
 #endif
 #ifndef RAZ_FRESH_K
-#define RAZ_FRESH_K 7
+#define RAZ_FRESH_K 15
 #endif
 template <int ON = 1>
 __device__ __forceinline__ int fresh_lane(int lane) {
@@ -94,7 +99,11 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
     const raz_engine_dev& E0 = E;
     for (uint32_t it = 0; it < iters; ++it) {
         const int lane = fresh_lane<(RAZ_FRESH_1 & 1)>(lane0);
+#if (RAZ_FRESH_1 >> 3) & 1
+        const raz_engine_dev& E = fresh_descriptor<1>(E0);
+#else
         const raz_engine_dev E = fresh_config<(RAZ_FRESH_1 >> 1) & 1>(E0);
+#endif
         uint32_t phase = G32(R, GW(phase));
         if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE) break;
         if (G32(R, GW(error))) break;
@@ -199,7 +208,11 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_par_net(raz_
     const raz_engine_dev& E0 = E;
     for (uint32_t it = 0; it < iters; ++it) {
         const int lane = fresh_lane<(RAZ_FRESH_K & 1)>(lane0);
+#if (RAZ_FRESH_K >> 3) & 1
+        const raz_engine_dev& E = fresh_descriptor<1>(E0);
+#else
         const raz_engine_dev E = fresh_config<(RAZ_FRESH_K >> 1) & 1>(E0);
+#endif
         {
             const uint32_t phase = G32(R, GW(phase));
             if (phase == RAZ_PHASE_DONE || phase == RAZ_PHASE_IDLE || G32(R, GW(error))) break;
