@@ -49,6 +49,15 @@ namespace {
 #ifndef RAZ_FRESH_K
 #define RAZ_FRESH_K 15
 #endif
+// -DRAZ_FUSED_PROF (measurement builds only): shader-clock ticks of a step's phases of k_tree_net into the engine's phase profile
+// (engine.phase_profile(): 0 backup, 1 controller, 2 select, 5 the in-wave forward; the engine created with phase_profile=True)
+#ifdef RAZ_FUSED_PROF
+#define RAZ_FUSED_T0() unsigned long long t_prof = prof_now()
+#define RAZ_FUSED_T(k) do { prof_add(E, g, (k), t_prof, lane); t_prof = prof_now(); } while (0)
+#else
+#define RAZ_FUSED_T0() ((void)0)
+#define RAZ_FUSED_T(k) ((void)0)
+#endif
 template <int ON = 1>
 __device__ __forceinline__ int fresh_lane(int lane) {
 #ifndef RAZ_WAVE_EMU
@@ -109,8 +118,10 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
         if (G32(R, GW(error))) break;
         // a descent suspended at an in-simulation solve (select_leaf) goes on where it stands, before anything else
         const bool suspended = SOLVER && G32(R, GW(leaf_kind)) == RAZ_LEAF_SOLVE_PENDING;
+        RAZ_FUSED_T0();
         if (!suspended) {
             if (G32(R, GW(leaf_kind)) != RAZ_LEAF_NONE) backup_leaf<false>(E, R, g, G32(R, GW(player)) - 1, lane, lds64);
+            RAZ_FUSED_T(0);
             for (int guard = 0; guard < 8; ++guard) {
                 phase = G32(R, GW(phase));
                 if (phase == RAZ_PHASE_NEW_MOVE) {
@@ -124,11 +135,13 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
                 }
                 break;
             }
+            RAZ_FUSED_T(1);
             phase = G32(R, GW(phase));
             if (phase != RAZ_PHASE_SEARCH || (int32_t)G32(R, GW(sims_left)) <= 0 || G32(R, GW(error))) break;
         }
         select_leaf<SOLVER, false>(E, R, g, lane, slds_p, g, suspended ? G32(R, GW(leaf_node)) : G32(R, GW(root_node)),
                                    suspended ? (int)G32(R, GW(depth)) : 0, false, suspended ? (int)G32(R, GW(leaf_action)) - 1 : -1);
+        RAZ_FUSED_T(2);
         const uint32_t lk = G32(R, GW(leaf_kind));
         if (lk == RAZ_LEAF_EXPAND) {
             // what select_leaf handed to the leaf exchange (nn_own / nn_enemy), recomputed from the control block: the
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(64) RAZ_TREE_WAVES(SOLVER) void k_tree_net(raz_engi
             const bool black_to_move = G32(R, GW(leaf_np)) == 1u;
             raz_net16_forward_in_wave(net_w, net_R, net_V, black_to_move ? tb : tw, black_to_move ? tw : tb, netbuf, lane, R.pol_raw, R.val);
             R.nn = 0u;
+            RAZ_FUSED_T(5);
         } else if (lk != RAZ_LEAF_TERMINAL && lk != RAZ_LEAF_SOLVED)
             break;
     }
