@@ -87,6 +87,14 @@ int raz_d4_batch(const uint64_t* in, uint64_t* out, const uint8_t* sym, size_t n
  * planes[i][0][sq] = bit sq of own[i], planes[i][1][sq] = bit sq of enemy[i], as float32. */
 int raz_planes_batch(const uint64_t* own, const uint64_t* enemy, float* planes, size_t n,
                      raz_stream_t stream);
+/* Which KERNEL FORM the whole superblocks (2048 boards) of a batch of n boards run on - large batches take the bit-sliced kernels
+ * (32 boards per lane: csrc/raz_sweep_sliced.h), the rest of the batch and small batches the board-per-lane ones; results are identical.
+ * The thresholds are read once per process (RAZ_SWEEP_SLICED_MIN=<boards> overrides them; RAZ_SWEEP_SLICED_STEP=0/1/2 forces the step form).
+ *   *legal_moves_form: 0 = k_legal_moves (a board per lane), 1 = k_legal_moves_sliced (from 2^25 boards on);
+ *   *step_form:        0 = k_step (a board per lane), 1 = k_step_sliced, 2 = k_step_hybrid (from 2^26 boards on; needs the player /
+ *                      status / action arrays 16-byte aligned - a batch whose arrays are not stays on k_step).
+ * For tests and benches that must know what they measured; no device work. */
+int raz_sweep_forms(size_t n, int* legal_moves_form, int* step_form);
 /* Uniform random playout driver for tests/benches (test infrastructure shipped with the library,
  * mirrors SURVEY §8(c) "random playout"): action[i] = the k-th set bit of legal[i] where
  * k = rnd[i] % popcount(legal[i]); 255 when legal[i] == 0. */

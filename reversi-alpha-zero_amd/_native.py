@@ -45,6 +45,7 @@ SIGNATURES = {
     "raz_legal_moves_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "raz_calc_flip_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "raz_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "raz_sweep_forms": (c_int, [c_size_t, c_void_p, c_void_p]),
     "raz_score_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "raz_d4_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "raz_planes_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -639,6 +639,14 @@ extern "C" int raz_step_batch(uint64_t* black, uint64_t* white, uint8_t* player,
     return raz_check_launch("raz_step_batch");
 }
 
+extern "C" int raz_sweep_forms(size_t n, int* legal_moves_form, int* step_form_out) {
+    RAZ_REQUIRE(legal_moves_form && step_form_out, "raz_sweep_forms: NULL result");
+    *legal_moves_form = n >= sliced_min_boards() && n >= 2048 ? 1 : 0;
+    const int form = step_form() < 0 ? 2 : step_form();
+    *step_form_out = form && n >= sliced_step_min_boards() && n >= 2048 ? form : 0;
+    return RAZ_OK;
+}
+
 extern "C" int raz_score_batch(const uint64_t* black, const uint64_t* white, uint8_t* winner,
                                int8_t* diff, size_t n, raz_stream_t stream) {
     if (n == 0) return RAZ_OK;

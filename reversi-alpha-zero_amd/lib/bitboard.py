@@ -123,6 +123,15 @@ def step_batch(black, white, player, status, legal, action):
           "raz_step_batch")
 
 
+def sweep_forms(n):
+    """(legal_moves_form, step_form) of a batch of n boards: which kernels its whole superblocks run on (include/raz.h raz_sweep_forms:
+    0 = a board per lane, 1 = bit-sliced, step 2 = the hybrid form)."""
+    import ctypes
+    a, b = ctypes.c_int(-1), ctypes.c_int(-1)
+    check(lib.raz_sweep_forms(int(n), ctypes.addressof(a), ctypes.addressof(b)), "raz_sweep_forms")
+    return a.value, b.value
+
+
 def score_batch(black, white):
     import torch
     winner = torch.empty(black.numel(), dtype=torch.uint8, device=black.device)

@@ -12,14 +12,28 @@ import sys
 # (read once by the library) every whole superblock of 2048 boards runs on the bit-sliced kernels: k_legal_moves_sliced, and for
 # ReversiEnv.step the form the library adopts for large batches, k_step_hybrid - by two waves, so that a wave takes several superblocks;
 # k_step_sliced (RAZ_SWEEP_SLICED_STEP=1) runs in a process of its own (test_emulated_everything_sliced_step_form_...)
-os.environ.setdefault("RAZ_SWEEP_HYBRID_WAVES", "2")
-os.environ.setdefault("RAZ_SWEEP_SLICED_MIN", "2048")
+_EMU_ENV = {"RAZ_SWEEP_HYBRID_WAVES": "2", "RAZ_SWEEP_SLICED_MIN": "2048"}
 
 import numpy as np
 import pytest
 
 import oracle as O
 from emu_util import load
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _every_superblock_sliced():
+    """Set while THIS module's tests run - not at import: collecting the file in a run of the GPU tests must not change what the device
+    library does (the emulator library reads the thresholds at its first sweep call, which is in here)."""
+    old = {k: os.environ.get(k) for k in _EMU_ENV}
+    for k, v in _EMU_ENV.items():
+        os.environ.setdefault(k, v)
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def _ptr(a):
@@ -81,7 +95,11 @@ def test_emulated_step_equals_oracle_incl_passes_and_finished_games(n):
     action[3::17] = 255                      # resignations
     b, w, p, s = black.copy(), white.copy(), player.copy(), status.copy()
     legal = np.zeros(n, np.uint64)
-    assert (_ptr(p) | _ptr(s) | _ptr(action)) % 16 == 0   # (k_step_hybrid's condition: otherwise the board-per-lane kernel would be what is tested)
+    if n >= 2048:   # what is tested: the sliced forms (the library's own answer), on arrays k_step_hybrid accepts
+        lf, sf = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib.raz_sweep_forms(n, ctypes.addressof(lf), ctypes.addressof(sf)) == 0
+        assert (lf.value, sf.value) == (1, int(os.environ.get("RAZ_SWEEP_SLICED_STEP", "2"))), (lf.value, sf.value)
+        assert (_ptr(p) | _ptr(s) | _ptr(action)) % 16 == 0
     assert lib.raz_step_batch(_ptr(b), _ptr(w), _ptr(p), _ptr(s), _ptr(legal), _ptr(action), n, None) == 0
     ob, ow, op, os_, ol = O.np_step(black, white, player, status, action)
     assert np.array_equal(b, ob) and np.array_equal(w, ow) and np.array_equal(p, op) and np.array_equal(s, os_) and np.array_equal(legal, ol)
@@ -151,11 +169,11 @@ def test_emulated_sliced_step_on_garbage_boards_and_every_kind_of_action():
 def test_emulated_everything_sliced_step_form_in_a_process_of_its_own():
     """k_step_sliced (RAZ_SWEEP_SLICED_STEP=1: the whole step bit-sliced, one wave per SIMD - kept beside k_step_hybrid, which the tests
     above run): the step tests with whole superblocks, in a child process (the library reads the form once)."""
-    if os.environ.get("RAZ_SWEEP_SLICED_STEP"):
+    if os.environ.get("RAZ_SWEEP_TEST_CHILD") or os.environ.get("RAZ_SWEEP_SLICED_STEP"):
         pytest.skip("a child of this test, or a run with the form forced from outside")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-p", "no:xdist",
                         "-k", "(step_equals_oracle and 2348) or garbage"],
-                       env={**os.environ, "RAZ_SWEEP_SLICED_STEP": "1"}, capture_output=True, text=True, timeout=1200,
+                       env={**os.environ, **_EMU_ENV, "RAZ_SWEEP_SLICED_STEP": "1", "RAZ_SWEEP_TEST_CHILD": "1"}, capture_output=True, text=True, timeout=1200,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 

@@ -191,6 +191,19 @@ def test_d4_and_planes_vs_oracle(orc, golden_bb):
     assert np.array_equal(planes[:, 1].reshape(n, 64), bits(y))
 
 
+def test_which_kernel_forms_the_batches_run_on():
+    """raz_sweep_forms: the library's own account of the forms - as adopted (board per lane below 2^25 boards, find_correct_moves
+    sliced from there, ReversiEnv.step hybrid from 2^26), or, in a child of the test below, every whole superblock on the form forced."""
+    from reversi_alpha_zero_amd.lib import bitboard as bb
+    if os.environ.get("RAZ_SWEEP_TEST_CHILD"):
+        assert bb.sweep_forms(2047) == (0, 0)
+        assert bb.sweep_forms(2048) == (1, int(os.environ.get("RAZ_SWEEP_SLICED_STEP", "2")))
+    elif not any(k.startswith("RAZ_SWEEP_") for k in os.environ):
+        assert bb.sweep_forms(1 << 24) == (0, 0) and bb.sweep_forms((1 << 25) - 1) == (0, 0)
+        assert bb.sweep_forms(1 << 25) == (1, 0) and bb.sweep_forms((1 << 26) - 1) == (1, 0)
+        assert bb.sweep_forms(1 << 26) == (1, 2)
+
+
 @pytest.mark.parametrize("env", [{}, {"RAZ_SWEEP_HYBRID_WAVES": "100"}, {"RAZ_SWEEP_SLICED_STEP": "1"}],
                          ids=["as_adopted_for_large_batches", "hybrid_step_by_100_waves", "everything_sliced_step"])
 def test_bit_sliced_forms_of_the_sweep_kernels_in_a_process_of_their_own(env):
@@ -198,11 +211,12 @@ def test_bit_sliced_forms_of_the_sweep_kernels_in_a_process_of_their_own(env):
     k_legal_moves_sliced from 2^25 boards on, k_step_hybrid from 2^26 - and reads the thresholds once per process: every test of this
     file again in a child with RAZ_SWEEP_SLICED_MIN=2048 (every whole superblock sliced), the step kernel (a) as adopted, (b) by 100
     waves so that each walks many superblocks, (c) in the everything-sliced form kept beside it (RAZ_SWEEP_SLICED_STEP=1)."""
-    if os.environ.get("RAZ_SWEEP_SLICED_MIN"):
-        pytest.skip("a child of this test, or a run with the thresholds forced from outside")
+    if os.environ.get("RAZ_SWEEP_TEST_CHILD"):
+        pytest.skip("a child of this test")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "not bit_sliced_forms"],
-                       env={**os.environ, "RAZ_SWEEP_SLICED_MIN": "2048", **env}, capture_output=True, text=True, timeout=1500,
+                       env={**{k: v for k, v in os.environ.items() if not k.startswith("RAZ_SWEEP_")}, "RAZ_SWEEP_SLICED_MIN": "2048", "RAZ_SWEEP_TEST_CHILD": "1", **env},
+                       capture_output=True, text=True, timeout=1500,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 

@@ -141,8 +141,7 @@ def run_sweep(args, rank, world, dev):
     e1.record()
     torch.cuda.synchronize()
     lm_ms = e0.elapsed_time(e1) / 10
-    env_min = os.environ.get("RAZ_SWEEP_SLICED_MIN")
-    sliced = n >= (max(2048, int(env_min)) if env_min else 1 << 25)   # csrc/raz_sweep.hip sliced_min_boards()
+    sliced = bb.sweep_forms(n)[0] == 1
     out["k_legal_moves"] = {"bound": "hbm", "kernel": ("k_legal_moves_sliced (32 boards per lane, bit-sliced: csrc/raz_sweep_sliced.h; batches from 2^25 boards on)"
                                                        if sliced else "k_legal_moves (a board per lane)"), "avg_kernel_ms": lm_ms, "achieved": 24 * n / (lm_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 24 * n,
@@ -155,14 +154,10 @@ def run_sweep(args, rank, world, dev):
 
 
 def step_kernel_name(n):
-    """Which kernel raz_step_batch runs the whole superblocks of a batch of n boards on (csrc/raz_sweep.hip step_form / sliced_step_min_boards)."""
-    form = os.environ.get("RAZ_SWEEP_SLICED_STEP", "")[:1]
-    env_min = os.environ.get("RAZ_SWEEP_SLICED_MIN")
-    least = max(2048, int(env_min)) if env_min else (1 << 26 if form not in ("0", "1", "2") else 1 << 21)
-    if form == "0" or n < least:
-        return "k_step (a board per lane)"
-    return ("k_step_sliced (32 boards per lane, everything bit-sliced)" if form == "1"
-            else "k_step_hybrid (32 boards per lane: the move per board, the legal moves after it bit-sliced; batches from 2^26 boards on)")
+    """Which kernel raz_step_batch runs the whole superblocks of a batch of n boards on (the library's own answer: raz_sweep_forms)."""
+    from reversi_alpha_zero_amd.lib import bitboard as bb
+    return {0: "k_step (a board per lane)", 1: "k_step_sliced (32 boards per lane, everything bit-sliced)",
+            2: "k_step_hybrid (32 boards per lane: the move per board, the legal moves after it bit-sliced; batches from 2^26 boards on)"}[bb.sweep_forms(n)[1]]
 
 
 def main():
