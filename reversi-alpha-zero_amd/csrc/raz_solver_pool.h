@@ -112,6 +112,9 @@ __device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_
     return l1 ? 1 : 2;
 }
 
+#ifndef RAZ_SOLVER_DRAW_GATE
+#define RAZ_SOLVER_DRAW_GATE 1   // idle lanes draw tasks in proportion to the tasks left (k_solve_run, "idle lanes draw tasks"); 0: every idle lane at every slow phase
+#endif
 #ifndef RAZ_SOLVER_NE_WINDOW
 #define RAZ_SOLVER_NE_WINDOW 0   // open root moves of a win/loss solve whose tasks are handed out; 0: all of them at once (the default: see k_solve_scan)
 #endif
@@ -500,6 +503,18 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
     bool wait_find = ((m1 >> 5) & 1ULL) != 0;
     const uint32_t lane_id = blockIdx.x * 64u + (uint32_t)lane, lanes_of_slice = wcount * 64u;
     uint32_t draws = 0u, next_solve = nact ? active[lane_id % nact] : 0u;
+    // how many tasks the solve of the lane's next draw had left when last looked at (requested a phase ahead, like the list entry): a lane
+    // only draws - an atomic on the solve's counter - when its turn among the lanes that walk to that solve comes up often enough for the
+    // tasks that are left.  Without this every idle lane of the slice drew at every slow phase: with a handful of solves listed (the
+    // first and the last few hundred steps of a batch) that is 65 000 atomics on a handful of addresses, ~88 per microsecond each -
+    // rounds of 1 ms that hand out a few hundred tasks (tools/solver_timeline.py)
+    const uint32_t lanes_per_solve = nact ? (lanes_of_slice + nact - 1u) / nact : 1u;
+    uint32_t peek_left = 0u;
+    if (nact) {
+        const raz_solve_hdr* hp = solve_hdr(E, next_solve);
+        const uint32_t pn = __hip_atomic_load(&hp->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pt = hp->total;
+        peek_left = pn < pt ? pt - pn : 0u;
+    }
     bool put_pending = false;
     raz_bb put_own = 0, put_enemy = 0;
     uint32_t put_tag = 0u, put_g = 0u;
@@ -533,11 +548,22 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
             // solve (w * 64 + L + q * lanes of the slice) mod nact at its q-th draw - all lanes together sweep the list evenly, and a solve's
             // tasks still leave in scan order (its `next` counter).  The list entry of a lane's next draw is requested one phase ahead
             if (!dry && nidle) {
-                bool got = false;
+                bool got = false, saw_tasks = false;
+                // (RAZ_SOLVER_DRAW_GATE: of the lanes_per_solve lanes that walk to this solve, about as many draw as it has tasks left -
+                // a lane's turn comes round with its draws)
+                const uint32_t every = peek_left ? (lanes_per_solve + peek_left - 1u) / peek_left : 0u;
+                const bool my_turn = !RAZ_SOLVER_DRAW_GATE || (every && (lane_id / nact + draws) % every == 0u);
                 if (!have) {
                     const uint32_t gg = next_solve;
+                    saw_tasks = peek_left != 0u;
                     ++draws;
                     next_solve = active[(lane_id + draws * lanes_of_slice) % nact];
+                    {
+                        const raz_solve_hdr* hp = solve_hdr(E, next_solve);
+                        const uint32_t pn = __hip_atomic_load(&hp->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pt = hp->total;
+                        peek_left = pn < pt ? pt - pn : 0u;
+                    }
+                    if (my_turn) {
                     raz_solve_hdr* hh = solve_hdr(E, gg);
                     const uint32_t t = atomicAdd(&hh->next, 1u);
                     const uint32_t total = hh->total, window = hh->limit, ex = xk_load32(conc, &hh->exact), hgen = xk_load32(conc, &hh->gen);   // (fixed while the pool runs: requested beside the draw; exact and gen are the tree kernels' words)
@@ -598,9 +624,11 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                         } else
                             ++st_skipped;
                     }
+                    }
                 }
                 if (__ballot(got) == 0ULL) {
-                    if (++empty_draws >= 2) dry = true;   // the listed solves have handed out everything (this launch)
+                    // (a phase in which lanes saw tasks but it was nobody's turn does not count: the tasks are still there)
+                    if (!(RAZ_SOLVER_DRAW_GATE && __ballot(!got && saw_tasks && !my_turn)) && ++empty_draws >= 2) dry = true;   // the listed solves have handed out everything (this launch)
                 } else
                     empty_draws = 0;
             }
