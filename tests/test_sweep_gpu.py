@@ -204,6 +204,47 @@ def test_which_kernel_forms_the_batches_run_on():
         assert bb.sweep_forms(1 << 26) == (1, 2)
 
 
+def test_batches_at_the_adopted_sizes_equal_the_board_per_lane_kernels_on_the_same_boards():
+    """At BASELINE's largest sweep size and beyond, with the thresholds AS ADOPTED (no override): 2^26 + 2048 + 5 boards run
+    find_correct_moves on k_legal_moves_sliced and ReversiEnv.step on k_step_hybrid (raz_sweep_forms says so); the same boards in pieces
+    below 2^25 run on the board-per-lane kernels - every array must come out bit-identical.  Boards: disjoint random discs of every
+    density, finished games, resignations, actions on occupied squares and on squares that flip nothing."""
+    from reversi_alpha_zero_amd.lib import bitboard as bb
+    if any(k.startswith("RAZ_SWEEP_") for k in os.environ):
+        pytest.skip("thresholds forced from outside")
+    n = (1 << 26) + 2048 + 5
+    assert bb.sweep_forms(n) == (1, 2)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rnd = lambda: torch.randint(-(1 << 63), (1 << 63) - 1, (n,), dtype=torch.int64, device=DEV, generator=g)
+    black = rnd()
+    black[: n // 2] &= rnd()[: n // 2]                     # thinner boards in the first half, sparse ones in the first quarter
+    black[: n // 4] &= rnd()[: n // 4]
+    white = rnd() & ~black
+    white[n // 8: n // 4] &= rnd()[n // 8: n // 4]
+    player = torch.randint(1, 3, (n,), dtype=torch.uint8, device=DEV, generator=g)
+    status = torch.where(torch.rand(n, device=DEV, generator=g) < 0.1, torch.randint(1, 4, (n,), dtype=torch.uint8, device=DEV, generator=g),
+                         torch.zeros(n, dtype=torch.uint8, device=DEV))
+    action = torch.randint(0, 64, (n,), dtype=torch.uint8, device=DEV, generator=g)
+    action[torch.rand(n, device=DEV, generator=g) < 0.03] = 255   # (the contract: 0..63 or 255, include/raz.h raz_step_batch)
+    own, enemy = torch.where(player == 1, black, white), torch.where(player == 1, white, black)
+    piece = (1 << 24) + 1000                               # below every threshold: the board-per-lane kernels
+    assert bb.sweep_forms(piece) == (0, 0)
+    legal_big = bb.legal_moves_batch(own, enemy)
+    for i in range(0, n, piece):
+        assert torch.equal(legal_big[i:i + piece], bb.legal_moves_batch(own[i:i + piece].clone(), enemy[i:i + piece].clone()))
+    del legal_big
+    big = [t.clone() for t in (black, white, player, status)] + [torch.zeros(n, dtype=torch.int64, device=DEV)]
+    bb.step_batch(*big, action)
+    moved = 0
+    for i in range(0, n, piece):
+        part = [t[i:i + piece].clone() for t in (black, white, player, status)] + [torch.zeros(min(piece, n - i), dtype=torch.int64, device=DEV)]
+        bb.step_batch(*part, action[i:i + piece].clone())
+        for name, a, b in zip(("black", "white", "player", "status", "legal"), big, part):
+            assert torch.equal(a[i:i + piece], b), (name, i)
+        moved += int((part[0] != black[i:i + piece]).sum())
+    assert moved > n // 8                                  # (the batch did step: moves that flip something are common on these boards)
+
+
 @pytest.mark.parametrize("env", [{}, {"RAZ_SWEEP_HYBRID_WAVES": "100"}, {"RAZ_SWEEP_SLICED_STEP": "1"}],
                          ids=["as_adopted_for_large_batches", "hybrid_step_by_100_waves", "everything_sliced_step"])
 def test_bit_sliced_forms_of_the_sweep_kernels_in_a_process_of_their_own(env):
