@@ -1035,7 +1035,7 @@ def config1_leg(dev, args, par=1, fused=True, net_kernel=None, shipped=False):
            "finished_games": st["finished_games"], "searched_plies_per_game": st["total_sims"] / games / sims}
     if shipped:
         out["solver_pool"] = dict(eng.solver_stats(), worker_waves=int(eng.cfg.solver_pool_waves) or min(1280, (games + 3) // 4),
-                                  iterations_per_round=(int(eng.cfg.reserved) >> 16 & 0xff) * 64 or 128,
+                                  iterations_per_round=(int(eng.cfg.reserved) >> 16 & 0xff) * 64 or 96,
                                   what="the end-game solver's pool of worker lanes (csrc/raz_solver_pool.h) over the whole leg: solves, rounds of the pool per answer, "
                                        "share of the worker lanes' iterations spent searching a subtree")
     if fused:

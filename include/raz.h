@@ -178,7 +178,7 @@ typedef struct {
                                                  slices/streams (0 = 3); bits 12-15: max simulations per game per tree launch
                                                  (0 = 2; slot kernel: simulations STARTED per launch beyond parallel_search_num);
                                                  bits 16-23: x 64 = iterations a worker lane of the end-game solver's pool runs between two
-                                                 tree launches (0 = 128); a game whose solve - the root's or one inside a simulation - is
+                                                 tree launches (0 = the default, 96); a game whose solve - the root's or one inside a simulation - is
                                                  not answered yet stays suspended: results do not depend on the value;
                                                  bits 24-27: tree launches per round of that pool (0 = the library's default; 1 = every
                                                  step waits for the pool's round; n > 1 = the round runs on a stream of its own beside

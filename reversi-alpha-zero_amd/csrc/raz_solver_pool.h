@@ -95,13 +95,67 @@ __device__ __forceinline__ bool solver_scan(const signed char* vals, int n, raz_
 
 // a position after `mover` (own, enemy) played square a: who moves next.  kind 0: the game ends (v = disc difference for `mover`);
 // 1: the opponent moves; 2: the opponent passes (the mover again); (no, ne, nm) = the next position from ITS mover's view and its moves
-__device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_bb& no, raz_bb& ne, raz_bb& nm, int& v) {
+// RAZ_SOLVER_INLINE_LAST: a position with ONE empty square left is not handed back as a node - it would cost the worker wave a whole
+// iteration to play its only move - but finished here: whoever can play the square plays it (one more calc_flip), the discs are counted,
+// and the move reports "the game ends there" with that count.  The same value the two steps give (a node with one move has nothing to
+// choose and nothing to cut off); in a full-width search every second node is such a node.
+#ifndef RAZ_SOLVER_INLINE_LAST
+#define RAZ_SOLVER_INLINE_LAST 1   // 2: positions with TWO empty squares are finished in the move function too (solver_last_two)
+// Measured on mini.yml as shipped (M sims/s: two-kernel lock-step / continuous batching / fused lock-step; tools/sessions/r6_s22-24.sh,
+// profiles/r6/solver_last_squares_finished_in_the_move_function_ab.json), level x iterations per round:
+//   0 x 128: 31.2 / 31.4 / 25.4 (4.61 rounds per answer)     1 x 128: 33.7 / 32.6 / 29.5 (3.28)     1 x 96: 34.2 / 33.7 / 27.5     1 x 64: 33.6 / 32.9 / 23.7
+//   2 x 128: 32.0 / 30.6 / 32.1 (2.15: fewer, longer iterations - a round of 128 takes too long)     2 x 96: 33.2 / 31.6 / 30.4     2 x 80: 33.8 / 32.5 / 29.5     2 x 64: 33.8 / 33.3 / 27.7
+// Level 1 at 96 iterations per round is the default (the worker runs the two-kernel pipeline with continuous batching when the solver is on).
+#endif
+// one empty square e, `own` to move: the final disc difference for `own` (env/reversi_env.py:68-85: the mover plays it if that flips
+// something, else the opponent does, else the game is over as it stands)
+__device__ __forceinline__ int solver_last_one(int e, raz_bb own, raz_bb enemy) {
+    const int f = bb_popcount(bbv_calc_flip(e, own, enemy));
+    const int po = bb_popcount(own), pe = bb_popcount(enemy);
+    if (f) return (po + f + 1) - (pe - f);
+    const int g = bb_popcount(bbv_calc_flip(e, enemy, own));
+    return g ? (po - g) - (pe + g + 1) : po - pe;
+}
+// two empty squares, `own` to move with the legal moves `moves` (not empty): the reference's loop over them (ascending, strict
+// improvement, non-exact: done at the first value > 0) with each reply finished by solver_last_one
+__device__ __forceinline__ int solver_last_two(raz_bb moves, raz_bb own, raz_bb enemy, bool exact) {
+    const raz_bb empties = ~(own | enemy);
+    int bs = -100;
+    for (raz_bb m = moves; m; m &= m - 1) {
+        const int s = __ffsll((long long)m) - 1;
+        const raz_bb fl = bbv_calc_flip(s, own, enemy);
+        const raz_bb o2 = (own ^ fl) | (1ULL << s), e2 = enemy ^ fl;
+        const int val = -solver_last_one(__ffsll((long long)(empties & ~(1ULL << s))) - 1, e2, o2);
+        if (bs < val) bs = val;
+        if (!exact && bs > 0) break;
+    }
+    return bs;
+}
+__device__ __forceinline__ int solver_play(int a, raz_bb own, raz_bb enemy, raz_bb& no, raz_bb& ne, raz_bb& nm, int& v, bool exact) {
     const raz_bb flipped = bbv_calc_flip(a, own, enemy);
     const raz_bb nown = (own ^ flipped) | (1ULL << a), nenemy = enemy ^ flipped;
     const raz_bb l1 = bbv_legal_moves(nenemy, nown);
     const raz_bb l2 = l1 ? 0ULL : bbv_legal_moves(nown, nenemy);
     if (!(l1 | l2)) {
         v = bb_popcount(nown) - bb_popcount(nenemy);
+        no = ne = nm = 0ULL;
+        return 0;
+    }
+    if (RAZ_SOLVER_INLINE_LAST >= 2 && bb_popcount(~(nown | nenemy)) == 2) {
+        // two squares left: the node's mover is the opponent if it can move (l1), else the mover of this move again (l2)
+        const bool opp = l1 != 0ULL;
+        const int nv = solver_last_two(l1 | l2, opp ? nenemy : nown, opp ? nown : nenemy, exact);
+        v = opp ? -nv : nv;
+        no = ne = nm = 0ULL;
+        return 0;
+    }
+    if (RAZ_SOLVER_INLINE_LAST && bb_popcount(~(nown | nenemy)) == 1) {
+        // the last square: the opponent's if it can play it (l1), else the mover's again (l2)
+        const bool opp = l1 != 0ULL;
+        const raz_bb last_own = opp ? nenemy : nown, last_enemy = opp ? nown : nenemy;
+        const int f = bb_popcount(bbv_calc_flip(__ffsll((long long)(l1 | l2)) - 1, last_own, last_enemy));
+        const int last = bb_popcount(last_own) + f + 1, other = bb_popcount(last_enemy) - f;
+        v = opp ? other - last : last - other;   // (for the mover of THIS move)
         no = ne = nm = 0ULL;
         return 0;
     }
@@ -161,7 +215,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             raz_bb m = legal0;
             for (int i = 0; i < lane; ++i) m &= m - 1;
             my_a = __ffsll((long long)m) - 1;
-            my_kind = solver_play(my_a, own0, enemy0, c_own, c_enemy, c_moves, my_v);
+            my_kind = solver_play(my_a, own0, enemy0, c_own, c_enemy, c_moves, my_v, exact != 0u);
             if (my_kind) {
                 int rm, rs;
                 if (bb_popcount(~(c_own | c_enemy)) >= 4 && memo_find_lane(E, g, c_own, c_enemy, exact, rm, rs)) {
@@ -197,7 +251,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
             for (int j = (int)P->c_first[ci]; j < n; ++j) m &= m - 1;
             raz_bb go, ge, gm;
             int gv;
-            int gk = solver_play(__ffsll((long long)m) - 1, P->c_own[ci], P->c_enemy[ci], go, ge, gm, gv);
+            int gk = solver_play(__ffsll((long long)m) - 1, P->c_own[ci], P->c_enemy[ci], go, ge, gm, gv, exact != 0u);
             int tasks = 0;
             if (gk) {
                 int rm, rs;
@@ -245,7 +299,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
                 for (int j = (int)P->g_first[n]; j < t; ++j) m &= m - 1;
                 raz_bb no, ne, nm;
                 int v, cnt = 0;
-                int kind = solver_play(__ffsll((long long)m) - 1, P->g_own[n], P->g_enemy[n], no, ne, nm, v);
+                int kind = solver_play(__ffsll((long long)m) - 1, P->g_own[n], P->g_enemy[n], no, ne, nm, v, exact != 0u);
                 if (!kind)
                     P->result[t] = (signed char)v;
                 else {
@@ -450,7 +504,7 @@ __global__ __launch_bounds__(64) void k_solve_scan(raz_engine_dev E, uint32_t g0
 #define RAZ_SOLVER_POOL_EVERY 1   // tree launches per round of the pool (raz_engine.hip: > 1 = the round runs beside them on its own stream)
 #endif
 #ifndef RAZ_SOLVER_POOL_BUDGET
-#define RAZ_SOLVER_POOL_BUDGET 128
+#define RAZ_SOLVER_POOL_BUDGET 96   // (128 until the move function finished the last square itself: see RAZ_SOLVER_INLINE_LAST)
 #endif
 #ifdef RAZ_WAVE_EMU
 #define RAZ_POOL_WAVES
@@ -589,7 +643,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                             if (!(hk & 8)) {
                                 raz_bb m = hm;
                                 for (int j = s0; j < (int)t; ++j) m &= m - 1;
-                                kind = solver_play(__ffsll((long long)m) - 1, ho, he, no, ne, nm, v);
+                                kind = solver_play(__ffsll((long long)m) - 1, ho, he, no, ne, nm, v, ex != 0u);
                             }
                             int pm = 0, ps = 0;
                             if (RAZ_SOLVER_PROBE_AT_DRAW && kind && bb_popcount(~(no | ne)) >= RAZ_SOLVER_LANE_MEMO_EMPTIES && memo_find_lane(E, gg, no, ne, ex, pm, ps)) {
@@ -733,7 +787,7 @@ __global__ __launch_bounds__(64) RAZ_POOL_WAVES void k_solve_run(raz_engine_dev 
                 left &= left - 1;
                 raz_bb no, ne, nm;
                 int score;
-                const int kind = solver_play(a, own, enemy, no, ne, nm, score);
+                const int kind = solver_play(a, own, enemy, no, ne, nm, score, exact != 0u);
                 if (kind) {   // down a ply
                     fr[(d * 4 + 0) * 64] = own;
                     fr[(d * 4 + 1) * 64] = enemy;

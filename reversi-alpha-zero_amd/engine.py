@@ -112,7 +112,7 @@ def engine_config_from(config, n_games, seed, nodes_per_game, max_plies=72, mirr
     """raz_engine_config from a Config-like object with `.play` / `.play_data` (reference names).
     play.parallel_search_num (config.py:142): 1 = the reference's reproducible mode (k_tree); 2..16 =
     that many simulations in flight per game on the raz-sched-v1 schedule (k_tree_par).
-    solver_budget: iterations a worker lane of the end-game solver's pool runs between two tree launches (rounded up to 64; 0 = 128);
+    solver_budget: iterations a worker lane of the end-game solver's pool runs between two tree launches (rounded up to 64; 0 = the library's default, 96);
     solver_pool_waves: worker wavefronts of that pool (0 = one per four games, at most 1280); solver_pool_every: tree launches per round
     of the pool (0 = the library's default, 1 = every step waits for the round, n > 1 = the round runs beside the next n - 1 steps on its
     own stream).  None of them changes a result."""
