@@ -529,6 +529,8 @@ def headline_leg(args, dev, rank, world, cdev, group=False):
     net_avg_ms, tree_avg_ms = net_ms / launches, tree_ms / launches
     ach = 2.0 * macs * leaves_per_launch / (net_avg_ms * 1e-3) / 1e12 if net_avg_ms else 0.0   # (--fused: no separate net kernel to time)
     traffic, traffic_src = conv_traffic() if args.net == "ch5" else (None, None)
+    if traffic is not None and args.games != 8192:   # (the committed counter passes are of the default command: a forward of 8192 games per GPU)
+        traffic, traffic_src = None, f"{traffic_src} - NOT reported: that is a forward of 8192 games per GPU, this run has {args.games}"
     v2 = "f16x3" in (net.kernel_name or "")
     net_kernel = {"ch5": ("one net forward = k_conv0_split + 20 x k_conv3x3_f16x3 (implicit GEMM on the f16 matrix cores, split operands: "
                           "3 MFMA flops per algorithmic flop; >99% of the forward) + k_heads_split") if v2 else
