@@ -21,12 +21,17 @@ def load(full=False):
     whole product incl. the real net kernels on emulated matrix cores (libraz_emu_full.so, a minute to build): what the fused
     tree + net kernel needs."""
     if full not in _libs:
-        with _locked("emu"):
-            r = subprocess.run(["make", "-C", EMU_DIR] + (["../libraz_emu_full.so"] if full else []), capture_output=True, text=True)
+        # RAZ_EMU_VARIANT=<name> RAZ_EMU_EXTRA=<flags>: a build of the tree kernels with other compile-time options, in a library of its own
+        # (a child process of a test that wants the kernels' optional forms checked: tests/test_engine_emu.py)
+        variant, extra = os.environ.get("RAZ_EMU_VARIANT"), os.environ.get("RAZ_EMU_EXTRA", "")
+        path = EMU_FULL_LIB if full else (os.path.join(ROOT, "tests", "native", f"libraz_emu_{variant}.so") if variant else EMU_LIB)
+        args = ["../libraz_emu_full.so"] if full else ([f"OUT=../libraz_emu_{variant}.so", f"EXTRA={extra}"] if variant else [])
+        with _locked("emu" + (f"_{variant}" if variant and not full else "")):
+            r = subprocess.run(["make", "-C", EMU_DIR] + args, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("wave-emulator build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
         from reversi_alpha_zero_amd import _native as N
-        lib = ctypes.CDLL(EMU_FULL_LIB if full else EMU_LIB)
+        lib = ctypes.CDLL(path)
         lib.raz_last_error.restype = ctypes.c_char_p
         for name, (res, args) in N.SIGNATURES.items():
             fn = getattr(lib, name, None)

@@ -454,3 +454,21 @@ def test_emulated_in_simulation_solves_of_11_to_13_empties_equal_oracle(golden, 
         off, _ = O.selfplay_game(ocfg_off, blob, 9, 300 + g, sims, stop_after_plies=1, start=start)
         mattered += off[0]["root_w"] != ref["root_w"] or off[0]["root_n"] != ref["root_n"]
     assert mattered >= 3      # (the solves decided what the simulations returned: without them the statistics differ)
+
+
+def test_emulated_solver_with_the_last_two_squares_finished_in_the_move_function_in_a_process_of_its_own():
+    """RAZ_SOLVER_INLINE_LAST=2 (csrc/raz_solver_pool.h solver_last_two: positions with TWO empty squares finished inside solver_play,
+    the reference's loop over the moves with its non-exact stop) is an option the library is not built with by default (level 1 is):
+    the device solver against the compiled reference solver and the pool serving several games, on a variant build of the emulated
+    kernels in a child process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RAZ_EMU_VARIANT"):
+        pytest.skip("a child of this test")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-p", "no:xdist",
+                        "-k", "device_solver_equals_compiled_cython or solver_pool_serves_several_games"],
+                       env={**os.environ, "RAZ_EMU_VARIANT": "last2", "RAZ_EMU_EXTRA": "-DRAZ_SOLVER_INLINE_LAST=2"},
+                       capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
