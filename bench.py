@@ -56,8 +56,6 @@ import sys
 import time
 import types
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (as reversi_alpha_zero_amd/_native.py sets it - here too, before anything can start the HIP runtime)
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

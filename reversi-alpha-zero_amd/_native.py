@@ -8,12 +8,9 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int8, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p, POINTER
 
-# The engine steps its slices on three streams and runs the solver pool's rounds on three more; the HIP runtime maps a process's streams onto
-# GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise), and streams that share a queue wait for each other.  8 queues: mini.yml as
-# shipped with continuous batching 33.7 -> 35.7 M sims/s, configs[1] two-kernel +2 % (profiles/r6/hardware_queues_ab.json).  Read by the
-# runtime when it initialises (the first HIP call of the process), so this default works whenever it is set before that; a caller's own
-# setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES: the HIP runtime maps a process's streams onto 4 hardware queues by default and the engine uses up to 7 streams.  8
+# queues help a process that runs only the continuous-batching solver legs (+6 %) and HALVE the two-kernel legs inside a full bench.py
+# run, where the streams of earlier legs have moved the mapping - INTEGRATION.md section 6, profiles/r6/hardware_queues_ab.json.  Not set here.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAZ_LIB_PATH") or os.path.join(_HERE, "csrc", "libraz.so")
